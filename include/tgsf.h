@@ -1,0 +1,257 @@
+/*
+ * tgsf.h -- C ABI of the MI355X per-read filtering hot path (libtgsf.so).
+ *
+ * This is the drop-in boundary for TGSFilter's worker body.  The reference has no
+ * FFI of its own: the seam this ABI replaces is
+ *
+ *   S1  void TGSFilterTask::filter_sequence(int tid)      src/TGSFilter.cpp:1919-2064
+ *         (per-read: CalcAvgQuality :1436, Get_5p/3p_base_qual :1481/:1528,
+ *          adapterMap :1325, GetEditDistance :1218) and
+ *   S2  EdlibAlignResult edlibAlign(query,qLen,target,tLen,config)
+ *                                                          include/edlib.h:242-246
+ *         as called in HW/PATH mode from src/TGSFilter.cpp:1239,1276,1301.
+ *
+ * The reference processes one read per call on std::string values; a GPU needs
+ * batches, so the ABI is the batch-granular form of S1 with S2 folded in:
+ * reads arrive CSR-packed (two byte buffers + offsets), results come back as
+ * "kept-read set + trim coordinates" (per-read record + per-fragment records)
+ * and the additive tallies (DropInfo[17] + QC accumulator tables) live in the
+ * context until fetched with tgsf_counters().
+ *
+ * Conventions: plain C, fixed-width ints, no exceptions; every entry point
+ * returns 0 (TGSF_OK) or a negative tgsf_status; tgsf_last_error() gives text.
+ * One context per GPU.  Calls on one context are serialised by the caller;
+ * different contexts may be driven concurrently from different host threads.
+ * The library owns all device memory it allocates.  There is NO CPU fallback:
+ * if no HIP device is usable tgsf_create fails with TGSF_E_NO_DEVICE.
+ */
+#ifndef TGSF_H
+#define TGSF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TGSF_ABI_VERSION 1
+#define TGSF_MAX_ADAPTERS 16      /* adapters.size(): 2 or 4 in practice (src/TGSFilter.cpp:3105-3125) */
+#define TGSF_MAX_ADAPTER_LEN 128  /* two 64-row blocks; library adapters are 22..64 bp (:2970-2991) */
+#define TGSF_N_DROPINFO 17        /* DropInfo row, src/TGSFilter.cpp:1776 */
+#define TGSF_N_QBINS 256          /* raw/cleanDiffQualReadsBases, :1777-1778 */
+#define TGSF_BIN_WIDTH 100        /* int(i/100) in CalcAvgQuality, :1460 */
+
+typedef enum tgsf_status {
+    TGSF_OK = 0,
+    TGSF_E_INVALID = -1,      /* bad argument / parameter outside the supported domain */
+    TGSF_E_NO_DEVICE = -2,    /* no usable HIP device (there is no CPU fallback)       */
+    TGSF_E_HIP = -3,          /* a HIP runtime call failed                              */
+    TGSF_E_CAPACITY = -4,     /* caller-provided output capacity too small              */
+    TGSF_E_UNSUPPORTED = -5,  /* feature named by the reference but not on this path    */
+    TGSF_E_DATA = -6          /* input bytes outside the supported domain (see below)   */
+} tgsf_status;
+
+/*
+ * The fields of Para_A24 (src/TGSFilter.cpp:82-172) and the globals the hot path
+ * reads, AFTER the pre-pass resolved them (MinQ, HeadTrim/TailTrim >= 0, qType,
+ * the adapter set).  Floats stay floats: the reference compares a double mean
+ * quality against a float threshold (:1947) and float(mlen)/qLen against a
+ * float similarity (:1250-1252), and so does the library.
+ */
+typedef struct tgsf_params {
+    uint32_t struct_size;     /* = sizeof(tgsf_params); ABI guard                    */
+    int32_t  min_len;         /* -l  MinLen                                           */
+    int32_t  max_len;         /* -L  MaxLen                                           */
+    float    min_q;           /* -q  MinQ (resolved, >= 0)                            */
+    float    max_q;           /* -Q  MaxQ                                             */
+    int32_t  bc_len;          /* -e  BCLen: positions in the 5'/3' QC tables          */
+    int32_t  head_trim;       /* -5  HeadTrim (resolved; <= 0 disables, :1334)        */
+    int32_t  tail_trim;       /* -3  TailTrim                                         */
+    int32_t  end_len;         /* -E  EndLen                                           */
+    int32_t  end_match_len;   /* -m  EndMatchLen                                      */
+    int32_t  mid_match_len;   /* -M  MidMatchLen                                      */
+    int32_t  extra_len;       /* -T  ExtraLen                                         */
+    float    end_sim;         /* -s  EndSim                                           */
+    float    mid_sim;         /* -S  MidSim                                           */
+    int32_t  discard;         /* -D  discard reads with a middle adapter              */
+    int32_t  filter;          /* Para_A24::Filter (0 with -F / --qc)                  */
+    int32_t  only_qc;         /* --qc                                                 */
+    int32_t  min_repeat;      /* -p  MinRepeat; must be 0 (GetKmerCount is a "next" row) */
+    int32_t  kmer;            /* -k  Kmer (unused while min_repeat == 0)              */
+    int32_t  qtype;           /* global qType: 33 or 64 (:80, :1042-1053)             */
+    int32_t  n_adapters;      /* size of the global `adapters` set (:1324)            */
+    const char* adapters[TGSF_MAX_ADAPTERS];     /* not NUL-terminated necessarily    */
+    int32_t  adapter_len[TGSF_MAX_ADAPTERS];
+    /* sizing hints (not in the reference) */
+    uint64_t max_batch_bases; /* largest sum of read lengths of one batch            */
+    uint32_t max_batch_reads; /* largest number of reads of one batch                */
+    uint32_t max_read_len;    /* longest read ever submitted (sizes the bin tables)  */
+} tgsf_params;
+
+/*
+ * One batch of reads, CSR-packed.  Read i is seq[offsets[i] .. offsets[i+1]) and
+ * its qualities are qual[offsets[i] .. offsets[i+1]) -- one offsets array for
+ * both, because the reference drops the stream at the first record whose
+ * lengths differ (src/TGSFilter.cpp:719-723).  Offsets are in bytes; aligning
+ * each read start to 16 bytes (leaving gaps) is allowed and is the fast layout:
+ * then pass `lengths` explicitly.  With lengths == NULL, read i has length
+ * offsets[i+1]-offsets[i].  Supported domain: 1 <= length <= max_read_len;
+ * quality bytes < 128 (ASCII) -- a batch with a byte >= 128 fails with
+ * TGSF_E_DATA (the reference would subtract qType from a negative char).
+ */
+typedef struct tgsf_batch_in {
+    const uint8_t*  seq;
+    const uint8_t*  qual;
+    const uint64_t* offsets;   /* n_reads + 1 entries (n_reads if lengths given)     */
+    const uint32_t* lengths;   /* optional, n_reads entries                           */
+    uint32_t        n_reads;
+    uint32_t        reserved;
+    uint64_t        n_bytes;   /* bytes spanned by seq / qual (>= last offset+len)    */
+} tgsf_batch_in;
+
+/* tgsf_read_result.flags */
+#define TGSF_RF_LOWQ       0x01u  /* dropped by the raw mean-quality gate (:1946-1953)        */
+#define TGSF_RF_AD5P       0x02u  /* num5p  > 0 (:1354-1370)                                  */
+#define TGSF_RF_AD3P       0x04u  /* num3p  > 0                                               */
+#define TGSF_RF_ADMID      0x08u  /* numMid > 0                                               */
+#define TGSF_RF_DISCARDED  0x10u  /* numMid > 0 && -D: no regions (:1372-1373)                */
+
+/* 32 bytes per read: the "trim coordinates" record */
+typedef struct tgsf_read_result {
+    uint64_t sum_q;        /* raw  Σ(qual[i]-qType) as uint64 (CalcAvgQuality sumQ, :1451-1458) */
+    uint32_t flags;        /* TGSF_RF_*                                                        */
+    uint32_t n_frags;      /* keepRegions.size() (:1960-1965); 0 if dropped                    */
+    uint32_t frag_begin;   /* index of this read's first record in tgsf_batch_out.frags        */
+    uint32_t trimmed;      /* bases this read added to DropInfo[10]                             */
+    int32_t  clip5;        /* end of the merged drop region starting at 0 (0 if none)          */
+    int32_t  clip3;        /* start of the merged drop region ending at L (L if none)          */
+} tgsf_read_result;
+
+/* tgsf_fragment.flags */
+#define TGSF_FF_PASS  0x01u   /* survived the post-split quality gate (:1995-2001) => emitted  */
+
+/* one keep-region {start,len} of adapterMap (:1404-1431), ascending within a read */
+typedef struct tgsf_fragment {
+    uint64_t sum_q;        /* clean Σ(qual-qType) over the fragment (:1994)                    */
+    uint32_t read;         /* index of the read within the batch                               */
+    int32_t  start;
+    int32_t  len;
+    uint32_t flags;        /* TGSF_FF_*                                                        */
+} tgsf_fragment;
+
+typedef struct tgsf_batch_out {
+    tgsf_read_result* reads;        /* caller-allocated, n_reads entries                      */
+    tgsf_fragment*    frags;        /* caller-allocated, frag_capacity entries                */
+    uint32_t          frag_capacity;
+    uint32_t          n_frags;      /* filled by the callee                                   */
+} tgsf_batch_out;
+
+/*
+ * The additive tallies (T2 + T3 of SURVEY §8a) as one flat uint64 vector so
+ * that a multi-GPU run can sum it with a single all-reduce.  Layout (u64 index):
+ *   [0,17)                          DropInfo            (:1776; meaning :3214-3231)
+ *   [17,273)                        rawDiffQualReadsBases   (:1777)
+ *   [273,529)                       cleanDiffQualReadsBases (:1778)
+ *   [529,531)                       rows used: raw bins, clean bins (max over reads of L/100+1)
+ *   [531,533)                       rows used: raw 5'/3' tables, clean 5'/3' tables (max min(e,L))
+ *   TGSF_CTR_END_TABLES + t*bc_len*5   t = 0..7, each [bc_len][5] :
+ *        raw5pQual raw5pCounts raw3pQual raw3pCounts clean5pQual clean5pCounts clean3pQual clean3pCounts
+ *   then 4 bin tables, each [n_bins][5] : rawBaseQual rawBaseCounts cleanBaseQual cleanBaseCounts
+ * Column order of every [..][5] table is the reference's: A,T,G,C,all (:1462-1476).
+ * The four "rows used" words are maxima, not sums: reduce them with MAX.
+ */
+#define TGSF_CTR_DROPINFO    0
+#define TGSF_CTR_RAW_DIFFQ   17
+#define TGSF_CTR_CLEAN_DIFFQ 273
+#define TGSF_CTR_ROWS        529
+#define TGSF_CTR_END_TABLES  533
+
+enum { TGSF_T_RAW5P_QUAL = 0, TGSF_T_RAW5P_CNT, TGSF_T_RAW3P_QUAL, TGSF_T_RAW3P_CNT,
+       TGSF_T_CLEAN5P_QUAL, TGSF_T_CLEAN5P_CNT, TGSF_T_CLEAN3P_QUAL, TGSF_T_CLEAN3P_CNT };
+enum { TGSF_B_RAW_QUAL = 0, TGSF_B_RAW_CNT, TGSF_B_CLEAN_QUAL, TGSF_B_CLEAN_CNT };
+
+static inline size_t tgsf_ctr_end_table(int t, int bc_len) {
+    return (size_t)TGSF_CTR_END_TABLES + (size_t)t * (size_t)bc_len * 5u;
+}
+static inline size_t tgsf_ctr_bin_table(int b, int bc_len, uint32_t n_bins) {
+    return (size_t)TGSF_CTR_END_TABLES + 8u * (size_t)bc_len * 5u + (size_t)b * (size_t)n_bins * 5u;
+}
+static inline size_t tgsf_ctr_len(int bc_len, uint32_t n_bins) {
+    return tgsf_ctr_bin_table(4, bc_len, n_bins);
+}
+/* number of 100-bp rows a context created with max_read_len allocates */
+static inline uint32_t tgsf_n_bins(uint32_t max_read_len) { return max_read_len / TGSF_BIN_WIDTH + 1u; }
+
+typedef struct tgsf_ctx tgsf_ctx;
+
+/* Library / ABI version (TGSF_ABI_VERSION). */
+int tgsf_abi_version(void);
+
+/*
+ * Create a context on HIP device `device`.  Replaces the construction of
+ * TGSFilterTask (:1757-1790: the accumulator rows) for one "worker" = one GPU.
+ */
+int tgsf_create(const tgsf_params* params, int device, tgsf_ctx** out_ctx);
+void tgsf_destroy(tgsf_ctx* ctx);
+
+/*
+ * Filter one batch held in HOST memory: H2D, run the kernels, D2H of results.
+ * Synchronous variant of the worker loop body (:1939-2061) for n_reads reads.
+ * Counters accumulate inside the context.
+ */
+int tgsf_submit(tgsf_ctx* ctx, const tgsf_batch_in* in, tgsf_batch_out* out);
+
+/*
+ * Same, but every pointer in `in` and `out` is a DEVICE pointer already
+ * resident in HBM and the work is enqueued on `hip_stream` (a hipStream_t, or
+ * NULL for the context's own stream) without synchronising: the caller
+ * synchronises the stream (or calls tgsf_wait) before reading results.
+ * out->n_frags is not filled; the fragment count is written to
+ * *d_n_frags (device uint32) if that pointer is non-NULL.
+ */
+int tgsf_submit_device(tgsf_ctx* ctx, const tgsf_batch_in* in, tgsf_batch_out* out,
+                       uint32_t* d_n_frags, void* hip_stream);
+
+/* Block until everything submitted on this context has finished; report async errors. */
+int tgsf_wait(tgsf_ctx* ctx);
+
+/* Number of uint64 words tgsf_counters() writes, and the table geometry. */
+int tgsf_counters_len(tgsf_ctx* ctx, uint64_t* n_words, int32_t* bc_len, uint32_t* n_bins);
+/* Copy the tallies to host memory (synchronises the context). Replaces the
+ * per-thread merge of src/TGSFilter.cpp:3208-3213 / :2673-2725 / :2586-2597. */
+int tgsf_counters(tgsf_ctx* ctx, uint64_t* dst, uint64_t n_words);
+/* Device address of the same vector (for an in-place RCCL all-reduce). */
+int tgsf_counters_device(tgsf_ctx* ctx, void** d_ptr, uint64_t* n_words);
+/* Zero the tallies (start of a new run). */
+int tgsf_reset_counters(tgsf_ctx* ctx);
+
+/*
+ * Stage timing (HIP events on the submit stream).  Enable, run batches, then read
+ * the accumulated milliseconds per pipeline stage since the last reset.
+ */
+#define TGSF_N_STAGES 12
+int tgsf_profile(tgsf_ctx* ctx, int enable);
+int tgsf_stage_times(tgsf_ctx* ctx, float ms[TGSF_N_STAGES], uint32_t* n_batches);
+const char* tgsf_stage_name(int stage);
+
+/*
+ * edlib-compatible single alignment on the device (S2), used by the parity tests
+ * and by the parameter pre-pass (adapterSearch, src/TGSFilter.cpp:1163): for each
+ * of n problems (adapter a[i], window = seq[win_off[i] .. +win_len[i])) with
+ * threshold k[i], HW mode, PATH task, writes
+ *   res[i*4+0] editDistance (-1 if > k), +1 numLocations, +2 alignmentLength,
+ *   +3 startLocations[0] ; ends[i*2+0] endLocations[0], ends[i*2+1] endLocations[last]
+ * All pointers are HOST pointers.
+ */
+int tgsf_align_windows(tgsf_ctx* ctx, const uint8_t* seq, uint64_t n_bytes,
+                       const uint64_t* win_off, const uint32_t* win_len,
+                       const uint8_t* adapter_id, const int32_t* k, uint32_t n,
+                       int32_t* res, int32_t* ends);
+
+const char* tgsf_last_error(tgsf_ctx* ctx);   /* ctx may be NULL: last create error */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TGSF_H */
