@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE.
+
+Run in the build container only (needs oracle/_ref/tgsfilter_ref, i.e. `make -C oracle ref`,
+which compiles the reference from /root/reference where it lies).  The outputs are data:
+  <case>.in.fq.gz      seeded synthetic input (tgsfilter_amd/synth.py)
+  <case>.out.fq.gz     the reference's clean FASTQ with -t 1 (byte-deterministic, input order)
+  <case>.stderr.txt    the reference's stderr (INFO: lines = counters, resolved parameters)
+  <case>.html.json     the <table> rows and the `var data = {...}` object of the HTML report
+  <case>.cmd.json      the flags used
+  edlib_vectors.json   kernel-level vectors from the reference's own edlib (HW/PATH)
+No reference source text is stored.
+"""
+import ctypes as C
+import gzip
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from tgsfilter_amd import synth  # noqa: E402
+
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "tgsfilter_ref")
+REF_EDLIB = os.path.join(ROOT, "oracle", "_ref", "libedlib_ref.so")
+
+LONG_ADAPTER = (b"GGCGTCTGCTTGGGTGTTTAACCTTTTTGTCAGAGAGGTTCCAAGTCAGAGAGGTTCCT"
+                b"ACGTTGCAATCGGATCCGATTACGGATCAAGT")  # 91 bp: two 64-row blocks
+
+CASES = {
+    # name: (synth kwargs, adapter fasta (list) or None, flags)
+    "ont_zoo": (dict(seed=11, n=96, kind="ont", mean_len=4000, zoo=True, pmid=0.05),
+                [synth.ONT_RAPID], "-x ont -l 1000 -q 10 -5 0 -3 0"),
+    "ont_trim": (dict(seed=12, n=96, kind="ont", mean_len=4000, zoo=True, pmid=0.05),
+                 [synth.ONT_RAPID], "-x ont -l 500 -L 7000 -q 8 -Q 16 -5 12 -3 9 -T 30 -M 30 -m 6 -s 0.8 -S 0.85"),
+    "ont_discard": (dict(seed=13, n=64, kind="ont", mean_len=4000, zoo=True, pmid=0.2),
+                    [synth.ONT_RAPID], "-x ont -l 1000 -q 10 -5 0 -3 0 -D"),
+    "hifi_zoo": (dict(seed=14, n=96, kind="hifi", mean_len=3000, zoo=True, p5=0.2, p3=0.2, pmid=0.05),
+                 [synth.PACBIO_BLUNT], "-x hifi -l 1000 -q 20 -5 0 -3 0"),
+    "long_adapter": (dict(seed=15, n=64, kind="ont", mean_len=3000, zoo=True, adapter=LONG_ADAPTER,
+                          pmid=0.1, err=0.05),
+                     [LONG_ADAPTER, b"AATGTACTTCGTTCAGTTACGTATTGCT"], "-x ont -l 800 -q 9 -5 3 -3 0"),
+    "ont_auto": (dict(seed=16, n=1500, kind="ont", mean_len=1300), None, "-x ont -l 1000 -b 8"),
+    "hifi_auto": (dict(seed=17, n=1200, kind="hifi", mean_len=1400, p5=0.5, p3=0.4), None, "-x hifi -l 1000 -b 8"),
+    "qc_only": (dict(seed=18, n=64, kind="ont", mean_len=3000, zoo=True), None, "--qc"),
+}
+
+
+def html_slices(html: str):
+    table = re.findall(r"<tr>.*?</tr>", html, flags=re.S)
+    m = re.search(r"var data = (\{.*?\});", html, flags=re.S)
+    return {"table_rows": table, "data": m.group(1) if m else None}
+
+
+def run_case(name, kwargs, adapters, flags):
+    reads = synth.make_reads(**kwargs)
+    with tempfile.TemporaryDirectory() as td:
+        fin = os.path.join(td, "in.fq")
+        fout = os.path.join(td, "out.fq")
+        synth.write_fastq(fin, reads)
+        cmd = [REF_BIN, "-i", fin, "-t", "1"] + flags.split()
+        if "--qc" not in flags:
+            cmd += ["-o", fout]
+        if adapters:
+            fa = os.path.join(td, "adapters.fa")
+            with open(fa, "wb") as f:
+                for i, a in enumerate(adapters):
+                    f.write(b">a%d\n" % i + a + b"\n")
+            cmd += ["-a", fa]
+        p = subprocess.run(cmd, capture_output=True, cwd=td)
+        stderr = p.stderr.decode().replace(td + "/", "")
+        out = open(fout, "rb").read() if os.path.exists(fout) else b""
+        htmlname = os.path.join(td, "out.html" if "--qc" not in flags else "in.html")
+        html = open(htmlname, encoding="utf-8", errors="replace").read() if os.path.exists(htmlname) else ""
+        raw = open(fin, "rb").read()
+    with gzip.GzipFile(os.path.join(HERE, name + ".in.fq.gz"), "wb", mtime=0) as f:
+        f.write(raw)
+    with gzip.GzipFile(os.path.join(HERE, name + ".out.fq.gz"), "wb", mtime=0) as f:
+        f.write(out)
+    open(os.path.join(HERE, name + ".stderr.txt"), "w").write(stderr)
+    json.dump(html_slices(html), open(os.path.join(HERE, name + ".html.json"), "w"), indent=0)
+    json.dump({"flags": flags, "adapters": [a.decode() for a in adapters] if adapters else None,
+               "synth": kwargs if "adapter" not in kwargs else {**kwargs, "adapter": kwargs["adapter"].decode()},
+               "returncode": p.returncode},
+              open(os.path.join(HERE, name + ".cmd.json"), "w"), indent=1)
+    print(name, "rc", p.returncode, "in", len(raw), "out", len(out))
+    print("   ", "\n    ".join(l for l in stderr.splitlines() if "reads" in l or "adapter" in l or "trim" in l))
+
+
+class _Cfg(C.Structure):
+    _fields_ = [("k", C.c_int), ("mode", C.c_int), ("task", C.c_int), ("eq", C.c_void_p), ("neq", C.c_int)]
+
+
+class _Res(C.Structure):
+    _fields_ = [("status", C.c_int), ("editDistance", C.c_int), ("endLocations", C.POINTER(C.c_int)),
+                ("startLocations", C.POINTER(C.c_int)), ("numLocations", C.c_int),
+                ("alignment", C.POINTER(C.c_ubyte)), ("alignmentLength", C.c_int), ("alphabetLength", C.c_int)]
+
+
+def edlib_vectors(n=600, seed=7):
+    """Kernel-level vectors: the reference's edlibAlign(HW=2, PATH=2) on seeded triples."""
+    lib = C.CDLL(REF_EDLIB)
+    lib.edlibAlign.restype = _Res
+    lib.edlibAlign.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, _Cfg]
+    lib.edlibFreeAlignResult.argtypes = [_Res]
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    lib22 = [synth.PACBIO_BLUNT, synth.PACBIO_BLUNT_RC, synth.ONT_RAPID, synth.ONT_RAPID_RC,
+             b"GCAATACGTAACTGAACGAAGT", LONG_ADAPTER,
+             b"GGAACCTCTCTGACTTGGAACCTCTCTGACAAAAAGGTTAAACACCCAAGCAGACGCCAGCAAT"]
+    vec = []
+    for i in range(n):
+        q = lib22[int(rng.integers(0, len(lib22)))]
+        Q = len(q)
+        T = int(rng.integers(5, 30)) if i % 7 == 0 else int(rng.integers(30, 400))
+        t = bytearray(acgt[rng.integers(0, 4, T)].tobytes())
+        if i % 5 == 4:
+            t = bytearray(b"A" * T)
+        for _ in range(int(rng.integers(0, 3))):
+            m = synth.mutate(rng, q, float(rng.choice([0.0, 0.05, 0.1, 0.2, 0.3])))
+            if rng.random() < 0.3:
+                m = m[int(rng.integers(0, len(m))):]
+            p = int(rng.integers(0, T))
+            t[p:p + len(m)] = m
+        t = bytes(t[:max(5, min(len(t), 400))])
+        k = int(rng.choice([Q - 3, Q - 34, Q - 14, Q // 3]))
+        k = max(0, k)
+        r = lib.edlibAlign(q, Q, t, len(t), _Cfg(k, 2, 2, None, 0))
+        vec.append({"q": q.decode(), "t": t.decode(), "k": k, "ed": r.editDistance, "n": r.numLocations,
+                    "starts": [r.startLocations[j] for j in range(r.numLocations)],
+                    "ends": [r.endLocations[j] for j in range(r.numLocations)],
+                    "alen": r.alignmentLength})
+        lib.edlibFreeAlignResult(r)
+    json.dump(vec, open(os.path.join(HERE, "edlib_vectors.json"), "w"))
+    print("edlib vectors", len(vec), "hits", sum(v["ed"] >= 0 for v in vec))
+
+
+if __name__ == "__main__":
+    only = sys.argv[1:]
+    for name, (kw, ad, fl) in CASES.items():
+        if not only or name in only:
+            run_case(name, kw, ad, fl)
+    if not only or "edlib" in only:
+        edlib_vectors()
