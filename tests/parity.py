@@ -1,0 +1,80 @@
+"""Shared parity checks: a libtgsf backend (HIP on the GPU box, the serial emulation of the same
+kernels on GPU-less boxes) against the oracle and the golden vectors."""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+
+from oracle import orc
+from tests import hostmodel
+from tgsfilter_amd import abi, capi, synth
+
+
+def sized(p: abi.Params, reads, extra=1):
+    n = len(reads)
+    p.max_batch_reads = n * extra
+    p.max_batch_bases = sum(len(r[1]) for r in reads) * extra + 64
+    p.max_read_len = max(len(r[1]) for r in reads)
+    return p
+
+
+def compare_batch(ctx: capi.Context, p: abi.Params, reads, *, align=16, explicit_lengths=True):
+    """Run one batch through the backend and the oracle; everything must be identical."""
+    seq, qual, offsets, lengths = synth.pack(reads, align=align)
+    if explicit_lengths:
+        got_r, got_f = ctx.submit(seq, qual, offsets[:-1].copy() if align > 1 else offsets, lengths)
+    else:
+        got_r, got_f = ctx.submit(seq, qual, offsets, None)
+    ctr = ctx.counters()
+    exp_ctr = np.zeros(ctx.ctr_words, dtype=np.uint64)
+    exp_r, exp_f, exp_ctr = orc.filter_batch(p, seq, qual, offsets, lengths if explicit_lengths else None,
+                                             n_bins=ctx.n_bins, ctr=exp_ctr)
+    for name in ("sum_q", "flags", "n_frags", "frag_begin", "trimmed"):
+        bad = np.nonzero(got_r[name] != exp_r[name])[0]
+        assert bad.size == 0, f"read field {name} differs at reads {bad[:8]}: got {got_r[name][bad[:8]]} exp {exp_r[name][bad[:8]]}"
+    assert len(got_f) == len(exp_f), (len(got_f), len(exp_f))
+    for name in ("sum_q", "read", "start", "len", "flags"):
+        bad = np.nonzero(got_f[name] != exp_f[name])[0]
+        assert bad.size == 0, f"fragment field {name} differs at {bad[:8]}"
+    bad = np.nonzero(ctr != exp_ctr)[0]
+    assert bad.size == 0, f"tally words differ at {bad[:12]}: got {ctr[bad[:12]]} exp {exp_ctr[bad[:12]]}"
+    return got_r, got_f, ctr
+
+
+def golden_case(lib_path, golden_dir, name):
+    case = hostmodel.GoldenCase(golden_dir, name)
+    p = sized(case.params(), case.reads)
+    ctx = capi.Context(p, 0, lib_path)
+    try:
+        res, frags, ctr = compare_batch(ctx, p, case.reads)
+        if name != "qc_only":
+            assert hostmodel.format_fastq(case.reads, res, frags) == case.ref_out
+            drop = ctr[abi.CTR_DROPINFO:abi.CTR_DROPINFO + 17]
+            for i, v in enumerate(case.info["drop"]):
+                if v is not None:
+                    assert int(drop[i]) == v, (i, int(drop[i]), v)
+    finally:
+        ctx.close()
+
+
+def edlib_vectors(lib_path, golden_dir):
+    vec = json.load(open(os.path.join(golden_dir, "edlib_vectors.json")))
+    adapters = sorted({v["q"] for v in vec})
+    p = abi.make_params("ont", adapters=[a.encode() for a in adapters], max_batch_bases=1 << 16,
+                        max_batch_reads=64, max_read_len=4096)
+    ctx = capi.Context(p, 0, lib_path)
+    try:
+        buf, off, ln, aid, ks = bytearray(), [], [], [], []
+        for v in vec:
+            off.append(len(buf)); ln.append(len(v["t"])); aid.append(adapters.index(v["q"])); ks.append(v["k"])
+            buf += v["t"].encode()
+        res, ends = ctx.align_windows(bytes(buf), off, ln, aid, ks)
+        for i, v in enumerate(vec):
+            exp = (v["ed"], v["n"], v["alen"], v["starts"][0] if v["n"] else -1,
+                   v["ends"][0] if v["n"] else -1, v["ends"][-1] if v["n"] else -1)
+            got = (int(res[i, 0]), int(res[i, 1]), int(res[i, 2]), int(res[i, 3]), int(ends[i, 0]), int(ends[i, 1]))
+            assert got == exp, (i, v["q"], v["t"], v["k"], got, exp)
+    finally:
+        ctx.close()

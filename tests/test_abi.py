@@ -1,0 +1,60 @@
+"""The C-ABI library loads on a GPU-less box, exports every symbol include/tgsf.h declares, and
+refuses to run without a device (there is no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from tgsfilter_amd import abi, capi, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tgsfilter_amd", "csrc")], check=True)
+    return capi.load()
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "tgsf.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|void|const char\*)\s+(tgsf_\w+)\s*\(", hdr, flags=re.M))
+    assert declared == set(capi.SYMBOLS), declared ^ set(capi.SYMBOLS)
+    for s in declared:
+        assert hasattr(lib, s)
+    assert lib.tgsf_abi_version() == abi.ABI_VERSION
+
+
+def test_struct_layout_matches_header():
+    """sizeof() of the ctypes mirrors == what the C compiler sees."""
+    src = r'''
+    #include <stdio.h>
+    #include "tgsf.h"
+    int main(void){ printf("%zu %zu %zu %zu %zu\n", sizeof(tgsf_params), sizeof(tgsf_batch_in),
+        sizeof(tgsf_batch_out), sizeof(tgsf_read_result), sizeof(tgsf_fragment)); return 0; }'''
+    exe = "/tmp/tgsf_sizes"
+    subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src.encode(), check=True)
+    out = subprocess.run([exe], capture_output=True, check=True).stdout.split()
+    got = [int(x) for x in out]
+    assert got == [C.sizeof(abi.Params), C.sizeof(abi.BatchIn), C.sizeof(abi.BatchOut),
+                   abi.READ_RESULT_DTYPE.itemsize, abi.FRAGMENT_DTYPE.itemsize]
+
+
+def test_no_device_fails_loudly(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    p = abi.make_params("ont", adapters=[synth.ONT_RAPID], max_batch_bases=1000, max_batch_reads=4, max_read_len=500)
+    with pytest.raises(capi.TgsfError) as ei:
+        capi.Context(p, 0)
+    assert ei.value.code == abi.E_NO_DEVICE
+    assert "no CPU fallback" in str(ei.value)
+
+
+def test_parameter_validation(lib):
+    p = abi.make_params("ont", adapters=[b"A" * 200], max_batch_bases=1000, max_batch_reads=4, max_read_len=500)
+    with pytest.raises(capi.TgsfError) as ei:
+        capi.Context(p, 0)
+    assert ei.value.code == abi.E_UNSUPPORTED

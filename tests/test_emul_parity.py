@@ -1,0 +1,51 @@
+"""Kernel-logic parity on a GPU-less box: tests/emul/libtgsf_emul.so is the SAME kernel source
+(tgsfilter_amd/csrc) compiled with -DTGSF_EMUL and executed lane by lane on the CPU.  It checks
+the kernels' decomposition (tiles, segments with warm-up, candidate lists, region merging) against
+the oracle before GPU time is spent; the -m gpu tests repeat these checks on the real HIP build."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import hostmodel, parity
+from tgsfilter_amd import abi, capi, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMUL_DIR = os.path.join(ROOT, "tests", "emul")
+EMUL = os.path.join(EMUL_DIR, "libtgsf_emul.so")
+
+
+@pytest.fixture(scope="module")
+def emul():
+    subprocess.run(["make", "-s", "-C", EMUL_DIR], check=True)
+    return EMUL
+
+
+def test_emul_edlib_vectors(emul, golden_dir):
+    parity.edlib_vectors(emul, golden_dir)
+
+
+@pytest.mark.parametrize("name", ["ont_zoo", "ont_trim", "ont_discard", "hifi_zoo", "long_adapter", "qc_only"])
+def test_emul_golden(emul, golden_dir, name):
+    parity.golden_case(emul, golden_dir, name)
+
+
+def test_emul_unaligned_offsets(emul):
+    """Tightly packed CSR (no padding, implicit lengths): every misalignment of tile starts."""
+    reads = synth.make_reads(5, 40, "ont", mean_len=2500, zoo=True, pmid=0.1)
+    p = parity.sized(abi.make_params("ont", adapters=[synth.ONT_RAPID, synth.ONT_RAPID_RC], min_q=9.0,
+                                     head_trim=7, tail_trim=3), reads)
+    ctx = capi.Context(p, 0, emul)
+    parity.compare_batch(ctx, p, reads, align=1, explicit_lengths=False)
+    ctx.close()
+
+
+def test_emul_long_reads_and_four_adapters(emul):
+    """Reads spanning several stats tiles and several middle segments; 4 adapters in one pass."""
+    reads = synth.make_reads(6, 12, "ont", mean_len=15000, zoo=True, pmid=0.3)
+    ads = [synth.ONT_RAPID, synth.ONT_RAPID_RC, synth.PACBIO_BLUNT, synth.PACBIO_BLUNT_RC]
+    p = parity.sized(abi.make_params("ont", adapters=ads, min_q=8.0), reads)
+    ctx = capi.Context(p, 0, emul)
+    parity.compare_batch(ctx, p, reads)
+    ctx.close()

@@ -1,0 +1,243 @@
+// tgsf_core.h -- lane-level primitives of the per-read filtering hot path (gfx950).
+//
+// Everything here is written once and compiled twice: by hipcc for the device
+// (the product, libtgsf.so) and by g++ with -DTGSF_EMUL for tests/emul, a
+// serial lane-by-lane emulation of the same kernels that lets the kernel logic
+// be checked against the oracle on a box without a GPU.  The emulation is test
+// infrastructure; the product has no CPU path.
+//
+// Reference behaviour restated here (file:line into /root/reference):
+//   Myers/Hyyro column step           include/edlib.cpp:409-444  (calculateBlock)
+//   infix (HW) scan, best + ends      include/edlib.cpp:547-704
+//   start locations (reverse SHW)     include/edlib.cpp:223-258
+//   path of the first location        include/edlib.cpp:945-1144 (traceback priority up,left,diag)
+//   per-base QC columns               src/TGSFilter.cpp:1462-1476
+#pragma once
+#include <stdint.h>
+
+#if defined(TGSF_EMUL)
+#define TGSF_HD inline
+#define TGSF_D inline
+#else
+#include <hip/hip_runtime.h>
+#define TGSF_HD __host__ __device__ __forceinline__
+#define TGSF_D __device__ __forceinline__
+#endif
+
+namespace tgsf {
+
+constexpr int kMaxAdapters = 16;
+constexpr int kMaxQ = 128;         // two 64-row words
+constexpr int kBin = 100;          // CalcAvgQuality bin width
+constexpr int kTileBins = 64;      // one bin per lane
+constexpr int kTileBases = kBin * kTileBins;   // 6400 bases per stats tile
+constexpr int kSegCols = 1024;     // columns of the read middle owned by one lane of the infix scan
+constexpr int kMaxRegions = 64;    // disjoint drop regions per read the region kernel can hold
+
+// ---------------------------------------------------------------------------
+// small intrinsics with host stand-ins (emulation only)
+// ---------------------------------------------------------------------------
+TGSF_HD uint32_t popc32(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_popcount(x);
+#else
+    return (uint32_t)__builtin_popcount(x);
+#endif
+}
+// sum_i a.byte[i] * b.byte[i] + c
+TGSF_HD uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_udot4(a, b, c, false);
+#else
+    uint32_t s = c;
+    for (int i = 0; i < 4; i++) s += ((a >> (8 * i)) & 0xFF) * ((b >> (8 * i)) & 0xFF);
+    return s;
+#endif
+}
+// bytes [sh, sh+4) of the 8-byte value hi:lo, sh in 0..3
+TGSF_HD uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbyte(hi, lo, sh);
+#else
+    uint64_t v = ((uint64_t)hi << 32) | lo;
+    return (uint32_t)(v >> (8 * sh));
+#endif
+}
+
+// ---------------------------------------------------------------------------
+// Bit-vector edit distance, standard layout: row r of the adapter is bit r%64 of
+// word r/64.  Rows >= Q of the last word are don't-care (information only moves
+// towards higher bits).  Used by every off-the-hot-loop search (end windows,
+// start locations) and by adapters of 65..128 bp in the middle scan.
+// ---------------------------------------------------------------------------
+template <int NW>
+struct Bv {
+    uint64_t p[NW], m[NW];
+    int score;           // value of row Q in the current column
+};
+
+template <int NW>
+TGSF_HD void bv_init(Bv<NW>& s, int Q) {
+#pragma unroll
+    for (int w = 0; w < NW; w++) { s.p[w] = ~0ull; s.m[w] = 0ull; }
+    s.score = Q;
+}
+
+// One text column.  eq[w]: rows equal to the text symbol.  hin_top: horizontal
+// delta entering row 1: 0 for an infix search (free start, edlib.cpp:584), +1 for
+// prefix/global searches.
+template <int NW>
+TGSF_HD void bv_step(Bv<NW>& s, const uint64_t* eq, int hin_top, int Q) {
+    int hin = hin_top;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        uint64_t Eq = eq[w], Pv = s.p[w], Mv = s.m[w];
+        uint64_t Xv = Eq | Mv;
+        if (hin < 0) Eq |= 1ull;
+        uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+        uint64_t Ph = Mv | ~(Xh | Pv);
+        uint64_t Mh = Pv & Xh;
+        const int bit = (w == NW - 1) ? ((Q - 1) & 63) : 63;
+        int hout = (int)((Ph >> bit) & 1ull) - (int)((Mh >> bit) & 1ull);
+        Ph <<= 1; Mh <<= 1;
+        if (hin < 0) Mh |= 1ull;
+        if (hin > 0) Ph |= 1ull;
+        s.p[w] = Mh | ~(Xv | Ph);
+        s.m[w] = Ph & Xv;
+        hin = hout;
+    }
+    s.score += hin;
+}
+
+// ---------------------------------------------------------------------------
+// Hot-loop variant for Q <= 64 in infix mode: the adapter sits in the TOP Q bits
+// of one 64-bit word; the low 64-Q bits are wildcard rows (Eq=1, Pv=Mv=0) which
+// stay at distance 0 for ever (D[0][j]=0 boundary), so the bottom row is bit 63
+// and its horizontal delta is the carry out of the <<1.  Same recurrences as
+// edlib.cpp:416-441 with hin = 0.
+// ---------------------------------------------------------------------------
+struct Hot {
+    uint64_t p, m;
+    int score;
+};
+TGSF_HD void hot_init(Hot& s, int Q) {
+    s.p = (Q >= 64) ? ~0ull : (~0ull << (64 - Q));
+    s.m = 0ull;
+    s.score = Q;
+}
+TGSF_HD void hot_step(Hot& s, uint64_t Eq) {
+    uint64_t Pv = s.p, Mv = s.m;
+    uint64_t Xv = Eq | Mv;
+    uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+    uint64_t Ph = Mv | ~(Xh | Pv);
+    uint64_t Mh = Pv & Xh;
+    s.score += (int)(Ph >> 63) - (int)(Mh >> 63);
+    Ph <<= 1; Mh <<= 1;
+    s.p = Mh | ~(Xv | Ph);
+    s.m = Ph & Xv;
+}
+
+// ---------------------------------------------------------------------------
+// Infix scan of a short window (read ends; single alignments for the pre-pass).
+// ---------------------------------------------------------------------------
+struct WinScan {
+    int best;        // min over columns of D[Q][j] if <= kk, else -1
+    int first_end;   // first / last column (0-based) attaining it
+    int last_end;
+    int n;           // number of such columns
+};
+
+template <int NW>
+TGSF_HD WinScan win_scan(const uint64_t* peq /*[256][NW]*/, int Q, const uint8_t* t, int T, int kk) {
+    Bv<NW> s;
+    bv_init(s, Q);
+    WinScan r;
+    r.best = -1; r.first_end = r.last_end = -1; r.n = 0;
+    int cur = kk + 1;
+    for (int j = 0; j < T; j++) {
+        bv_step<NW>(s, peq + (size_t)t[j] * NW, 0, Q);
+        if (s.score < cur) { cur = s.score; r.first_end = j; r.n = 0; }
+        if (s.score == cur && cur <= kk) { r.last_end = j; r.n++; }
+    }
+    if (cur <= kk) r.best = cur;
+    return r;
+}
+
+// startLocations[i]: longest suffix t[s..end] whose global distance to the adapter
+// equals `best` (edlib.cpp:246-255, "taking last location").  peq_rev is the Peq
+// table of the reversed adapter.
+template <int NW>
+TGSF_HD int win_start(const uint64_t* peq_rev, int Q, const uint8_t* t, int end, int best) {
+    Bv<NW> s;
+    bv_init(s, Q);
+    int maxl = end + 1;
+    if (maxl > Q + best) maxl = Q + best;
+    int best_l = 1;
+    for (int l = 1; l <= maxl; l++) {
+        bv_step<NW>(s, peq_rev + (size_t)t[end - (l - 1)] * NW, 1, Q);
+        if (s.score == best) best_l = l;
+    }
+    return end - best_l + 1;
+}
+
+// alignmentLength of the path edlib reports for adapter q vs t[0..T): number of
+// columns of the global alignment chosen by tracing back from the bottom-right
+// cell with priority up > left > diagonal (edlib.cpp:1023/1057/1088).  Each cell
+// has exactly one predecessor under that rule, so the length of the canonical
+// path to every cell can be carried FORWARD with the distances; one column of
+// (distance, length) pairs is the whole working set.  col(i) is lane-private
+// storage for row i (uint32: distance | length << 16).
+template <class Col>
+TGSF_HD int path_len(const uint8_t* q, int Q, const uint8_t* t, int T, Col col) {
+    for (int i = 0; i <= Q; i++) col(i) = (uint32_t)i | ((uint32_t)i << 16);
+    for (int j = 1; j <= T; j++) {
+        uint32_t d = col(0);
+        int diagN = (int)(d & 0xFFFF), diagL = (int)(d >> 16);
+        col(0) = (uint32_t)j | ((uint32_t)j << 16);
+        int upN = j, upL = j;
+        uint8_t tc = t[j - 1];
+        for (int i = 1; i <= Q; i++) {
+            uint32_t lf = col(i);
+            int leftN = (int)(lf & 0xFFFF), leftL = (int)(lf >> 16);
+            int v = diagN + (q[i - 1] != tc);
+            if (upN + 1 < v) v = upN + 1;
+            if (leftN + 1 < v) v = leftN + 1;
+            int l = (upN + 1 == v) ? upL + 1 : (leftN + 1 == v) ? leftL + 1 : diagL + 1;
+            diagN = leftN; diagL = leftL;
+            col(i) = (uint32_t)v | ((uint32_t)l << 16);
+            upN = v; upL = l;
+        }
+    }
+    return (int)(col(Q) >> 16);
+}
+
+// ---------------------------------------------------------------------------
+// QC columns for 4 bases at a time (SWAR).  s: 4 sequence bytes, q: 4 quality
+// bytes (already masked to the valid ones; invalid bytes are 0 in both).
+// cnt[c] += #bases of class c; qs[c] += 128 * sum of their quality bytes
+// (c: A,T,G,C -- src/TGSFilter.cpp:1462-1474, case-insensitive); qs[4] += sum
+// of all 4 quality bytes.  Quality bytes must be < 128.
+// ---------------------------------------------------------------------------
+TGSF_HD void qc_accum4(uint32_t s, uint32_t q, uint32_t* cnt /*[4]*/, uint32_t* qs /*[5]*/) {
+    const uint32_t x = s & 0xDFDFDFDFu;          // fold lower case onto upper case
+    const uint32_t x7 = x & 0x7F7F7F7Fu;
+    const uint32_t K[4] = {0x41414141u, 0x54545454u, 0x47474747u, 0x43434343u};   // A T G C
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        uint32_t t = x7 ^ K[c];
+        uint32_t nz = (t + 0x7F7F7F7Fu) | x;     // bit 7 of each byte: byte differs from K[c]
+        uint32_t m = ~nz & 0x80808080u;          // 0x80 where the base is of class c
+        cnt[c] += popc32(m);
+        qs[c] = udot4(q, m, qs[c]);
+    }
+    qs[4] = udot4(q, 0x01010101u, qs[4]);
+}
+
+// mean-quality gate: src/TGSFilter.cpp:1478 (double(sumQ)/len), :1947 (compare
+// against float thresholds promoted to double).  sum is the uint64 accumulator.
+TGSF_HD double mean_q(uint64_t sum, uint32_t len) { return (double)sum / (double)len; }
+TGSF_HD bool q_fail(double mq, float min_q, float max_q) {
+    return (mq < (double)min_q) || (mq > (double)max_q);
+}
+
+}  // namespace tgsf

@@ -1,0 +1,97 @@
+// tgsf_dev.h -- device-side data layout shared by the kernels and the host API.
+#pragma once
+#include <stdint.h>
+#include "tgsf_core.h"
+
+namespace tgsf {
+
+// Resolved parameters + adapter tables, passed to kernels by value (kernarg).
+struct DevParams {
+    int min_len, max_len;
+    float min_q, max_q;
+    int bc_len, head_trim, tail_trim, end_len, end_match_len, mid_match_len, extra_len;
+    float end_sim, mid_sim;
+    int discard, filter, only_qc, qtype;
+    int n_adapters;
+    int max_nw;                       // 1 if every adapter is <= 64 bp, else 2
+    int Q[kMaxAdapters];
+    int k_mid[kMaxAdapters];          // min(Q, Q - MidMatchLen + 1)   src/TGSFilter.cpp:1233, edlib.cpp:565
+    int k_end[kMaxAdapters];          // min(Q, Q - EndMatchLen + 1)   :1271
+    int w5[kMaxAdapters];             // EndLen + int(Q / EndSim)      :1267 (before clamping to L)
+    int min_Q;                        // shortest adapter
+    uint32_t n_bins;                  // rows of the 100-bp tables
+    const uint8_t* adapter;           // [kMaxAdapters][kMaxQ] bytes
+    const uint64_t* peq_fwd;          // [kMaxAdapters][256][2]  standard layout
+    const uint64_t* peq_rev;          // [kMaxAdapters][256][2]  reversed adapter
+    const uint64_t* peq_top;          // [kMaxAdapters][256]     top-aligned single word (Q <= 64)
+};
+
+// Candidate column of the middle scan / resolved drop region (same 16-byte slot).
+struct MidCand {
+    int32_t pos;      // scan: end column in window coordinates;  resolved: region start (read coords)
+    int32_t aux;      // scan: score | adapter << 8;              resolved: region end
+    int32_t next;     // next slot of the same read, -1 = end of list
+    int32_t state;    // 0 = candidate, 1 = resolved region, 2 = rejected
+};
+
+// Everything a batch needs on the device.  Arrays are sized for max_batch_reads /
+// max_batch_bases at context creation.
+struct DevBatch {
+    const uint8_t* seq;
+    const uint8_t* qual;
+    const uint64_t* off;       // [n] (or [n+1] when len_in == nullptr)
+    const uint32_t* len_in;    // optional explicit lengths
+    uint32_t n;
+    uint64_t n_bytes;
+
+    uint32_t* len;             // [n] resolved lengths
+    uint64_t* sumq;            // [n] raw sumQ
+    uint32_t* flags;           // [n] TGSF_RF_*
+    int32_t*  clip5;           // [n*A] 5' hit: end of drop region (0 = no hit)
+    int32_t*  clip3;           // [n*A] 3' hit: start of drop region (-1 = no hit)
+    int32_t*  mid_head;        // [n] head of the candidate list, -1
+    MidCand*  pool;            // candidate / region pool
+    uint32_t  pool_cap;
+    uint32_t* pool_n;          // number of slots used
+    uint32_t* seg_cnt;         // [n+1] middle segments per read, scanned in place to bases
+    uint32_t* nfr;             // [n+1] fragments per read, scanned in place to frag_begin
+    uint32_t* trimmed;         // [n]
+
+    // stats work lists (raw: items are reads; clean: items are fragments)
+    uint32_t* tile_hist;       // [max_tiles+2]
+    uint32_t* tile_cnt;        // [max_tiles+2]  cnt[t] = #items with more than t tiles
+    uint32_t* tile_base;       // [max_tiles+2]  exclusive prefix of cnt
+    uint32_t* tile_fill;       // [max_tiles+2]
+    uint32_t* perm;            // items sorted by tile count, descending
+    uint32_t  max_tiles;
+
+    // fragments
+    uint64_t* frag_off;        // [fcap] absolute byte offset of the fragment
+    uint32_t* frag_len;        // [fcap]
+    uint64_t* frag_sum;        // [fcap]
+    uint32_t* frag_read;       // [fcap]
+    int32_t*  frag_start;      // [fcap]
+    uint32_t* frag_flags;      // [fcap]
+    uint32_t  fcap;
+
+    uint64_t* ctr;             // the flat tally vector (include/tgsf.h layout)
+    uint32_t* status;          // [4] device-side error words: [0] code, [1] detail
+};
+
+// include/tgsf.h layout of the tally vector, callable from device code
+TGSF_HD size_t ctr_end_table(int t, int bc_len) { return (size_t)533 + (size_t)t * (size_t)bc_len * 5u; }
+TGSF_HD size_t ctr_bin_table(int b, int bc_len, uint32_t n_bins) {
+    return (size_t)533 + 8u * (size_t)bc_len * 5u + (size_t)b * (size_t)n_bins * 5u;
+}
+
+enum DevStatus : uint32_t {
+    DS_OK = 0,
+    DS_BAD_LEN = 1,        // read length 0 or > max_read_len
+    DS_BAD_QUAL = 2,       // quality byte >= 128
+    DS_POOL_FULL = 3,      // candidate pool overflow
+    DS_TOO_MANY_REGIONS = 4,
+    DS_FRAG_CAP = 5,
+    DS_BAD_MEANQ = 6,      // mean quality outside [0,256): the reference indexes out of bounds
+};
+
+}  // namespace tgsf

@@ -1,0 +1,1020 @@
+// tgsf_kernels.h -- the HIP kernels of the per-read filtering hot path (gfx950, wave64).
+//
+// Pipeline per batch (all on one stream, no host round trip):
+//   k_prepare        lengths, per-read state, stats-tile histogram
+//   k_tile_scan/k_tile_scatter   counting sort of items by tile count (work list of k_stats)
+//   k_stats<raw>     CalcAvgQuality on every read: 100-bp bin tables + sumQ          [HBM-bound]
+//   k_gate_reads     mean-Q gate, rawDiffQual, middle-scan segment counts
+//   k_end_tables<raw>   Get_5p/3p_base_qual
+//   k_end_windows    GetEditDistance 5'/3' windows (edlib HW/PATH semantics)
+//   k_scan_u32       exclusive scan (segment bases)
+//   k_mid_scan*      GetEditDistance middle: Myers infix scan, 1 lane = 1024 columns  [VALU-bound, dominant]
+//   k_mid_resolve    start locations + path of the first location + similarity gates
+//   k_regions<count|emit>   adapterMap: merge drop regions, keep regions, DropInfo
+//   k_frag_prepare + sort + k_stats<clean> + k_gate_frags + k_end_tables<clean>
+//   k_finalize       tgsf_read_result / tgsf_fragment records
+//
+// Reference lines are cited at each kernel.  The file compiles for the device
+// (hipcc) and, with -DTGSF_EMUL, as plain C++ for tests/emul (serial emulation).
+#pragma once
+#include "tgsf_dev.h"
+#include "../../include/tgsf.h"
+static_assert(TGSF_CTR_END_TABLES == 533, "tally layout");
+
+// ---------------------------------------------------------------------------
+// execution-model shims
+// ---------------------------------------------------------------------------
+#if defined(TGSF_EMUL)
+namespace tgsf_emul {
+struct Dim3 { unsigned x, y, z; };
+extern thread_local Dim3 threadIdx, blockIdx, blockDim, gridDim;
+}
+using tgsf_emul::threadIdx; using tgsf_emul::blockIdx; using tgsf_emul::blockDim; using tgsf_emul::gridDim;
+#define TGSF_KERNEL static void
+#define TGSF_SHARED static
+#define TGSF_BLOCK_SYNC() ((void)0)
+#define TGSF_WAVE_SYNC() ((void)0)
+// cooperative loops: every emulated thread performs all iterations (idempotent fills)
+#define TGSF_COOP_BEGIN 0u
+#define TGSF_COOP_STRIDE 1u
+#define TGSF_WCOOP_BEGIN(lane) 0u
+#define TGSF_WCOOP_STRIDE 1u
+template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <class T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <class T> static inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
+template <class T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
+template <class T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+#else
+#define TGSF_KERNEL __global__ void
+#define TGSF_SHARED __shared__
+#define TGSF_BLOCK_SYNC() __syncthreads()
+#define TGSF_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#define TGSF_COOP_BEGIN threadIdx.x
+#define TGSF_COOP_STRIDE blockDim.x
+#define TGSF_WCOOP_BEGIN(lane) (lane)
+#define TGSF_WCOOP_STRIDE 64u
+#endif
+
+namespace tgsf {
+
+typedef unsigned long long ull;
+
+// ---- wave-level reductions (emulation: one lane at a time, every lane is a leader) ----
+TGSF_D uint64_t wave_sum(uint64_t v) {
+#if defined(TGSF_EMUL)
+    return v;
+#else
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+#endif
+}
+TGSF_D uint32_t wave_max(uint32_t v) {
+#if defined(TGSF_EMUL)
+    return v;
+#else
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { uint32_t u = __shfl_xor(v, o, 64); v = u > v ? u : v; }
+    return v;
+#endif
+}
+TGSF_D uint32_t wave_or(uint32_t v) {
+#if defined(TGSF_EMUL)
+    return v;
+#else
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
+    return v;
+#endif
+}
+TGSF_D bool wave_leader() {
+#if defined(TGSF_EMUL)
+    return true;
+#else
+    return (threadIdx.x & 63u) == 0u;
+#endif
+}
+// add a per-lane contribution to one global u64 word: one atomic per wave.
+// Must be reached by all lanes of the wave (pass 0 for lanes with nothing to add).
+TGSF_D void wave_add_u64(uint64_t* dst, uint64_t v) {
+    uint64_t t = wave_sum(v);
+    if (wave_leader() && t) atomicAdd((ull*)dst, (ull)t);
+}
+TGSF_D void wave_max_u64(uint64_t* dst, uint32_t v) {
+    uint32_t t = wave_max(v);
+    if (wave_leader() && t) atomicMax((ull*)dst, (ull)t);
+}
+TGSF_D void set_status(const DevBatch& B, uint32_t code, uint32_t detail) {
+    if (atomicMax(&B.status[0], code) < code) B.status[1] = detail;
+}
+
+// fragments actually stored (the count may exceed the capacity: DS_FRAG_CAP)
+TGSF_D uint32_t stored_frags(const DevBatch& B) { uint32_t nf = B.nfr[B.n]; return nf < B.fcap ? nf : B.fcap; }
+
+TGSF_D uint32_t gtid() { return blockIdx.x * blockDim.x + threadIdx.x; }
+TGSF_D uint32_t gsize() { return gridDim.x * blockDim.x; }
+
+// largest i in [0,n) with a[i] <= v, for a non-decreasing a[0..n] with a[0] <= v < a[n]
+TGSF_D uint32_t find_owner(const uint32_t* a, uint32_t n, uint32_t v) {
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (a[mid] <= v) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// ---------------------------------------------------------------------------
+// k_prepare: per-read state.  Items of the raw stats pass are the reads.
+// ---------------------------------------------------------------------------
+TGSF_KERNEL k_prepare(DevParams P, DevBatch B, uint32_t max_read_len)
+{
+    const int A = P.n_adapters;
+    uint32_t rows = 0, erows = 0;
+    for (uint32_t r = gtid(); r < B.n; r += gsize()) {
+        uint32_t L = B.len_in ? B.len_in[r] : (uint32_t)(B.off[r + 1] - B.off[r]);
+        B.len[r] = L;
+        B.sumq[r] = 0;
+        B.flags[r] = 0;
+        B.mid_head[r] = -1;
+        B.trimmed[r] = 0;
+        B.seg_cnt[r] = 0;
+        B.nfr[r] = 0;
+        for (int a = 0; a < A; a++) { B.clip5[(size_t)r * A + a] = 0; B.clip3[(size_t)r * A + a] = -1; }
+        if (L == 0 || L > max_read_len) { set_status(B, DS_BAD_LEN, r); B.len[r] = 0; continue; }
+        atomicAdd(&B.tile_hist[(L + kTileBases - 1) / kTileBases], 1u);
+        uint32_t rw = L / kBin + 1;                                     // src/TGSFilter.cpp:1445
+        rows = rw > rows ? rw : rows;
+        uint32_t er = (uint32_t)P.bc_len < L ? (uint32_t)P.bc_len : L;  // :1490-1493
+        erows = er > erows ? er : erows;
+    }
+    wave_max_u64(&B.ctr[TGSF_CTR_ROWS + 0], rows);
+    wave_max_u64(&B.ctr[TGSF_CTR_ROWS + 2], erows);
+}
+
+// Items of the clean stats pass are the fragments (keep regions).
+TGSF_KERNEL k_frag_prepare(DevParams P, DevBatch B)
+{
+    const uint32_t nf = stored_frags(B);
+    uint32_t rows = 0;
+    for (uint32_t f = gtid(); f < nf; f += gsize()) {
+        uint32_t L = B.frag_len[f];
+        atomicAdd(&B.tile_hist[(L + kTileBases - 1) / kTileBases], 1u);
+        uint32_t rw = L / kBin + 1;
+        rows = rw > rows ? rw : rows;
+    }
+    wave_max_u64(&B.ctr[TGSF_CTR_ROWS + 1], rows);
+}
+
+// ---------------------------------------------------------------------------
+// Counting sort of items by tile count, descending, so that "items with more
+// than t tiles" is the prefix perm[0..cnt[t]).  One thread: <= 400 buckets.
+//   hist[v]  #items with exactly v tiles
+//   cnt[t]   #items with more than t tiles  (= first slot of value t in perm)
+//   base[t]  #work items (item,tile) with tile index < t;  base[max_tiles+1] = total
+// ---------------------------------------------------------------------------
+TGSF_KERNEL k_tile_scan(DevBatch B)
+{
+    if (gtid() != 0) return;
+    const uint32_t mt = B.max_tiles;
+    uint32_t run = 0;
+    for (int v = (int)mt; v >= 0; v--) {        // cnt[v] = sum_{u>v} hist[u]
+        B.tile_cnt[v] = run;
+        run += B.tile_hist[v];
+    }
+    B.tile_cnt[mt + 1] = 0;
+    uint32_t acc = 0;
+    for (uint32_t t = 0; t <= mt; t++) { B.tile_base[t] = acc; acc += B.tile_cnt[t]; }
+    B.tile_base[mt + 1] = acc;
+}
+
+template <bool CLEAN>
+TGSF_KERNEL k_tile_scatter(DevBatch B)
+{
+    const uint32_t n = CLEAN ? stored_frags(B) : B.n;
+    for (uint32_t i = gtid(); i < n; i += gsize()) {
+        uint32_t L = CLEAN ? B.frag_len[i] : B.len[i];
+        if (L == 0) continue;
+        uint32_t v = (L + kTileBases - 1) / kTileBases;
+        uint32_t slot = B.tile_cnt[v] + atomicAdd(&B.tile_fill[v], 1u);
+        B.perm[slot] = i;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_stats: CalcAvgQuality (src/TGSFilter.cpp:1436-1479) for every item.
+//
+// Work item = (item, tile of 64 bins x 100 bases).  Items are visited tile-index
+// major, so consecutive work items of a wave hit the SAME 64 table rows: each
+// lane owns one bin and keeps its 10 tallies in registers across items, and the
+// tables see one atomic per lane per tile-index change instead of one per tile.
+// The tile is staged through LDS with coalesced 16-byte loads (both streams),
+// then lane b reads its 100 bytes at stride 25 dwords (odd => bank-conflict free).
+// Algorithmic traffic: 2 bytes per base, each read once.
+// ---------------------------------------------------------------------------
+constexpr int kStatsWaves = 4;
+constexpr int kTileChunks = kTileBases / 16 + 2;   // +1 misalignment, +1 zero guard
+
+template <bool CLEAN>
+TGSF_KERNEL k_stats(DevParams P, DevBatch B)
+{
+    TGSF_SHARED uint4 lds[kStatsWaves][2][kTileChunks];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t gw = blockIdx.x * kStatsWaves + wave, nw = gridDim.x * kStatsWaves;
+    const uint32_t mt = B.max_tiles;
+    const uint32_t W = B.tile_base[mt + 1];
+    const uint32_t per = (W + nw - 1) / nw;
+    uint32_t w0 = gw * per, w1 = w0 + per;
+    if (w1 > W) w1 = W;
+    if (w0 >= w1) return;
+
+    uint64_t* tab_q = B.ctr + ctr_bin_table(CLEAN ? TGSF_B_CLEAN_QUAL : TGSF_B_RAW_QUAL, P.bc_len, P.n_bins);
+    uint64_t* tab_c = B.ctr + ctr_bin_table(CLEAN ? TGSF_B_CLEAN_CNT : TGSF_B_RAW_CNT, P.bc_len, P.n_bins);
+    const uint64_t* it_off = CLEAN ? B.frag_off : B.off;
+    const uint32_t* it_len = CLEAN ? B.frag_len : B.len;
+    uint64_t* it_sum = CLEAN ? B.frag_sum : B.sumq;
+    const int64_t qt = P.qtype;
+
+    uint32_t t = find_owner(B.tile_base, mt + 1, w0);
+    uint32_t j = w0 - B.tile_base[t];
+    uint32_t cnt[4] = {0, 0, 0, 0}, qs[5] = {0, 0, 0, 0, 0}, call = 0, since = 0, qor = 0;
+    uint32_t* S = reinterpret_cast<uint32_t*>(&lds[wave][0][0]);
+    uint32_t* Qd = reinterpret_cast<uint32_t*>(&lds[wave][1][0]);
+
+    auto flush = [&](uint32_t tt) {
+        if (call) {
+            size_t row = ((size_t)tt * kTileBins + lane) * 5;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                if (cnt[c]) {
+                    atomicAdd((ull*)&tab_c[row + c], (ull)cnt[c]);
+                    atomicAdd((ull*)&tab_q[row + c], (ull)((int64_t)(qs[c] >> 7) - qt * (int64_t)cnt[c]));
+                }
+            }
+            atomicAdd((ull*)&tab_c[row + 4], (ull)call);
+            atomicAdd((ull*)&tab_q[row + 4], (ull)((int64_t)qs[4] - qt * (int64_t)call));
+        }
+        cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0;
+        qs[0] = qs[1] = qs[2] = qs[3] = qs[4] = 0;
+        call = 0; since = 0;
+    };
+
+    for (uint32_t w = w0; w < w1; ++w, ++j) {
+        while (j >= B.tile_cnt[t]) { flush(t); ++t; j = 0; }
+        if (since >= 2048) flush(t);          // qs[c] carries 128*sum: stay below 2^32
+        ++since;
+        const uint32_t item = B.perm[j];
+        const uint32_t L = it_len[item];
+        const uint64_t a0 = it_off[item] + (uint64_t)t * kTileBases;
+        uint32_t nb = L - t * kTileBases;
+        if (nb > (uint32_t)kTileBases) nb = kTileBases;
+        const uint32_t sh = (uint32_t)(a0 & 15u);
+        const uint64_t ab = a0 - sh;
+        const uint32_t endb = sh + nb;                         // first invalid byte, chunk coords
+        const uint32_t nch = (endb + 15u) / 16u + 1u;          // + one all-zero guard chunk
+        TGSF_WAVE_SYNC();                                      // previous tile fully consumed
+        for (uint32_t c = TGSF_WCOOP_BEGIN(lane); c < nch; c += TGSF_WCOOP_STRIDE) {
+            uint4 vs = {0, 0, 0, 0}, vq = {0, 0, 0, 0};
+            const uint32_t cb = c * 16u;
+            if (cb < endb) {
+                vs = *reinterpret_cast<const uint4*>(B.seq + ab + cb);
+                vq = *reinterpret_cast<const uint4*>(B.qual + ab + cb);
+                if (cb + 16u > endb) {                         // zero the bytes past the item
+                    uint32_t keep = endb - cb;                 // 1..15
+                    uint32_t* ps = reinterpret_cast<uint32_t*>(&vs);
+                    uint32_t* pq = reinterpret_cast<uint32_t*>(&vq);
+#pragma unroll
+                    for (int d = 0; d < 4; d++) {
+                        int kb = (int)keep - 4 * d;
+                        uint32_t m = kb >= 4 ? 0xFFFFFFFFu : (kb <= 0 ? 0u : ((1u << (8 * kb)) - 1u));
+                        ps[d] &= m; pq[d] &= m;
+                    }
+                }
+            }
+            lds[wave][0][c] = vs;
+            lds[wave][1][c] = vq;
+        }
+        TGSF_WAVE_SYNC();
+        const int nvalid = (int)nb - (int)lane * kBin;         // bases of this lane's bin in the tile
+        uint32_t q4_before = qs[4];
+        int nv = 0;
+        if (nvalid > 0) {
+            nv = nvalid > kBin ? kBin : nvalid;
+            const uint32_t bo = sh + lane * kBin;
+            const uint32_t d0 = bo >> 2, bs = bo & 3u;
+            const int ndw = (nv + 3) >> 2;
+            if (bs == 0) {
+                for (int i = 0; i < ndw; i++) {
+                    uint32_t q = Qd[d0 + i];
+                    qor |= q;
+                    qc_accum4(S[d0 + i], q, cnt, qs);
+                }
+            } else {
+                uint32_t slo = S[d0], qlo = Qd[d0];
+                for (int i = 0; i < ndw; i++) {
+                    uint32_t shi = S[d0 + i + 1], qhi = Qd[d0 + i + 1];
+                    uint32_t q = alignbyte(qhi, qlo, bs);
+                    // bytes past the item are zero in LDS; bytes before it never enter (bs skips them)
+                    qor |= q;
+                    qc_accum4(alignbyte(shi, slo, bs), q, cnt, qs);
+                    slo = shi; qlo = qhi;
+                }
+            }
+            call += (uint32_t)nv;
+        }
+        // sumQ of the item: sum over the tile of (qual - qType), two's complement in u64 (:1457-1458)
+        int64_t part = (int64_t)(qs[4] - q4_before) - qt * (int64_t)nv;
+        uint64_t tot = wave_sum((uint64_t)part);
+        if (wave_leader()) atomicAdd((ull*)&it_sum[item], (ull)tot);
+    }
+    flush(t);
+    if (wave_or(qor & 0x80808080u) && wave_leader()) set_status(B, DS_BAD_QUAL, 0);
+}
+
+// ---------------------------------------------------------------------------
+// k_gate_reads: the raw mean-quality gate (src/TGSFilter.cpp:1943, :1946-1953) and
+// the number of middle-scan segments of each surviving read.
+// ---------------------------------------------------------------------------
+TGSF_KERNEL k_gate_reads(DevParams P, DevBatch B)
+{
+    uint64_t lowq_reads = 0, lowq_bases = 0;
+    for (uint32_t r0 = blockIdx.x * blockDim.x; r0 < B.n; r0 += gsize()) {   // whole waves stay convergent
+        const uint32_t r = r0 + threadIdx.x;
+        if (r < B.n && B.len[r]) {
+            const uint32_t L = B.len[r];
+            const double mq = mean_q(B.sumq[r], L);
+            if (!(mq >= 0.0 && mq < 256.0)) { set_status(B, DS_BAD_MEANQ, r); }
+            else {
+                atomicAdd((ull*)&B.ctr[TGSF_CTR_RAW_DIFFQ + (int)mq], (ull)L);
+                uint32_t segs = 0;
+                if (P.filter) {
+                    if (q_fail(mq, P.min_q, P.max_q)) {
+                        B.flags[r] = TGSF_RF_LOWQ;
+                        lowq_reads++; lowq_bases += L;
+                    } else {
+                        int ML = (int)L - 2 * P.end_len;              // :1236 tsmLen
+                        if (ML >= P.min_Q) segs = ((uint32_t)ML + kSegCols - 1) / kSegCols;
+                    }
+                }
+                B.seg_cnt[r] = segs;
+            }
+        }
+    }
+    wave_add_u64(&B.ctr[TGSF_CTR_DROPINFO + 0], lowq_reads);
+    wave_add_u64(&B.ctr[TGSF_CTR_DROPINFO + 1], lowq_bases);
+}
+
+// ---------------------------------------------------------------------------
+// k_scan_u32: exclusive prefix sum in place over a[0..n], a[n] receives the total.
+// One block; each thread owns 16 consecutive elements per sweep.
+// ---------------------------------------------------------------------------
+constexpr int kScanPer = 16;
+TGSF_KERNEL k_scan_u32(uint32_t* a, const uint32_t* n_ptr, uint32_t n_fixed)
+{
+    TGSF_SHARED uint32_t part[1024];
+    TGSF_SHARED uint32_t carry_s;
+    const uint32_t n = n_ptr ? *n_ptr : n_fixed;
+    const uint32_t T = blockDim.x;
+    if (threadIdx.x == 0) carry_s = 0;
+    TGSF_BLOCK_SYNC();
+    for (uint32_t base = 0; base < n; base += T * kScanPer) {
+        uint32_t v[kScanPer];
+        uint32_t s = 0;
+        const uint32_t i0 = base + threadIdx.x * kScanPer;
+#pragma unroll
+        for (int k = 0; k < kScanPer; k++) { v[k] = (i0 + k < n) ? a[i0 + k] : 0u; s += v[k]; }
+        part[threadIdx.x] = s;
+        TGSF_BLOCK_SYNC();
+        // Hillis-Steele over the per-thread sums
+        for (uint32_t o = 1; o < T; o <<= 1) {
+            uint32_t add = (threadIdx.x >= o) ? part[threadIdx.x - o] : 0u;
+            TGSF_BLOCK_SYNC();
+            part[threadIdx.x] += add;
+            TGSF_BLOCK_SYNC();
+        }
+        uint32_t excl = carry_s + part[threadIdx.x] - s;
+        const uint32_t total = part[T - 1];
+        TGSF_BLOCK_SYNC();
+#pragma unroll
+        for (int k = 0; k < kScanPer; k++) { if (i0 + k < n) a[i0 + k] = excl; excl += v[k]; }
+        if (threadIdx.x == 0) carry_s += total;
+        TGSF_BLOCK_SYNC();
+    }
+    if (threadIdx.x == 0) a[n] = carry_s;
+}
+
+// ---------------------------------------------------------------------------
+// k_end_tables: Get_5p_base_qual / Get_3p_base_qual (src/TGSFilter.cpp:1481-1575).
+// Lane = position; a wave walks a strided set of items and keeps its tallies in
+// lane-private LDS rows, so the [bc_len][5] tables see one atomic per lane-slot
+// per wave, not per read.
+// ---------------------------------------------------------------------------
+constexpr int kEndWaves = 1;       // 40 KB of lane-private LDS tallies per wave
+constexpr int kMaxBcLen = 512;
+TGSF_D int base_col(uint32_t b) {
+    b &= 0xDFu;
+    return b == 'A' ? 0 : b == 'T' ? 1 : b == 'G' ? 2 : b == 'C' ? 3 : 4;
+}
+template <bool CLEAN>
+TGSF_KERNEL k_end_tables(DevParams P, DevBatch B)
+{
+    // [wave][end][pos][10]: 5 counts, 5 quality sums
+    TGSF_SHARED uint32_t acc[kEndWaves][2][kMaxBcLen / 64][10][64];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t gw = blockIdx.x * kEndWaves + wave, nw = gridDim.x * kEndWaves;
+    const uint32_t n = CLEAN ? stored_frags(B) : B.n;
+    const uint32_t bc = (uint32_t)P.bc_len;
+    const uint32_t slots = (bc + 63u) / 64u;
+    for (uint32_t e = 0; e < 2; e++)
+        for (uint32_t s = 0; s < slots; s++)
+            for (int k = 0; k < 10; k++) acc[wave][e][s][k][lane] = 0;
+    for (uint32_t i = gw; i < n; i += nw) {
+        uint32_t L; uint64_t off;
+        if (CLEAN) { if (!(B.frag_flags[i] & TGSF_FF_PASS)) continue; L = B.frag_len[i]; off = B.frag_off[i]; }
+        else { L = B.len[i]; off = B.off[i]; if (!L) continue; }
+        const uint32_t m = bc < L ? bc : L;
+        for (uint32_t s = 0; s < slots; s++) {
+            const uint32_t p = s * 64u + lane;
+            if (p < m) {
+                uint32_t b5 = B.seq[off + p], q5 = B.qual[off + p];
+                uint32_t b3 = B.seq[off + L - 1 - p], q3 = B.qual[off + L - 1 - p];   // :1554-1557
+                int c = base_col(b5);
+                if (c < 4) { acc[wave][0][s][c][lane]++; acc[wave][0][s][5 + c][lane] += q5; }
+                acc[wave][0][s][4][lane]++; acc[wave][0][s][9][lane] += q5;
+                c = base_col(b3);
+                if (c < 4) { acc[wave][1][s][c][lane]++; acc[wave][1][s][5 + c][lane] += q3; }
+                acc[wave][1][s][4][lane]++; acc[wave][1][s][9][lane] += q3;
+            }
+        }
+    }
+    const int64_t qt = P.qtype;
+    for (uint32_t e = 0; e < 2; e++) {
+        uint64_t* tq = B.ctr + ctr_end_table((CLEAN ? 4 : 0) + (e ? 2 : 0), P.bc_len);
+        uint64_t* tc = B.ctr + ctr_end_table((CLEAN ? 4 : 0) + (e ? 2 : 0) + 1, P.bc_len);
+        for (uint32_t s = 0; s < slots; s++) {
+            const uint32_t p = s * 64u + lane;
+            if (p >= bc) continue;
+            for (int c = 0; c < 5; c++) {
+                uint32_t k = acc[wave][e][s][c][lane];
+                if (k) {
+                    atomicAdd((ull*)&tc[(size_t)p * 5 + c], (ull)k);
+                    atomicAdd((ull*)&tq[(size_t)p * 5 + c],
+                              (ull)((int64_t)acc[wave][e][s][5 + c][lane] - qt * (int64_t)k));
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Alignment of one adapter against one short window with edlib's HW/PATH
+// semantics as TGSFilter consumes them.  colbuf is the
+// lane-private column for path_len.
+// ---------------------------------------------------------------------------
+struct LaneCol {
+    uint32_t* base;     // &colbuf[0][lane]
+    TGSF_HD uint32_t& operator()(int i) const { return base[(size_t)i * 64]; }
+};
+
+struct WinAln {
+    int best;          // -1: nothing within k
+    int n;
+    int first_end, last_end;
+    int start0;
+    int mlen;          // alignmentLength - editDistance of the first location
+};
+
+template <int NW>
+TGSF_D WinAln align_window(const DevParams& P, int a, const uint8_t* t, int T, int kk, LaneCol col)
+{
+    const int Q = P.Q[a];
+    const uint64_t* pf = P.peq_fwd + (size_t)a * 512;
+    const uint64_t* pr = P.peq_rev + (size_t)a * 512;
+    WinAln r;
+    r.best = -1; r.n = 0; r.first_end = r.last_end = -1; r.start0 = 0; r.mlen = 0;
+    // peq tables are [256][2]; with NW == 1 only word 0 of each symbol is used
+    Bv<NW> s;
+    bv_init(s, Q);
+    int cur = kk + 1;
+    for (int j = 0; j < T; j++) {
+        bv_step<NW>(s, pf + (size_t)t[j] * 2, 0, Q);
+        if (s.score < cur) { cur = s.score; r.first_end = j; r.n = 0; }
+        if (s.score == cur && cur <= kk) { r.last_end = j; r.n++; }
+    }
+    if (cur > kk) return r;
+    r.best = cur;
+    // start of the first location (edlib.cpp:246-255)
+    {
+        Bv<NW> b;
+        bv_init(b, Q);
+        int maxl = r.first_end + 1;
+        if (maxl > Q + cur) maxl = Q + cur;
+        int best_l = 1;
+        for (int l = 1; l <= maxl; l++) {
+            bv_step<NW>(b, pr + (size_t)t[r.first_end - (l - 1)] * 2, 1, Q);
+            if (b.score == cur) best_l = l;
+        }
+        r.start0 = r.first_end - best_l + 1;
+    }
+    const uint8_t* q = P.adapter + (size_t)a * kMaxQ;
+    int plen = path_len(q, Q, t + r.start0, r.first_end - r.start0 + 1, col);
+    r.mlen = plen - cur;
+    return r;
+}
+
+template <int NW>
+TGSF_D int start_of(const DevParams& P, int a, const uint8_t* t, int end, int best)
+{
+    const int Q = P.Q[a];
+    const uint64_t* pr = P.peq_rev + (size_t)a * 512;
+    Bv<NW> b;
+    bv_init(b, Q);
+    int maxl = end + 1;
+    if (maxl > Q + best) maxl = Q + best;
+    int best_l = 1;
+    for (int l = 1; l <= maxl; l++) {
+        bv_step<NW>(b, pr + (size_t)t[end - (l - 1)] * 2, 1, Q);
+        if (b.score == best) best_l = l;
+    }
+    return end - best_l + 1;
+}
+
+// smallest start over all locations of a window whose optimum is `best`
+template <int NW>
+TGSF_D int min_start_all(const DevParams& P, int a, const uint8_t* t, int T, int best)
+{
+    const int Q = P.Q[a];
+    const uint64_t* pf = P.peq_fwd + (size_t)a * 512;
+    Bv<NW> s;
+    bv_init(s, Q);
+    int mn = T;
+    for (int j = 0; j < T; j++) {
+        bv_step<NW>(s, pf + (size_t)t[j] * 2, 0, Q);
+        if (s.score == best) {
+            int st = start_of<NW>(P, a, t, j, best);
+            mn = st < mn ? st : mn;
+        }
+    }
+    return mn;
+}
+
+// ---------------------------------------------------------------------------
+// k_end_windows: the 5' and 3' searches of GetEditDistance (src/TGSFilter.cpp:1266-1321).
+// One lane per (read, adapter, end).  Every reported location pushes [0, end+1)
+// (5') or [L-W5+start, L) (3'); only their union matters downstream, i.e. the
+// last end / the smallest start.
+// ---------------------------------------------------------------------------
+TGSF_KERNEL k_end_windows(DevParams P, DevBatch B)
+{
+    TGSF_SHARED uint32_t colbuf[kMaxQ + 1][64];
+    const int A = P.n_adapters;
+    const uint32_t idx = gtid();
+    const uint32_t total = B.n * (uint32_t)A * 2u;
+    if (idx >= total || !P.filter) return;
+    const uint32_t r = idx / (2u * A);
+    const int a = (int)((idx >> 1) % (uint32_t)A);
+    const int e = (int)(idx & 1u);
+    const uint32_t Lr = B.len[r];
+    if (!Lr || (B.flags[r] & TGSF_RF_LOWQ)) return;
+    const int L = (int)Lr, Q = P.Q[a];
+    int W5 = P.w5[a];
+    if (W5 > L) W5 = L;                                   // :1268-1270
+    if (W5 < 5) return;                                   // :1274
+    if (P.k_end[a] < 0) return;                           // match length > adapter: can never pass :1283
+    const uint8_t* t = B.seq + B.off[r] + (e ? (L - W5) : 0);
+    LaneCol col{&colbuf[0][threadIdx.x & 63u]};
+    WinAln w = (Q <= 64) ? align_window<1>(P, a, t, W5, P.k_end[a], col)
+                         : align_window<2>(P, a, t, W5, P.k_end[a], col);
+    if (w.best < 0) return;
+    if (w.mlen < P.end_match_len) return;                 // :1283
+    if (!((float)w.mlen / (float)Q >= P.end_sim)) return; // :1287-1288
+    if (e == 0) {
+        B.clip5[(size_t)r * A + a] = w.last_end + 1;      // union of [0, end_i+1)
+        atomicOr(&B.flags[r], (uint32_t)TGSF_RF_AD5P);
+    } else {
+        int mn = w.start0;
+        if (w.n > 1) mn = (Q <= 64) ? min_start_all<1>(P, a, t, W5, w.best) : min_start_all<2>(P, a, t, W5, w.best);
+        B.clip3[(size_t)r * A + a] = L - W5 + mn;         // union of [L-W5+start_i, L)
+        atomicOr(&B.flags[r], (uint32_t)TGSF_RF_AD3P);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_mid_scan: the middle search of GetEditDistance (src/TGSFilter.cpp:1233-1264),
+// i.e. edlib's infix scan (include/edlib.cpp:586-677) over read[E, L-E).
+//
+// One lane owns kSegCols columns of one read's middle window and scans them
+// sequentially for up to AT adapters at once (independent dependency chains ->
+// ILP).  Columns before the lane's own range are a warm-up: an alignment with
+// distance <= k spans at most Q+k columns, so after Q+k warm-up columns every
+// bottom-row value <= k is exact.  Reported locations are the columns at the
+// global minimum; each lane appends the columns whose value ties or beats the
+// best it has seen so far (a superset of the global-minimum columns it owns) to
+// the read's candidate list; k_mid_resolve picks the minimum.  Candidates are
+// rare (about 1e-6 per column on random sequence at default thresholds), so the
+// value is only examined every 4 columns: it moves by at most 1 per column.
+//
+// Pure integer/bit work: ~30 VALU ops per column per adapter against one byte
+// of sequence.  Peq rows live in LDS ([symbol][adapter]), sequence bytes are
+// fetched 16 at a time per lane.
+// ---------------------------------------------------------------------------
+TGSF_D void push_candidate(const DevBatch& B, uint32_t r, int pos, int score, int a)
+{
+    uint32_t idx = atomicAdd(B.pool_n, 1u);
+    if (idx >= B.pool_cap) { set_status(B, DS_POOL_FULL, r); return; }
+    MidCand c;
+    c.pos = pos;
+    c.aux = score | (a << 8);
+    c.state = 0;
+    c.next = atomicExch(&B.mid_head[r], (int32_t)idx);
+    B.pool[idx] = c;
+}
+
+template <int AT>
+TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
+{
+    TGSF_SHARED uint64_t eqt[256][AT];
+    for (uint32_t i = TGSF_COOP_BEGIN; i < 256u * AT; i += TGSF_COOP_STRIDE) {
+        uint32_t sym = i / AT, j = i % AT;
+        eqt[sym][j] = (int)j < na ? P.peq_top[(size_t)(a0 + j) * 256 + sym] : 0ull;
+    }
+    TGSF_BLOCK_SYNC();
+    const uint32_t g = gtid();
+    const uint32_t total = B.seg_cnt[B.n];
+    if (g >= total) return;
+    const uint32_t r = find_owner(B.seg_cnt, B.n, g);
+    const uint32_t seg = g - B.seg_cnt[r];
+    const int L = (int)B.len[r];
+    const int E = P.end_len;
+    const int ML = L - 2 * E;
+    const int c0 = (int)seg * kSegCols;
+    int c1 = c0 + kSegCols;
+    if (c1 > ML) c1 = ML;
+    const uint8_t* mid = B.seq + B.off[r] + E;
+
+    Hot st[AT];
+    int lim[AT];              // record columns whose value is <= lim (then lim := value)
+    int wu = 0;
+#pragma unroll
+    for (int j = 0; j < AT; j++) {
+        const int a = a0 + j;
+        const bool on = j < na && ML >= P.Q[a] && P.k_mid[a] >= 0;    // :1237 tsmLen >= qLen
+        hot_init(st[j], j < na ? P.Q[a] : 1);
+        lim[j] = on ? P.k_mid[a] : -1000;
+        if (on) { int w = P.Q[a] + P.k_mid[a]; wu = w > wu ? w : wu; }
+    }
+    int c = c0 - wu;
+    if (c < 0) c = 0;
+    else if (c > 0) { int al = c - (int)((uintptr_t)(mid + c) & 15u); c = al > 0 ? al : c; }  // longer warm-up, aligned
+
+    auto step_all = [&](uint32_t byte) {
+#pragma unroll
+        for (int j = 0; j < AT; j++) hot_step(st[j], eqt[byte][j]);
+    };
+    auto check_col = [&](int col) {
+#pragma unroll
+        for (int j = 0; j < AT; j++)
+            if (st[j].score <= lim[j]) { lim[j] = st[j].score; push_candidate(B, r, col, st[j].score, a0 + j); }
+    };
+
+    // warm-up: [c, c0)
+    while (c < c0 && ((uintptr_t)(mid + c) & 15u)) { step_all(mid[c]); c++; }
+    while (c + 16 <= c0) {
+        uint4 v = *reinterpret_cast<const uint4*>(mid + c);
+        const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            step_all(d[k] & 0xFFu); step_all((d[k] >> 8) & 0xFFu);
+            step_all((d[k] >> 16) & 0xFFu); step_all(d[k] >> 24);
+        }
+        c += 16;
+    }
+    while (c < c0) { step_all(mid[c]); c++; }
+
+    // owned columns: [c0, c1)
+    while (c < c1 && ((uintptr_t)(mid + c) & 15u)) { step_all(mid[c]); check_col(c); c++; }
+    while (c + 16 <= c1) {
+        uint4 v = *reinterpret_cast<const uint4*>(mid + c);
+        const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int s1[AT], s2[AT], s3[AT];
+            step_all(d[k] & 0xFFu);
+#pragma unroll
+            for (int j = 0; j < AT; j++) s1[j] = st[j].score;
+            step_all((d[k] >> 8) & 0xFFu);
+#pragma unroll
+            for (int j = 0; j < AT; j++) s2[j] = st[j].score;
+            step_all((d[k] >> 16) & 0xFFu);
+#pragma unroll
+            for (int j = 0; j < AT; j++) s3[j] = st[j].score;
+            step_all(d[k] >> 24);
+            bool any = false;
+#pragma unroll
+            for (int j = 0; j < AT; j++) any |= (st[j].score <= lim[j] + 3);
+            if (any) {
+#pragma unroll
+                for (int j = 0; j < AT; j++) {
+                    const int cc = c + 4 * k;
+                    if (s1[j] <= lim[j]) { lim[j] = s1[j]; push_candidate(B, r, cc, s1[j], a0 + j); }
+                    if (s2[j] <= lim[j]) { lim[j] = s2[j]; push_candidate(B, r, cc + 1, s2[j], a0 + j); }
+                    if (s3[j] <= lim[j]) { lim[j] = s3[j]; push_candidate(B, r, cc + 2, s3[j], a0 + j); }
+                    if (st[j].score <= lim[j]) { lim[j] = st[j].score; push_candidate(B, r, cc + 3, st[j].score, a0 + j); }
+                }
+            }
+        }
+        c += 16;
+    }
+    while (c < c1) { step_all(mid[c]); check_col(c); c++; }
+}
+
+// adapters of 65..128 bp: two-word standard layout, one adapter per pass
+TGSF_KERNEL k_mid_scan2(DevParams P, DevBatch B, int a)
+{
+    TGSF_SHARED uint64_t eqt[256][2];
+    for (uint32_t i = TGSF_COOP_BEGIN; i < 512u; i += TGSF_COOP_STRIDE)
+        eqt[i >> 1][i & 1] = P.peq_fwd[(size_t)a * 512 + i];
+    TGSF_BLOCK_SYNC();
+    const uint32_t g = gtid();
+    const uint32_t total = B.seg_cnt[B.n];
+    if (g >= total) return;
+    const uint32_t r = find_owner(B.seg_cnt, B.n, g);
+    const uint32_t seg = g - B.seg_cnt[r];
+    const int L = (int)B.len[r];
+    const int E = P.end_len;
+    const int ML = L - 2 * E;
+    const int Q = P.Q[a];
+    if (ML < Q || P.k_mid[a] < 0) return;
+    const int c0 = (int)seg * kSegCols;
+    int c1 = c0 + kSegCols;
+    if (c1 > ML) c1 = ML;
+    const uint8_t* mid = B.seq + B.off[r] + E;
+    Bv<2> s;
+    bv_init(s, Q);
+    int lim = P.k_mid[a];
+    int c = c0 - (Q + P.k_mid[a]);
+    if (c < 0) c = 0;
+    for (; c < c0; c++) bv_step<2>(s, eqt[mid[c]], 0, Q);
+    for (; c < c1; c++) {
+        bv_step<2>(s, eqt[mid[c]], 0, Q);
+        if (s.score <= lim) { lim = s.score; push_candidate(B, r, c, s.score, a); }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_mid_resolve: one lane per (read, adapter).  Among the read's candidates for
+// this adapter the minimum value is edlib's editDistance and the columns that
+// attain it are its endLocations (include/edlib.cpp:660-672).  The path of the
+// FIRST location gives mlen, which gates ALL locations (src/TGSFilter.cpp:1245-1260).
+// ---------------------------------------------------------------------------
+TGSF_KERNEL k_mid_resolve(DevParams P, DevBatch B)
+{
+    TGSF_SHARED uint32_t colbuf[kMaxQ + 1][64];
+    const int A = P.n_adapters;
+    const uint32_t idx = gtid();
+    if (idx >= B.n * (uint32_t)A || !P.filter) return;
+    const uint32_t r = idx / (uint32_t)A;
+    const int a = (int)(idx % (uint32_t)A);
+    const int32_t head = B.mid_head[r];
+    if (head < 0) return;
+    int best = 1 << 30, e0 = 1 << 30;
+    for (int32_t i = head; i >= 0; i = B.pool[i].next) {
+        const int aux = B.pool[i].aux;
+        if ((aux >> 8) != a) continue;
+        const int sc = aux & 0xFF, pos = B.pool[i].pos;
+        if (sc < best || (sc == best && pos < e0)) { best = sc; e0 = pos; }
+    }
+    if (best == (1 << 30)) return;
+    const int L = (int)B.len[r], E = P.end_len, Q = P.Q[a];
+    const uint8_t* win = B.seq + B.off[r] + E;
+    LaneCol col{&colbuf[0][threadIdx.x & 63u]};
+    const int s0 = (Q <= 64) ? start_of<1>(P, a, win, e0, best) : start_of<2>(P, a, win, e0, best);
+    const int plen = path_len(P.adapter + (size_t)a * kMaxQ, Q, win + s0, e0 - s0 + 1, col);
+    const int mlen = plen - best;
+    if (mlen < P.mid_match_len) return;                                  // :1246
+    if (!((float)mlen / (float)Q >= P.mid_sim)) return;                  // :1250-1252
+    atomicOr(&B.flags[r], (uint32_t)TGSF_RF_ADMID);
+    for (int32_t i = head; i >= 0; i = B.pool[i].next) {
+        const int aux = B.pool[i].aux;
+        if ((aux >> 8) != a || (aux & 0xFF) != best) continue;
+        const int pos = B.pool[i].pos;
+        const int st = (pos == e0) ? s0 : ((Q <= 64) ? start_of<1>(P, a, win, pos, best) : start_of<2>(P, a, win, pos, best));
+        int ts = st + E - P.extra_len, te = pos + E + 1 + P.extra_len;   // :1248-1256
+        if (ts < 0) ts = 0;
+        if (te > L) te = L;
+        // the slot is only ever touched by its own adapter's lane
+        B.pool[i].pos = ts;
+        B.pool[i].state = (te << 2) | 1;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_regions: adapterMap (src/TGSFilter.cpp:1325-1434) for one read per lane.
+// The reference sorts the drop regions by (start,end) and merges neighbours with
+// prev.end >= next.start, i.e. it forms the union of the intervals with touching
+// intervals joined; that union is built here by insertion into a small sorted
+// list.  EMIT=false counts the keep regions, EMIT=true (after the scan of the
+// counts) writes them and adds the DropInfo tallies.
+// ---------------------------------------------------------------------------
+struct RegList {
+    int s[kMaxRegions], e[kMaxRegions];
+    int n;
+    bool overflow;
+};
+TGSF_D void reg_insert(RegList& R, int s, int e)
+{
+    // find the run of stored regions that overlap or touch [s,e)
+    int i = 0;
+    while (i < R.n && R.e[i] < s) i++;
+    int j = i;
+    while (j < R.n && R.s[j] <= e) {
+        if (R.s[j] < s) s = R.s[j];
+        if (R.e[j] > e) e = R.e[j];
+        j++;
+    }
+    if (j == i) {                       // disjoint: open a slot at i
+        if (R.n == kMaxRegions) { R.overflow = true; return; }
+        for (int k = R.n; k > i; k--) { R.s[k] = R.s[k - 1]; R.e[k] = R.e[k - 1]; }
+        R.n++;
+    } else if (j - i > 1) {             // swallowed several: close the gap
+        int d = j - i - 1;
+        for (int k = i + 1; k + d < R.n; k++) { R.s[k] = R.s[k + d]; R.e[k] = R.e[k + d]; }
+        R.n -= d;
+    }
+    R.s[i] = s; R.e[i] = e;
+}
+
+template <bool EMIT>
+TGSF_KERNEL k_regions(DevParams P, DevBatch B)
+{
+    const int A = P.n_adapters;
+    uint64_t d[TGSF_N_DROPINFO];
+#pragma unroll
+    for (int k = 0; k < TGSF_N_DROPINFO; k++) d[k] = 0;
+    for (uint32_t r0 = blockIdx.x * blockDim.x; r0 < B.n; r0 += gsize()) {
+        const uint32_t r = r0 + threadIdx.x;
+        if (r >= B.n) continue;
+        const int L = (int)B.len[r];
+        uint32_t nf = 0;
+        const uint32_t fb = EMIT ? B.nfr[r] : 0u;
+        auto keep = [&](int s, int l) {
+            if (EMIT) {
+                const uint32_t f = fb + nf;
+                if (f < B.fcap) {
+                    B.frag_off[f] = B.off[r] + (uint64_t)s;
+                    B.frag_len[f] = (uint32_t)l;
+                    B.frag_sum[f] = 0;
+                    B.frag_read[f] = r;
+                    B.frag_start[f] = s;
+                    B.frag_flags[f] = 0;
+                } else set_status(B, DS_FRAG_CAP, r);
+            }
+            nf++;
+        };
+        const uint32_t fl = L ? B.flags[r] : (uint32_t)TGSF_RF_LOWQ;
+        if (L == 0 || (fl & TGSF_RF_LOWQ)) {
+            /* dropped before adapterMap (:1946-1953) */
+        } else if (!P.filter) {
+            if (!P.only_qc) keep(0, L);                                   // :1963-1965, :1976
+        } else {
+            RegList R;
+            R.n = 0; R.overflow = false;
+            if (P.head_trim > 0) reg_insert(R, 0, P.head_trim >= L ? L : P.head_trim);          // :1334-1340
+            if (P.tail_trim > 0) {                                                               // :1342-1348
+                if (P.tail_trim >= L) reg_insert(R, 0, L); else reg_insert(R, L - P.tail_trim, L);
+            }
+            int n5 = 0, n3 = 0, nm = 0;
+            for (int a = 0; a < A; a++) {
+                int c5 = B.clip5[(size_t)r * A + a], c3 = B.clip3[(size_t)r * A + a];
+                if (c5 > 0) { n5++; reg_insert(R, 0, c5); }
+                if (c3 >= 0) { n3++; reg_insert(R, c3, L); }
+            }
+            for (int32_t i = B.mid_head[r]; i >= 0; i = B.pool[i].next) {
+                const int stt = B.pool[i].state;
+                if ((stt & 3) == 1) { nm++; reg_insert(R, B.pool[i].pos, stt >> 2); }
+            }
+            if (R.overflow) set_status(B, DS_TOO_MANY_REGIONS, r);
+            if (EMIT) {                                                                          // :1354-1370
+                const int cls = (nm > 0 && n5 > 0 && n3 > 0) ? 2 : (nm > 0 && n5 > 0) ? 3 : (nm > 0 && n3 > 0) ? 4
+                        : (n5 > 0 && n3 > 0) ? 5 : (nm > 0) ? 6 : (n5 > 0) ? 7 : (n3 > 0) ? 8 : 9;
+#pragma unroll
+                for (int k = 2; k <= 9; k++) d[k] += (uint64_t)(cls == k);
+            }
+            if (nm > 0 && P.discard) {                                                           // :1372-1373
+                if (EMIT) { d[10] += (uint64_t)L; B.trimmed[r] = (uint32_t)L; atomicOr(&B.flags[r], (uint32_t)TGSF_RF_DISCARDED); }
+            } else if (R.n >= 1) {                                                               // :1396-1424
+                int cur = 0;
+                uint32_t tr = 0;
+                for (int i = 0; i < R.n; i++) {
+                    const int dl = R.e[i] - R.s[i];
+                    d[10] += (uint64_t)dl; tr += (uint32_t)dl;
+                    if (dl == L) d[11]++;
+                    if (R.s[i] > cur) {
+                        const int kl = R.s[i] - cur;
+                        if (kl >= P.min_len && kl <= P.max_len) keep(cur, kl);
+                        else { d[11]++; d[12] += (uint64_t)kl; }
+                    }
+                    cur = R.e[i];
+                }
+                if (cur < L) {
+                    const int kl = L - cur;
+                    if (kl >= P.min_len && kl <= P.max_len) keep(cur, kl);
+                    else { d[11]++; d[12] += (uint64_t)kl; }
+                }
+                if (EMIT) B.trimmed[r] = tr;
+            } else {                                                                             // :1425-1432
+                if (L >= P.min_len && L <= P.max_len) keep(0, L);
+                else { d[11]++; d[12] += (uint64_t)L; }
+            }
+        }
+        if (P.only_qc) nf = 0;
+        if (!EMIT) B.nfr[r] = nf;
+    }
+    if (EMIT) {
+        for (int k = 2; k <= 12; k++) wave_add_u64(&B.ctr[TGSF_CTR_DROPINFO + k], d[k]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_gate_frags: the post-split quality gate (src/TGSFilter.cpp:1995-2002).
+// ---------------------------------------------------------------------------
+TGSF_KERNEL k_gate_frags(DevParams P, DevBatch B)
+{
+    const uint32_t nf = stored_frags(B);
+    uint64_t lq_n = 0, lq_b = 0;
+    uint32_t erows = 0;
+    for (uint32_t f0 = blockIdx.x * blockDim.x; f0 < nf; f0 += gsize()) {
+        const uint32_t f = f0 + threadIdx.x;
+        if (f >= nf || f >= B.fcap) continue;
+        const uint32_t L = B.frag_len[f];
+        const double cm = mean_q(B.frag_sum[f], L);
+        if (P.filter && q_fail(cm, P.min_q, P.max_q)) { lq_n++; lq_b += L; continue; }
+        if (!(cm >= 0.0 && cm < 256.0)) { set_status(B, DS_BAD_MEANQ, B.frag_read[f]); continue; }
+        atomicAdd((ull*)&B.ctr[TGSF_CTR_CLEAN_DIFFQ + (int)cm], (ull)L);
+        B.frag_flags[f] = TGSF_FF_PASS;
+        uint32_t er = (uint32_t)P.bc_len < L ? (uint32_t)P.bc_len : L;
+        erows = er > erows ? er : erows;
+    }
+    wave_add_u64(&B.ctr[TGSF_CTR_DROPINFO + 13], lq_n);
+    wave_add_u64(&B.ctr[TGSF_CTR_DROPINFO + 14], lq_b);
+    wave_max_u64(&B.ctr[TGSF_CTR_ROWS + 3], erows);
+}
+
+// ---------------------------------------------------------------------------
+// k_finalize: the records handed back across the C ABI.
+// ---------------------------------------------------------------------------
+TGSF_KERNEL k_finalize(DevBatch B, tgsf_read_result* out_reads, tgsf_fragment* out_frags,
+                       uint32_t out_fcap, uint32_t* out_nfrags)
+{
+    const uint32_t nf = B.nfr[B.n];
+    if (gtid() == 0) {
+        if (out_nfrags) *out_nfrags = nf;
+        if (nf > out_fcap) set_status(B, DS_FRAG_CAP, nf);
+    }
+    for (uint32_t r = gtid(); r < B.n; r += gsize()) {
+        tgsf_read_result o;
+        o.sum_q = B.sumq[r];
+        o.flags = B.flags[r];
+        o.n_frags = B.nfr[r + 1] - B.nfr[r];
+        o.frag_begin = B.nfr[r];
+        o.trimmed = B.trimmed[r];
+        o.clip5 = 0; o.clip3 = 0;
+        out_reads[r] = o;
+    }
+    for (uint32_t f = gtid(); f < nf && f < out_fcap; f += gsize()) {
+        tgsf_fragment o;
+        o.sum_q = B.frag_sum[f];
+        o.read = B.frag_read[f];
+        o.start = B.frag_start[f];
+        o.len = (int32_t)B.frag_len[f];
+        o.flags = B.frag_flags[f];
+        out_frags[f] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_align_windows: stand-alone edlib-compatible alignments (tgsf_align_windows).
+// ---------------------------------------------------------------------------
+TGSF_KERNEL k_align_windows(DevParams P, const uint8_t* seq, const uint64_t* win_off, const uint32_t* win_len,
+                            const uint8_t* adapter_id, const int32_t* kk, uint32_t n, int32_t* res, int32_t* ends)
+{
+    TGSF_SHARED uint32_t colbuf[kMaxQ + 1][64];
+    const uint32_t i = gtid();
+    if (i >= n) return;
+    const int a = adapter_id[i];
+    const int Q = P.Q[a];
+    int k = kk[i];
+    if (k > Q) k = Q;                                    // edlib.cpp:565-567
+    LaneCol col{&colbuf[0][threadIdx.x & 63u]};
+    const uint8_t* t = seq + win_off[i];
+    WinAln w = (Q <= 64) ? align_window<1>(P, a, t, (int)win_len[i], k, col)
+                         : align_window<2>(P, a, t, (int)win_len[i], k, col);
+    res[i * 4 + 0] = w.best;
+    res[i * 4 + 1] = w.best < 0 ? 0 : w.n;
+    res[i * 4 + 2] = w.best < 0 ? 0 : w.mlen + w.best;
+    res[i * 4 + 3] = w.best < 0 ? -1 : w.start0;
+    ends[i * 2 + 0] = w.best < 0 ? -1 : w.first_end;
+    ends[i * 2 + 1] = w.best < 0 ? -1 : w.last_end;
+}
+
+}  // namespace tgsf

@@ -1,0 +1,651 @@
+// tgsf_lib.hip -- libtgsf.so: the C ABI of include/tgsf.h on top of the HIP kernels.
+//
+// Built two ways from this one source:
+//   hipcc --offload-arch=gfx950            -> tgsfilter_amd/libtgsf.so   (the product)
+//   g++ -x c++ -DTGSF_EMUL                 -> tests/emul/libtgsf_emul.so (serial lane-by-lane
+//                                             emulation of the same kernels; test infrastructure)
+// The product has no CPU path: tgsf_create fails when no HIP device is usable.
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#if defined(TGSF_EMUL)
+struct uint4 { uint32_t x, y, z, w; };
+#include "tgsf_kernels.h"
+namespace tgsf_emul { thread_local Dim3 threadIdx, blockIdx, blockDim, gridDim; }
+typedef void* rt_stream;
+typedef int rt_error;
+#else
+#include <hip/hip_runtime.h>
+#include "tgsf_kernels.h"
+typedef hipStream_t rt_stream;
+#endif
+
+using namespace tgsf;
+
+// ---------------------------------------------------------------------------
+// runtime layer
+// ---------------------------------------------------------------------------
+static thread_local std::string g_create_error;
+
+struct tgsf_ctx {
+    tgsf_params params;
+    std::vector<std::string> adapters;
+    DevParams P;
+    DevBatch B;               // internal buffers (template for each batch)
+    int device;
+    rt_stream stream;
+    rt_stream last_stream;     // stream of the most recent submit
+    bool own_stream;
+    std::string error;
+    // capacities
+    uint64_t cap_bases;
+    uint32_t cap_reads, max_read_len, n_bins;
+    uint64_t ctr_words;
+    // internal input / output staging for tgsf_submit
+    uint8_t *d_seq, *d_qual;
+    uint64_t* d_off;
+    uint32_t* d_lenin;
+    tgsf_read_result* d_out_reads;
+    tgsf_fragment* d_out_frags;
+    uint32_t* d_out_nfrags;
+    std::vector<void*> allocs;
+    // profiling
+    bool profile;
+    float stage_ms[TGSF_N_STAGES];
+    uint32_t prof_batches;
+#if !defined(TGSF_EMUL)
+    // ring of event sets: one set per profiled batch, harvested at tgsf_wait (no per-batch sync)
+    static constexpr int kProfRing = 64;
+    hipEvent_t ev[kProfRing][TGSF_N_STAGES + 1];
+    int prof_pending;
+#endif
+    uint32_t h_status[4];
+};
+
+static int fail(tgsf_ctx* c, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->error = buf; else g_create_error = buf;
+    return code;
+}
+
+#if defined(TGSF_EMUL)
+static int rt_malloc(void** p, size_t n) { *p = calloc(n ? n : 1, 1); return *p ? 0 : 1; }
+static void rt_free(void* p) { free(p); }
+static int rt_memset(void* p, int v, size_t n, rt_stream) { memset(p, v, n); return 0; }
+static int rt_h2d(void* d, const void* s, size_t n, rt_stream) { memcpy(d, s, n); return 0; }
+static int rt_d2h(void* d, const void* s, size_t n, rt_stream) { memcpy(d, s, n); return 0; }
+static int rt_sync(rt_stream) { return 0; }
+static const char* rt_errstr(int) { return "emulation error"; }
+template <class F>
+static void emul_launch(unsigned grid, unsigned block, F f)
+{
+    using namespace tgsf_emul;
+    gridDim = {grid, 1, 1}; blockDim = {block, 1, 1};
+    for (unsigned b = 0; b < grid; b++)
+        for (unsigned t = 0; t < block; t++) { blockIdx = {b, 0, 0}; threadIdx = {t, 0, 0}; f(); }
+}
+#define TGSF_LAUNCH(kernel, grid, block, stream, ...) emul_launch((grid), (block), [&] { kernel(__VA_ARGS__); })
+// block-cooperative kernels are written for any block size; emulate them with one thread
+#define TGSF_LAUNCH_COOP(kernel, grid, block, stream, ...) emul_launch((grid), 1u, [&] { kernel(__VA_ARGS__); })
+// the emulation trades speed for fidelity: small grids
+static unsigned grid_cap(unsigned g) { return g > 8u ? 8u : g; }
+#else
+static int rt_malloc(void** p, size_t n) { return (int)hipMalloc(p, n ? n : 1); }
+static void rt_free(void* p) { (void)hipFree(p); }
+static int rt_memset(void* p, int v, size_t n, rt_stream s) { return (int)hipMemsetAsync(p, v, n, s); }
+static int rt_h2d(void* d, const void* s, size_t n, rt_stream st) { return (int)hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, st); }
+static int rt_d2h(void* d, const void* s, size_t n, rt_stream st) { return (int)hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, st); }
+static int rt_sync(rt_stream s) { return (int)hipStreamSynchronize(s); }
+static const char* rt_errstr(int e) { return hipGetErrorString((hipError_t)e); }
+#define TGSF_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (stream), __VA_ARGS__)
+#define TGSF_LAUNCH_COOP TGSF_LAUNCH
+static unsigned grid_cap(unsigned g) { return g; }
+#endif
+
+template <class T>
+static int dev_alloc(tgsf_ctx* c, T** p, size_t count)
+{
+    void* v = nullptr;
+    int e = rt_malloc(&v, count * sizeof(T) + 64);
+    if (e) return fail(c, TGSF_E_HIP, "device allocation of %zu bytes failed: %s", count * sizeof(T), rt_errstr(e));
+    c->allocs.push_back(v);
+    *p = (T*)v;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// adapter tables
+// ---------------------------------------------------------------------------
+static int build_tables(tgsf_ctx* c)
+{
+    const tgsf_params& p = c->params;
+    DevParams& P = c->P;
+    const int A = p.n_adapters;
+    std::vector<uint8_t> ad((size_t)kMaxAdapters * kMaxQ, 0);
+    std::vector<uint64_t> fwd((size_t)kMaxAdapters * 512, 0), rev((size_t)kMaxAdapters * 512, 0),
+        top((size_t)kMaxAdapters * 256, 0);
+    P.max_nw = 1;
+    P.min_Q = 1 << 30;
+    for (int a = 0; a < A; a++) {
+        const std::string& s = c->adapters[a];
+        const int Q = (int)s.size();
+        P.Q[a] = Q;
+        if (Q > 64) P.max_nw = 2;
+        if (Q < P.min_Q) P.min_Q = Q;
+        int km = Q - p.mid_match_len + 1;                 // src/TGSFilter.cpp:1233
+        int ke = Q - p.end_match_len + 1;                 // :1271
+        P.k_mid[a] = km > Q ? Q : km;                     // include/edlib.cpp:565-567 (negative: see k_end_windows)
+        P.k_end[a] = ke > Q ? Q : ke;
+        P.w5[a] = p.end_len + (int)((float)Q / p.end_sim);   // :1267 int(qLen / endSim), float division
+        memcpy(&ad[(size_t)a * kMaxQ], s.data(), (size_t)Q);
+        for (int r = 0; r < Q; r++) {
+            uint8_t cf = (uint8_t)s[r], cr = (uint8_t)s[Q - 1 - r];
+            fwd[(size_t)a * 512 + (size_t)cf * 2 + (r >> 6)] |= 1ull << (r & 63);
+            rev[(size_t)a * 512 + (size_t)cr * 2 + (r >> 6)] |= 1ull << (r & 63);
+        }
+        if (Q <= 64) {
+            const int sh = 64 - Q;
+            const uint64_t pad = sh ? ((1ull << sh) - 1ull) : 0ull;    // wildcard rows below the adapter
+            for (int sym = 0; sym < 256; sym++)
+                top[(size_t)a * 256 + sym] = (fwd[(size_t)a * 512 + (size_t)sym * 2] << sh) | pad;
+        }
+    }
+    if (A == 0) P.min_Q = 1 << 30;
+    uint8_t* d_ad; uint64_t *d_f, *d_r, *d_t;
+    int e;
+    if ((e = dev_alloc(c, &d_ad, ad.size()))) return e;
+    if ((e = dev_alloc(c, &d_f, fwd.size()))) return e;
+    if ((e = dev_alloc(c, &d_r, rev.size()))) return e;
+    if ((e = dev_alloc(c, &d_t, top.size()))) return e;
+    rt_h2d(d_ad, ad.data(), ad.size(), c->stream);
+    rt_h2d(d_f, fwd.data(), fwd.size() * 8, c->stream);
+    rt_h2d(d_r, rev.data(), rev.size() * 8, c->stream);
+    rt_h2d(d_t, top.data(), top.size() * 8, c->stream);
+    rt_sync(c->stream);
+    P.adapter = d_ad; P.peq_fwd = d_f; P.peq_rev = d_r; P.peq_top = d_t;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// create / destroy
+// ---------------------------------------------------------------------------
+extern "C" int tgsf_abi_version(void) { return TGSF_ABI_VERSION; }
+
+extern "C" const char* tgsf_last_error(tgsf_ctx* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+extern "C" void tgsf_destroy(tgsf_ctx* c)
+{
+    if (!c) return;
+#if !defined(TGSF_EMUL)
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (int k = 0; k < tgsf_ctx::kProfRing; k++)
+        for (int i = 0; i <= TGSF_N_STAGES; i++) if (c->ev[k][i]) (void)hipEventDestroy(c->ev[k][i]);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+#endif
+    for (void* p : c->allocs) rt_free(p);
+    delete c;
+}
+
+extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
+{
+    if (!p || !out) return fail(nullptr, TGSF_E_INVALID, "null argument");
+    *out = nullptr;
+    if (p->struct_size != sizeof(tgsf_params))
+        return fail(nullptr, TGSF_E_INVALID, "tgsf_params.struct_size %u != %zu (ABI mismatch)", p->struct_size, sizeof(tgsf_params));
+    if (p->n_adapters < 0 || p->n_adapters > TGSF_MAX_ADAPTERS)
+        return fail(nullptr, TGSF_E_INVALID, "n_adapters %d outside [0,%d]", p->n_adapters, TGSF_MAX_ADAPTERS);
+    if (p->min_repeat > 0)
+        return fail(nullptr, TGSF_E_UNSUPPORTED, "-p/-k repeat filter (GetKmerCount) is not on this path yet");
+    if (p->qtype != 33 && p->qtype != 64) return fail(nullptr, TGSF_E_INVALID, "qtype must be 33 or 64");
+    if (p->bc_len < 0 || p->bc_len > kMaxBcLen) return fail(nullptr, TGSF_E_INVALID, "bc_len (-e) outside [0,%d]", kMaxBcLen);
+    if (p->filter && p->n_adapters > 0) {
+        if (!(p->end_sim > 0.f) || !(p->mid_sim > 0.f)) return fail(nullptr, TGSF_E_INVALID, "similarities must be > 0");
+        if (p->end_len < 0 || p->extra_len < 0) return fail(nullptr, TGSF_E_INVALID, "end_len / extra_len must be >= 0");
+        // k >= Q ("-m 1"/"-M 1") makes edlib report the location -1 (edlib.cpp:232-244); not reproduced
+        if (p->end_match_len < 2 || p->mid_match_len < 2)
+            return fail(nullptr, TGSF_E_UNSUPPORTED, "match lengths < 2 (edlib k >= adapter length) are outside the supported domain");
+    }
+    for (int a = 0; a < p->n_adapters; a++) {
+        if (!p->adapters[a] || p->adapter_len[a] < 1 || p->adapter_len[a] > TGSF_MAX_ADAPTER_LEN)
+            return fail(nullptr, TGSF_E_UNSUPPORTED, "adapter %d: length %d outside [1,%d]", a, p->adapter_len[a], TGSF_MAX_ADAPTER_LEN);
+    }
+    if (!p->max_batch_bases || !p->max_batch_reads || !p->max_read_len)
+        return fail(nullptr, TGSF_E_INVALID, "max_batch_bases / max_batch_reads / max_read_len must be set");
+    if (p->max_read_len > (1u << 28)) return fail(nullptr, TGSF_E_INVALID, "max_read_len above 2^28");
+
+    tgsf_ctx* c = new tgsf_ctx();
+    c->params = *p;
+    c->device = device;
+    c->profile = false;
+    c->prof_batches = 0;
+    memset(c->stage_ms, 0, sizeof c->stage_ms);
+    memset(c->h_status, 0, sizeof c->h_status);
+    for (int a = 0; a < p->n_adapters; a++) {
+        c->adapters.emplace_back(p->adapters[a], (size_t)p->adapter_len[a]);
+        c->params.adapters[a] = c->adapters.back().data();
+    }
+    for (int a = 0; a < p->n_adapters; a++) c->params.adapters[a] = c->adapters[a].data();
+#if !defined(TGSF_EMUL)
+    memset(c->ev, 0, sizeof c->ev);
+    int ndev = 0;
+    hipError_t he = hipGetDeviceCount(&ndev);
+    if (he != hipSuccess || ndev <= 0) {
+        delete c;
+        return fail(nullptr, TGSF_E_NO_DEVICE, "no HIP device available (%s); libtgsf has no CPU fallback", hipGetErrorString(he));
+    }
+    if (device < 0 || device >= ndev) { delete c; return fail(nullptr, TGSF_E_NO_DEVICE, "device %d out of range (%d devices)", device, ndev); }
+    if ((he = hipSetDevice(device)) != hipSuccess) { delete c; return fail(nullptr, TGSF_E_HIP, "hipSetDevice: %s", hipGetErrorString(he)); }
+    if ((he = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+        delete c; return fail(nullptr, TGSF_E_HIP, "hipStreamCreate: %s", hipGetErrorString(he));
+    }
+    c->own_stream = true;
+    c->prof_pending = 0;
+#else
+    c->stream = nullptr; c->own_stream = false;
+#endif
+    c->last_stream = c->stream;
+    DevParams& P = c->P;
+    memset(&P, 0, sizeof P);
+    P.min_len = p->min_len; P.max_len = p->max_len; P.min_q = p->min_q; P.max_q = p->max_q;
+    P.bc_len = p->bc_len; P.head_trim = p->head_trim; P.tail_trim = p->tail_trim; P.end_len = p->end_len;
+    P.end_match_len = p->end_match_len; P.mid_match_len = p->mid_match_len; P.extra_len = p->extra_len;
+    P.end_sim = p->end_sim; P.mid_sim = p->mid_sim; P.discard = p->discard; P.filter = p->filter;
+    P.only_qc = p->only_qc; P.qtype = p->qtype; P.n_adapters = p->n_adapters;
+    c->cap_bases = p->max_batch_bases;
+    c->cap_reads = p->max_batch_reads;
+    c->max_read_len = p->max_read_len;
+    c->n_bins = tgsf_n_bins(p->max_read_len);
+    P.n_bins = c->n_bins;
+    c->ctr_words = tgsf_ctr_len(p->bc_len, c->n_bins);
+
+    int e = build_tables(c);
+    DevBatch& B = c->B;
+    memset(&B, 0, sizeof B);
+    const size_t n = c->cap_reads;
+    const int A = p->n_adapters > 0 ? p->n_adapters : 1;
+    // every read start may be padded to 16 bytes by the caller
+    const uint64_t cap_bytes = c->cap_bases + 16ull * n + 64;
+    const int min_len = p->min_len > 0 ? p->min_len : 1;
+    uint64_t fcap64 = p->filter ? (c->cap_bases / (uint64_t)min_len + 16) : (uint64_t)n + 16;
+    if (fcap64 > c->cap_bases + 16) fcap64 = c->cap_bases + 16;
+    if (fcap64 < n + 16 && !p->filter) fcap64 = n + 16;
+    B.fcap = (uint32_t)std::min<uint64_t>(fcap64, 0x7FFFFFF0ull);
+    B.max_tiles = (c->max_read_len + kTileBases - 1) / kTileBases;
+    uint64_t pool = c->cap_bases / 64 + 65536;
+    B.pool_cap = (uint32_t)std::min<uint64_t>(pool, 1ull << 28);
+    const size_t nitems = std::max<size_t>(n, B.fcap);
+    if (!e) e = dev_alloc(c, &c->d_seq, cap_bytes);
+    if (!e) e = dev_alloc(c, &c->d_qual, cap_bytes);
+    if (!e) e = dev_alloc(c, &c->d_off, n + 1);
+    if (!e) e = dev_alloc(c, &c->d_lenin, n);
+    if (!e) e = dev_alloc(c, &B.len, n);
+    if (!e) e = dev_alloc(c, &B.sumq, n);
+    if (!e) e = dev_alloc(c, &B.flags, n);
+    if (!e) e = dev_alloc(c, &B.clip5, n * A);
+    if (!e) e = dev_alloc(c, &B.clip3, n * A);
+    if (!e) e = dev_alloc(c, &B.mid_head, n);
+    if (!e) e = dev_alloc(c, &B.pool, (size_t)B.pool_cap);
+    if (!e) e = dev_alloc(c, &B.pool_n, 4);
+    if (!e) e = dev_alloc(c, &B.seg_cnt, n + 1);
+    if (!e) e = dev_alloc(c, &B.nfr, n + 1);
+    if (!e) e = dev_alloc(c, &B.trimmed, n);
+    if (!e) e = dev_alloc(c, &B.tile_hist, (size_t)B.max_tiles + 2);
+    if (!e) e = dev_alloc(c, &B.tile_cnt, (size_t)B.max_tiles + 2);
+    if (!e) e = dev_alloc(c, &B.tile_base, (size_t)B.max_tiles + 2);
+    if (!e) e = dev_alloc(c, &B.tile_fill, (size_t)B.max_tiles + 2);
+    if (!e) e = dev_alloc(c, &B.perm, nitems);
+    if (!e) e = dev_alloc(c, &B.frag_off, (size_t)B.fcap);
+    if (!e) e = dev_alloc(c, &B.frag_len, (size_t)B.fcap);
+    if (!e) e = dev_alloc(c, &B.frag_sum, (size_t)B.fcap);
+    if (!e) e = dev_alloc(c, &B.frag_read, (size_t)B.fcap);
+    if (!e) e = dev_alloc(c, &B.frag_start, (size_t)B.fcap);
+    if (!e) e = dev_alloc(c, &B.frag_flags, (size_t)B.fcap);
+    if (!e) e = dev_alloc(c, &B.ctr, (size_t)c->ctr_words);
+    if (!e) e = dev_alloc(c, &B.status, 4);
+    if (!e) e = dev_alloc(c, &c->d_out_reads, n);
+    if (!e) e = dev_alloc(c, &c->d_out_frags, (size_t)B.fcap);
+    if (!e) e = dev_alloc(c, &c->d_out_nfrags, 4);
+    if (e) {
+        g_create_error = c->error;
+        tgsf_destroy(c);
+        return e;
+    }
+    rt_memset(B.ctr, 0, c->ctr_words * 8, c->stream);
+    rt_memset(B.status, 0, 16, c->stream);
+    rt_sync(c->stream);
+    *out = c;
+    return TGSF_OK;
+}
+
+// ---------------------------------------------------------------------------
+// the pipeline
+// ---------------------------------------------------------------------------
+static const char* kStageNames[TGSF_N_STAGES] = {
+    "prepare+sort", "stats_raw", "gate_reads", "end_tables_raw", "end_windows", "mid_scan",
+    "mid_resolve", "regions", "stats_clean", "gate_frags+end_tables_clean", "finalize", "reserved"};
+
+extern "C" const char* tgsf_stage_name(int s) { return (s >= 0 && s < TGSF_N_STAGES) ? kStageNames[s] : ""; }
+
+static unsigned blocks_for(uint64_t n, unsigned block) { return (unsigned)std::max<uint64_t>(1, (n + block - 1) / block); }
+
+#if !defined(TGSF_EMUL)
+// add the stage durations of every profiled batch not yet accounted for
+static int harvest_profile(tgsf_ctx* c, rt_stream st)
+{
+    if (!c->prof_pending) return TGSF_OK;
+    hipError_t he = hipStreamSynchronize(st);
+    if (he != hipSuccess) return fail(c, TGSF_E_HIP, "stream synchronize failed: %s", hipGetErrorString(he));
+    for (int k = 0; k < c->prof_pending; k++)
+        for (int i = 0; i < TGSF_N_STAGES - 1; i++) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, c->ev[k][i], c->ev[k][i + 1]) == hipSuccess) c->stage_ms[i] += ms;
+        }
+    c->prof_pending = 0;
+    return TGSF_OK;
+}
+#endif
+
+static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* d_reads, tgsf_fragment* d_frags,
+                        uint32_t out_fcap, uint32_t* d_nfrags, rt_stream st)
+{
+    DevBatch B = c->B;
+    const DevParams& P = c->P;
+    B.seq = in->seq; B.qual = in->qual; B.off = in->offsets; B.len_in = in->lengths;
+    B.n = in->n_reads; B.n_bytes = in->n_bytes;
+    const uint32_t n = B.n;
+    const int A = P.n_adapters;
+    const unsigned T = 256;
+    c->last_stream = st;
+    const unsigned gsmall = grid_cap(std::min(blocks_for(n, T), 2048u));
+    const unsigned gstats = grid_cap(512u);     // 2048 waves: 8 per CU on 256 CUs
+    const size_t tl = ((size_t)B.max_tiles + 2) * 4;
+    int stage = 0;
+#if !defined(TGSF_EMUL)
+    if (c->profile && c->prof_pending == tgsf_ctx::kProfRing) { int e = harvest_profile(c, st); if (e) return e; }
+    hipEvent_t* evs = c->ev[c->profile ? c->prof_pending : 0];
+    if (c->profile) for (int i = 0; i <= TGSF_N_STAGES; i++) if (!evs[i]) (void)hipEventCreate(&evs[i]);
+#define STAGE_MARK() do { if (c->profile) (void)hipEventRecord(evs[stage], st); stage++; } while (0)
+#else
+#define STAGE_MARK() do { stage++; } while (0)
+#endif
+    STAGE_MARK();
+    // -- prepare + counting sort of reads by tile count
+    rt_memset(B.tile_hist, 0, tl, st);
+    rt_memset(B.tile_fill, 0, tl, st);
+    rt_memset(B.pool_n, 0, 4, st);
+    TGSF_LAUNCH(k_prepare, gsmall, T, st, P, B, c->max_read_len);
+    TGSF_LAUNCH(k_tile_scan, 1, 1, st, B);
+    TGSF_LAUNCH(k_tile_scatter<false>, gsmall, T, st, B);
+    STAGE_MARK();
+    // -- raw stats
+    TGSF_LAUNCH(k_stats<false>, gstats, 64 * kStatsWaves, st, P, B);
+    STAGE_MARK();
+    TGSF_LAUNCH(k_gate_reads, gsmall, T, st, P, B);
+    STAGE_MARK();
+    if (P.bc_len > 0) TGSF_LAUNCH(k_end_tables<false>, grid_cap(256u), 64 * kEndWaves, st, P, B);
+    STAGE_MARK();
+    if (P.filter && A > 0) {
+        const uint64_t nw = (uint64_t)n * A * 2;
+        TGSF_LAUNCH(k_end_windows, blocks_for(nw, 64), 64, st, P, B);
+    }
+    STAGE_MARK();
+    if (P.filter && A > 0) {
+        TGSF_LAUNCH_COOP(k_scan_u32, 1, 1024, st, B.seg_cnt, (const uint32_t*)nullptr, n);
+        // upper bound of the segment count, known on the host: no device round trip
+        const uint64_t max_segs = in->n_bytes / kSegCols + n + 1;
+        const unsigned gseg = blocks_for(max_segs, T);
+        int a = 0;
+        while (a < A) {
+            if (P.Q[a] > 64) { TGSF_LAUNCH(k_mid_scan2, gseg, T, st, P, B, a); a++; continue; }
+            int na = 0;
+            while (a + na < A && na < 4 && P.Q[a + na] <= 64) na++;
+            switch (na) {
+            case 1: TGSF_LAUNCH(k_mid_scan1<1>, gseg, T, st, P, B, a, na); break;
+            case 2: TGSF_LAUNCH(k_mid_scan1<2>, gseg, T, st, P, B, a, na); break;
+            case 3: TGSF_LAUNCH(k_mid_scan1<3>, gseg, T, st, P, B, a, na); break;
+            default: TGSF_LAUNCH(k_mid_scan1<4>, gseg, T, st, P, B, a, na); break;
+            }
+            a += na;
+        }
+    }
+    STAGE_MARK();
+    if (P.filter && A > 0) TGSF_LAUNCH(k_mid_resolve, blocks_for((uint64_t)n * A, 64), 64, st, P, B);
+    STAGE_MARK();
+    TGSF_LAUNCH(k_regions<false>, gsmall, T, st, P, B);
+    TGSF_LAUNCH_COOP(k_scan_u32, 1, 1024, st, B.nfr, (const uint32_t*)nullptr, n);
+    TGSF_LAUNCH(k_regions<true>, gsmall, T, st, P, B);
+    STAGE_MARK();
+    // -- clean stats over the fragments
+    rt_memset(B.tile_hist, 0, tl, st);
+    rt_memset(B.tile_fill, 0, tl, st);
+    const unsigned gfr = grid_cap(std::min(blocks_for(B.fcap, T), 2048u));
+    TGSF_LAUNCH(k_frag_prepare, gfr, T, st, P, B);
+    TGSF_LAUNCH(k_tile_scan, 1, 1, st, B);
+    TGSF_LAUNCH(k_tile_scatter<true>, gfr, T, st, B);
+    TGSF_LAUNCH(k_stats<true>, gstats, 64 * kStatsWaves, st, P, B);
+    STAGE_MARK();
+    TGSF_LAUNCH(k_gate_frags, gfr, T, st, P, B);
+    if (P.bc_len > 0) TGSF_LAUNCH(k_end_tables<true>, grid_cap(256u), 64 * kEndWaves, st, P, B);
+    STAGE_MARK();
+    TGSF_LAUNCH(k_finalize, gsmall, T, st, B, d_reads, d_frags, out_fcap, d_nfrags);
+    STAGE_MARK();
+#if !defined(TGSF_EMUL)
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) return fail(c, TGSF_E_HIP, "kernel launch failed: %s", hipGetErrorString(he));
+    if (c->profile) { c->prof_batches++; c->prof_pending++; }
+#endif
+    return TGSF_OK;
+}
+
+static int check_batch(tgsf_ctx* c, const tgsf_batch_in* in)
+{
+    if (!in || !in->seq || !in->qual || !in->offsets) return fail(c, TGSF_E_INVALID, "null batch pointer");
+    if (in->n_reads == 0) return fail(c, TGSF_E_INVALID, "empty batch");
+    if (in->n_reads > c->cap_reads) return fail(c, TGSF_E_CAPACITY, "batch has %u reads, context was sized for %u", in->n_reads, c->cap_reads);
+    return TGSF_OK;
+}
+
+static int check_status(tgsf_ctx* c)
+{
+    const uint32_t code = c->h_status[0], detail = c->h_status[1];
+    if (!code) return TGSF_OK;
+    rt_memset(c->B.status, 0, 16, c->stream);
+    rt_sync(c->stream);
+    switch (code) {
+    case DS_BAD_LEN: return fail(c, TGSF_E_DATA, "read %u: length 0 or above max_read_len %u", detail, c->max_read_len);
+    case DS_BAD_QUAL: return fail(c, TGSF_E_DATA, "quality byte >= 128 in the batch (outside the supported domain)");
+    case DS_POOL_FULL: return fail(c, TGSF_E_CAPACITY, "middle-adapter candidate pool overflow (read %u)", detail);
+    case DS_TOO_MANY_REGIONS: return fail(c, TGSF_E_CAPACITY, "read %u has more than %d disjoint drop regions", detail, kMaxRegions);
+    case DS_FRAG_CAP: return fail(c, TGSF_E_CAPACITY, "fragment capacity exceeded (%u)", detail);
+    case DS_BAD_MEANQ: return fail(c, TGSF_E_DATA, "read %u: mean quality outside [0,256)", detail);
+    default: return fail(c, TGSF_E_HIP, "device status %u", code);
+    }
+}
+
+extern "C" int tgsf_wait(tgsf_ctx* c)
+{
+    if (!c) return TGSF_E_INVALID;
+    int e = rt_d2h(c->h_status, c->B.status, 16, c->stream);
+    if (!e) e = rt_sync(c->stream);
+    if (e) return fail(c, TGSF_E_HIP, "stream synchronize failed: %s", rt_errstr(e));
+    return check_status(c);
+}
+
+extern "C" int tgsf_submit_device(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_batch_out* out,
+                                  uint32_t* d_n_frags, void* hip_stream)
+{
+    if (!c) return TGSF_E_INVALID;
+    int e = check_batch(c, in);
+    if (e) return e;
+    if (!out || !out->reads) return fail(c, TGSF_E_INVALID, "null output");
+    if (((uintptr_t)in->seq & 15u) || ((uintptr_t)in->qual & 15u)) return fail(c, TGSF_E_INVALID, "seq/qual device pointers must be 16-byte aligned");
+#if !defined(TGSF_EMUL)
+    (void)hipSetDevice(c->device);
+#endif
+    rt_stream st = hip_stream ? (rt_stream)hip_stream : c->stream;
+    return run_pipeline(c, in, out->reads, out->frags, out->frags ? out->frag_capacity : 0u, d_n_frags, st);
+}
+
+extern "C" int tgsf_submit(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_batch_out* out)
+{
+    if (!c) return TGSF_E_INVALID;
+    int e = check_batch(c, in);
+    if (e) return e;
+    if (!out || !out->reads) return fail(c, TGSF_E_INVALID, "null output");
+    const uint32_t n = in->n_reads;
+    uint64_t span = in->n_bytes;
+    if (!span) span = in->lengths ? in->offsets[n - 1] + in->lengths[n - 1] : in->offsets[n];
+    if (span > c->cap_bases + 16ull * c->cap_reads) return fail(c, TGSF_E_CAPACITY, "batch spans %llu bytes, context was sized for %llu bases", (unsigned long long)span, (unsigned long long)c->cap_bases);
+#if !defined(TGSF_EMUL)
+    (void)hipSetDevice(c->device);
+#endif
+    rt_stream st = c->stream;
+    int he = 0;
+    he |= rt_h2d(c->d_seq, in->seq, span, st);
+    he |= rt_h2d(c->d_qual, in->qual, span, st);
+    he |= rt_h2d(c->d_off, in->offsets, (size_t)(in->lengths ? n : n + 1) * 8, st);
+    if (in->lengths) he |= rt_h2d(c->d_lenin, in->lengths, (size_t)n * 4, st);
+    if (he) return fail(c, TGSF_E_HIP, "host to device copy failed");
+    tgsf_batch_in din = *in;
+    din.seq = c->d_seq; din.qual = c->d_qual; din.offsets = c->d_off;
+    din.lengths = in->lengths ? c->d_lenin : nullptr;
+    din.n_bytes = span;
+    e = run_pipeline(c, &din, c->d_out_reads, c->d_out_frags, c->B.fcap, c->d_out_nfrags, st);
+    if (e) return e;
+    uint32_t nf = 0;
+    he |= rt_d2h(&nf, c->d_out_nfrags, 4, st);
+    he |= rt_d2h(out->reads, c->d_out_reads, (size_t)n * sizeof(tgsf_read_result), st);
+    if (he) return fail(c, TGSF_E_HIP, "device to host copy failed");
+    e = tgsf_wait(c);
+    if (e) return e;
+    out->n_frags = nf;
+    if (nf > out->frag_capacity || (nf && !out->frags))
+        return fail(c, TGSF_E_CAPACITY, "batch produced %u fragments, caller provided room for %u", nf, out->frag_capacity);
+    if (nf) {
+        he = rt_d2h(out->frags, c->d_out_frags, (size_t)nf * sizeof(tgsf_fragment), st);
+        if (!he) he = rt_sync(st);
+        if (he) return fail(c, TGSF_E_HIP, "device to host copy failed");
+    }
+    return TGSF_OK;
+}
+
+// ---------------------------------------------------------------------------
+// tallies
+// ---------------------------------------------------------------------------
+extern "C" int tgsf_counters_len(tgsf_ctx* c, uint64_t* n_words, int32_t* bc_len, uint32_t* n_bins)
+{
+    if (!c) return TGSF_E_INVALID;
+    if (n_words) *n_words = c->ctr_words;
+    if (bc_len) *bc_len = c->P.bc_len;
+    if (n_bins) *n_bins = c->n_bins;
+    return TGSF_OK;
+}
+
+extern "C" int tgsf_counters(tgsf_ctx* c, uint64_t* dst, uint64_t n_words)
+{
+    if (!c || !dst) return TGSF_E_INVALID;
+    if (n_words < c->ctr_words) return fail(c, TGSF_E_CAPACITY, "counter buffer too small");
+    int e = tgsf_wait(c);
+    if (e) return e;
+    int he = rt_d2h(dst, c->B.ctr, c->ctr_words * 8, c->stream);
+    if (!he) he = rt_sync(c->stream);
+    return he ? fail(c, TGSF_E_HIP, "device to host copy failed") : TGSF_OK;
+}
+
+extern "C" int tgsf_counters_device(tgsf_ctx* c, void** d_ptr, uint64_t* n_words)
+{
+    if (!c || !d_ptr) return TGSF_E_INVALID;
+    *d_ptr = c->B.ctr;
+    if (n_words) *n_words = c->ctr_words;
+    return TGSF_OK;
+}
+
+extern "C" int tgsf_reset_counters(tgsf_ctx* c)
+{
+    if (!c) return TGSF_E_INVALID;
+    int he = rt_memset(c->B.ctr, 0, c->ctr_words * 8, c->stream);
+    if (!he) he = rt_sync(c->stream);
+    return he ? fail(c, TGSF_E_HIP, "memset failed") : TGSF_OK;
+}
+
+extern "C" int tgsf_profile(tgsf_ctx* c, int enable)
+{
+    if (!c) return TGSF_E_INVALID;
+#if !defined(TGSF_EMUL)
+    { int e = harvest_profile(c, c->last_stream); if (e) return e; }
+#endif
+    c->profile = enable != 0;
+    memset(c->stage_ms, 0, sizeof c->stage_ms);
+    c->prof_batches = 0;
+    return TGSF_OK;
+}
+
+extern "C" int tgsf_stage_times(tgsf_ctx* c, float ms[TGSF_N_STAGES], uint32_t* n_batches)
+{
+    if (!c || !ms) return TGSF_E_INVALID;
+#if !defined(TGSF_EMUL)
+    // batches submitted on a caller stream are complete once the caller synchronised it
+    { int e = harvest_profile(c, c->last_stream); if (e) return e; }
+#endif
+    memcpy(ms, c->stage_ms, sizeof c->stage_ms);
+    if (n_batches) *n_batches = c->prof_batches;
+    return TGSF_OK;
+}
+
+// ---------------------------------------------------------------------------
+// stand-alone alignments
+// ---------------------------------------------------------------------------
+extern "C" int tgsf_align_windows(tgsf_ctx* c, const uint8_t* seq, uint64_t n_bytes, const uint64_t* win_off,
+                                  const uint32_t* win_len, const uint8_t* adapter_id, const int32_t* k, uint32_t n,
+                                  int32_t* res, int32_t* ends)
+{
+    if (!c || !seq || !win_off || !win_len || !adapter_id || !k || !res || !ends) return TGSF_E_INVALID;
+    if (!n) return TGSF_OK;
+    for (uint32_t i = 0; i < n; i++) {
+        if (adapter_id[i] >= c->P.n_adapters) return fail(c, TGSF_E_INVALID, "problem %u: adapter id out of range", i);
+        if (win_len[i] == 0 || win_off[i] + win_len[i] > n_bytes) return fail(c, TGSF_E_INVALID, "problem %u: window outside the buffer", i);
+        if (k[i] < 0) return fail(c, TGSF_E_INVALID, "problem %u: k < 0", i);
+    }
+#if !defined(TGSF_EMUL)
+    (void)hipSetDevice(c->device);
+#endif
+    uint8_t *d_seq = nullptr, *d_aid = nullptr; uint64_t* d_off = nullptr; uint32_t* d_len = nullptr;
+    int32_t *d_k = nullptr, *d_res = nullptr, *d_ends = nullptr;
+    int e = 0;
+    e |= rt_malloc((void**)&d_seq, n_bytes + 16);
+    e |= rt_malloc((void**)&d_aid, n);
+    e |= rt_malloc((void**)&d_off, (size_t)n * 8);
+    e |= rt_malloc((void**)&d_len, (size_t)n * 4);
+    e |= rt_malloc((void**)&d_k, (size_t)n * 4);
+    e |= rt_malloc((void**)&d_res, (size_t)n * 16);
+    e |= rt_malloc((void**)&d_ends, (size_t)n * 8);
+    rt_stream st = c->stream;
+    if (!e) {
+        e |= rt_h2d(d_seq, seq, n_bytes, st);
+        e |= rt_h2d(d_aid, adapter_id, n, st);
+        e |= rt_h2d(d_off, win_off, (size_t)n * 8, st);
+        e |= rt_h2d(d_len, win_len, (size_t)n * 4, st);
+        e |= rt_h2d(d_k, k, (size_t)n * 4, st);
+    }
+    if (!e) {
+        TGSF_LAUNCH(k_align_windows, blocks_for(n, 64), 64, st, c->P, (const uint8_t*)d_seq, (const uint64_t*)d_off,
+                    (const uint32_t*)d_len, (const uint8_t*)d_aid, (const int32_t*)d_k, n, d_res, d_ends);
+        e |= rt_d2h(res, d_res, (size_t)n * 16, st);
+        e |= rt_d2h(ends, d_ends, (size_t)n * 8, st);
+        e |= rt_sync(st);
+    }
+    rt_free(d_seq); rt_free(d_aid); rt_free(d_off); rt_free(d_len); rt_free(d_k); rt_free(d_res); rt_free(d_ends);
+    return e ? fail(c, TGSF_E_HIP, "tgsf_align_windows: device operation failed") : TGSF_OK;
+}
