@@ -18,6 +18,8 @@ struct DevParams {
     int k_mid[kMaxAdapters];          // min(Q, Q - MidMatchLen + 1)   src/TGSFilter.cpp:1233, edlib.cpp:565
     int k_end[kMaxAdapters];          // min(Q, Q - EndMatchLen + 1)   :1271
     int w5[kMaxAdapters];             // EndLen + int(Q / EndSim)      :1267 (before clamping to L)
+    int need_end[kMaxAdapters];       // smallest mlen with mlen >= EndMatchLen && float(mlen)/Q >= EndSim  (:1283-1288)
+    int need_mid[kMaxAdapters];       // smallest mlen with mlen >= MidMatchLen && float(mlen)/Q >= MidSim  (:1246-1252)
     int min_Q;                        // shortest adapter
     uint32_t n_bins;                  // rows of the 100-bp tables
     const uint8_t* adapter;           // [kMaxAdapters][kMaxQ] bytes
@@ -63,6 +65,8 @@ struct DevBatch {
     uint32_t* tile_base;       // [max_tiles+2]  exclusive prefix of cnt
     uint32_t* tile_fill;       // [max_tiles+2]
     uint32_t* perm;            // items sorted by tile count, descending
+    uint4*    work;            // [work_cap] stats work items: {addr lo, addr hi, bases | tile<<13, item}
+    uint32_t  work_cap;
     uint32_t  max_tiles;
 
     // fragments
@@ -73,6 +77,9 @@ struct DevBatch {
     int32_t*  frag_start;      // [fcap]
     uint32_t* frag_flags;      // [fcap]
     uint32_t  fcap;
+
+    uint64_t* scratch;         // traceback columns, one region per wave: [column][word][lane]
+    size_t    scratch_wave_words;
 
     uint64_t* ctr;             // the flat tally vector (include/tgsf.h layout)
     uint32_t* status;          // [4] device-side error words: [0] code, [1] detail

@@ -125,11 +125,22 @@ TGSF_D uint32_t find_owner(const uint32_t* a, uint32_t n, uint32_t v) {
 }
 
 // ---------------------------------------------------------------------------
+// Block-local histogram of tile counts: same-address global atomics serialise in
+// L2 (all reads of a batch fall into a handful of buckets), LDS atomics do not.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kHistLds = 4096;
+
+// ---------------------------------------------------------------------------
 // k_prepare: per-read state.  Items of the raw stats pass are the reads.
 // ---------------------------------------------------------------------------
 TGSF_KERNEL k_prepare(DevParams P, DevBatch B, uint32_t max_read_len)
 {
+    TGSF_SHARED uint32_t h[kHistLds];
     const int A = P.n_adapters;
+    const uint32_t nbuck = B.max_tiles + 2;
+    const bool use_lds = nbuck <= kHistLds;
+    if (use_lds) for (uint32_t i = TGSF_COOP_BEGIN; i < nbuck; i += TGSF_COOP_STRIDE) h[i] = 0;
+    TGSF_BLOCK_SYNC();
     uint32_t rows = 0, erows = 0;
     for (uint32_t r = gtid(); r < B.n; r += gsize()) {
         uint32_t L = B.len_in ? B.len_in[r] : (uint32_t)(B.off[r + 1] - B.off[r]);
@@ -142,7 +153,8 @@ TGSF_KERNEL k_prepare(DevParams P, DevBatch B, uint32_t max_read_len)
         B.nfr[r] = 0;
         for (int a = 0; a < A; a++) { B.clip5[(size_t)r * A + a] = 0; B.clip3[(size_t)r * A + a] = -1; }
         if (L == 0 || L > max_read_len) { set_status(B, DS_BAD_LEN, r); B.len[r] = 0; continue; }
-        atomicAdd(&B.tile_hist[(L + kTileBases - 1) / kTileBases], 1u);
+        const uint32_t v = (L + kTileBases - 1) / kTileBases;
+        if (use_lds) atomicAdd(&h[v], 1u); else atomicAdd(&B.tile_hist[v], 1u);
         uint32_t rw = L / kBin + 1;                                     // src/TGSFilter.cpp:1445
         rows = rw > rows ? rw : rows;
         uint32_t er = (uint32_t)P.bc_len < L ? (uint32_t)P.bc_len : L;  // :1490-1493
@@ -150,54 +162,105 @@ TGSF_KERNEL k_prepare(DevParams P, DevBatch B, uint32_t max_read_len)
     }
     wave_max_u64(&B.ctr[TGSF_CTR_ROWS + 0], rows);
     wave_max_u64(&B.ctr[TGSF_CTR_ROWS + 2], erows);
+    TGSF_BLOCK_SYNC();
+    if (use_lds)
+        for (uint32_t i = TGSF_COOP_BEGIN; i < nbuck; i += TGSF_COOP_STRIDE)
+            if (h[i]) atomicAdd(&B.tile_hist[i], h[i]);
 }
 
 // Items of the clean stats pass are the fragments (keep regions).
 TGSF_KERNEL k_frag_prepare(DevParams P, DevBatch B)
 {
+    TGSF_SHARED uint32_t h[kHistLds];
+    const uint32_t nbuck = B.max_tiles + 2;
+    const bool use_lds = nbuck <= kHistLds;
+    if (use_lds) for (uint32_t i = TGSF_COOP_BEGIN; i < nbuck; i += TGSF_COOP_STRIDE) h[i] = 0;
+    TGSF_BLOCK_SYNC();
     const uint32_t nf = stored_frags(B);
     uint32_t rows = 0;
     for (uint32_t f = gtid(); f < nf; f += gsize()) {
         uint32_t L = B.frag_len[f];
-        atomicAdd(&B.tile_hist[(L + kTileBases - 1) / kTileBases], 1u);
+        const uint32_t v = (L + kTileBases - 1) / kTileBases;
+        if (use_lds) atomicAdd(&h[v], 1u); else atomicAdd(&B.tile_hist[v], 1u);
         uint32_t rw = L / kBin + 1;
         rows = rw > rows ? rw : rows;
     }
     wave_max_u64(&B.ctr[TGSF_CTR_ROWS + 1], rows);
+    TGSF_BLOCK_SYNC();
+    if (use_lds)
+        for (uint32_t i = TGSF_COOP_BEGIN; i < nbuck; i += TGSF_COOP_STRIDE)
+            if (h[i]) atomicAdd(&B.tile_hist[i], h[i]);
 }
 
 // ---------------------------------------------------------------------------
 // Counting sort of items by tile count, descending, so that "items with more
-// than t tiles" is the prefix perm[0..cnt[t]).  One thread: <= 400 buckets.
+// than t tiles" is the prefix perm[0..cnt[t]).
 //   hist[v]  #items with exactly v tiles
 //   cnt[t]   #items with more than t tiles  (= first slot of value t in perm)
 //   base[t]  #work items (item,tile) with tile index < t;  base[max_tiles+1] = total
+// One block; thread i owns a contiguous chunk of buckets; chunk sums are combined
+// by thread 0 (a few hundred buckets in all).
 // ---------------------------------------------------------------------------
 TGSF_KERNEL k_tile_scan(DevBatch B)
 {
-    if (gtid() != 0) return;
+    TGSF_SHARED uint32_t part[1024];
     const uint32_t mt = B.max_tiles;
-    uint32_t run = 0;
-    for (int v = (int)mt; v >= 0; v--) {        // cnt[v] = sum_{u>v} hist[u]
-        B.tile_cnt[v] = run;
-        run += B.tile_hist[v];
-    }
-    B.tile_cnt[mt + 1] = 0;
-    uint32_t acc = 0;
-    for (uint32_t t = 0; t <= mt; t++) { B.tile_base[t] = acc; acc += B.tile_cnt[t]; }
-    B.tile_base[mt + 1] = acc;
+    const uint32_t nb = mt + 1;                          // buckets 0..mt
+    const uint32_t T = blockDim.x;
+    const uint32_t per = (nb + T - 1) / T;
+    const uint32_t lo = threadIdx.x * per;
+    uint32_t hi = lo + per;
+    if (hi > nb) hi = nb;
+    // suffix sums: cnt[v] = sum_{u>v} hist[u]
+    uint32_t s = 0;
+    for (uint32_t v = lo; v < hi; v++) s += B.tile_hist[v];
+    part[threadIdx.x] = s;
+    TGSF_BLOCK_SYNC();
+    if (threadIdx.x == 0) { uint32_t run = 0; for (int i = (int)T - 1; i >= 0; i--) { uint32_t x = part[i]; part[i] = run; run += x; } }
+    TGSF_BLOCK_SYNC();
+    uint32_t run = part[threadIdx.x];                    // sum of hist over all buckets above this chunk
+    uint32_t csum = 0;
+    for (int v = (int)hi - 1; v >= (int)lo; v--) { uint32_t hv = B.tile_hist[v]; B.tile_cnt[v] = run; csum += run; run += hv; }
+    if (threadIdx.x == 0) B.tile_cnt[mt + 1] = 0;
+    TGSF_BLOCK_SYNC();
+    // prefix sums of cnt: base[t] = sum_{u<t} cnt[u]
+    part[threadIdx.x] = csum;
+    TGSF_BLOCK_SYNC();
+    if (threadIdx.x == 0) { uint32_t acc = 0; for (uint32_t i = 0; i < T; i++) { uint32_t x = part[i]; part[i] = acc; acc += x; } B.tile_base[mt + 1] = acc; }
+    TGSF_BLOCK_SYNC();
+    uint32_t acc = part[threadIdx.x];
+    for (uint32_t v = lo; v < hi; v++) { B.tile_base[v] = acc; acc += B.tile_cnt[v]; }
 }
 
 template <bool CLEAN>
 TGSF_KERNEL k_tile_scatter(DevBatch B)
 {
+    TGSF_SHARED uint32_t h[kHistLds];
+    TGSF_SHARED uint32_t hb[kHistLds];
+    const uint32_t nbuck = B.max_tiles + 2;
+    const bool use_lds = nbuck <= kHistLds;
     const uint32_t n = CLEAN ? stored_frags(B) : B.n;
-    for (uint32_t i = gtid(); i < n; i += gsize()) {
-        uint32_t L = CLEAN ? B.frag_len[i] : B.len[i];
-        if (L == 0) continue;
-        uint32_t v = (L + kTileBases - 1) / kTileBases;
-        uint32_t slot = B.tile_cnt[v] + atomicAdd(&B.tile_fill[v], 1u);
-        B.perm[slot] = i;
+    for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gsize()) {     // whole blocks stay in step
+        const uint32_t i = i0 + threadIdx.x;
+        if (use_lds) for (uint32_t k = TGSF_COOP_BEGIN; k < nbuck; k += TGSF_COOP_STRIDE) h[k] = 0;
+        TGSF_BLOCK_SYNC();
+        uint32_t L = 0, v = 0, local = 0;
+        if (i < n) {
+            L = CLEAN ? B.frag_len[i] : B.len[i];
+            v = (L + kTileBases - 1) / kTileBases;
+            if (L && use_lds) local = atomicAdd(&h[v], 1u);
+        }
+        TGSF_BLOCK_SYNC();
+        if (use_lds)
+            for (uint32_t k = TGSF_COOP_BEGIN; k < nbuck; k += TGSF_COOP_STRIDE)
+                if (h[k]) hb[k] = atomicAdd(&B.tile_fill[k], h[k]);
+        TGSF_BLOCK_SYNC();
+        if (L) {
+            const uint32_t slot = use_lds ? B.tile_cnt[v] + hb[v] + local
+                                          : B.tile_cnt[v] + atomicAdd(&B.tile_fill[v], 1u);
+            B.perm[slot] = i;
+        }
+        TGSF_BLOCK_SYNC();
     }
 }
 
@@ -208,12 +271,55 @@ TGSF_KERNEL k_tile_scatter(DevBatch B)
 // major, so consecutive work items of a wave hit the SAME 64 table rows: each
 // lane owns one bin and keeps its 10 tallies in registers across items, and the
 // tables see one atomic per lane per tile-index change instead of one per tile.
-// The tile is staged through LDS with coalesced 16-byte loads (both streams),
-// then lane b reads its 100 bytes at stride 25 dwords (odd => bank-conflict free).
+// k_build_work writes the (address, bases, item, tile) of every work item once,
+// so a wave fetches the metadata of 64 work items with one coalesced load.
+// The tile is staged through LDS with coalesced 16-byte loads (both streams,
+// all 14 loads of a lane in flight together, and the NEXT tile's loads issued
+// before the current one is reduced), then lane b reads its 100 bytes at stride
+// 25 dwords (odd => bank-conflict free).
 // Algorithmic traffic: 2 bytes per base, each read once.
 // ---------------------------------------------------------------------------
 constexpr int kStatsWaves = 4;
 constexpr int kTileChunks = kTileBases / 16 + 2;   // +1 misalignment, +1 zero guard
+constexpr int kLaneChunks = (kTileChunks + 63) / 64;   // 16-byte chunks a lane stages per stream
+
+// work[w] = { address lo, address hi, bases | tile << 13, item }
+template <bool CLEAN>
+TGSF_KERNEL k_build_work(DevBatch B)
+{
+    const uint32_t mt = B.max_tiles;
+    const uint32_t W = B.tile_base[mt + 1];
+    const uint64_t* it_off = CLEAN ? B.frag_off : B.off;
+    const uint32_t* it_len = CLEAN ? B.frag_len : B.len;
+    for (uint32_t w = gtid(); w < W && w < B.work_cap; w += gsize()) {
+        const uint32_t t = find_owner(B.tile_base, mt + 1, w);
+        const uint32_t item = B.perm[w - B.tile_base[t]];
+        const uint32_t L = it_len[item];
+        const uint64_t a0 = it_off[item] + (uint64_t)t * kTileBases;
+        uint32_t nb = L - t * kTileBases;
+        if (nb > (uint32_t)kTileBases) nb = kTileBases;
+        uint4 e;
+        e.x = (uint32_t)a0; e.y = (uint32_t)(a0 >> 32); e.z = nb | (t << 13); e.w = item;
+        B.work[w] = e;
+    }
+}
+
+TGSF_D uint32_t wave_bcast(uint32_t v, uint32_t src_lane) {
+#if defined(TGSF_EMUL)
+    (void)src_lane; return v;
+#else
+    return (uint32_t)__shfl((int)v, (int)src_lane, 64);
+#endif
+}
+TGSF_D int32_t wave_sum_i32(int32_t v) {
+#if defined(TGSF_EMUL)
+    return v;
+#else
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+#endif
+}
 
 template <bool CLEAN>
 TGSF_KERNEL k_stats(DevParams P, DevBatch B)
@@ -222,7 +328,8 @@ TGSF_KERNEL k_stats(DevParams P, DevBatch B)
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t gw = blockIdx.x * kStatsWaves + wave, nw = gridDim.x * kStatsWaves;
     const uint32_t mt = B.max_tiles;
-    const uint32_t W = B.tile_base[mt + 1];
+    uint32_t W = B.tile_base[mt + 1];
+    if (W > B.work_cap) W = B.work_cap;
     const uint32_t per = (W + nw - 1) / nw;
     uint32_t w0 = gw * per, w1 = w0 + per;
     if (w1 > W) w1 = W;
@@ -230,14 +337,11 @@ TGSF_KERNEL k_stats(DevParams P, DevBatch B)
 
     uint64_t* tab_q = B.ctr + ctr_bin_table(CLEAN ? TGSF_B_CLEAN_QUAL : TGSF_B_RAW_QUAL, P.bc_len, P.n_bins);
     uint64_t* tab_c = B.ctr + ctr_bin_table(CLEAN ? TGSF_B_CLEAN_CNT : TGSF_B_RAW_CNT, P.bc_len, P.n_bins);
-    const uint64_t* it_off = CLEAN ? B.frag_off : B.off;
-    const uint32_t* it_len = CLEAN ? B.frag_len : B.len;
     uint64_t* it_sum = CLEAN ? B.frag_sum : B.sumq;
     const int64_t qt = P.qtype;
 
-    uint32_t t = find_owner(B.tile_base, mt + 1, w0);
-    uint32_t j = w0 - B.tile_base[t];
     uint32_t cnt[4] = {0, 0, 0, 0}, qs[5] = {0, 0, 0, 0, 0}, call = 0, since = 0, qor = 0;
+    uint32_t t_acc = 0xFFFFFFFFu;
     uint32_t* S = reinterpret_cast<uint32_t*>(&lds[wave][0][0]);
     uint32_t* Qd = reinterpret_cast<uint32_t*>(&lds[wave][1][0]);
 
@@ -259,75 +363,133 @@ TGSF_KERNEL k_stats(DevParams P, DevBatch B)
         call = 0; since = 0;
     };
 
-    for (uint32_t w = w0; w < w1; ++w, ++j) {
-        while (j >= B.tile_cnt[t]) { flush(t); ++t; j = 0; }
-        if (since >= 2048) flush(t);          // qs[c] carries 128*sum: stay below 2^32
-        ++since;
-        const uint32_t item = B.perm[j];
-        const uint32_t L = it_len[item];
-        const uint64_t a0 = it_off[item] + (uint64_t)t * kTileBases;
-        uint32_t nb = L - t * kTileBases;
-        if (nb > (uint32_t)kTileBases) nb = kTileBases;
+    // register staging of one tile: chunk c = lane + 64*k of each stream
+    uint4 rs[kLaneChunks], rq[kLaneChunks];
+    auto issue = [&](uint64_t a0, uint32_t nb) {
+#if !defined(TGSF_EMUL)
         const uint32_t sh = (uint32_t)(a0 & 15u);
-        const uint64_t ab = a0 - sh;
-        const uint32_t endb = sh + nb;                         // first invalid byte, chunk coords
-        const uint32_t nch = (endb + 15u) / 16u + 1u;          // + one all-zero guard chunk
-        TGSF_WAVE_SYNC();                                      // previous tile fully consumed
-        for (uint32_t c = TGSF_WCOOP_BEGIN(lane); c < nch; c += TGSF_WCOOP_STRIDE) {
+        const uint8_t* ps = B.seq + (a0 - sh);
+        const uint8_t* pq = B.qual + (a0 - sh);
+        const uint32_t endb = sh + nb;
+#pragma unroll
+        for (int k = 0; k < kLaneChunks; k++) {
+            const uint32_t cb = (lane + 64u * k) * 16u;
+            uint4 z = {0, 0, 0, 0};
+            rs[k] = z; rq[k] = z;
+            if (cb < endb) {
+                rs[k] = *reinterpret_cast<const uint4*>(ps + cb);
+                rq[k] = *reinterpret_cast<const uint4*>(pq + cb);
+            }
+        }
+#else
+        (void)a0; (void)nb;
+#endif
+    };
+    auto mask_tail = [](uint4& v, uint32_t keep) {          // keep the first `keep` (1..15) bytes
+        uint32_t* p = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            int kb = (int)keep - 4 * d;
+            p[d] &= kb >= 4 ? 0xFFFFFFFFu : (kb <= 0 ? 0u : ((1u << (8 * kb)) - 1u));
+        }
+    };
+    auto commit = [&](uint64_t a0, uint32_t nb) {
+        const uint32_t sh = (uint32_t)(a0 & 15u);
+        const uint32_t endb = sh + nb;
+        const uint32_t nch = (endb + 15u) / 16u + 1u;         // + one all-zero guard chunk
+#if !defined(TGSF_EMUL)
+#pragma unroll
+        for (int k = 0; k < kLaneChunks; k++) {
+            const uint32_t c = lane + 64u * k, cb = c * 16u;
+            if (c < nch) {
+                if (cb < endb && cb + 16u > endb) { mask_tail(rs[k], endb - cb); mask_tail(rq[k], endb - cb); }
+                lds[wave][0][c] = rs[k];
+                lds[wave][1][c] = rq[k];
+            }
+        }
+#else
+        // emulation: one lane at a time, so every emulated lane stages the whole tile
+        for (uint32_t c = 0; c < nch; c++) {
             uint4 vs = {0, 0, 0, 0}, vq = {0, 0, 0, 0};
             const uint32_t cb = c * 16u;
             if (cb < endb) {
-                vs = *reinterpret_cast<const uint4*>(B.seq + ab + cb);
-                vq = *reinterpret_cast<const uint4*>(B.qual + ab + cb);
-                if (cb + 16u > endb) {                         // zero the bytes past the item
-                    uint32_t keep = endb - cb;                 // 1..15
-                    uint32_t* ps = reinterpret_cast<uint32_t*>(&vs);
-                    uint32_t* pq = reinterpret_cast<uint32_t*>(&vq);
-#pragma unroll
-                    for (int d = 0; d < 4; d++) {
-                        int kb = (int)keep - 4 * d;
-                        uint32_t m = kb >= 4 ? 0xFFFFFFFFu : (kb <= 0 ? 0u : ((1u << (8 * kb)) - 1u));
-                        ps[d] &= m; pq[d] &= m;
-                    }
-                }
+                vs = *reinterpret_cast<const uint4*>(B.seq + (a0 - sh) + cb);
+                vq = *reinterpret_cast<const uint4*>(B.qual + (a0 - sh) + cb);
+                if (cb + 16u > endb) { mask_tail(vs, endb - cb); mask_tail(vq, endb - cb); }
             }
             lds[wave][0][c] = vs;
             lds[wave][1][c] = vq;
         }
-        TGSF_WAVE_SYNC();
-        const int nvalid = (int)nb - (int)lane * kBin;         // bases of this lane's bin in the tile
-        uint32_t q4_before = qs[4];
-        int nv = 0;
-        if (nvalid > 0) {
-            nv = nvalid > kBin ? kBin : nvalid;
-            const uint32_t bo = sh + lane * kBin;
-            const uint32_t d0 = bo >> 2, bs = bo & 3u;
-            const int ndw = (nv + 3) >> 2;
-            if (bs == 0) {
-                for (int i = 0; i < ndw; i++) {
-                    uint32_t q = Qd[d0 + i];
-                    qor |= q;
-                    qc_accum4(S[d0 + i], q, cnt, qs);
-                }
-            } else {
-                uint32_t slo = S[d0], qlo = Qd[d0];
-                for (int i = 0; i < ndw; i++) {
-                    uint32_t shi = S[d0 + i + 1], qhi = Qd[d0 + i + 1];
-                    uint32_t q = alignbyte(qhi, qlo, bs);
-                    // bytes past the item are zero in LDS; bytes before it never enter (bs skips them)
-                    qor |= q;
-                    qc_accum4(alignbyte(shi, slo, bs), q, cnt, qs);
-                    slo = shi; qlo = qhi;
-                }
+#endif
+    };
+
+    for (uint32_t g0 = w0; g0 < w1; g0 += 64u) {
+        const uint32_t ng = (w1 - g0) < 64u ? (w1 - g0) : 64u;
+        uint4 me = {0, 0, 0, 0};
+#if defined(TGSF_EMUL)
+        (void)me;
+#else
+        if (lane < ng) me = B.work[g0 + lane];
+#endif
+        auto entry = [&](uint32_t i, uint64_t& a0, uint32_t& nb, uint32_t& tt, uint32_t& item) {
+#if defined(TGSF_EMUL)
+            const uint4 e = B.work[g0 + i];
+            a0 = (uint64_t)e.x | ((uint64_t)e.y << 32); nb = e.z & 0x1FFFu; tt = e.z >> 13; item = e.w;
+#else
+            const uint32_t x = wave_bcast(me.x, i), y = wave_bcast(me.y, i), z = wave_bcast(me.z, i);
+            item = wave_bcast(me.w, i);
+            a0 = (uint64_t)x | ((uint64_t)y << 32); nb = z & 0x1FFFu; tt = z >> 13;
+#endif
+        };
+        uint64_t a0; uint32_t nb, tt, item;
+        entry(0, a0, nb, tt, item);
+        issue(a0, nb);
+        for (uint32_t i = 0; i < ng; i++) {
+            TGSF_WAVE_SYNC();                                  // previous tile fully consumed
+            commit(a0, nb);
+            TGSF_WAVE_SYNC();
+            const uint64_t ca0 = a0; const uint32_t cnb = nb, ctt = tt, citem = item;
+            if (i + 1 < ng) { entry(i + 1, a0, nb, tt, item); issue(a0, nb); }   // in flight during the reduce
+            if (ctt != t_acc || since >= 2048) {               // qs[c] carries 128*sum: stay below 2^32
+                if (t_acc != 0xFFFFFFFFu) flush(t_acc);
+                t_acc = ctt;
             }
-            call += (uint32_t)nv;
+            ++since;
+            const uint32_t sh = (uint32_t)(ca0 & 15u);
+            const int nvalid = (int)cnb - (int)lane * kBin;     // bases of this lane's bin in the tile
+            const uint32_t q4_before = qs[4];
+            int nv = 0;
+            if (nvalid > 0) {
+                nv = nvalid > kBin ? kBin : nvalid;
+                const uint32_t bo = sh + lane * kBin;
+                const uint32_t d0 = bo >> 2, bs = bo & 3u;
+                const int ndw = (nv + 3) >> 2;
+                if (bs == 0) {
+                    for (int k = 0; k < ndw; k++) {
+                        uint32_t q = Qd[d0 + k];
+                        qor |= q;
+                        qc_accum4(S[d0 + k], q, cnt, qs);
+                    }
+                } else {
+                    uint32_t slo = S[d0], qlo = Qd[d0];
+                    for (int k = 0; k < ndw; k++) {
+                        uint32_t shi = S[d0 + k + 1], qhi = Qd[d0 + k + 1];
+                        uint32_t q = alignbyte(qhi, qlo, bs);
+                        // bytes past the item are zero in LDS; bytes before it never enter (bs skips them)
+                        qor |= q;
+                        qc_accum4(alignbyte(shi, slo, bs), q, cnt, qs);
+                        slo = shi; qlo = qhi;
+                    }
+                }
+                call += (uint32_t)nv;
+            }
+            // sumQ of the item: sum over the tile of (qual - qType), two's complement in u64 (:1457-1458)
+            const int32_t part = (int32_t)(qs[4] - q4_before) - (int32_t)qt * nv;
+            const int32_t tot = wave_sum_i32(part);
+            if (wave_leader()) atomicAdd((ull*)&it_sum[citem], (ull)(int64_t)tot);
         }
-        // sumQ of the item: sum over the tile of (qual - qType), two's complement in u64 (:1457-1458)
-        int64_t part = (int64_t)(qs[4] - q4_before) - qt * (int64_t)nv;
-        uint64_t tot = wave_sum((uint64_t)part);
-        if (wave_leader()) atomicAdd((ull*)&it_sum[item], (ull)tot);
     }
-    flush(t);
+    if (t_acc != 0xFFFFFFFFu) flush(t_acc);
     if (wave_or(qor & 0x80808080u) && wave_leader()) set_status(B, DS_BAD_QUAL, 0);
 }
 
@@ -337,6 +499,9 @@ TGSF_KERNEL k_stats(DevParams P, DevBatch B)
 // ---------------------------------------------------------------------------
 TGSF_KERNEL k_gate_reads(DevParams P, DevBatch B)
 {
+    TGSF_SHARED ull hq[TGSF_N_QBINS];
+    for (uint32_t i = TGSF_COOP_BEGIN; i < (uint32_t)TGSF_N_QBINS; i += TGSF_COOP_STRIDE) hq[i] = 0;
+    TGSF_BLOCK_SYNC();
     uint64_t lowq_reads = 0, lowq_bases = 0;
     for (uint32_t r0 = blockIdx.x * blockDim.x; r0 < B.n; r0 += gsize()) {   // whole waves stay convergent
         const uint32_t r = r0 + threadIdx.x;
@@ -345,7 +510,7 @@ TGSF_KERNEL k_gate_reads(DevParams P, DevBatch B)
             const double mq = mean_q(B.sumq[r], L);
             if (!(mq >= 0.0 && mq < 256.0)) { set_status(B, DS_BAD_MEANQ, r); }
             else {
-                atomicAdd((ull*)&B.ctr[TGSF_CTR_RAW_DIFFQ + (int)mq], (ull)L);
+                atomicAdd(&hq[(int)mq], (ull)L);                          // :1943
                 uint32_t segs = 0;
                 if (P.filter) {
                     if (q_fail(mq, P.min_q, P.max_q)) {
@@ -362,6 +527,9 @@ TGSF_KERNEL k_gate_reads(DevParams P, DevBatch B)
     }
     wave_add_u64(&B.ctr[TGSF_CTR_DROPINFO + 0], lowq_reads);
     wave_add_u64(&B.ctr[TGSF_CTR_DROPINFO + 1], lowq_bases);
+    TGSF_BLOCK_SYNC();
+    for (uint32_t i = TGSF_COOP_BEGIN; i < (uint32_t)TGSF_N_QBINS; i += TGSF_COOP_STRIDE)
+        if (hq[i]) atomicAdd((ull*)&B.ctr[TGSF_CTR_RAW_DIFFQ + i], hq[i]);
 }
 
 // ---------------------------------------------------------------------------
@@ -409,7 +577,7 @@ TGSF_KERNEL k_scan_u32(uint32_t* a, const uint32_t* n_ptr, uint32_t n_fixed)
 // lane-private LDS rows, so the [bc_len][5] tables see one atomic per lane-slot
 // per wave, not per read.
 // ---------------------------------------------------------------------------
-constexpr int kEndWaves = 1;       // 40 KB of lane-private LDS tallies per wave
+constexpr int kEndWaves = 8;       // waves of a block share one 40 KB set of LDS tallies (LDS atomics)
 constexpr int kMaxBcLen = 512;
 TGSF_D int base_col(uint32_t b) {
     b &= 0xDFu;
@@ -418,64 +586,77 @@ TGSF_D int base_col(uint32_t b) {
 template <bool CLEAN>
 TGSF_KERNEL k_end_tables(DevParams P, DevBatch B)
 {
-    // [wave][end][pos][10]: 5 counts, 5 quality sums
-    TGSF_SHARED uint32_t acc[kEndWaves][2][kMaxBcLen / 64][10][64];
+    // [end][slot][10][lane]: 5 counts, 5 quality sums; position = slot*64 + lane
+    TGSF_SHARED uint32_t acc[2][kMaxBcLen / 64][10][64];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t gw = blockIdx.x * kEndWaves + wave, nw = gridDim.x * kEndWaves;
     const uint32_t n = CLEAN ? stored_frags(B) : B.n;
     const uint32_t bc = (uint32_t)P.bc_len;
     const uint32_t slots = (bc + 63u) / 64u;
-    for (uint32_t e = 0; e < 2; e++)
-        for (uint32_t s = 0; s < slots; s++)
-            for (int k = 0; k < 10; k++) acc[wave][e][s][k][lane] = 0;
-    for (uint32_t i = gw; i < n; i += nw) {
-        uint32_t L; uint64_t off;
-        if (CLEAN) { if (!(B.frag_flags[i] & TGSF_FF_PASS)) continue; L = B.frag_len[i]; off = B.frag_off[i]; }
-        else { L = B.len[i]; off = B.off[i]; if (!L) continue; }
-        const uint32_t m = bc < L ? bc : L;
-        for (uint32_t s = 0; s < slots; s++) {
-            const uint32_t p = s * 64u + lane;
-            if (p < m) {
-                uint32_t b5 = B.seq[off + p], q5 = B.qual[off + p];
-                uint32_t b3 = B.seq[off + L - 1 - p], q3 = B.qual[off + L - 1 - p];   // :1554-1557
-                int c = base_col(b5);
-                if (c < 4) { acc[wave][0][s][c][lane]++; acc[wave][0][s][5 + c][lane] += q5; }
-                acc[wave][0][s][4][lane]++; acc[wave][0][s][9][lane] += q5;
-                c = base_col(b3);
-                if (c < 4) { acc[wave][1][s][c][lane]++; acc[wave][1][s][5 + c][lane] += q3; }
-                acc[wave][1][s][4][lane]++; acc[wave][1][s][9][lane] += q3;
+    uint32_t* flat = &acc[0][0][0][0];
+    for (uint32_t i = TGSF_COOP_BEGIN; i < 2u * (kMaxBcLen / 64) * 10u * 64u; i += TGSF_COOP_STRIDE) flat[i] = 0;
+    TGSF_BLOCK_SYNC();
+    auto add = [&](uint32_t e, uint32_t s, uint32_t b, uint32_t q) {
+        const int c = base_col(b);
+        if (c < 4) { atomicAdd(&acc[e][s][c][lane], 1u); atomicAdd(&acc[e][s][5 + c][lane], q); }
+        atomicAdd(&acc[e][s][4][lane], 1u); atomicAdd(&acc[e][s][9][lane], q);
+    };
+    for (uint32_t i = gw; i < n; i += 2 * nw) {                 // two items in flight per wave
+        uint32_t L[2] = {0, 0}; uint64_t off[2] = {0, 0};
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const uint32_t it = i + u * nw;
+            if (it < n) {
+                if (CLEAN) { if (B.frag_flags[it] & TGSF_FF_PASS) { L[u] = B.frag_len[it]; off[u] = B.frag_off[it]; } }
+                else { L[u] = B.len[it]; off[u] = B.off[it]; }
             }
         }
-    }
-    const int64_t qt = P.qtype;
-    for (uint32_t e = 0; e < 2; e++) {
-        uint64_t* tq = B.ctr + ctr_end_table((CLEAN ? 4 : 0) + (e ? 2 : 0), P.bc_len);
-        uint64_t* tc = B.ctr + ctr_end_table((CLEAN ? 4 : 0) + (e ? 2 : 0) + 1, P.bc_len);
         for (uint32_t s = 0; s < slots; s++) {
             const uint32_t p = s * 64u + lane;
-            if (p >= bc) continue;
-            for (int c = 0; c < 5; c++) {
-                uint32_t k = acc[wave][e][s][c][lane];
-                if (k) {
-                    atomicAdd((ull*)&tc[(size_t)p * 5 + c], (ull)k);
-                    atomicAdd((ull*)&tq[(size_t)p * 5 + c],
-                              (ull)((int64_t)acc[wave][e][s][5 + c][lane] - qt * (int64_t)k));
+            uint32_t b5[2], q5[2], b3[2], q3[2];
+            bool on[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const uint32_t m = bc < L[u] ? bc : L[u];
+                on[u] = p < m;
+                if (on[u]) {
+                    b5[u] = B.seq[off[u] + p]; q5[u] = B.qual[off[u] + p];
+                    b3[u] = B.seq[off[u] + L[u] - 1 - p]; q3[u] = B.qual[off[u] + L[u] - 1 - p];   // :1554-1557
                 }
             }
+#pragma unroll
+            for (int u = 0; u < 2; u++) if (on[u]) { add(0, s, b5[u], q5[u]); add(1, s, b3[u], q3[u]); }
         }
+    }
+    TGSF_BLOCK_SYNC();
+    const int64_t qt = P.qtype;
+    for (uint32_t k = TGSF_COOP_BEGIN; k < 2u * slots * 5u * 64u; k += TGSF_COOP_STRIDE) {
+        const uint32_t ln = k & 63u, c = (k >> 6) % 5u, s = ((k >> 6) / 5u) % slots, e = (k >> 6) / (5u * slots);
+        const uint32_t p = s * 64u + ln;
+        if (p >= bc) continue;
+        const uint32_t cn = acc[e][s][c][ln];
+        if (!cn) continue;
+        uint64_t* tq = B.ctr + ctr_end_table((CLEAN ? 4 : 0) + (e ? 2 : 0), P.bc_len);
+        uint64_t* tc = B.ctr + ctr_end_table((CLEAN ? 4 : 0) + (e ? 2 : 0) + 1, P.bc_len);
+        atomicAdd((ull*)&tc[(size_t)p * 5 + c], (ull)cn);
+        atomicAdd((ull*)&tq[(size_t)p * 5 + c], (ull)((int64_t)acc[e][s][5 + c][ln] - qt * (int64_t)cn));
     }
 }
 
 // ---------------------------------------------------------------------------
 // Alignment of one adapter against one short window with edlib's HW/PATH
-// semantics as TGSFilter consumes them.  colbuf is the
-// lane-private column for path_len.
+// semantics as TGSFilter consumes them.
+//
+// mlen = alignmentLength - editDistance is the number of match columns on the
+// path edlib's traceback picks.  With T' = end0-start0+1 window columns and
+// `ins` up-moves on that path:  mlen = T' - best + ins,  0 <= ins - max(0,Q-T')
+// and 2*ins <= best - (T'-Q).  When those bounds already decide "mlen >= need"
+// the path is not needed; otherwise it is recovered bit-parallel: a global-mode
+// Myers pass stores the vertical (+1) and horizontal (+1) delta words of every
+// column, and the traceback (priority up > left > diagonal, edlib.cpp:1023/
+// 1057/1088) is a walk over single bits: "up" iff Pv_j[i], "left" iff Ph_j[i].
+// The per-column words live in a lane-interleaved scratch ([column][lane]).
 // ---------------------------------------------------------------------------
-struct LaneCol {
-    uint32_t* base;     // &colbuf[0][lane]
-    TGSF_HD uint32_t& operator()(int i) const { return base[(size_t)i * 64]; }
-};
-
 struct WinAln {
     int best;          // -1: nothing within k
     int n;
@@ -484,42 +665,61 @@ struct WinAln {
     int mlen;          // alignmentLength - editDistance of the first location
 };
 
+// one text column in global mode (hin = +1 at the top); returns the horizontal +1 words
 template <int NW>
-TGSF_D WinAln align_window(const DevParams& P, int a, const uint8_t* t, int T, int kk, LaneCol col)
+TGSF_HD void bv_step_global(Bv<NW>& s, const uint64_t* eq, uint64_t* ph_out, int Q) {
+    int hin = 1;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        uint64_t Eq = eq[w], Pv = s.p[w], Mv = s.m[w];
+        uint64_t Xv = Eq | Mv;
+        if (hin < 0) Eq |= 1ull;
+        uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+        uint64_t Ph = Mv | ~(Xh | Pv);
+        uint64_t Mh = Pv & Xh;
+        ph_out[w] = Ph;
+        const int bit = (w == NW - 1) ? ((Q - 1) & 63) : 63;
+        int hout = (int)((Ph >> bit) & 1ull) - (int)((Mh >> bit) & 1ull);
+        Ph <<= 1; Mh <<= 1;
+        if (hin < 0) Mh |= 1ull;
+        if (hin > 0) Ph |= 1ull;
+        s.p[w] = Mh | ~(Xv | Ph);
+        s.m[w] = Ph & Xv;
+        hin = hout;
+    }
+    s.score += hin;
+}
+
+// lane-private scratch: word k of column j of this lane
+struct LaneScratch {
+    uint64_t* base;       // &scratch[wave region][lane]
+    TGSF_HD uint64_t& at(int j, int k, int nwords) const { return base[((size_t)j * nwords + k) * 64]; }
+};
+
+// number of columns of the canonical global alignment of the adapter against t[0..T)
+template <int NW>
+TGSF_D int path_len_bv(const uint64_t* pf /*[256][2]*/, int Q, const uint8_t* t, int T, LaneScratch sc)
 {
-    const int Q = P.Q[a];
-    const uint64_t* pf = P.peq_fwd + (size_t)a * 512;
-    const uint64_t* pr = P.peq_rev + (size_t)a * 512;
-    WinAln r;
-    r.best = -1; r.n = 0; r.first_end = r.last_end = -1; r.start0 = 0; r.mlen = 0;
-    // peq tables are [256][2]; with NW == 1 only word 0 of each symbol is used
     Bv<NW> s;
     bv_init(s, Q);
-    int cur = kk + 1;
-    for (int j = 0; j < T; j++) {
-        bv_step<NW>(s, pf + (size_t)t[j] * 2, 0, Q);
-        if (s.score < cur) { cur = s.score; r.first_end = j; r.n = 0; }
-        if (s.score == cur && cur <= kk) { r.last_end = j; r.n++; }
+    for (int j = 1; j <= T; j++) {
+        uint64_t ph[NW];
+        bv_step_global<NW>(s, pf + (size_t)t[j - 1] * 2, ph, Q);
+#pragma unroll
+        for (int w = 0; w < NW; w++) { sc.at(j, w, 2 * NW) = s.p[w]; sc.at(j, NW + w, 2 * NW) = ph[w]; }
     }
-    if (cur > kk) return r;
-    r.best = cur;
-    // start of the first location (edlib.cpp:246-255)
-    {
-        Bv<NW> b;
-        bv_init(b, Q);
-        int maxl = r.first_end + 1;
-        if (maxl > Q + cur) maxl = Q + cur;
-        int best_l = 1;
-        for (int l = 1; l <= maxl; l++) {
-            bv_step<NW>(b, pr + (size_t)t[r.first_end - (l - 1)] * 2, 1, Q);
-            if (b.score == cur) best_l = l;
+    int i = Q, j = T, len = 0;
+    while (i > 0 && j > 0) {
+        const int r = i - 1;
+        const uint64_t pv = sc.at(j, r >> 6, 2 * NW);
+        if ((pv >> (r & 63)) & 1ull) { i--; }
+        else {
+            const uint64_t ph = sc.at(j, NW + (r >> 6), 2 * NW);
+            if ((ph >> (r & 63)) & 1ull) j--; else { i--; j--; }
         }
-        r.start0 = r.first_end - best_l + 1;
+        len++;
     }
-    const uint8_t* q = P.adapter + (size_t)a * kMaxQ;
-    int plen = path_len(q, Q, t + r.start0, r.first_end - r.start0 + 1, col);
-    r.mlen = plen - cur;
-    return r;
+    return len + i + j;        // straight along the border (edlib.cpp:1028-1032, :1062-1067)
 }
 
 template <int NW>
@@ -537,6 +737,47 @@ TGSF_D int start_of(const DevParams& P, int a, const uint8_t* t, int end, int be
         if (b.score == best) best_l = l;
     }
     return end - best_l + 1;
+}
+
+// mlen of the first location, or -1 when the bounds prove it is below `need`
+// (the caller only compares mlen with need), or a value >= need when they prove that.
+template <int NW>
+TGSF_D int first_mlen(const DevParams& P, int a, const uint8_t* t, int start0, int end0, int best, int need,
+                      LaneScratch sc, bool exact)
+{
+    const int Q = P.Q[a];
+    const int T = end0 - start0 + 1;
+    if (!exact) {
+        const int lo = T - best + (Q > T ? Q - T : 0);
+        const int slack = best - (T - Q);
+        const int hi = T - best + (slack > 0 ? slack / 2 : 0);
+        if (lo >= need) return lo;          // passes whatever the path
+        if (hi < need) return -1;           // fails whatever the path
+    }
+    return path_len_bv<NW>(P.peq_fwd + (size_t)a * 512, Q, t + start0, T, sc) - best;
+}
+
+template <int NW>
+TGSF_D WinAln align_window(const DevParams& P, int a, const uint8_t* t, int T, int kk, int need, LaneScratch sc, bool exact)
+{
+    const int Q = P.Q[a];
+    const uint64_t* pf = P.peq_fwd + (size_t)a * 512;
+    WinAln r;
+    r.best = -1; r.n = 0; r.first_end = r.last_end = -1; r.start0 = 0; r.mlen = 0;
+    // peq tables are [256][2]; with NW == 1 only word 0 of each symbol is used
+    Bv<NW> s;
+    bv_init(s, Q);
+    int cur = kk + 1;
+    for (int j = 0; j < T; j++) {
+        bv_step<NW>(s, pf + (size_t)t[j] * 2, 0, Q);
+        if (s.score < cur) { cur = s.score; r.first_end = j; r.n = 0; }
+        if (s.score == cur && cur <= kk) { r.last_end = j; r.n++; }
+    }
+    if (cur > kk) return r;
+    r.best = cur;
+    r.start0 = start_of<NW>(P, a, t, r.first_end, cur);          // edlib.cpp:246-255
+    r.mlen = first_mlen<NW>(P, a, t, r.start0, r.first_end, cur, need, sc, exact);
+    return r;
 }
 
 // smallest start over all locations of a window whose optimum is `best`
@@ -558,6 +799,15 @@ TGSF_D int min_start_all(const DevParams& P, int a, const uint8_t* t, int T, int
     return mn;
 }
 
+TGSF_D LaneScratch lane_scratch(const DevBatch& B)
+{
+    // one region per wave of the launch: [column][word][lane]
+    const size_t wave_id = (size_t)gtid() >> 6;
+    LaneScratch sc;
+    sc.base = B.scratch + wave_id * B.scratch_wave_words + (threadIdx.x & 63u);
+    return sc;
+}
+
 // ---------------------------------------------------------------------------
 // k_end_windows: the 5' and 3' searches of GetEditDistance (src/TGSFilter.cpp:1266-1321).
 // One lane per (read, adapter, end).  Every reported location pushes [0, end+1)
@@ -566,7 +816,6 @@ TGSF_D int min_start_all(const DevParams& P, int a, const uint8_t* t, int T, int
 // ---------------------------------------------------------------------------
 TGSF_KERNEL k_end_windows(DevParams P, DevBatch B)
 {
-    TGSF_SHARED uint32_t colbuf[kMaxQ + 1][64];
     const int A = P.n_adapters;
     const uint32_t idx = gtid();
     const uint32_t total = B.n * (uint32_t)A * 2u;
@@ -582,12 +831,12 @@ TGSF_KERNEL k_end_windows(DevParams P, DevBatch B)
     if (W5 < 5) return;                                   // :1274
     if (P.k_end[a] < 0) return;                           // match length > adapter: can never pass :1283
     const uint8_t* t = B.seq + B.off[r] + (e ? (L - W5) : 0);
-    LaneCol col{&colbuf[0][threadIdx.x & 63u]};
-    WinAln w = (Q <= 64) ? align_window<1>(P, a, t, W5, P.k_end[a], col)
-                         : align_window<2>(P, a, t, W5, P.k_end[a], col);
+    const LaneScratch sc = lane_scratch(B);
+    const int need = P.need_end[a];                        // mlen >= EndMatchLen && float(mlen)/Q >= EndSim (:1283-1288)
+    WinAln w = (Q <= 64) ? align_window<1>(P, a, t, W5, P.k_end[a], need, sc, false)
+                         : align_window<2>(P, a, t, W5, P.k_end[a], need, sc, false);
     if (w.best < 0) return;
-    if (w.mlen < P.end_match_len) return;                 // :1283
-    if (!((float)w.mlen / (float)Q >= P.end_sim)) return; // :1287-1288
+    if (w.mlen < need) return;
     if (e == 0) {
         B.clip5[(size_t)r * A + a] = w.last_end + 1;      // union of [0, end_i+1)
         atomicOr(&B.flags[r], (uint32_t)TGSF_RF_AD5P);
@@ -769,7 +1018,6 @@ TGSF_KERNEL k_mid_scan2(DevParams P, DevBatch B, int a)
 // ---------------------------------------------------------------------------
 TGSF_KERNEL k_mid_resolve(DevParams P, DevBatch B)
 {
-    TGSF_SHARED uint32_t colbuf[kMaxQ + 1][64];
     const int A = P.n_adapters;
     const uint32_t idx = gtid();
     if (idx >= B.n * (uint32_t)A || !P.filter) return;
@@ -787,12 +1035,12 @@ TGSF_KERNEL k_mid_resolve(DevParams P, DevBatch B)
     if (best == (1 << 30)) return;
     const int L = (int)B.len[r], E = P.end_len, Q = P.Q[a];
     const uint8_t* win = B.seq + B.off[r] + E;
-    LaneCol col{&colbuf[0][threadIdx.x & 63u]};
+    const LaneScratch sc = lane_scratch(B);
+    const int need = P.need_mid[a];                                      // :1246, :1250-1252
     const int s0 = (Q <= 64) ? start_of<1>(P, a, win, e0, best) : start_of<2>(P, a, win, e0, best);
-    const int plen = path_len(P.adapter + (size_t)a * kMaxQ, Q, win + s0, e0 - s0 + 1, col);
-    const int mlen = plen - best;
-    if (mlen < P.mid_match_len) return;                                  // :1246
-    if (!((float)mlen / (float)Q >= P.mid_sim)) return;                  // :1250-1252
+    const int mlen = (Q <= 64) ? first_mlen<1>(P, a, win, s0, e0, best, need, sc, false)
+                               : first_mlen<2>(P, a, win, s0, e0, best, need, sc, false);
+    if (mlen < need) return;
     atomicOr(&B.flags[r], (uint32_t)TGSF_RF_ADMID);
     for (int32_t i = head; i >= 0; i = B.pool[i].next) {
         const int aux = B.pool[i].aux;
@@ -940,17 +1188,20 @@ TGSF_KERNEL k_regions(DevParams P, DevBatch B)
 // ---------------------------------------------------------------------------
 TGSF_KERNEL k_gate_frags(DevParams P, DevBatch B)
 {
+    TGSF_SHARED ull hq[TGSF_N_QBINS];
+    for (uint32_t i = TGSF_COOP_BEGIN; i < (uint32_t)TGSF_N_QBINS; i += TGSF_COOP_STRIDE) hq[i] = 0;
+    TGSF_BLOCK_SYNC();
     const uint32_t nf = stored_frags(B);
     uint64_t lq_n = 0, lq_b = 0;
     uint32_t erows = 0;
     for (uint32_t f0 = blockIdx.x * blockDim.x; f0 < nf; f0 += gsize()) {
         const uint32_t f = f0 + threadIdx.x;
-        if (f >= nf || f >= B.fcap) continue;
+        if (f >= nf) continue;
         const uint32_t L = B.frag_len[f];
         const double cm = mean_q(B.frag_sum[f], L);
         if (P.filter && q_fail(cm, P.min_q, P.max_q)) { lq_n++; lq_b += L; continue; }
         if (!(cm >= 0.0 && cm < 256.0)) { set_status(B, DS_BAD_MEANQ, B.frag_read[f]); continue; }
-        atomicAdd((ull*)&B.ctr[TGSF_CTR_CLEAN_DIFFQ + (int)cm], (ull)L);
+        atomicAdd(&hq[(int)cm], (ull)L);                                  // :2002
         B.frag_flags[f] = TGSF_FF_PASS;
         uint32_t er = (uint32_t)P.bc_len < L ? (uint32_t)P.bc_len : L;
         erows = er > erows ? er : erows;
@@ -958,6 +1209,9 @@ TGSF_KERNEL k_gate_frags(DevParams P, DevBatch B)
     wave_add_u64(&B.ctr[TGSF_CTR_DROPINFO + 13], lq_n);
     wave_add_u64(&B.ctr[TGSF_CTR_DROPINFO + 14], lq_b);
     wave_max_u64(&B.ctr[TGSF_CTR_ROWS + 3], erows);
+    TGSF_BLOCK_SYNC();
+    for (uint32_t i = TGSF_COOP_BEGIN; i < (uint32_t)TGSF_N_QBINS; i += TGSF_COOP_STRIDE)
+        if (hq[i]) atomicAdd((ull*)&B.ctr[TGSF_CTR_CLEAN_DIFFQ + i], hq[i]);
 }
 
 // ---------------------------------------------------------------------------
@@ -995,20 +1249,19 @@ TGSF_KERNEL k_finalize(DevBatch B, tgsf_read_result* out_reads, tgsf_fragment* o
 // ---------------------------------------------------------------------------
 // k_align_windows: stand-alone edlib-compatible alignments (tgsf_align_windows).
 // ---------------------------------------------------------------------------
-TGSF_KERNEL k_align_windows(DevParams P, const uint8_t* seq, const uint64_t* win_off, const uint32_t* win_len,
+TGSF_KERNEL k_align_windows(DevParams P, DevBatch B, const uint8_t* seq, const uint64_t* win_off, const uint32_t* win_len,
                             const uint8_t* adapter_id, const int32_t* kk, uint32_t n, int32_t* res, int32_t* ends)
 {
-    TGSF_SHARED uint32_t colbuf[kMaxQ + 1][64];
     const uint32_t i = gtid();
     if (i >= n) return;
     const int a = adapter_id[i];
     const int Q = P.Q[a];
     int k = kk[i];
     if (k > Q) k = Q;                                    // edlib.cpp:565-567
-    LaneCol col{&colbuf[0][threadIdx.x & 63u]};
+    const LaneScratch sc = lane_scratch(B);
     const uint8_t* t = seq + win_off[i];
-    WinAln w = (Q <= 64) ? align_window<1>(P, a, t, (int)win_len[i], k, col)
-                         : align_window<2>(P, a, t, (int)win_len[i], k, col);
+    WinAln w = (Q <= 64) ? align_window<1>(P, a, t, (int)win_len[i], k, 0, sc, true)
+                         : align_window<2>(P, a, t, (int)win_len[i], k, 0, sc, true);
     res[i * 4 + 0] = w.best;
     res[i * 4 + 1] = w.best < 0 ? 0 : w.n;
     res[i * 4 + 2] = w.best < 0 ? 0 : w.mlen + w.best;

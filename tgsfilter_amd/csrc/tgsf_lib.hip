@@ -47,6 +47,7 @@ struct tgsf_ctx {
     uint64_t cap_bases;
     uint32_t cap_reads, max_read_len, n_bins;
     uint64_t ctr_words;
+    int scratch_cols;
     // internal input / output staging for tgsf_submit
     uint8_t *d_seq, *d_qual;
     uint64_t* d_off;
@@ -148,6 +149,12 @@ static int build_tables(tgsf_ctx* c)
         P.k_mid[a] = km > Q ? Q : km;                     // include/edlib.cpp:565-567 (negative: see k_end_windows)
         P.k_end[a] = ke > Q ? Q : ke;
         P.w5[a] = p.end_len + (int)((float)Q / p.end_sim);   // :1267 int(qLen / endSim), float division
+        // the similarity gates are monotone in mlen: evaluate the reference's float predicates here, once
+        P.need_end[a] = P.need_mid[a] = Q + 1;                // Q+1: cannot pass (mlen <= Q)
+        for (int m = Q; m >= 0; m--) {
+            if (m >= p.end_match_len && (float)m / (float)Q >= p.end_sim) P.need_end[a] = m;
+            if (m >= p.mid_match_len && (float)m / (float)Q >= p.mid_sim) P.need_mid[a] = m;
+        }
         memcpy(&ad[(size_t)a * kMaxQ], s.data(), (size_t)Q);
         for (int r = 0; r < Q; r++) {
             uint8_t cf = (uint8_t)s[r], cr = (uint8_t)s[Q - 1 - r];
@@ -306,12 +313,26 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     if (!e) e = dev_alloc(c, &B.tile_base, (size_t)B.max_tiles + 2);
     if (!e) e = dev_alloc(c, &B.tile_fill, (size_t)B.max_tiles + 2);
     if (!e) e = dev_alloc(c, &B.perm, nitems);
+    B.work_cap = (uint32_t)std::min<uint64_t>(c->cap_bases / kTileBases + nitems + 16, 0x7FFFFFF0ull);
+    if (!e) e = dev_alloc(c, &B.work, (size_t)B.work_cap);
     if (!e) e = dev_alloc(c, &B.frag_off, (size_t)B.fcap);
     if (!e) e = dev_alloc(c, &B.frag_len, (size_t)B.fcap);
     if (!e) e = dev_alloc(c, &B.frag_sum, (size_t)B.fcap);
     if (!e) e = dev_alloc(c, &B.frag_read, (size_t)B.fcap);
     if (!e) e = dev_alloc(c, &B.frag_start, (size_t)B.fcap);
     if (!e) e = dev_alloc(c, &B.frag_flags, (size_t)B.fcap);
+    {
+        // traceback scratch: a window of the first location spans at most Q + k columns
+        int maxcols = 1;
+        for (int a = 0; a < p->n_adapters; a++) {
+            int kmax = std::max(std::max(P.k_end[a], P.k_mid[a]), 0);
+            maxcols = std::max(maxcols, P.Q[a] + std::min(P.Q[a], kmax) + 1);
+        }
+        c->scratch_cols = maxcols;
+        B.scratch_wave_words = (size_t)(maxcols + 1) * 2 * P.max_nw * 64;
+        const size_t waves = ((size_t)n * A * 2 + 63) / 64 + 1;
+        if (!e) e = dev_alloc(c, &B.scratch, waves * B.scratch_wave_words);
+    }
     if (!e) e = dev_alloc(c, &B.ctr, (size_t)c->ctr_words);
     if (!e) e = dev_alloc(c, &B.status, 4);
     if (!e) e = dev_alloc(c, &c->d_out_reads, n);
@@ -369,7 +390,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     const unsigned T = 256;
     c->last_stream = st;
     const unsigned gsmall = grid_cap(std::min(blocks_for(n, T), 2048u));
-    const unsigned gstats = grid_cap(512u);     // 2048 waves: 8 per CU on 256 CUs
+    const unsigned gstats = grid_cap(768u);     // 3 blocks (12 waves) per CU on 256 CUs: LDS-limited
     const size_t tl = ((size_t)B.max_tiles + 2) * 4;
     int stage = 0;
 #if !defined(TGSF_EMUL)
@@ -386,15 +407,17 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     rt_memset(B.tile_fill, 0, tl, st);
     rt_memset(B.pool_n, 0, 4, st);
     TGSF_LAUNCH(k_prepare, gsmall, T, st, P, B, c->max_read_len);
-    TGSF_LAUNCH(k_tile_scan, 1, 1, st, B);
+    TGSF_LAUNCH_COOP(k_tile_scan, 1, 1024, st, B);
     TGSF_LAUNCH(k_tile_scatter<false>, gsmall, T, st, B);
+    const unsigned gwork = grid_cap(std::min(blocks_for(in->n_bytes / kTileBases + n + 1, T), 4096u));
+    TGSF_LAUNCH(k_build_work<false>, gwork, T, st, B);
     STAGE_MARK();
     // -- raw stats
     TGSF_LAUNCH(k_stats<false>, gstats, 64 * kStatsWaves, st, P, B);
     STAGE_MARK();
     TGSF_LAUNCH(k_gate_reads, gsmall, T, st, P, B);
     STAGE_MARK();
-    if (P.bc_len > 0) TGSF_LAUNCH(k_end_tables<false>, grid_cap(256u), 64 * kEndWaves, st, P, B);
+    if (P.bc_len > 0) TGSF_LAUNCH(k_end_tables<false>, grid_cap(128u), 64 * kEndWaves, st, P, B);
     STAGE_MARK();
     if (P.filter && A > 0) {
         const uint64_t nw = (uint64_t)n * A * 2;
@@ -432,12 +455,13 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     rt_memset(B.tile_fill, 0, tl, st);
     const unsigned gfr = grid_cap(std::min(blocks_for(B.fcap, T), 2048u));
     TGSF_LAUNCH(k_frag_prepare, gfr, T, st, P, B);
-    TGSF_LAUNCH(k_tile_scan, 1, 1, st, B);
+    TGSF_LAUNCH_COOP(k_tile_scan, 1, 1024, st, B);
     TGSF_LAUNCH(k_tile_scatter<true>, gfr, T, st, B);
+    TGSF_LAUNCH(k_build_work<true>, gwork, T, st, B);
     TGSF_LAUNCH(k_stats<true>, gstats, 64 * kStatsWaves, st, P, B);
     STAGE_MARK();
     TGSF_LAUNCH(k_gate_frags, gfr, T, st, P, B);
-    if (P.bc_len > 0) TGSF_LAUNCH(k_end_tables<true>, grid_cap(256u), 64 * kEndWaves, st, P, B);
+    if (P.bc_len > 0) TGSF_LAUNCH(k_end_tables<true>, grid_cap(128u), 64 * kEndWaves, st, P, B);
     STAGE_MARK();
     TGSF_LAUNCH(k_finalize, gsmall, T, st, B, d_reads, d_frags, out_fcap, d_nfrags);
     STAGE_MARK();
@@ -617,7 +641,12 @@ extern "C" int tgsf_align_windows(tgsf_ctx* c, const uint8_t* seq, uint64_t n_by
         if (adapter_id[i] >= c->P.n_adapters) return fail(c, TGSF_E_INVALID, "problem %u: adapter id out of range", i);
         if (win_len[i] == 0 || win_off[i] + win_len[i] > n_bytes) return fail(c, TGSF_E_INVALID, "problem %u: window outside the buffer", i);
         if (k[i] < 0) return fail(c, TGSF_E_INVALID, "problem %u: k < 0", i);
+        const int Q = c->P.Q[adapter_id[i]];
+        if (Q + std::min(Q, (int)k[i]) + 1 > c->scratch_cols)
+            return fail(c, TGSF_E_CAPACITY, "problem %u: k larger than the context's thresholds allow for", i);
     }
+    if ((size_t)n > (size_t)c->cap_reads * std::max(c->P.n_adapters, 1) * 2)
+        return fail(c, TGSF_E_CAPACITY, "more alignment problems than the context was sized for");
 #if !defined(TGSF_EMUL)
     (void)hipSetDevice(c->device);
 #endif
@@ -640,7 +669,7 @@ extern "C" int tgsf_align_windows(tgsf_ctx* c, const uint8_t* seq, uint64_t n_by
         e |= rt_h2d(d_k, k, (size_t)n * 4, st);
     }
     if (!e) {
-        TGSF_LAUNCH(k_align_windows, blocks_for(n, 64), 64, st, c->P, (const uint8_t*)d_seq, (const uint64_t*)d_off,
+        TGSF_LAUNCH(k_align_windows, blocks_for(n, 64), 64, st, c->P, c->B, (const uint8_t*)d_seq, (const uint64_t*)d_off,
                     (const uint32_t*)d_len, (const uint8_t*)d_aid, (const int32_t*)d_k, n, d_res, d_ends);
         e |= rt_d2h(res, d_res, (size_t)n * 16, st);
         e |= rt_d2h(ends, d_ends, (size_t)n * 8, st);
