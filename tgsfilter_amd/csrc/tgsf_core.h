@@ -112,30 +112,38 @@ TGSF_HD void bv_step(Bv<NW>& s, const uint64_t* eq, int hin_top, int Q) {
 // ---------------------------------------------------------------------------
 // Hot-loop variant for Q <= 64 in infix mode: the adapter sits in the TOP Q bits
 // of one 64-bit word; the low 64-Q bits are wildcard rows (Eq=1, Pv=Mv=0) which
-// stay at distance 0 for ever (D[0][j]=0 boundary), so the bottom row is bit 63
-// and its horizontal delta is the carry out of the <<1.  Same recurrences as
-// edlib.cpp:416-441 with hin = 0.
+// stay at distance 0 for ever (D[0][j]=0 boundary).  Same recurrences as
+// edlib.cpp:416-441 with hin = 0, rearranged for gfx950, where every VALU op of a
+// loop that contains 3-input ops issues in 4 cycles, so instruction COUNT is what
+// matters (measured: tools/valu_rates.hip):
+//   Xh | Pv  =  ((sum ^ Pv) | Eq) | Pv  =  sum | Pv | Eq          one v_or3 per half
+//   Pv & Xh  =  (Pv & ~sum) | (Eq & Pv) =  bfi(sum, t, Pv)         one v_bfi per half  (t = Eq & Pv <= Pv)
+//   Mv | ~u  =  bfi(u, Mv, ~0)                                      one v_bfi per half
+// and the bottom-row value is not carried along: D[Q][j] is the sum of the
+// vertical deltas of column j, i.e. popcount(Pv) - popcount(Mv) (wildcard rows
+// contribute 0), evaluated only where it is needed.
 // ---------------------------------------------------------------------------
 struct Hot {
     uint64_t p, m;
-    int score;
 };
+TGSF_HD uint32_t popc64(uint64_t x) { return (uint32_t)__builtin_popcountll(x); }
 TGSF_HD void hot_init(Hot& s, int Q) {
     s.p = (Q >= 64) ? ~0ull : (~0ull << (64 - Q));
     s.m = 0ull;
-    s.score = Q;
 }
 TGSF_HD void hot_step(Hot& s, uint64_t Eq) {
-    uint64_t Pv = s.p, Mv = s.m;
-    uint64_t Xv = Eq | Mv;
-    uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
-    uint64_t Ph = Mv | ~(Xh | Pv);
-    uint64_t Mh = Pv & Xh;
-    s.score += (int)(Ph >> 63) - (int)(Mh >> 63);
+    const uint64_t Pv = s.p, Mv = s.m;
+    const uint64_t t = Eq & Pv;
+    const uint64_t sum = t + Pv;
+    const uint64_t u = sum | Pv | Eq;
+    uint64_t Ph = Mv | ~u;
+    uint64_t Mh = (sum & t) | (~sum & Pv);
     Ph <<= 1; Mh <<= 1;
+    const uint64_t Xv = Eq | Mv;
     s.p = Mh | ~(Xv | Ph);
     s.m = Ph & Xv;
 }
+TGSF_HD int hot_score(const Hot& s) { return (int)popc64(s.p) - (int)popc64(s.m); }
 
 // ---------------------------------------------------------------------------
 // Infix scan of a short window (read ends; single alignments for the pre-pass).
@@ -178,37 +186,6 @@ TGSF_HD int win_start(const uint64_t* peq_rev, int Q, const uint8_t* t, int end,
         if (s.score == best) best_l = l;
     }
     return end - best_l + 1;
-}
-
-// alignmentLength of the path edlib reports for adapter q vs t[0..T): number of
-// columns of the global alignment chosen by tracing back from the bottom-right
-// cell with priority up > left > diagonal (edlib.cpp:1023/1057/1088).  Each cell
-// has exactly one predecessor under that rule, so the length of the canonical
-// path to every cell can be carried FORWARD with the distances; one column of
-// (distance, length) pairs is the whole working set.  col(i) is lane-private
-// storage for row i (uint32: distance | length << 16).
-template <class Col>
-TGSF_HD int path_len(const uint8_t* q, int Q, const uint8_t* t, int T, Col col) {
-    for (int i = 0; i <= Q; i++) col(i) = (uint32_t)i | ((uint32_t)i << 16);
-    for (int j = 1; j <= T; j++) {
-        uint32_t d = col(0);
-        int diagN = (int)(d & 0xFFFF), diagL = (int)(d >> 16);
-        col(0) = (uint32_t)j | ((uint32_t)j << 16);
-        int upN = j, upL = j;
-        uint8_t tc = t[j - 1];
-        for (int i = 1; i <= Q; i++) {
-            uint32_t lf = col(i);
-            int leftN = (int)(lf & 0xFFFF), leftL = (int)(lf >> 16);
-            int v = diagN + (q[i - 1] != tc);
-            if (upN + 1 < v) v = upN + 1;
-            if (leftN + 1 < v) v = leftN + 1;
-            int l = (upN + 1 == v) ? upL + 1 : (leftN + 1 == v) ? leftL + 1 : diagL + 1;
-            diagN = leftN; diagL = leftL;
-            col(i) = (uint32_t)v | ((uint32_t)l << 16);
-            upN = v; upL = l;
-        }
-    }
-    return (int)(col(Q) >> 16);
 }
 
 // ---------------------------------------------------------------------------

@@ -922,8 +922,10 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
     };
     auto check_col = [&](int col) {
 #pragma unroll
-        for (int j = 0; j < AT; j++)
-            if (st[j].score <= lim[j]) { lim[j] = st[j].score; push_candidate(B, r, col, st[j].score, a0 + j); }
+        for (int j = 0; j < AT; j++) {
+            const int sc = hot_score(st[j]);
+            if (sc <= lim[j]) { lim[j] = sc; push_candidate(B, r, col, sc, a0 + j); }
+        }
     };
 
     // warm-up: [c, c0)
@@ -940,35 +942,39 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
     }
     while (c < c0) { step_all(mid[c]); c++; }
 
-    // owned columns: [c0, c1)
+    // owned columns: [c0, c1).  The bottom-row value moves by at most 1 per column, so it is
+    // evaluated after every 4th column only; the 3 skipped columns are re-examined (from the
+    // states kept in registers) when that value comes within 3 of the recording limit.
     while (c < c1 && ((uintptr_t)(mid + c) & 15u)) { step_all(mid[c]); check_col(c); c++; }
     while (c + 16 <= c1) {
         uint4 v = *reinterpret_cast<const uint4*>(mid + c);
         const uint32_t d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            int s1[AT], s2[AT], s3[AT];
+            Hot h1[AT], h2[AT], h3[AT];
             step_all(d[k] & 0xFFu);
 #pragma unroll
-            for (int j = 0; j < AT; j++) s1[j] = st[j].score;
+            for (int j = 0; j < AT; j++) h1[j] = st[j];
             step_all((d[k] >> 8) & 0xFFu);
 #pragma unroll
-            for (int j = 0; j < AT; j++) s2[j] = st[j].score;
+            for (int j = 0; j < AT; j++) h2[j] = st[j];
             step_all((d[k] >> 16) & 0xFFu);
 #pragma unroll
-            for (int j = 0; j < AT; j++) s3[j] = st[j].score;
+            for (int j = 0; j < AT; j++) h3[j] = st[j];
             step_all(d[k] >> 24);
+            int s4[AT];
             bool any = false;
 #pragma unroll
-            for (int j = 0; j < AT; j++) any |= (st[j].score <= lim[j] + 3);
+            for (int j = 0; j < AT; j++) { s4[j] = hot_score(st[j]); any |= (s4[j] <= lim[j] + 3); }
             if (any) {
 #pragma unroll
                 for (int j = 0; j < AT; j++) {
                     const int cc = c + 4 * k;
-                    if (s1[j] <= lim[j]) { lim[j] = s1[j]; push_candidate(B, r, cc, s1[j], a0 + j); }
-                    if (s2[j] <= lim[j]) { lim[j] = s2[j]; push_candidate(B, r, cc + 1, s2[j], a0 + j); }
-                    if (s3[j] <= lim[j]) { lim[j] = s3[j]; push_candidate(B, r, cc + 2, s3[j], a0 + j); }
-                    if (st[j].score <= lim[j]) { lim[j] = st[j].score; push_candidate(B, r, cc + 3, st[j].score, a0 + j); }
+                    const int s1 = hot_score(h1[j]), s2 = hot_score(h2[j]), s3 = hot_score(h3[j]);
+                    if (s1 <= lim[j]) { lim[j] = s1; push_candidate(B, r, cc, s1, a0 + j); }
+                    if (s2 <= lim[j]) { lim[j] = s2; push_candidate(B, r, cc + 1, s2, a0 + j); }
+                    if (s3 <= lim[j]) { lim[j] = s3; push_candidate(B, r, cc + 2, s3, a0 + j); }
+                    if (s4[j] <= lim[j]) { lim[j] = s4[j]; push_candidate(B, r, cc + 3, s4[j], a0 + j); }
                 }
             }
         }
