@@ -134,6 +134,9 @@ def main():
     ap.add_argument("--max-len", type=int, default=2_000_000)
     ap.add_argument("--cpu-sample-reads", type=int, default=6000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="batches in flight per GPU (one context + one HIP stream each); >1 overlaps the "
+                         "HBM-bound stats kernels of one batch with the VALU-bound adapter scan of another")
     args = ap.parse_args()
 
     import torch
@@ -158,23 +161,41 @@ def main():
     p = abi.make_params("ont", adapters=[synth.ONT_RAPID, synth.ONT_RAPID_RC], min_len=1000, min_q=10.0,
                         head_trim=0, tail_trim=0, max_batch_bases=max_bases + 64, max_batch_reads=args.reads,
                         max_read_len=max_len)
-    ctx = capi.Context(p, local_rank)
+    NS = max(1, args.streams)
+    ctxs = [capi.Context(p, local_rank) for _ in range(NS)]
+    ctx = ctxs[0]
     fcap = max_bases // 1000 + args.reads + 16
-    d_reads = torch.empty(args.reads * 32, dtype=torch.uint8, device=device)
-    d_frags = torch.empty(fcap * 24, dtype=torch.uint8, device=device)
-    d_nfr = torch.zeros(4, dtype=torch.int32, device=device)
-    h_reads = torch.empty(args.reads * 32, dtype=torch.uint8).pin_memory()
-    stream = torch.cuda.current_stream()
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=device) for _ in range(NS - 1)]
+    outs = [dict(reads=torch.empty(args.reads * 32, dtype=torch.uint8, device=device),
+                 frags=torch.empty(fcap * 24, dtype=torch.uint8, device=device),
+                 nfr=torch.zeros(4, dtype=torch.int32, device=device),
+                 h_reads=torch.empty(args.reads * 32, dtype=torch.uint8).pin_memory()) for _ in range(NS)]
 
     def step(i):
         b = batches[i % 2]
-        ctx.submit_device(b["seq"].data_ptr(), b["qual"].data_ptr(), b["offsets"].data_ptr(), b["lengths"].data_ptr(),
-                          b["n"], b["n_bytes"], d_reads.data_ptr(), d_frags.data_ptr(), fcap, d_nfr.data_ptr(),
-                          stream.cuda_stream)
-        h_reads.copy_(d_reads, non_blocking=True)      # the per-read records go back to the host every step
+        k = i % NS
+        o = outs[k]
+        with torch.cuda.stream(streams[k]):
+            ctxs[k].submit_device(b["seq"].data_ptr(), b["qual"].data_ptr(), b["offsets"].data_ptr(),
+                                  b["lengths"].data_ptr(), b["n"], b["n_bytes"], o["reads"].data_ptr(),
+                                  o["frags"].data_ptr(), fcap, o["nfr"].data_ptr(), streams[k].cuda_stream)
+            o["h_reads"].copy_(o["reads"], non_blocking=True)   # the per-read records go back to the host every step
         return b["bases"], b["n"]
 
-    d_ctr_ptr, ctr_words = ctx.counters_device_ptr()
+    ctr_words = ctx.ctr_words
+
+    def all_wait():
+        for c in ctxs:
+            c.wait()
+
+    def all_counters():
+        tot = ctxs[0].counters()
+        for c in ctxs[1:]:
+            o = c.counters()
+            rows = np.maximum(tot[abi.CTR_ROWS:abi.CTR_ROWS + 4], o[abi.CTR_ROWS:abi.CTR_ROWS + 4])
+            tot = tot + o
+            tot[abi.CTR_ROWS:abi.CTR_ROWS + 4] = rows
+        return tot
 
     def barrier():
         if world > 1:
@@ -183,9 +204,10 @@ def main():
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
-    ctx.wait()
-    ctx.reset_counters()
-    ctx.profile(True)
+    all_wait()
+    for c in ctxs:
+        c.reset_counters()
+        c.profile(True)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -196,13 +218,9 @@ def main():
         reads += n
     if world > 1:
         # the job's only exchange: sum the tally vector over ranks (the 4 "rows used" words are maxima)
-        ctr = torch.empty(0)
-        import ctypes
-        buf = (ctypes.c_int64 * ctr_words).from_address(0)  # placeholder type only
-        del buf
         t = torch.zeros(ctr_words, dtype=torch.int64, device=device)
-        ctx.wait()
-        t.copy_(torch.from_numpy(ctx.counters().view(np.int64)))
+        all_wait()
+        t.copy_(torch.from_numpy(all_counters().view(np.int64)))
         rows = t[abi.CTR_ROWS:abi.CTR_ROWS + 4].clone()
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         dist.all_reduce(rows, op=dist.ReduceOp.MAX)
@@ -211,9 +229,9 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    ctx.wait()
+    all_wait()
     if world == 1:
-        total_ctr = ctx.counters()
+        total_ctr = all_counters()
 
     # max over ranks of the elapsed time; sum of the bases
     if world > 1:
@@ -230,7 +248,12 @@ def main():
     drop = total_ctr[:17]
     assert int(drop[0]) + int(drop[2:10].sum()) == reads_all, (drop, reads_all)
 
-    stages, nb = ctx.stage_times()
+    stages, nb = {}, 0
+    for c in ctxs:
+        st_c, nb_c = c.stage_times()
+        nb += nb_c
+        for k, v in st_c.items():
+            stages[k] = stages.get(k, 0.0) + v
     dom = "mid_scan"
     t_dom = stages[dom] / max(nb, 1) / 1e3                   # seconds per launch of the dominant stage
     t_all = sum(stages.values()) / max(nb, 1) / 1e3
@@ -258,6 +281,7 @@ def main():
                            int(np.ceil(4_000_000 / args.reads))),
             "reads_per_step_per_gpu": args.reads,
             "parallelism": "reads sharded over %d GPU(s), one all-reduce of the tallies" % world,
+            "batches_in_flight_per_gpu": NS,
         },
         "roofline": {
             "bound": "hbm", "kernel": "k_mid_scan1<2> (Myers infix scan, stage 'mid_scan')",

@@ -80,6 +80,7 @@ struct DevBatch {
 
     uint64_t* scratch;         // traceback columns, one region per wave: [column][word][lane]
     size_t    scratch_wave_words;
+    size_t    scratch_mid_wave0; // first wave region of k_mid_resolve (after those of k_end_windows)
 
     uint64_t* ctr;             // the flat tally vector (include/tgsf.h layout)
     uint32_t* status;          // [4] device-side error words: [0] code, [1] detail

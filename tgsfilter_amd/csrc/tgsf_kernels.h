@@ -799,10 +799,11 @@ TGSF_D int min_start_all(const DevParams& P, int a, const uint8_t* t, int T, int
     return mn;
 }
 
-TGSF_D LaneScratch lane_scratch(const DevBatch& B)
+TGSF_D LaneScratch lane_scratch(const DevBatch& B, size_t first_wave)
 {
-    // one region per wave of the launch: [column][word][lane]
-    const size_t wave_id = (size_t)gtid() >> 6;
+    // one region per wave of the launch: [column][word][lane].  k_end_windows and k_mid_resolve may
+    // run concurrently (different streams): they use disjoint wave ranges.
+    const size_t wave_id = first_wave + ((size_t)gtid() >> 6);
     LaneScratch sc;
     sc.base = B.scratch + wave_id * B.scratch_wave_words + (threadIdx.x & 63u);
     return sc;
@@ -831,7 +832,7 @@ TGSF_KERNEL k_end_windows(DevParams P, DevBatch B)
     if (W5 < 5) return;                                   // :1274
     if (P.k_end[a] < 0) return;                           // match length > adapter: can never pass :1283
     const uint8_t* t = B.seq + B.off[r] + (e ? (L - W5) : 0);
-    const LaneScratch sc = lane_scratch(B);
+    const LaneScratch sc = lane_scratch(B, 0);
     const int need = P.need_end[a];                        // mlen >= EndMatchLen && float(mlen)/Q >= EndSim (:1283-1288)
     WinAln w = (Q <= 64) ? align_window<1>(P, a, t, W5, P.k_end[a], need, sc, false)
                          : align_window<2>(P, a, t, W5, P.k_end[a], need, sc, false);
@@ -1041,7 +1042,7 @@ TGSF_KERNEL k_mid_resolve(DevParams P, DevBatch B)
     if (best == (1 << 30)) return;
     const int L = (int)B.len[r], E = P.end_len, Q = P.Q[a];
     const uint8_t* win = B.seq + B.off[r] + E;
-    const LaneScratch sc = lane_scratch(B);
+    const LaneScratch sc = lane_scratch(B, B.scratch_mid_wave0);
     const int need = P.need_mid[a];                                      // :1246, :1250-1252
     const int s0 = (Q <= 64) ? start_of<1>(P, a, win, e0, best) : start_of<2>(P, a, win, e0, best);
     const int mlen = (Q <= 64) ? first_mlen<1>(P, a, win, s0, e0, best, need, sc, false)
@@ -1264,7 +1265,7 @@ TGSF_KERNEL k_align_windows(DevParams P, DevBatch B, const uint8_t* seq, const u
     const int Q = P.Q[a];
     int k = kk[i];
     if (k > Q) k = Q;                                    // edlib.cpp:565-567
-    const LaneScratch sc = lane_scratch(B);
+    const LaneScratch sc = lane_scratch(B, 0);
     const uint8_t* t = seq + win_off[i];
     WinAln w = (Q <= 64) ? align_window<1>(P, a, t, (int)win_len[i], k, 0, sc, true)
                          : align_window<2>(P, a, t, (int)win_len[i], k, 0, sc, true);

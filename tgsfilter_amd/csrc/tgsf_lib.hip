@@ -64,7 +64,10 @@ struct tgsf_ctx {
     // ring of event sets: one set per profiled batch, harvested at tgsf_wait (no per-batch sync)
     static constexpr int kProfRing = 64;
     hipEvent_t ev[kProfRing][TGSF_N_STAGES + 1];
+    hipEvent_t ev_aux[kProfRing][3];      // around the two kernels that run on the auxiliary stream
     int prof_pending;
+    hipStream_t aux;                      // end-window / end-table kernels overlap the middle scan here
+    hipEvent_t ev_fork, ev_join;
 #endif
     uint32_t h_status[4];
 };
@@ -197,8 +200,13 @@ extern "C" void tgsf_destroy(tgsf_ctx* c)
 #if !defined(TGSF_EMUL)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (int k = 0; k < tgsf_ctx::kProfRing; k++)
+    for (int k = 0; k < tgsf_ctx::kProfRing; k++) {
         for (int i = 0; i <= TGSF_N_STAGES; i++) if (c->ev[k][i]) (void)hipEventDestroy(c->ev[k][i]);
+        for (int i = 0; i < 3; i++) if (c->ev_aux[k][i]) (void)hipEventDestroy(c->ev_aux[k][i]);
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
 #endif
     for (void* p : c->allocs) rt_free(p);
@@ -246,6 +254,8 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     for (int a = 0; a < p->n_adapters; a++) c->params.adapters[a] = c->adapters[a].data();
 #if !defined(TGSF_EMUL)
     memset(c->ev, 0, sizeof c->ev);
+    memset(c->ev_aux, 0, sizeof c->ev_aux);
+    c->aux = nullptr; c->ev_fork = c->ev_join = nullptr;
     int ndev = 0;
     hipError_t he = hipGetDeviceCount(&ndev);
     if (he != hipSuccess || ndev <= 0) {
@@ -259,6 +269,11 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     }
     c->own_stream = true;
     c->prof_pending = 0;
+    if ((he = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking)) != hipSuccess ||
+        (he = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess ||
+        (he = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) {
+        tgsf_destroy(c); return fail(nullptr, TGSF_E_HIP, "auxiliary stream: %s", hipGetErrorString(he));
+    }
 #else
     c->stream = nullptr; c->own_stream = false;
 #endif
@@ -330,7 +345,8 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
         }
         c->scratch_cols = maxcols;
         B.scratch_wave_words = (size_t)(maxcols + 1) * 2 * P.max_nw * 64;
-        const size_t waves = ((size_t)n * A * 2 + 63) / 64 + 1;
+        B.scratch_mid_wave0 = ((size_t)n * A * 2 + 63) / 64 + 1;
+        const size_t waves = B.scratch_mid_wave0 + ((size_t)n * A + 63) / 64 + 1;
         if (!e) e = dev_alloc(c, &B.scratch, waves * B.scratch_wave_words);
     }
     if (!e) e = dev_alloc(c, &B.ctr, (size_t)c->ctr_words);
@@ -368,10 +384,14 @@ static int harvest_profile(tgsf_ctx* c, rt_stream st)
     if (!c->prof_pending) return TGSF_OK;
     hipError_t he = hipStreamSynchronize(st);
     if (he != hipSuccess) return fail(c, TGSF_E_HIP, "stream synchronize failed: %s", hipGetErrorString(he));
+    (void)hipStreamSynchronize(c->aux);
     for (int k = 0; k < c->prof_pending; k++)
         for (int i = 0; i < TGSF_N_STAGES - 1; i++) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, c->ev[k][i], c->ev[k][i + 1]) == hipSuccess) c->stage_ms[i] += ms;
+            // stages 3 (end_tables_raw) and 4 (end_windows) run on the auxiliary stream, beside stage 5
+            hipError_t e = (i == 3 || i == 4) ? hipEventElapsedTime(&ms, c->ev_aux[k][i - 3], c->ev_aux[k][i - 2])
+                                              : hipEventElapsedTime(&ms, c->ev[k][i], c->ev[k][i + 1]);
+            if (e == hipSuccess) c->stage_ms[i] += ms;
         }
     c->prof_pending = 0;
     return TGSF_OK;
@@ -396,7 +416,12 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
 #if !defined(TGSF_EMUL)
     if (c->profile && c->prof_pending == tgsf_ctx::kProfRing) { int e = harvest_profile(c, st); if (e) return e; }
     hipEvent_t* evs = c->ev[c->profile ? c->prof_pending : 0];
-    if (c->profile) for (int i = 0; i <= TGSF_N_STAGES; i++) if (!evs[i]) (void)hipEventCreate(&evs[i]);
+    hipEvent_t* evx = c->ev_aux[c->profile ? c->prof_pending : 0];
+    if (c->profile) {
+        for (int i = 0; i <= TGSF_N_STAGES; i++) if (!evs[i]) (void)hipEventCreate(&evs[i]);
+        for (int i = 0; i < 3; i++) if (!evx[i]) (void)hipEventCreate(&evx[i]);
+    }
+    hipStream_t ax = c->aux;
 #define STAGE_MARK() do { if (c->profile) (void)hipEventRecord(evs[stage], st); stage++; } while (0)
 #else
 #define STAGE_MARK() do { stage++; } while (0)
@@ -417,12 +442,28 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     STAGE_MARK();
     TGSF_LAUNCH(k_gate_reads, gsmall, T, st, P, B);
     STAGE_MARK();
-    if (P.bc_len > 0) TGSF_LAUNCH(k_end_tables<false>, grid_cap(128u), 64 * kEndWaves, st, P, B);
-    STAGE_MARK();
+    // The 5'/3' QC tables and the end-window searches only need the gate; they are short,
+    // latency-bound kernels, so they run on the auxiliary stream beside the middle scan.
+#if !defined(TGSF_EMUL)
+    (void)hipEventRecord(c->ev_fork, st);
+    (void)hipStreamWaitEvent(ax, c->ev_fork, 0);
+    if (c->profile) (void)hipEventRecord(evx[0], ax);
+#else
+    rt_stream ax = st;
+#endif
+    if (P.bc_len > 0) TGSF_LAUNCH(k_end_tables<false>, grid_cap(128u), 64 * kEndWaves, ax, P, B);
+#if !defined(TGSF_EMUL)
+    if (c->profile) (void)hipEventRecord(evx[1], ax);
+#endif
     if (P.filter && A > 0) {
         const uint64_t nw = (uint64_t)n * A * 2;
-        TGSF_LAUNCH(k_end_windows, blocks_for(nw, 64), 64, st, P, B);
+        TGSF_LAUNCH(k_end_windows, blocks_for(nw, 64), 64, ax, P, B);
     }
+#if !defined(TGSF_EMUL)
+    if (c->profile) (void)hipEventRecord(evx[2], ax);
+    (void)hipEventRecord(c->ev_join, ax);
+#endif
+    STAGE_MARK();
     STAGE_MARK();
     if (P.filter && A > 0) {
         TGSF_LAUNCH_COOP(k_scan_u32, 1, 1024, st, B.seg_cnt, (const uint32_t*)nullptr, n);
@@ -446,6 +487,9 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     STAGE_MARK();
     if (P.filter && A > 0) TGSF_LAUNCH(k_mid_resolve, blocks_for((uint64_t)n * A, 64), 64, st, P, B);
     STAGE_MARK();
+#if !defined(TGSF_EMUL)
+    (void)hipStreamWaitEvent(st, c->ev_join, 0);      // regions need the end-window results
+#endif
     TGSF_LAUNCH(k_regions<false>, gsmall, T, st, P, B);
     TGSF_LAUNCH_COOP(k_scan_u32, 1, 1024, st, B.nfr, (const uint32_t*)nullptr, n);
     TGSF_LAUNCH(k_regions<true>, gsmall, T, st, P, B);
