@@ -127,14 +127,14 @@ def cpu_baseline(torch, batch, flags, adapter_fa, sample_reads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads", type=int, default=32768, help="reads per step per GPU")
+    ap.add_argument("--reads", type=int, default=65536, help="reads per step per GPU")
     ap.add_argument("--mean-len", type=float, default=45000.0)
     ap.add_argument("--max-len", type=int, default=2_000_000)
     ap.add_argument("--cpu-sample-reads", type=int, default=6000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=1,
+    ap.add_argument("--streams", type=int, default=2,
                     help="batches in flight per GPU (one context + one HIP stream each); >1 overlaps the "
                          "HBM-bound stats kernels of one batch with the VALU-bound adapter scan of another")
     args = ap.parse_args()
@@ -142,6 +142,7 @@ def main():
     import torch
     import torch.distributed as dist
     from tgsfilter_amd import abi, capi, synth
+    from tgsfilter_amd import dist as tdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -173,7 +174,7 @@ def main():
 
     def step(i):
         b = batches[i % 2]
-        k = i % NS
+        k = i % NS if NS > 1 else 0
         o = outs[k]
         with torch.cuda.stream(streams[k]):
             ctxs[k].submit_device(b["seq"].data_ptr(), b["qual"].data_ptr(), b["offsets"].data_ptr(),
@@ -189,13 +190,7 @@ def main():
             c.wait()
 
     def all_counters():
-        tot = ctxs[0].counters()
-        for c in ctxs[1:]:
-            o = c.counters()
-            rows = np.maximum(tot[abi.CTR_ROWS:abi.CTR_ROWS + 4], o[abi.CTR_ROWS:abi.CTR_ROWS + 4])
-            tot = tot + o
-            tot[abi.CTR_ROWS:abi.CTR_ROWS + 4] = rows
-        return tot
+        return tdist.merge_counters([c.counters() for c in ctxs])
 
     def barrier():
         if world > 1:
@@ -218,14 +213,8 @@ def main():
         reads += n
     if world > 1:
         # the job's only exchange: sum the tally vector over ranks (the 4 "rows used" words are maxima)
-        t = torch.zeros(ctr_words, dtype=torch.int64, device=device)
         all_wait()
-        t.copy_(torch.from_numpy(all_counters().view(np.int64)))
-        rows = t[abi.CTR_ROWS:abi.CTR_ROWS + 4].clone()
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        dist.all_reduce(rows, op=dist.ReduceOp.MAX)
-        t[abi.CTR_ROWS:abi.CTR_ROWS + 4] = rows
-        total_ctr = t.cpu().numpy().view(np.uint64)
+        total_ctr = tdist.allreduce_counters(all_counters(), device=device)
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
@@ -248,17 +237,43 @@ def main():
     drop = total_ctr[:17]
     assert int(drop[0]) + int(drop[2:10].sum()) == reads_all, (drop, reads_all)
 
-    stages, nb = {}, 0
+    def harvest():
+        st, nbat = {}, 0
+        for c in ctxs:
+            st_c, nb_c = c.stage_times()
+            nbat += nb_c
+            for k, v in st_c.items():
+                st[k] = st.get(k, 0.0) + v
+        return {k: v / max(nbat, 1) for k, v in st.items() if v > 0}, nbat
+
+    # kernel durations inside the timed region (with --streams > 1 kernels of different batches
+    # share the GPU, so a kernel's elapsed time is longer than its cost) ...
+    timed_stage_ms, _ = harvest()
+    # ... and the same kernels with the GPU to themselves: a few more steps on ONE stream, timed with
+    # the same HIP events on the launch stream.  The roofline figures use these exclusive durations.
     for c in ctxs:
-        st_c, nb_c = c.stage_times()
-        nb += nb_c
-        for k, v in st_c.items():
-            stages[k] = stages.get(k, 0.0) + v
+        c.profile(False)
+    NS_saved, nprof = NS, 4
+    ctxs[0].profile(True)
+    NS = 1
+    for i in range(nprof):
+        step(i)
+    torch.cuda.synchronize()
+    ctxs[0].wait()
+    excl_stage_ms, _ = harvest()
+    NS = NS_saved
     dom = "mid_scan"
-    t_dom = stages[dom] / max(nb, 1) / 1e3                   # seconds per launch of the dominant stage
-    t_all = sum(stages.values()) / max(nb, 1) / 1e3
+    t_dom = excl_stage_ms[dom] / 1e3                       # seconds per launch of the dominant kernel
+    # stages 'end_tables_raw' and 'end_windows' run on the library's auxiliary stream beside 'mid_scan'
+    t_all = sum(v for k, v in excl_stage_ms.items() if k not in ("end_tables_raw", "end_windows")) / 1e3
     alg_bytes = 2.0 * (bases / args.steps) + 32.0 * (reads / args.steps)    # 2 B/base + 32 B/read
     achieved = alg_bytes / t_dom / 1e9 if t_dom > 0 else 0.0
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tj):
+        tr = json.load(open(tj))
+        if tr.get("reads_per_step") == args.reads:
+            traffic = tr.get("mid_scan_hbm_bytes_per_launch")
 
     out = {
         "metric": "filtered Gbases/sec (end-to-end, excl. gzip I/O)",
@@ -286,10 +301,18 @@ def main():
         "roofline": {
             "bound": "hbm", "kernel": "k_mid_scan1<2> (Myers infix scan, stage 'mid_scan')",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic,
+            "measured": "HIP events on the launch stream around every stage (inside libtgsf); kernel durations "
+                        "of %d single-stream steps run right after the timed region (the GPU is not shared with "
+                        "another batch); 'timed_region_stage_ms' are the same events inside the timed region with "
+                        "%d batches in flight" % (nprof, NS),
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "kernel_ms": excl_stage_ms[dom],
             "pipeline_achieved": alg_bytes / t_all / 1e9 if t_all > 0 else 0.0,
             "pipeline_frac": (alg_bytes / t_all / 1e9 / HBM_PEAK_GBS) if t_all > 0 else 0.0,
-            "stage_ms_per_step": {k: v / max(nb, 1) for k, v in stages.items() if v > 0},
+            "whole_job_frac": (2.0 * bases_all / world + 32.0 * reads_all / world) / dt / 1e9 / HBM_PEAK_GBS,
+            "stage_ms_per_step": excl_stage_ms,
+            "timed_region_stage_ms": timed_stage_ms,
         },
     }
     if rank == 0:

@@ -21,6 +21,7 @@ struct DevParams {
     int need_end[kMaxAdapters];       // smallest mlen with mlen >= EndMatchLen && float(mlen)/Q >= EndSim  (:1283-1288)
     int need_mid[kMaxAdapters];       // smallest mlen with mlen >= MidMatchLen && float(mlen)/Q >= MidSim  (:1246-1252)
     int min_Q;                        // shortest adapter
+    int seg_cols;                     // columns of a read's middle owned by one lane of the infix scan
     uint32_t n_bins;                  // rows of the 100-bp tables
     const uint8_t* adapter;           // [kMaxAdapters][kMaxQ] bytes
     const uint64_t* peq_fwd;          // [kMaxAdapters][256][2]  standard layout

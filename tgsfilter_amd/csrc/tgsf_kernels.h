@@ -518,7 +518,7 @@ TGSF_KERNEL k_gate_reads(DevParams P, DevBatch B)
                         lowq_reads++; lowq_bases += L;
                     } else {
                         int ML = (int)L - 2 * P.end_len;              // :1236 tsmLen
-                        if (ML >= P.min_Q) segs = ((uint32_t)ML + kSegCols - 1) / kSegCols;
+                        if (ML >= P.min_Q) segs = ((uint32_t)ML + (uint32_t)P.seg_cols - 1) / (uint32_t)P.seg_cols;
                     }
                 }
                 B.seg_cnt[r] = segs;
@@ -897,8 +897,8 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
     const int L = (int)B.len[r];
     const int E = P.end_len;
     const int ML = L - 2 * E;
-    const int c0 = (int)seg * kSegCols;
-    int c1 = c0 + kSegCols;
+    const int c0 = (int)seg * P.seg_cols;
+    int c1 = c0 + P.seg_cols;
     if (c1 > ML) c1 = ML;
     const uint8_t* mid = B.seq + B.off[r] + E;
 
@@ -1001,8 +1001,8 @@ TGSF_KERNEL k_mid_scan2(DevParams P, DevBatch B, int a)
     const int ML = L - 2 * E;
     const int Q = P.Q[a];
     if (ML < Q || P.k_mid[a] < 0) return;
-    const int c0 = (int)seg * kSegCols;
-    int c1 = c0 + kSegCols;
+    const int c0 = (int)seg * P.seg_cols;
+    int c1 = c0 + P.seg_cols;
     if (c1 > ML) c1 = ML;
     const uint8_t* mid = B.seq + B.off[r] + E;
     Bv<2> s;

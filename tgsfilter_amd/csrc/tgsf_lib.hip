@@ -291,6 +291,8 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     c->n_bins = tgsf_n_bins(p->max_read_len);
     P.n_bins = c->n_bins;
     c->ctr_words = tgsf_ctr_len(p->bc_len, c->n_bins);
+    P.seg_cols = kSegCols;
+    if (const char* e = getenv("TGSF_SEG_COLS")) { int v = atoi(e); if (v >= 256 && v <= 65536) P.seg_cols = v & ~15; }   // tuning knob
 
     int e = build_tables(c);
     DevBatch& B = c->B;
@@ -468,7 +470,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     if (P.filter && A > 0) {
         TGSF_LAUNCH_COOP(k_scan_u32, 1, 1024, st, B.seg_cnt, (const uint32_t*)nullptr, n);
         // upper bound of the segment count, known on the host: no device round trip
-        const uint64_t max_segs = in->n_bytes / kSegCols + n + 1;
+        const uint64_t max_segs = in->n_bytes / (uint64_t)P.seg_cols + n + 1;
         const unsigned gseg = blocks_for(max_segs, T);
         int a = 0;
         while (a < A) {
