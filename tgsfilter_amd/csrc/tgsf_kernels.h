@@ -518,7 +518,12 @@ TGSF_KERNEL k_gate_reads(DevParams P, DevBatch B)
                         lowq_reads++; lowq_bases += L;
                     } else {
                         int ML = (int)L - 2 * P.end_len;              // :1236 tsmLen
-                        if (ML >= P.min_Q) segs = ((uint32_t)ML + (uint32_t)P.seg_cols - 1) / (uint32_t)P.seg_cols;
+                        if (ML >= P.min_Q) {
+                            // segments are seg_cols-aligned blocks of the absolute address space
+                            const uint64_t a0 = (uint64_t)(uintptr_t)B.seq + B.off[r] + (uint64_t)P.end_len;
+                            const uint64_t S = (uint64_t)P.seg_cols;
+                            segs = (uint32_t)((a0 + (uint64_t)ML - 1) / S - a0 / S + 1);
+                        }
                     }
                 }
                 B.seg_cnt[r] = segs;
@@ -897,10 +902,14 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
     const int L = (int)B.len[r];
     const int E = P.end_len;
     const int ML = L - 2 * E;
-    const int c0 = (int)seg * P.seg_cols;
-    int c1 = c0 + P.seg_cols;
-    if (c1 > ML) c1 = ML;
     const uint8_t* mid = B.seq + B.off[r] + E;
+    // this lane owns the seg-th seg_cols-aligned block (absolute addresses) that overlaps the window
+    const uint64_t S = (uint64_t)P.seg_cols;
+    const uint64_t amid = (uint64_t)(uintptr_t)mid;
+    const uint64_t blk = amid / S + seg;
+    const int c0 = blk * S > amid ? (int)(blk * S - amid) : 0;
+    int c1 = (int)((blk + 1) * S - amid);
+    if (c1 > ML) c1 = ML;
 
     Hot st[AT];
     int lim[AT];              // record columns whose value is <= lim (then lim := value)
@@ -915,7 +924,7 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
     }
     int c = c0 - wu;
     if (c < 0) c = 0;
-    else if (c > 0) { int al = c - (int)((uintptr_t)(mid + c) & 15u); c = al > 0 ? al : c; }  // longer warm-up, aligned
+    else if (c > 0) { int al = c - (int)((amid + (uint64_t)c) & 63u); c = al > 0 ? al : c; }  // longer warm-up, 64-B aligned
 
     auto step_all = [&](uint32_t byte) {
 #pragma unroll
@@ -928,27 +937,19 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
             if (sc <= lim[j]) { lim[j] = sc; push_candidate(B, r, col, sc, a0 + j); }
         }
     };
-
-    // warm-up: [c, c0)
-    while (c < c0 && ((uintptr_t)(mid + c) & 15u)) { step_all(mid[c]); c++; }
-    while (c + 16 <= c0) {
-        uint4 v = *reinterpret_cast<const uint4*>(mid + c);
+    // 16 warm-up columns (nothing recorded)
+    auto warm16 = [&](const uint4& v) {
         const uint32_t d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             step_all(d[k] & 0xFFu); step_all((d[k] >> 8) & 0xFFu);
             step_all((d[k] >> 16) & 0xFFu); step_all(d[k] >> 24);
         }
-        c += 16;
-    }
-    while (c < c0) { step_all(mid[c]); c++; }
-
-    // owned columns: [c0, c1).  The bottom-row value moves by at most 1 per column, so it is
-    // evaluated after every 4th column only; the 3 skipped columns are re-examined (from the
-    // states kept in registers) when that value comes within 3 of the recording limit.
-    while (c < c1 && ((uintptr_t)(mid + c) & 15u)) { step_all(mid[c]); check_col(c); c++; }
-    while (c + 16 <= c1) {
-        uint4 v = *reinterpret_cast<const uint4*>(mid + c);
+    };
+    // 16 owned columns starting at column cc.  The bottom-row value moves by at most 1 per column,
+    // so it is evaluated after every 4th column only; the 3 skipped columns are re-examined (from
+    // the states kept in registers) when that value comes within 3 of the recording limit.
+    auto own16 = [&](const uint4& v, int cc0) {
         const uint32_t d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -970,7 +971,7 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
             if (any) {
 #pragma unroll
                 for (int j = 0; j < AT; j++) {
-                    const int cc = c + 4 * k;
+                    const int cc = cc0 + 4 * k;
                     const int s1 = hot_score(h1[j]), s2 = hot_score(h2[j]), s3 = hot_score(h3[j]);
                     if (s1 <= lim[j]) { lim[j] = s1; push_candidate(B, r, cc, s1, a0 + j); }
                     if (s2 <= lim[j]) { lim[j] = s2; push_candidate(B, r, cc + 1, s2, a0 + j); }
@@ -979,8 +980,24 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
                 }
             }
         }
-        c += 16;
+    };
+
+    // warm-up: [c, c0)
+    while (c < c0 && ((amid + (uint64_t)c) & 15u)) { step_all(mid[c]); c++; }
+    while (c + 16 <= c0) { warm16(*reinterpret_cast<const uint4*>(mid + c)); c += 16; }
+    while (c < c0) { step_all(mid[c]); c++; }
+
+    // owned columns: [c0, c1).  64 bytes per lane per fetch: a 128-byte line is touched by two
+    // fetch groups only (16-byte fetches were re-fetching evicted lines: 2.1x the bytes).
+    while (c < c1 && ((amid + (uint64_t)c) & 15u)) { step_all(mid[c]); check_col(c); c++; }
+    while (c + 16 <= c1 && ((amid + (uint64_t)c) & 63u)) { own16(*reinterpret_cast<const uint4*>(mid + c), c); c += 16; }
+    while (c + 64 <= c1) {
+        const uint4* p4 = reinterpret_cast<const uint4*>(mid + c);
+        const uint4 v0 = p4[0], v1 = p4[1], v2 = p4[2], v3 = p4[3];
+        own16(v0, c); own16(v1, c + 16); own16(v2, c + 32); own16(v3, c + 48);
+        c += 64;
     }
+    while (c + 16 <= c1) { own16(*reinterpret_cast<const uint4*>(mid + c), c); c += 16; }
     while (c < c1) { step_all(mid[c]); check_col(c); c++; }
 }
 
@@ -1001,10 +1018,13 @@ TGSF_KERNEL k_mid_scan2(DevParams P, DevBatch B, int a)
     const int ML = L - 2 * E;
     const int Q = P.Q[a];
     if (ML < Q || P.k_mid[a] < 0) return;
-    const int c0 = (int)seg * P.seg_cols;
-    int c1 = c0 + P.seg_cols;
-    if (c1 > ML) c1 = ML;
     const uint8_t* mid = B.seq + B.off[r] + E;
+    const uint64_t S = (uint64_t)P.seg_cols;
+    const uint64_t amid = (uint64_t)(uintptr_t)mid;
+    const uint64_t blk = amid / S + seg;
+    const int c0 = blk * S > amid ? (int)(blk * S - amid) : 0;
+    int c1 = (int)((blk + 1) * S - amid);
+    if (c1 > ML) c1 = ML;
     Bv<2> s;
     bv_init(s, Q);
     int lim = P.k_mid[a];

@@ -470,7 +470,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     if (P.filter && A > 0) {
         TGSF_LAUNCH_COOP(k_scan_u32, 1, 1024, st, B.seg_cnt, (const uint32_t*)nullptr, n);
         // upper bound of the segment count, known on the host: no device round trip
-        const uint64_t max_segs = in->n_bytes / (uint64_t)P.seg_cols + n + 1;
+        const uint64_t max_segs = in->n_bytes / (uint64_t)P.seg_cols + 2ull * n + 1;
         const unsigned gseg = blocks_for(max_segs, T);
         int a = 0;
         while (a < A) {
