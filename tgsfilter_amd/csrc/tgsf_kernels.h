@@ -937,19 +937,11 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
             if (sc <= lim[j]) { lim[j] = sc; push_candidate(B, r, col, sc, a0 + j); }
         }
     };
-    // 16 warm-up columns (nothing recorded)
-    auto warm16 = [&](const uint4& v) {
-        const uint32_t d[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            step_all(d[k] & 0xFFu); step_all((d[k] >> 8) & 0xFFu);
-            step_all((d[k] >> 16) & 0xFFu); step_all(d[k] >> 24);
-        }
-    };
-    // 16 owned columns starting at column cc.  The bottom-row value moves by at most 1 per column,
-    // so it is evaluated after every 4th column only; the 3 skipped columns are re-examined (from
-    // the states kept in registers) when that value comes within 3 of the recording limit.
-    auto own16 = [&](const uint4& v, int cc0) {
+    // 16 columns starting at column cc0; `own` = the lane records candidates there (false during
+    // the warm-up).  The bottom-row value moves by at most 1 per column, so it is evaluated after
+    // every 4th column only; the 3 skipped columns are re-examined (from the states kept in
+    // registers) when that value comes within 3 of the recording limit.
+    auto chunk16 = [&](const uint4& v, int cc0, bool own) {
         const uint32_t d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -968,7 +960,7 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
             bool any = false;
 #pragma unroll
             for (int j = 0; j < AT; j++) { s4[j] = hot_score(st[j]); any |= (s4[j] <= lim[j] + 3); }
-            if (any) {
+            if (any && own) {
 #pragma unroll
                 for (int j = 0; j < AT; j++) {
                     const int cc = cc0 + 4 * k;
@@ -982,23 +974,28 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
         }
     };
 
-    // warm-up: [c, c0)
-    while (c < c0 && ((amid + (uint64_t)c) & 15u)) { step_all(mid[c]); c++; }
-    while (c + 16 <= c0) { warm16(*reinterpret_cast<const uint4*>(mid + c)); c += 16; }
-    while (c < c0) { step_all(mid[c]); c++; }
-
-    // owned columns: [c0, c1).  64 bytes per lane per fetch: a 128-byte line is touched by two
-    // fetch groups only (16-byte fetches were re-fetching evicted lines: 2.1x the bytes).
-    while (c < c1 && ((amid + (uint64_t)c) & 15u)) { step_all(mid[c]); check_col(c); c++; }
-    while (c + 16 <= c1 && ((amid + (uint64_t)c) & 63u)) { own16(*reinterpret_cast<const uint4*>(mid + c), c); c += 16; }
-    while (c + 64 <= c1) {
+    // One instruction stream for warm-up and owned columns (a per-lane flag decides whether
+    // candidates are recorded), so lanes with different warm-up lengths stay converged and the
+    // 16-column body exists once in the code.  Block starts are seg_cols-aligned, so a 16-byte chunk
+    // never straddles c0; only the first block of a read (c0 = 0, no warm-up) starts unaligned.
+    while (c < c1 && ((amid + (uint64_t)c) & 15u)) { step_all(mid[c]); if (c >= c0) check_col(c); c++; }
+    // 64 bytes per lane per fetch: a 128-byte line is touched by two fetch groups only
+    // (16-byte fetches were re-fetching evicted lines: 2.1x the bytes, see profiles/).
+    while (c + 16 <= c1) {
         const uint4* p4 = reinterpret_cast<const uint4*>(mid + c);
-        const uint4 v0 = p4[0], v1 = p4[1], v2 = p4[2], v3 = p4[3];
-        own16(v0, c); own16(v1, c + 16); own16(v2, c + 32); own16(v3, c + 48);
-        c += 64;
+        uint4 v0 = p4[0], v1 = v0, v2 = v0, v3 = v0;
+        int nq = 1;
+        if (c + 32 <= c1) { v1 = p4[1]; nq = 2; }
+        if (c + 48 <= c1) { v2 = p4[2]; nq = 3; }
+        if (c + 64 <= c1) { v3 = p4[3]; nq = 4; }
+#pragma unroll 1
+        for (int q = 0; q < nq; q++) {
+            chunk16(v0, c, c >= c0);
+            c += 16;
+            v0 = v1; v1 = v2; v2 = v3;
+        }
     }
-    while (c + 16 <= c1) { own16(*reinterpret_cast<const uint4*>(mid + c), c); c += 16; }
-    while (c < c1) { step_all(mid[c]); check_col(c); c++; }
+    while (c < c1) { step_all(mid[c]); if (c >= c0) check_col(c); c++; }
 }
 
 // adapters of 65..128 bp: two-word standard layout, one adapter per pass
