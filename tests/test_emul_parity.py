@@ -49,3 +49,13 @@ def test_emul_long_reads_and_four_adapters(emul):
     ctx = capi.Context(p, 0, emul)
     parity.compare_batch(ctx, p, reads)
     ctx.close()
+
+
+def test_emul_edge_lengths(emul):
+    from tests.test_gpu_parity import _edge_reads
+    reads = _edge_reads()
+    p = parity.sized(abi.make_params("ont", adapters=[synth.ONT_RAPID, synth.ONT_RAPID_RC], min_q=7.0,
+                                     min_len=100, head_trim=3, tail_trim=2), reads)
+    ctx = capi.Context(p, 0, emul)
+    parity.compare_batch(ctx, p, reads)
+    ctx.close()

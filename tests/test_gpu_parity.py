@@ -55,3 +55,68 @@ def test_gpu_counters_accumulate_over_batches():
     ctx.reset_counters()
     assert not ctx.counters().any()
     ctx.close()
+
+
+def _edge_reads(seed=5):
+    """Tiny reads (1..8 bases: windows below 5, no middle), reads around the E / 2E+Q boundaries."""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    reads = []
+    for i, L in enumerate([1, 2, 3, 4, 5, 6, 7, 8, 49, 50, 51, 99, 100, 101, 149, 150, 151, 215, 216, 217, 299, 300, 301,
+                           349, 350, 351, 999, 1000, 1001, 6399, 6400, 6401, 12800, 12801]):
+        s = acgt[rng.integers(0, 4, L)].tobytes()
+        q = (rng.integers(5, 40, L) + 33).astype(np.uint8).tobytes()
+        reads.append((b"e%d" % i, s, q))
+    return reads
+
+
+def test_gpu_edge_lengths():
+    reads = _edge_reads()
+    p = parity.sized(abi.make_params("ont", adapters=[synth.ONT_RAPID, synth.ONT_RAPID_RC], min_q=7.0,
+                                     min_len=100, head_trim=3, tail_trim=2), reads)
+    ctx = capi.Context(p, 0)
+    parity.compare_batch(ctx, p, reads)
+    ctx.reset_counters()
+    parity.compare_batch(ctx, p, reads, align=1, explicit_lengths=False)
+    ctx.close()
+
+
+def test_gpu_phred64():
+    reads = [(n, s, bytes(b + 31 for b in q)) for n, s, q in synth.make_reads(41, 60, "ont", mean_len=4000, zoo=True)]
+    p = parity.sized(abi.make_params("ont", adapters=[synth.ONT_RAPID, synth.ONT_RAPID_RC], min_q=10.0, qtype=64), reads)
+    ctx = capi.Context(p, 0)
+    parity.compare_batch(ctx, p, reads)
+    ctx.close()
+
+
+def test_gpu_ultra_long_reads():
+    """Config C5 shape: a few reads of 0.3-2 Mb among ordinary ones (hundreds of stats tiles and
+    middle segments per read, candidate lists across many lanes)."""
+    rng = np.random.default_rng(9)
+    reads = synth.make_reads(9, 24, "ont", mean_len=20000, zoo=True, pmid=0.2)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for i, L in enumerate([300_000, 1_000_003, 2_000_000]):
+        s = bytearray(acgt[rng.integers(0, 4, L)].tobytes())
+        for frac in (0.2, 0.5, 0.9):
+            p0 = int(L * frac)
+            a = synth.mutate(rng, synth.ONT_RAPID if i % 2 else synth.ONT_RAPID_RC, 0.04)
+            s[p0:p0 + len(a)] = a
+        q = (np.clip(np.rint(rng.normal(14, 4, L)), 1, 50) + 33).astype(np.uint8).tobytes()
+        reads.append((b"ul%d" % i, bytes(s), q))
+    p = parity.sized(abi.make_params("ont", adapters=[synth.ONT_RAPID, synth.ONT_RAPID_RC], min_q=10.0), reads)
+    ctx = capi.Context(p, 0)
+    parity.compare_batch(ctx, p, reads)
+    ctx.close()
+
+
+def test_gpu_bad_quality_byte_is_reported():
+    reads = synth.make_reads(43, 8, "ont", mean_len=2000)
+    n, s, q = reads[3]
+    reads[3] = (n, s, q[:100] + bytes([200]) + q[101:])
+    p = parity.sized(abi.make_params("ont", adapters=[synth.ONT_RAPID]), reads)
+    ctx = capi.Context(p, 0)
+    seq, qual, off, ln = synth.pack(reads)
+    with pytest.raises(capi.TgsfError) as ei:
+        ctx.submit(seq, qual, off[:-1].copy(), ln)
+    assert ei.value.code == abi.E_DATA
+    ctx.close()
