@@ -36,7 +36,7 @@ extern "C" {
 #endif
 
 #define TGSF_ABI_VERSION 1
-#define TGSF_MAX_ADAPTERS 16      /* adapters.size(): 2 or 4 in practice (src/TGSFilter.cpp:3105-3125) */
+#define TGSF_MAX_ADAPTERS 32      /* adapters.size(): 2 or 4 in practice (src/TGSFilter.cpp:3105-3125) */
 #define TGSF_MAX_ADAPTER_LEN 128  /* two 64-row blocks; library adapters are 22..64 bp (:2970-2991) */
 #define TGSF_N_DROPINFO 17        /* DropInfo row, src/TGSFilter.cpp:1776 */
 #define TGSF_N_QBINS 256          /* raw/cleanDiffQualReadsBases, :1777-1778 */
@@ -124,8 +124,8 @@ typedef struct tgsf_read_result {
     uint32_t n_frags;      /* keepRegions.size() (:1960-1965); 0 if dropped                    */
     uint32_t frag_begin;   /* index of this read's first record in tgsf_batch_out.frags        */
     uint32_t trimmed;      /* bases this read added to DropInfo[10]                             */
-    int32_t  clip5;        /* end of the merged drop region starting at 0 (0 if none)          */
-    int32_t  clip3;        /* start of the merged drop region ending at L (L if none)          */
+    int32_t  reserved0;    /* 0 */
+    int32_t  reserved1;    /* 0 */
 } tgsf_read_result;
 
 /* tgsf_fragment.flags */

@@ -54,7 +54,9 @@ CASES = {
 
 def html_slices(html: str):
     table = re.findall(r"<tr>.*?</tr>", html, flags=re.S)
-    m = re.search(r"var data = (\{.*?\});", html, flags=re.S)
+    # the data object only: it ends at the "}" right before </script> (nothing of the page's
+    # own script text is kept)
+    m = re.search(r"var data = (\{.*?\})\n</script>", html, flags=re.S)
     return {"table_rows": table, "data": m.group(1) if m else None}
 
 

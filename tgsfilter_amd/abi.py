@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 ABI_VERSION = 1
-MAX_ADAPTERS = 16
+MAX_ADAPTERS = 32
 MAX_ADAPTER_LEN = 128
 N_DROPINFO = 17
 N_QBINS = 256
@@ -63,7 +63,7 @@ class BatchOut(C.Structure):
 
 READ_RESULT_DTYPE = np.dtype([
     ("sum_q", "<u8"), ("flags", "<u4"), ("n_frags", "<u4"), ("frag_begin", "<u4"),
-    ("trimmed", "<u4"), ("clip5", "<i4"), ("clip3", "<i4"),
+    ("trimmed", "<u4"), ("reserved0", "<i4"), ("reserved1", "<i4"),
 ])
 FRAGMENT_DTYPE = np.dtype([
     ("sum_q", "<u8"), ("read", "<u4"), ("start", "<i4"), ("len", "<i4"), ("flags", "<u4"),

@@ -26,7 +26,7 @@
 
 namespace tgsf {
 
-constexpr int kMaxAdapters = 16;
+constexpr int kMaxAdapters = 32;
 constexpr int kMaxQ = 128;         // two 64-row words
 constexpr int kBin = 100;          // CalcAvgQuality bin width
 constexpr int kTileBins = 64;      // one bin per lane

@@ -1256,7 +1256,7 @@ TGSF_KERNEL k_finalize(DevBatch B, tgsf_read_result* out_reads, tgsf_fragment* o
         o.n_frags = B.nfr[r + 1] - B.nfr[r];
         o.frag_begin = B.nfr[r];
         o.trimmed = B.trimmed[r];
-        o.clip5 = 0; o.clip3 = 0;
+        o.reserved0 = 0; o.reserved1 = 0;
         out_reads[r] = o;
     }
     for (uint32_t f = gtid(); f < nf && f < out_fcap; f += gsize()) {

@@ -1,0 +1,107 @@
+#include "fastx.h"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <cstring>
+#include <iostream>
+
+namespace host {
+
+static bool ends_with(const std::string& v, const std::string& e)
+{
+    return e.size() <= v.size() && std::equal(e.rbegin(), e.rend(), v.rbegin());
+}
+
+InputBytes::~InputBytes()
+{
+    if (map_) munmap(map_, map_len_);
+}
+
+bool InputBytes::open(const std::string& path)
+{
+    if (ends_with(path, ".gz")) {
+        gzFile g = gzopen(path.c_str(), "rb");          // multi-member gzip is handled by zlib (:632-639)
+        if (!g) { std::cerr << "Failed to open file: " << path << std::endl; return false; }
+        gzbuffer(g, 1 << 20);
+        std::vector<char> chunk(8 << 20);
+        int n;
+        while ((n = gzread(g, chunk.data(), (unsigned)chunk.size())) > 0) owned_.insert(owned_.end(), chunk.data(), chunk.data() + n);
+        if (n < 0) { std::cerr << "Error: Error encountered while decompressing file: " << path << std::endl; exit(-1); }
+        gzclose(g);
+        data_ = owned_.data(); size_ = owned_.size();
+        return true;
+    }
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) { std::cerr << "Failed to open file: " << path << std::endl; return false; }
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return false; }
+    size_ = (size_t)st.st_size;
+    if (size_ == 0) { close(fd); data_ = ""; return true; }
+    void* m = mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) { std::cerr << "Failed to open file: " << path << std::endl; return false; }
+    madvise(m, size_, MADV_SEQUENTIAL);
+    map_ = m; map_len_ = size_;
+    data_ = static_cast<const char*>(m);
+    return true;
+}
+
+std::string_view FastxReader::line()
+{
+    if (p_ >= end_) { done_ = true; return {}; }
+    const char* nl = static_cast<const char*>(memchr(p_, '\n', (size_t)(end_ - p_)));
+    const char* e = nl ? nl : end_;          // a last line without '\n' is still a line here (the reference reads out of bounds)
+    size_t n = (size_t)(e - p_);
+    if (n > 0 && e[-1] == '\r') n--;         // :666-668
+    std::string_view v(p_, n);
+    p_ = nl ? nl + 1 : end_;
+    return v;
+}
+
+bool FastxReader::next(Record& r) { return fastq_ ? next_fastq(r) : next_fasta(r); }
+
+bool FastxReader::next_fastq(Record& r)
+{
+    std::string_view name, seq, strand;
+    for (int i = 0; i < 5; i++) {                                     // :689-698
+        name = line();
+        if (!name.empty() && name[0] == '@') {
+            seq = line();
+            strand = line();
+            if (!strand.empty() && strand[0] == '+' && !seq.empty()) break;
+        }
+    }
+    if (done_) return false;                                          // :700-702
+    if (name.empty()) { std::cerr << "Error: input format wrong!" << std::endl; return false; }
+    name.remove_prefix(1);                                            // :709
+    std::string_view qual = line();
+    if (qual.empty()) { std::cerr << "Error: quality are empty:" << name << std::endl; return false; }
+    if (qual.size() != seq.size()) {
+        std::cerr << "warning: sequence and quality have different length:" << name << std::endl;
+        return false;
+    }
+    r.name = name; r.seq = seq; r.qual = qual;
+    return true;
+}
+
+bool FastxReader::next_fasta(Record& r)
+{
+    std::string_view name;
+    for (int i = 0; i < 3; i++) {                                     // :732-737
+        name = line();
+        if (!name.empty() && name[0] == '>') break;
+    }
+    if (done_) return false;
+    if (name.empty()) { std::cerr << "Error: input format wrong!" << std::endl; return false; }
+    name.remove_prefix(1);
+    std::string_view seq = line();
+    if (seq.empty()) { std::cerr << "Error: sequence are empty:" << name << std::endl; return false; }
+    r.name = name; r.seq = seq; r.qual = {};
+    return true;
+}
+
+}  // namespace host

@@ -1,0 +1,44 @@
+// fastx.h -- FASTA/FASTQ record reader with the reference's record semantics
+// (FastxReader, src/TGSFilter.cpp:521-782): strict 4-line FASTQ / 2-line FASTA, "\r\n" tolerated
+// (:666-668), header = everything after '@'/'>' (:709, :748), up to 5 (FASTQ) / 3 (FASTA) lines are
+// tried for a header (:689-698, :732-737), the stream ENDS at the first malformed record (:700-723).
+// Input is a flat byte range: plain files are mmap'ed, .gz files are inflated into memory (zlib).
+#pragma once
+#include <cstddef>
+#include <string>
+#include <string_view>
+#include <vector>
+
+namespace host {
+
+class InputBytes {
+public:
+    ~InputBytes();
+    bool open(const std::string& path);         // prints "Failed to open file: <path>" on failure (:564)
+    const char* data() const { return data_; }
+    size_t size() const { return size_; }
+private:
+    const char* data_ = nullptr;
+    size_t size_ = 0;
+    void* map_ = nullptr;
+    size_t map_len_ = 0;
+    std::vector<char> owned_;
+};
+
+struct Record { std::string_view name, seq, qual; };
+
+class FastxReader {
+public:
+    FastxReader(const char* data, size_t size, bool fastq) : p_(data), end_(data + size), fastq_(fastq) {}
+    bool next(Record& r);        // false: end of input (or first malformed record, after the reference's message)
+private:
+    std::string_view line();     // "" at end of input (then done_ is set, like getLine :676-680)
+    bool next_fastq(Record& r);
+    bool next_fasta(Record& r);
+    const char* p_;
+    const char* end_;
+    bool fastq_;
+    bool done_ = false;
+};
+
+}  // namespace host

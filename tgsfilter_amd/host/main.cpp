@@ -1,0 +1,348 @@
+// main.cpp -- `tgsfilter` for MI355X: the reference's command line, stderr lines and report around
+// the batch pipeline  reader -> [batch queue] -> GPU feeder (tgsf_submit) -> [batch queue] -> writer.
+//
+// Replaces main (src/TGSFilter.cpp:2945-3332) and TGSFilterTask (:1755-2162): the reference moves one
+// read at a time as three std::string copies through lock-free queues to N worker threads; here reads
+// are packed once into 16-byte-aligned CSR batches, filtered on the GPU through the C ABI, and the kept
+// fragments are formatted straight from the batch buffers in input order (= the reference's -t 1 order).
+#include <zlib.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <fstream>
+#include <iostream>
+#include <memory>
+#include <mutex>
+#include <thread>
+
+#include "fastx.h"
+#include "options.h"
+#include "prepass.h"
+#include "report.h"
+#include "tgsf.h"
+
+using namespace host;
+
+namespace {
+
+struct Batch {
+    std::vector<uint8_t> seq, qual;
+    std::vector<uint64_t> off;
+    std::vector<uint32_t> len;
+    std::vector<std::string_view> names;     // views into the (mmap'ed) input
+    std::vector<tgsf_read_result> res;
+    std::vector<tgsf_fragment> frags;
+    uint32_t n_frags = 0;
+    uint64_t bases = 0;
+};
+
+template <class T>
+class Channel {                               // small bounded queue; nullptr closes it
+public:
+    explicit Channel(size_t cap) : cap_(cap) {}
+    void put(T v) {
+        std::unique_lock<std::mutex> l(m_);
+        not_full_.wait(l, [&] { return q_.size() < cap_; });
+        q_.push_back(std::move(v));
+        not_empty_.notify_one();
+    }
+    T get() {
+        std::unique_lock<std::mutex> l(m_);
+        not_empty_.wait(l, [&] { return !q_.empty(); });
+        T v = std::move(q_.front());
+        q_.pop_front();
+        not_full_.notify_one();
+        return v;
+    }
+private:
+    std::mutex m_;
+    std::condition_variable not_full_, not_empty_;
+    std::deque<T> q_;
+    size_t cap_;
+};
+
+// newSeqName, src/TGSFilter.cpp:1680-1701: ":<n>" goes before the first whitespace of the header
+void append_name(std::string& out, std::string_view raw, int number)
+{
+    if (number < 2) { out.append(raw); return; }
+    const std::string add = ":" + std::to_string(number);
+    size_t i = 0;
+    while (i < raw.size() && !std::isspace((unsigned char)raw[i])) i++;
+    out.append(raw.substr(0, i));
+    out += add;
+    out.append(raw.substr(i));
+}
+
+class Output {                                // plain or per-record gzip members (:2020-2053, :786-812)
+public:
+    bool open(const Options& o) {
+        gz_ = o.out_gz;
+        if (o.out_file.empty()) f_ = stdout;
+        else f_ = fopen(o.out_file.c_str(), "wb");
+        if (!f_) { std::cerr << "Error: Failed to open file: " << o.out_file << std::endl; return false; }
+        setvbuf(f_, nullptr, _IOFBF, 8 << 20);
+        if (gz_) {
+            memset(&z_, 0, sizeof z_);
+            if (deflateInit2(&z_, o.comp_level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+        }
+        return true;
+    }
+    void write(const std::string& rec) {
+        if (!gz_) { fwrite(rec.data(), 1, rec.size(), f_); return; }
+        deflateReset(&z_);
+        zbuf_.resize(deflateBound(&z_, (uLong)rec.size()) + 64);
+        z_.next_in = (Bytef*)rec.data(); z_.avail_in = (uInt)rec.size();
+        z_.next_out = (Bytef*)zbuf_.data(); z_.avail_out = (uInt)zbuf_.size();
+        deflate(&z_, Z_FINISH);
+        fwrite(zbuf_.data(), 1, zbuf_.size() - z_.avail_out, f_);
+    }
+    void close() {
+        if (gz_) deflateEnd(&z_);
+        if (f_ && f_ != stdout) fclose(f_); else if (f_) fflush(f_);
+        f_ = nullptr;
+    }
+private:
+    FILE* f_ = nullptr;
+    bool gz_ = false;
+    z_stream z_;
+    std::vector<char> zbuf_;
+};
+
+[[noreturn]] void die(const std::string& msg)
+{
+    std::cerr << "Error: " << msg << std::endl;
+    exit(-1);
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    Options o;
+    if (parse_args(argc, argv, o)) return 1;
+
+    // file types and report name, :2993-3033
+    o.in_type = file_type(o.in_file);
+    const std::string prefix = file_prefix(o.in_file);
+    std::string html = prefix + ".html";
+    if (!o.out_file.empty() && !o.only_qc) {
+        html = file_prefix(o.out_file) + ".html";
+        o.out_type = file_type(o.out_file);
+        if (file_extension(o.out_file) == "gz") o.out_gz = true;
+    } else {
+        o.out_type = o.fasta_out ? 0 : (o.in_type == 2 ? 1 : o.in_type);
+    }
+    if (o.in_type == 3 || o.out_type == 3) {
+        std::cerr << "Error: The file name suffix should be '.[fastq|fq|fasta|fa][.gz] or .[sam|bam]'" << std::endl;
+        if (o.in_type == 3) std::cerr << "Error: Please check your input file name: " << o.in_file << std::endl;
+        else std::cerr << "Error: Please check your output file name: " << o.out_file << std::endl;
+        return 1;
+    }
+    if (o.in_type == 0 && o.out_type == 1) { std::cerr << "Error: Fasta format input file can't output fastq format file" << std::endl; return 1; }
+    // rows of SURVEY 8(f) that are not built yet fail loudly instead of silently doing something else
+    if (o.in_type == 2) die("BAM/SAM input is not supported by this build (SURVEY 8f-4)");
+    if (o.in_type == 0) die("FASTA input (no qualities) is not supported by this build");
+    if (o.downsample || o.min_repeat > 0) die("downsampling (-g/-d/-r/-R) and the repeat filter (-p/-k) are not supported by this build (SURVEY 8f-3)");
+
+    InputBytes in;
+    if (!in.open(o.in_file)) return 1;
+
+    // ---- pre-pass, :3058-3126 ----
+    PrepassResult pp = run_prepass(o, in);
+    std::vector<std::string> adapters;
+    if (o.filter) {
+        if (o.head_trim < 0) o.head_trim = pp.trim5p;
+        if (o.tail_trim < 0) o.tail_trim = pp.trim3p;
+        std::cerr << "INFO: trim 5' end length: " << o.head_trim << std::endl;
+        std::cerr << "INFO: trim 3' end length: " << o.tail_trim << std::endl;
+        std::cerr << "INFO: min output reads length: " << o.min_len << std::endl;
+        std::cerr << "INFO: min Phred average quality score: " << o.min_q << std::endl;
+        auto add = [&](const std::string& a) { if (std::find(adapters.begin(), adapters.end(), a) == adapters.end()) adapters.push_back(a); };
+        if (!o.adapter_file.empty()) {                                 // Get_adapters, :2923-2942
+            InputBytes af;
+            if (af.open(o.adapter_file)) {
+                const int t = file_type(o.adapter_file);
+                FastxReader rd(af.data(), af.size(), t == 1);
+                Record r;
+                while (rd.next(r)) { add(std::string(r.seq)); add(rev_comp(std::string(r.seq))); }
+            }
+            int num = 0;
+            for (const std::string& a : adapters) std::cerr << "INFO: input adapter " << ++num << " :" << a << std::endl;
+        } else {
+            std::string a5 = pp.adapter5p, a3 = pp.adapter3p;
+            float d5 = pp.depth5p, d3 = pp.depth3p;
+            if (d5 > 5 * d3) { a3.clear(); d3 = 0; } else if (d3 > 5 * d5) { a5.clear(); d5 = 0; }   // :3086-3092
+            std::cerr << "INFO: 5' adapter: " << a5 << std::endl;
+            std::cerr << "INFO: 3' adapter: " << a3 << std::endl;
+            std::cerr << "INFO: mean depth of 5' adapter: " << d5 << std::endl;
+            std::cerr << "INFO: mean depth of 3' adapter: " << d3 << std::endl;
+            if (o.only_adapters) return 0;
+            if (!a5.empty()) { add(a5); add(rev_comp(a5)); }
+            if (!a3.empty()) { add(a3); add(rev_comp(a3)); }
+            if (a5.empty() && a3.empty()) {                            // :3115-3125
+                if (o.read_type == "hifi" || o.read_type == "clr") {
+                    add(kAdapterLib[0]); add(kAdapterLib[1]);
+                    std::cerr << "INFO: set PacBio blunt adapter to trim: " << kAdapterLib[0] << std::endl;
+                } else if (o.read_type == "ont") {
+                    add(kAdapterLib[8]); add(kAdapterLib[9]);
+                    std::cerr << "INFO: set NanoPore rapid adapter to trim: " << kAdapterLib[8] << std::endl;
+                }
+            }
+        }
+    }
+
+    // ---- context ----
+    const uint64_t batch_bases = std::min<uint64_t>(1ull << 30, std::max<uint64_t>(in.size() / 2 + 4096, 1 << 16));
+    const uint32_t batch_reads = 1u << 16;
+    tgsf_params p;
+    memset(&p, 0, sizeof p);
+    p.struct_size = sizeof p;
+    p.min_len = o.min_len; p.max_len = o.max_len; p.min_q = o.min_q < 0 ? 0.f : o.min_q; p.max_q = o.max_q;
+    p.bc_len = o.bc_len; p.head_trim = o.head_trim < 0 ? 0 : o.head_trim; p.tail_trim = o.tail_trim < 0 ? 0 : o.tail_trim;
+    p.end_len = o.end_len; p.end_match_len = o.end_match_len; p.mid_match_len = o.mid_match_len; p.extra_len = o.extra_len;
+    p.end_sim = o.end_sim; p.mid_sim = o.mid_sim; p.discard = o.discard; p.filter = o.filter; p.only_qc = o.only_qc;
+    p.min_repeat = 0; p.kmer = o.kmer; p.qtype = pp.qtype ? pp.qtype : 33;
+    if (adapters.size() > TGSF_MAX_ADAPTERS) die("more than " + std::to_string(TGSF_MAX_ADAPTERS) + " adapter sequences");
+    p.n_adapters = (int)adapters.size();
+    for (size_t a = 0; a < adapters.size(); a++) { p.adapters[a] = adapters[a].data(); p.adapter_len[a] = (int)adapters[a].size(); }
+    p.max_batch_bases = batch_bases;
+    p.max_batch_reads = batch_reads;
+    p.max_read_len = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(in.size() / 2, 1024), 1u << 26);
+    tgsf_ctx* ctx = nullptr;
+    if (tgsf_create(&p, o.device, &ctx) != TGSF_OK) die(tgsf_last_error(nullptr));
+
+    // ---- pipeline ----
+    Channel<std::unique_ptr<Batch>> to_gpu(2), to_writer(2);
+    std::vector<int> raw_lens, clean_lens;
+    uint64_t raw_bases = 0, clean_bases = 0;
+    const bool fastq_out = o.out_type == 1;
+    Output out;
+    if (!o.only_qc && !out.open(o)) return 1;
+
+    std::thread reader([&] {                                           // read_fastx, :1845-1870
+        FastxReader rd(in.data(), in.size(), true);
+        Record r;
+        std::unique_ptr<Batch> b(new Batch);
+        auto flush = [&] { if (!b->names.empty()) { to_gpu.put(std::move(b)); b.reset(new Batch); } };
+        while (rd.next(r)) {
+            const size_t L = r.seq.size();
+            if (L > p.max_read_len) die("read longer than the supported maximum");
+            if (b->bases + L > batch_bases || b->names.size() >= batch_reads) flush();
+            const size_t o0 = (b->seq.size() + 15) & ~size_t(15);      // 16-byte aligned read starts
+            b->seq.resize(o0 + L); b->qual.resize(o0 + L);
+            memcpy(b->seq.data() + o0, r.seq.data(), L);
+            memcpy(b->qual.data() + o0, r.qual.data(), L);
+            b->off.push_back(o0); b->len.push_back((uint32_t)L); b->names.push_back(r.name);
+            b->bases += L;
+            raw_bases += L; raw_lens.push_back((int)L);
+        }
+        flush();
+        to_gpu.put(nullptr);
+    });
+
+    std::thread feeder([&] {                                           // filter_sequence, :1919-2064, one batch per call
+        for (;;) {
+            std::unique_ptr<Batch> b = to_gpu.get();
+            if (!b) break;
+            b->res.resize(b->names.size());
+            b->frags.resize((size_t)(b->bases / (uint64_t)std::max(p.min_len, 1)) + b->names.size() + 16);
+            b->seq.resize(b->seq.size() + 64); b->qual.resize(b->qual.size() + 64);   // slack for 16-byte tail loads
+            tgsf_batch_in bi{b->seq.data(), b->qual.data(), b->off.data(), b->len.data(), (uint32_t)b->names.size(), 0,
+                             (uint64_t)b->seq.size() - 64};
+            tgsf_batch_out bo{b->res.data(), b->frags.data(), (uint32_t)b->frags.size(), 0};
+            if (tgsf_submit(ctx, &bi, &bo) != TGSF_OK) die(tgsf_last_error(ctx));
+            b->n_frags = bo.n_frags;
+            to_writer.put(std::move(b));
+        }
+        to_writer.put(nullptr);
+    });
+
+    std::thread writer([&] {                                           // record formatting :2011-2053 + write_output :2095-2145
+        std::string rec;
+        for (;;) {
+            std::unique_ptr<Batch> b = to_writer.get();
+            if (!b) break;
+            for (size_t r = 0; r < b->names.size(); r++) {
+                int pass_num = 1;
+                const tgsf_read_result& rr = b->res[r];
+                for (uint32_t f = rr.frag_begin; f < rr.frag_begin + rr.n_frags; f++) {
+                    const tgsf_fragment& fr = b->frags[f];
+                    if (!(fr.flags & TGSF_FF_PASS)) continue;
+                    rec.clear();
+                    rec += fastq_out ? '@' : '>';
+                    append_name(rec, b->names[r], pass_num++);
+                    rec += '\n';
+                    rec.append((const char*)b->seq.data() + b->off[r] + fr.start, (size_t)fr.len);
+                    if (fastq_out) {
+                        rec += "\n+\n";
+                        rec.append((const char*)b->qual.data() + b->off[r] + fr.start, (size_t)fr.len);
+                    }
+                    rec += '\n';
+                    out.write(rec);
+                    clean_bases += (uint64_t)fr.len;
+                    clean_lens.push_back(fr.len);
+                }
+            }
+        }
+    });
+    reader.join(); feeder.join(); writer.join();
+    if (!o.only_qc) out.close();
+
+    // ---- statistics, stderr, report: :3146-3235, :3285-3328 ----
+    uint64_t nw = 0; int32_t bc = 0; uint32_t nbins = 0;
+    tgsf_counters_len(ctx, &nw, &bc, &nbins);
+    std::vector<uint64_t> t(nw);
+    if (tgsf_counters(ctx, t.data(), nw) != TGSF_OK) die(tgsf_last_error(ctx));
+    tgsf_destroy(ctx);
+    if (raw_lens.empty()) die("no reads in the input");
+    auto tables = [&](bool clean) {
+        SideTables s;
+        s.bin_qual = &t[tgsf_ctr_bin_table(clean ? TGSF_B_CLEAN_QUAL : TGSF_B_RAW_QUAL, bc, nbins)];
+        s.bin_cnt = &t[tgsf_ctr_bin_table(clean ? TGSF_B_CLEAN_CNT : TGSF_B_RAW_CNT, bc, nbins)];
+        s.bin_rows = t[TGSF_CTR_ROWS + (clean ? 1 : 0)];
+        s.q5 = &t[tgsf_ctr_end_table(clean ? TGSF_T_CLEAN5P_QUAL : TGSF_T_RAW5P_QUAL, bc)];
+        s.c5 = &t[tgsf_ctr_end_table(clean ? TGSF_T_CLEAN5P_CNT : TGSF_T_RAW5P_CNT, bc)];
+        s.q3 = &t[tgsf_ctr_end_table(clean ? TGSF_T_CLEAN3P_QUAL : TGSF_T_RAW3P_QUAL, bc)];
+        s.c3 = &t[tgsf_ctr_end_table(clean ? TGSF_T_CLEAN3P_CNT : TGSF_T_RAW3P_CNT, bc)];
+        s.end_rows = t[TGSF_CTR_ROWS + (clean ? 3 : 2)];
+        s.diff_qual = &t[clean ? TGSF_CTR_CLEAN_DIFFQ : TGSF_CTR_RAW_DIFFQ];
+        return s;
+    };
+    SideStats raw, clean;
+    std::sort(raw_lens.begin(), raw_lens.end());
+    side_stats(bc, raw_lens, raw_bases, tables(false), raw);
+    const int clean_num = (int)clean_lens.size();
+    if (!o.only_qc) {
+        if (clean_lens.empty()) die("no reads passed the filters");      // the reference dereferences an empty vector here (:3183)
+        std::sort(clean_lens.begin(), clean_lens.end());
+        side_stats(bc, clean_lens, clean_bases, tables(true), clean);
+    }
+    const uint64_t* d = &t[TGSF_CTR_DROPINFO];
+    std::cerr << "INFO: " << raw_lens.size() << " reads with a total of " << raw_bases << " bases were input." << std::endl;
+    if (!o.only_qc) {
+        std::cerr << "INFO: " << d[0] << " reads were discarded with " << d[1] << " bases due to low quality." << std::endl;
+        std::cerr << "INFO: " << d[2] << " reads have adapter at 5', 3' and middle." << std::endl;
+        std::cerr << "INFO: " << d[3] << " reads have adapter at 5' and middle." << std::endl;
+        std::cerr << "INFO: " << d[4] << " reads have adapter at 3' and middle." << std::endl;
+        std::cerr << "INFO: " << d[5] << " reads have adapter at 5' and 3' end." << std::endl;
+        std::cerr << "INFO: " << d[6] << " reads only have adapter at middle." << std::endl;
+        std::cerr << "INFO: " << d[7] << " reads only have adapter at 5' end." << std::endl;
+        std::cerr << "INFO: " << d[8] << " reads only have adapter at 3' end." << std::endl;
+        std::cerr << "INFO: " << d[9] << " reads didn't have any adapter." << std::endl;
+        std::cerr << "INFO: " << d[10] << " bases were trimmed due to the adapter or base content bias." << std::endl;
+        std::cerr << "INFO: " << d[11] << " reads were discarded with " << d[12] << " bases due to the short length." << std::endl;
+        std::cerr << "INFO: " << d[13] << " reads were discarded with " << d[14] << " bases due to low quality after split." << std::endl;
+        std::cerr << "INFO: " << clean_num << " reads with a total of " << clean_bases << " bases after filtering." << std::endl;
+        if (!o.out_file.empty()) std::cerr << "INFO: Filtered reads were written to: " << o.out_file << "." << std::endl;
+    }
+    std::string qc = "1";                                              // fastq input
+    qc += o.only_qc ? "0" : "2";                                       // :3293-3299
+    std::ofstream ofs(html);
+    write_report(ofs, qc, raw, clean);
+    ofs.close();
+    std::cerr << "INFO: Quality control report was written to: " << html << "." << std::endl;
+    return 0;
+}
