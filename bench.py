@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--reads", type=int, default=65536, help="reads per step per GPU")
     ap.add_argument("--mean-len", type=float, default=45000.0)
     ap.add_argument("--max-len", type=int, default=2_000_000)
-    ap.add_argument("--cpu-sample-reads", type=int, default=6000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=24000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=2,
                     help="batches in flight per GPU (one context + one HIP stream each); >1 overlaps the "

@@ -59,3 +59,13 @@ def test_emul_edge_lengths(emul):
     ctx = capi.Context(p, 0, emul)
     parity.compare_batch(ctx, p, reads)
     ctx.close()
+
+
+def test_emul_loose_thresholds(emul):
+    """-M far below the default: most columns are within k, every lane records ties all the time."""
+    reads = synth.make_reads(8, 16, "ont", mean_len=5000, zoo=True, pmid=0.3)
+    p = parity.sized(abi.make_params("ont", adapters=[synth.ONT_RAPID, synth.ONT_RAPID_RC], min_q=8.0,
+                                     mid_match_len=18, end_match_len=8, mid_sim=0.8, end_sim=0.7), reads)
+    ctx = capi.Context(p, 0, emul)
+    parity.compare_batch(ctx, p, reads)
+    ctx.close()

@@ -120,3 +120,13 @@ def test_gpu_bad_quality_byte_is_reported():
         ctx.submit(seq, qual, off[:-1].copy(), ln)
     assert ei.value.code == abi.E_DATA
     ctx.close()
+
+
+def test_gpu_loose_thresholds():
+    """-M far below the default: most columns are within k, every lane records ties all the time."""
+    reads = synth.make_reads(8, 120, "ont", mean_len=6000, zoo=True, pmid=0.3)
+    p = parity.sized(abi.make_params("ont", adapters=[synth.ONT_RAPID, synth.ONT_RAPID_RC], min_q=8.0,
+                                     mid_match_len=18, end_match_len=8, mid_sim=0.8, end_sim=0.7), reads)
+    ctx = capi.Context(p, 0)
+    parity.compare_batch(ctx, p, reads)
+    ctx.close()

@@ -889,6 +889,8 @@ template <int AT>
 TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
 {
     TGSF_SHARED uint64_t eqt[256][AT];
+    // per lane and adapter: up to 4 columns that tie the lane's best value so far (slow path only)
+    TGSF_SHARED int32_t tie_col[256][AT][4];
     for (uint32_t i = TGSF_COOP_BEGIN; i < 256u * AT; i += TGSF_COOP_STRIDE) {
         uint32_t sym = i / AT, j = i % AT;
         eqt[sym][j] = (int)j < na ? P.peq_top[(size_t)(a0 + j) * 256 + sym] : 0ull;
@@ -912,14 +914,16 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
     if (c1 > ML) c1 = ML;
 
     Hot st[AT];
-    int lim[AT];              // record columns whose value is <= lim (then lim := value)
+    int lim[AT];              // best bottom-row value seen so far in the owned columns (k+1: none yet)
+    int ntie[AT];             // buffered columns attaining it
     int wu = 0;
 #pragma unroll
     for (int j = 0; j < AT; j++) {
         const int a = a0 + j;
         const bool on = j < na && ML >= P.Q[a] && P.k_mid[a] >= 0;    // :1237 tsmLen >= qLen
         hot_init(st[j], j < na ? P.Q[a] : 1);
-        lim[j] = on ? P.k_mid[a] : -1000;
+        lim[j] = on ? P.k_mid[a] + 1 : -1000;
+        ntie[j] = 0;
         if (on) { int w = P.Q[a] + P.k_mid[a]; wu = w > wu ? w : wu; }
     }
     int c = c0 - wu;
@@ -930,11 +934,26 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
 #pragma unroll
         for (int j = 0; j < AT; j++) hot_step(st[j], eqt[byte][j]);
     };
+    // Only the columns at the GLOBAL minimum of the read matter (edlib.cpp:660-672), so a lane keeps
+    // the columns tying ITS best value in a 4-slot buffer and pushes them to the read's candidate
+    // list when the buffer fills or the block ends: the pool stays small for any threshold.
+    int32_t (*ties)[4] = tie_col[threadIdx.x];
+    auto flush_ties = [&](int j) {
+        for (int i = 0; i < ntie[j]; i++) push_candidate(B, r, ties[j][i], lim[j], a0 + j);
+        ntie[j] = 0;
+    };
+    auto note = [&](int j, int sc, int col) {
+        if (sc < lim[j]) { lim[j] = sc; ntie[j] = 0; }            // strictly better: older ties are void
+        if (sc == lim[j]) {                                          // lim <= k here (init k+1 is never equalled... see below)
+            if (ntie[j] == 4) flush_ties(j);
+            ties[j][ntie[j]++] = col;
+        }
+    };
     auto check_col = [&](int col) {
 #pragma unroll
         for (int j = 0; j < AT; j++) {
             const int sc = hot_score(st[j]);
-            if (sc <= lim[j]) { lim[j] = sc; push_candidate(B, r, col, sc, a0 + j); }
+            if (sc < lim[j] || (sc == lim[j] && ntie[j] > 0)) note(j, sc, col);
         }
     };
     // 16 columns starting at column cc0; `own` = the lane records candidates there (false during
@@ -965,10 +984,10 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
                 for (int j = 0; j < AT; j++) {
                     const int cc = cc0 + 4 * k;
                     const int s1 = hot_score(h1[j]), s2 = hot_score(h2[j]), s3 = hot_score(h3[j]);
-                    if (s1 <= lim[j]) { lim[j] = s1; push_candidate(B, r, cc, s1, a0 + j); }
-                    if (s2 <= lim[j]) { lim[j] = s2; push_candidate(B, r, cc + 1, s2, a0 + j); }
-                    if (s3 <= lim[j]) { lim[j] = s3; push_candidate(B, r, cc + 2, s3, a0 + j); }
-                    if (s4[j] <= lim[j]) { lim[j] = s4[j]; push_candidate(B, r, cc + 3, s4[j], a0 + j); }
+                    if (s1 < lim[j] || (s1 == lim[j] && ntie[j] > 0)) note(j, s1, cc);
+                    if (s2 < lim[j] || (s2 == lim[j] && ntie[j] > 0)) note(j, s2, cc + 1);
+                    if (s3 < lim[j] || (s3 == lim[j] && ntie[j] > 0)) note(j, s3, cc + 2);
+                    if (s4[j] < lim[j] || (s4[j] == lim[j] && ntie[j] > 0)) note(j, s4[j], cc + 3);
                 }
             }
         }
@@ -996,6 +1015,8 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
         }
     }
     while (c < c1) { step_all(mid[c]); if (c >= c0) check_col(c); c++; }
+#pragma unroll
+    for (int j = 0; j < AT; j++) flush_ties(j);
 }
 
 // adapters of 65..128 bp: two-word standard layout, one adapter per pass

@@ -8,6 +8,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
@@ -111,6 +112,11 @@ private:
     std::vector<char> zbuf_;
 };
 
+double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 [[noreturn]] void die(const std::string& msg)
 {
     std::cerr << "Error: " << msg << std::endl;
@@ -123,6 +129,9 @@ int main(int argc, char** argv)
 {
     Options o;
     if (parse_args(argc, argv, o)) return 1;
+    const bool timing = getenv("TGSF_TIMING") != nullptr;      // stage wall times on stderr (not part of the surface)
+    const double t_start = now_s();
+    double t_prepass = 0, t_create = 0, t_pipe = 0, t_parse = 0, t_gpu = 0, t_write = 0;
 
     // file types and report name, :2993-3033
     o.in_type = file_type(o.in_file);
@@ -152,6 +161,7 @@ int main(int argc, char** argv)
 
     // ---- pre-pass, :3058-3126 ----
     PrepassResult pp = run_prepass(o, in);
+    t_prepass = now_s() - t_start;
     std::vector<std::string> adapters;
     if (o.filter) {
         if (o.head_trim < 0) o.head_trim = pp.trim5p;
@@ -212,7 +222,10 @@ int main(int argc, char** argv)
     p.max_batch_reads = batch_reads;
     p.max_read_len = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(in.size() / 2, 1024), 1u << 26);
     tgsf_ctx* ctx = nullptr;
+    const double t_c0 = now_s();
     if (tgsf_create(&p, o.device, &ctx) != TGSF_OK) die(tgsf_last_error(nullptr));
+    t_create = now_s() - t_c0;
+    const double t_p0 = now_s();
 
     // ---- pipeline ----
     Channel<std::unique_ptr<Batch>> to_gpu(2), to_writer(2);
@@ -225,35 +238,52 @@ int main(int argc, char** argv)
     std::thread reader([&] {                                           // read_fastx, :1845-1870
         FastxReader rd(in.data(), in.size(), true);
         Record r;
-        std::unique_ptr<Batch> b(new Batch);
-        auto flush = [&] { if (!b->names.empty()) { to_gpu.put(std::move(b)); b.reset(new Batch); } };
+        const size_t cap = (size_t)batch_bases + 16 * (size_t)batch_reads + 4096;
+        auto fresh = [&] {
+            std::unique_ptr<Batch> nb(new Batch);
+            nb->seq.reserve(cap); nb->qual.reserve(cap);
+            nb->off.reserve(batch_reads); nb->len.reserve(batch_reads); nb->names.reserve(batch_reads);
+            return nb;
+        };
+        std::unique_ptr<Batch> b = fresh();
+        const double t0 = now_s();
+        double waited = 0;
+        auto flush = [&] {
+            if (b->names.empty()) return;
+            const double w0 = now_s();
+            to_gpu.put(std::move(b));
+            waited += now_s() - w0;
+            b = fresh();
+        };
         while (rd.next(r)) {
             const size_t L = r.seq.size();
             if (L > p.max_read_len) die("read longer than the supported maximum");
             if (b->bases + L > batch_bases || b->names.size() >= batch_reads) flush();
             const size_t o0 = (b->seq.size() + 15) & ~size_t(15);      // 16-byte aligned read starts
-            b->seq.resize(o0 + L); b->qual.resize(o0 + L);
-            memcpy(b->seq.data() + o0, r.seq.data(), L);
-            memcpy(b->qual.data() + o0, r.qual.data(), L);
+            b->seq.resize(o0); b->qual.resize(o0);                       // pad (zero) up to the aligned start
+            b->seq.insert(b->seq.end(), r.seq.begin(), r.seq.end());     // one copy, no zero fill
+            b->qual.insert(b->qual.end(), r.qual.begin(), r.qual.end());
             b->off.push_back(o0); b->len.push_back((uint32_t)L); b->names.push_back(r.name);
             b->bases += L;
             raw_bases += L; raw_lens.push_back((int)L);
         }
         flush();
         to_gpu.put(nullptr);
+        t_parse = now_s() - t0 - waited;
     });
 
     std::thread feeder([&] {                                           // filter_sequence, :1919-2064, one batch per call
         for (;;) {
             std::unique_ptr<Batch> b = to_gpu.get();
             if (!b) break;
+            const double g0 = now_s();
             b->res.resize(b->names.size());
             b->frags.resize((size_t)(b->bases / (uint64_t)std::max(p.min_len, 1)) + b->names.size() + 16);
-            b->seq.resize(b->seq.size() + 64); b->qual.resize(b->qual.size() + 64);   // slack for 16-byte tail loads
             tgsf_batch_in bi{b->seq.data(), b->qual.data(), b->off.data(), b->len.data(), (uint32_t)b->names.size(), 0,
-                             (uint64_t)b->seq.size() - 64};
+                             (uint64_t)b->seq.size()};
             tgsf_batch_out bo{b->res.data(), b->frags.data(), (uint32_t)b->frags.size(), 0};
             if (tgsf_submit(ctx, &bi, &bo) != TGSF_OK) die(tgsf_last_error(ctx));
+            t_gpu += now_s() - g0;
             b->n_frags = bo.n_frags;
             to_writer.put(std::move(b));
         }
@@ -265,6 +295,7 @@ int main(int argc, char** argv)
         for (;;) {
             std::unique_ptr<Batch> b = to_writer.get();
             if (!b) break;
+            const double w0 = now_s();
             for (size_t r = 0; r < b->names.size(); r++) {
                 int pass_num = 1;
                 const tgsf_read_result& rr = b->res[r];
@@ -286,10 +317,12 @@ int main(int argc, char** argv)
                     clean_lens.push_back(fr.len);
                 }
             }
+            t_write += now_s() - w0;
         }
     });
     reader.join(); feeder.join(); writer.join();
     if (!o.only_qc) out.close();
+    t_pipe = now_s() - t_p0;
 
     // ---- statistics, stderr, report: :3146-3235, :3285-3328 ----
     uint64_t nw = 0; int32_t bc = 0; uint32_t nbins = 0;
@@ -344,5 +377,9 @@ int main(int argc, char** argv)
     write_report(ofs, qc, raw, clean);
     ofs.close();
     std::cerr << "INFO: Quality control report was written to: " << html << "." << std::endl;
+    if (timing)
+        fprintf(stderr, "TIMING: total %.3f s | prepass %.3f | tgsf_create %.3f | pipeline %.3f (parse+pack %.3f, tgsf_submit %.3f, "
+                        "format+write %.3f; stages overlap) | stats+report %.3f\n",
+                now_s() - t_start, t_prepass, t_create, t_pipe, t_parse, t_gpu, t_write, now_s() - t_p0 - t_pipe);
     return 0;
 }
