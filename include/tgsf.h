@@ -108,6 +108,10 @@ typedef struct tgsf_batch_in {
     uint32_t        n_reads;
     uint32_t        reserved;
     uint64_t        n_bytes;   /* bytes spanned by seq / qual (>= last offset+len)    */
+    /* Optional: qualities of read i start at qual[qual_offsets[i]] instead of qual[offsets[i]]
+     * (n_reads entries; requires `lengths`).  With seq == qual this lets both streams be read IN
+     * PLACE from one buffer holding the raw FASTQ text: the caller only indexes the records. */
+    const uint64_t* qual_offsets;
 } tgsf_batch_in;
 
 /* tgsf_read_result.flags */

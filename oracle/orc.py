@@ -52,7 +52,7 @@ def align_hw(q: bytes, t: bytes, k: int):
 
 
 def filter_batch(params: abi.Params, seq, qual, offsets, lengths=None, n_bins=None, ctr=None,
-                 frag_capacity=None):
+                 frag_capacity=None, qual_offsets=None):
     """Run the oracle over a CSR batch.  Returns (reads, frags, counters) numpy arrays."""
     seq = np.ascontiguousarray(seq, dtype=np.uint8)
     qual = np.ascontiguousarray(qual, dtype=np.uint8)
@@ -71,8 +71,11 @@ def filter_batch(params: abi.Params, seq, qual, offsets, lengths=None, n_bins=No
         frag_capacity = max(16, int((lengths.sum() if lengths is not None else offsets[-1]) // 100 + n + 16))
     reads = np.zeros(n, dtype=abi.READ_RESULT_DTYPE)
     frags = np.zeros(frag_capacity, dtype=abi.FRAGMENT_DTYPE)
+    if qual_offsets is not None:
+        qual_offsets = np.ascontiguousarray(qual_offsets, dtype=np.uint64)
     bi = abi.BatchIn(seq.ctypes.data, qual.ctypes.data, offsets.ctypes.data,
-                     lengths.ctypes.data if lengths is not None else None, n, 0, seq.size)
+                     lengths.ctypes.data if lengths is not None else None, n, 0, seq.size,
+                     qual_offsets.ctypes.data if qual_offsets is not None else None)
     bo = abi.BatchOut(reads.ctypes.data, frags.ctypes.data, frag_capacity, 0)
     rc = lib().orc_filter_batch(C.byref(params), C.byref(bi), C.byref(bo), ctr.ctypes.data, n_bins)
     if rc != 0:

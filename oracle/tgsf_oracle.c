@@ -414,7 +414,7 @@ int orc_filter_batch(const tgsf_params* p, const tgsf_batch_in* in, tgsf_batch_o
         uint64_t off = in->offsets[r];
         uint64_t len64 = in->lengths ? in->lengths[r] : in->offsets[r + 1] - off;
         const uint8_t* seq = in->seq + off;
-        const uint8_t* qual = in->qual + off;
+        const uint8_t* qual = in->qual + (in->qual_offsets ? in->qual_offsets[r] : off);
         tgsf_read_result* rr = &out->reads[r];
         memset(rr, 0, sizeof(*rr));
         rr->frag_begin = nf;

@@ -78,3 +78,32 @@ def edlib_vectors(lib_path, golden_dir):
             assert got == exp, (i, v["q"], v["t"], v["k"], got, exp)
     finally:
         ctx.close()
+
+
+def fastq_text_layout(reads):
+    """The raw FASTQ text of `reads` plus the in-place index a caller would build over it."""
+    buf = bytearray()
+    off, qoff, ln = [], [], []
+    for name, s, q in reads:
+        buf += b"@" + name + b"\n"
+        off.append(len(buf)); buf += s + b"\n+\n"
+        qoff.append(len(buf)); buf += q + b"\n"
+        ln.append(len(s))
+    text = np.frombuffer(bytes(buf) + b"\0" * 64, dtype=np.uint8)
+    return text, np.array(off, np.uint64), np.array(qoff, np.uint64), np.array(ln, np.uint32)
+
+
+def compare_batch_in_place(ctx: capi.Context, p: abi.Params, reads):
+    """seq == qual == the FASTQ text itself, two offset arrays: must equal the oracle on the same layout
+    (and therefore the packed layout, which the oracle is indifferent to)."""
+    text, off, qoff, ln = fastq_text_layout(reads)
+    got_r, got_f = ctx.submit(text, text, off, ln, qual_offsets=qoff)
+    ctr = ctx.counters()
+    exp_r, exp_f, exp_ctr = orc.filter_batch(p, text, text, off, ln, n_bins=ctx.n_bins, qual_offsets=qoff)
+    assert np.array_equal(got_r, exp_r)
+    assert np.array_equal(got_f, exp_f)
+    bad = np.nonzero(ctr != exp_ctr)[0]
+    assert bad.size == 0, f"tally words differ at {bad[:12]}: got {ctr[bad[:12]]} exp {exp_ctr[bad[:12]]}"
+    seq, qual, offsets, lengths = synth.pack(reads)
+    pk_r, pk_f, pk_ctr = orc.filter_batch(p, seq, qual, offsets, lengths, n_bins=ctx.n_bins)
+    assert np.array_equal(pk_ctr, exp_ctr) and np.array_equal(pk_f, exp_f)

@@ -130,3 +130,15 @@ def test_gpu_loose_thresholds():
     ctx = capi.Context(p, 0)
     parity.compare_batch(ctx, p, reads)
     ctx.close()
+
+
+def test_gpu_in_place_fastq_text():
+    """Both streams read in place from the raw FASTQ text (separate seq / qual offsets, any alignment)."""
+    reads = synth.make_reads(12, 300, "ont", mean_len=5000, zoo=True, pmid=0.1)
+    p = abi.make_params("ont", adapters=[synth.ONT_RAPID, synth.ONT_RAPID_RC], min_q=9.0, head_trim=4)
+    p.max_batch_reads = len(reads)
+    p.max_batch_bases = 2 * sum(len(r[1]) for r in reads) + 64 * len(reads) + 4096
+    p.max_read_len = max(len(r[1]) for r in reads)
+    ctx = capi.Context(p, 0)
+    parity.compare_batch_in_place(ctx, p, reads)
+    ctx.close()

@@ -51,6 +51,7 @@ class BatchIn(C.Structure):
     _fields_ = [
         ("seq", C.c_void_p), ("qual", C.c_void_p), ("offsets", C.c_void_p), ("lengths", C.c_void_p),
         ("n_reads", C.c_uint32), ("reserved", C.c_uint32), ("n_bytes", C.c_uint64),
+        ("qual_offsets", C.c_void_p),
     ]
 
 

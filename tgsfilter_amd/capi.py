@@ -95,7 +95,7 @@ class Context:
             pass
 
     # ---- host-buffer path -------------------------------------------------
-    def submit(self, seq, qual, offsets, lengths=None, frag_capacity=None):
+    def submit(self, seq, qual, offsets, lengths=None, frag_capacity=None, qual_offsets=None):
         """Filter one CSR batch held in host memory; returns (reads, frags) structured arrays."""
         seq = np.ascontiguousarray(seq, dtype=np.uint8)
         qual = np.ascontiguousarray(qual, dtype=np.uint8)
@@ -111,16 +111,20 @@ class Context:
             frag_capacity = total // 100 + n + 16
         reads = np.zeros(n, dtype=abi.READ_RESULT_DTYPE)
         frags = np.zeros(frag_capacity, dtype=abi.FRAGMENT_DTYPE)
-        bi = abi.BatchIn(seq.ctypes.data, qual.ctypes.data, offsets.ctypes.data,
-                         lengths.ctypes.data if lengths is not None else None, n, 0, seq.size)
+        if qual_offsets is not None:
+            qual_offsets = np.ascontiguousarray(qual_offsets, dtype=np.uint64)
+        same = qual is seq or (qual.ctypes.data == seq.ctypes.data)
+        bi = abi.BatchIn(seq.ctypes.data, seq.ctypes.data if same else qual.ctypes.data, offsets.ctypes.data,
+                         lengths.ctypes.data if lengths is not None else None, n, 0, seq.size,
+                         qual_offsets.ctypes.data if qual_offsets is not None else None)
         bo = abi.BatchOut(reads.ctypes.data, frags.ctypes.data, frag_capacity, 0)
         self._chk(self.lib.tgsf_submit(self.h, C.byref(bi), C.byref(bo)))
         return reads, frags[:bo.n_frags].copy()
 
     # ---- device-resident path (pointers already in HBM) --------------------
     def submit_device(self, d_seq, d_qual, d_offsets, d_lengths, n_reads, n_bytes, d_reads, d_frags,
-                      frag_capacity, d_nfrags=None, stream=None):
-        bi = abi.BatchIn(d_seq, d_qual, d_offsets, d_lengths, n_reads, 0, n_bytes)
+                      frag_capacity, d_nfrags=None, stream=None, d_qual_offsets=None):
+        bi = abi.BatchIn(d_seq, d_qual, d_offsets, d_lengths, n_reads, 0, n_bytes, d_qual_offsets)
         bo = abi.BatchOut(d_reads, d_frags, frag_capacity, 0)
         self._chk(self.lib.tgsf_submit_device(self.h, C.byref(bi), C.byref(bo), d_nfrags, stream))
 

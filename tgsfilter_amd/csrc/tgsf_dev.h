@@ -43,6 +43,7 @@ struct DevBatch {
     const uint8_t* seq;
     const uint8_t* qual;
     const uint64_t* off;       // [n] (or [n+1] when len_in == nullptr)
+    const uint64_t* qoff;      // [n] start of the qualities of read i in `qual` (== off unless the caller says otherwise)
     const uint32_t* len_in;    // optional explicit lengths
     uint32_t n;
     uint64_t n_bytes;
@@ -66,12 +67,13 @@ struct DevBatch {
     uint32_t* tile_base;       // [max_tiles+2]  exclusive prefix of cnt
     uint32_t* tile_fill;       // [max_tiles+2]
     uint32_t* perm;            // items sorted by tile count, descending
-    uint4*    work;            // [work_cap] stats work items: {addr lo, addr hi, bases | tile<<13, item}
+    uint4*    work;            // [2*work_cap] stats work items: {seq addr lo, hi, bases | tile<<13, item}, {qual addr lo, hi, 0, 0}
     uint32_t  work_cap;
     uint32_t  max_tiles;
 
     // fragments
     uint64_t* frag_off;        // [fcap] absolute byte offset of the fragment
+    uint64_t* frag_qoff;       // [fcap] ... and of its qualities
     uint32_t* frag_len;        // [fcap]
     uint64_t* frag_sum;        // [fcap]
     uint32_t* frag_read;       // [fcap]

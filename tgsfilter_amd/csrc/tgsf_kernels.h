@@ -283,13 +283,14 @@ constexpr int kStatsWaves = 4;
 constexpr int kTileChunks = kTileBases / 16 + 2;   // +1 misalignment, +1 zero guard
 constexpr int kLaneChunks = (kTileChunks + 63) / 64;   // 16-byte chunks a lane stages per stream
 
-// work[w] = { address lo, address hi, bases | tile << 13, item }
+// work[2w] = { seq address lo, hi, bases | tile << 13, item },  work[2w+1] = { qual address lo, hi, 0, 0 }
 template <bool CLEAN>
 TGSF_KERNEL k_build_work(DevBatch B)
 {
     const uint32_t mt = B.max_tiles;
     const uint32_t W = B.tile_base[mt + 1];
     const uint64_t* it_off = CLEAN ? B.frag_off : B.off;
+    const uint64_t* it_qoff = CLEAN ? B.frag_qoff : B.qoff;
     const uint32_t* it_len = CLEAN ? B.frag_len : B.len;
     for (uint32_t w = gtid(); w < W && w < B.work_cap; w += gsize()) {
         const uint32_t t = find_owner(B.tile_base, mt + 1, w);
@@ -298,9 +299,12 @@ TGSF_KERNEL k_build_work(DevBatch B)
         const uint64_t a0 = it_off[item] + (uint64_t)t * kTileBases;
         uint32_t nb = L - t * kTileBases;
         if (nb > (uint32_t)kTileBases) nb = kTileBases;
-        uint4 e;
+        const uint64_t aq = it_qoff[item] + (uint64_t)t * kTileBases;
+        uint4 e, q;
         e.x = (uint32_t)a0; e.y = (uint32_t)(a0 >> 32); e.z = nb | (t << 13); e.w = item;
-        B.work[w] = e;
+        q.x = (uint32_t)aq; q.y = (uint32_t)(aq >> 32); q.z = 0; q.w = 0;
+        B.work[2 * (size_t)w] = e;
+        B.work[2 * (size_t)w + 1] = q;
     }
 }
 
@@ -363,26 +367,25 @@ TGSF_KERNEL k_stats(DevParams P, DevBatch B)
         call = 0; since = 0;
     };
 
-    // register staging of one tile: chunk c = lane + 64*k of each stream
+    // register staging of one tile: chunk c = lane + 64*k of each stream.  The two streams may sit at
+    // different alignments (raw FASTQ text: seq and qual of a read are different lines of one buffer).
     uint4 rs[kLaneChunks], rq[kLaneChunks];
-    auto issue = [&](uint64_t a0, uint32_t nb) {
+    auto issue = [&](uint64_t a0, uint64_t aq, uint32_t nb) {
 #if !defined(TGSF_EMUL)
-        const uint32_t sh = (uint32_t)(a0 & 15u);
-        const uint8_t* ps = B.seq + (a0 - sh);
-        const uint8_t* pq = B.qual + (a0 - sh);
-        const uint32_t endb = sh + nb;
+        const uint32_t shs = (uint32_t)(a0 & 15u), shq = (uint32_t)(aq & 15u);
+        const uint8_t* ps = B.seq + (a0 - shs);
+        const uint8_t* pq = B.qual + (aq - shq);
+        const uint32_t ends = shs + nb, endq = shq + nb;
 #pragma unroll
         for (int k = 0; k < kLaneChunks; k++) {
             const uint32_t cb = (lane + 64u * k) * 16u;
             uint4 z = {0, 0, 0, 0};
             rs[k] = z; rq[k] = z;
-            if (cb < endb) {
-                rs[k] = *reinterpret_cast<const uint4*>(ps + cb);
-                rq[k] = *reinterpret_cast<const uint4*>(pq + cb);
-            }
+            if (cb < ends) rs[k] = *reinterpret_cast<const uint4*>(ps + cb);
+            if (cb < endq) rq[k] = *reinterpret_cast<const uint4*>(pq + cb);
         }
 #else
-        (void)a0; (void)nb;
+        (void)a0; (void)aq; (void)nb;
 #endif
     };
     auto mask_tail = [](uint4& v, uint32_t keep) {          // keep the first `keep` (1..15) bytes
@@ -393,91 +396,97 @@ TGSF_KERNEL k_stats(DevParams P, DevBatch B)
             p[d] &= kb >= 4 ? 0xFFFFFFFFu : (kb <= 0 ? 0u : ((1u << (8 * kb)) - 1u));
         }
     };
-    auto commit = [&](uint64_t a0, uint32_t nb) {
-        const uint32_t sh = (uint32_t)(a0 & 15u);
-        const uint32_t endb = sh + nb;
-        const uint32_t nch = (endb + 15u) / 16u + 1u;         // + one all-zero guard chunk
+    auto commit = [&](uint64_t a0, uint64_t aq, uint32_t nb) {
+        const uint32_t shs = (uint32_t)(a0 & 15u), shq = (uint32_t)(aq & 15u);
+        const uint32_t ends = shs + nb, endq = shq + nb;
+        const uint32_t nchs = (ends + 15u) / 16u + 1u, nchq = (endq + 15u) / 16u + 1u;   // + one all-zero guard chunk
 #if !defined(TGSF_EMUL)
 #pragma unroll
         for (int k = 0; k < kLaneChunks; k++) {
             const uint32_t c = lane + 64u * k, cb = c * 16u;
-            if (c < nch) {
-                if (cb < endb && cb + 16u > endb) { mask_tail(rs[k], endb - cb); mask_tail(rq[k], endb - cb); }
+            if (c < nchs) {
+                if (cb < ends && cb + 16u > ends) mask_tail(rs[k], ends - cb);
                 lds[wave][0][c] = rs[k];
+            }
+            if (c < nchq) {
+                if (cb < endq && cb + 16u > endq) mask_tail(rq[k], endq - cb);
                 lds[wave][1][c] = rq[k];
             }
         }
 #else
         // emulation: one lane at a time, so every emulated lane stages the whole tile
-        for (uint32_t c = 0; c < nch; c++) {
-            uint4 vs = {0, 0, 0, 0}, vq = {0, 0, 0, 0};
+        for (uint32_t c = 0; c < nchs; c++) {
+            uint4 v = {0, 0, 0, 0};
             const uint32_t cb = c * 16u;
-            if (cb < endb) {
-                vs = *reinterpret_cast<const uint4*>(B.seq + (a0 - sh) + cb);
-                vq = *reinterpret_cast<const uint4*>(B.qual + (a0 - sh) + cb);
-                if (cb + 16u > endb) { mask_tail(vs, endb - cb); mask_tail(vq, endb - cb); }
-            }
-            lds[wave][0][c] = vs;
-            lds[wave][1][c] = vq;
+            if (cb < ends) { v = *reinterpret_cast<const uint4*>(B.seq + (a0 - shs) + cb); if (cb + 16u > ends) mask_tail(v, ends - cb); }
+            lds[wave][0][c] = v;
+        }
+        for (uint32_t c = 0; c < nchq; c++) {
+            uint4 v = {0, 0, 0, 0};
+            const uint32_t cb = c * 16u;
+            if (cb < endq) { v = *reinterpret_cast<const uint4*>(B.qual + (aq - shq) + cb); if (cb + 16u > endq) mask_tail(v, endq - cb); }
+            lds[wave][1][c] = v;
         }
 #endif
     };
 
     for (uint32_t g0 = w0; g0 < w1; g0 += 64u) {
         const uint32_t ng = (w1 - g0) < 64u ? (w1 - g0) : 64u;
-        uint4 me = {0, 0, 0, 0};
+        uint4 me = {0, 0, 0, 0}, mq = {0, 0, 0, 0};
 #if defined(TGSF_EMUL)
-        (void)me;
+        (void)me; (void)mq;
 #else
-        if (lane < ng) me = B.work[g0 + lane];
+        if (lane < ng) { me = B.work[2 * (size_t)(g0 + lane)]; mq = B.work[2 * (size_t)(g0 + lane) + 1]; }
 #endif
-        auto entry = [&](uint32_t i, uint64_t& a0, uint32_t& nb, uint32_t& tt, uint32_t& item) {
+        auto entry = [&](uint32_t i, uint64_t& a0, uint64_t& aq, uint32_t& nb, uint32_t& tt, uint32_t& item) {
 #if defined(TGSF_EMUL)
-            const uint4 e = B.work[g0 + i];
+            const uint4 e = B.work[2 * (size_t)(g0 + i)], q = B.work[2 * (size_t)(g0 + i) + 1];
             a0 = (uint64_t)e.x | ((uint64_t)e.y << 32); nb = e.z & 0x1FFFu; tt = e.z >> 13; item = e.w;
+            aq = (uint64_t)q.x | ((uint64_t)q.y << 32);
 #else
             const uint32_t x = wave_bcast(me.x, i), y = wave_bcast(me.y, i), z = wave_bcast(me.z, i);
+            const uint32_t qx = wave_bcast(mq.x, i), qy = wave_bcast(mq.y, i);
             item = wave_bcast(me.w, i);
             a0 = (uint64_t)x | ((uint64_t)y << 32); nb = z & 0x1FFFu; tt = z >> 13;
+            aq = (uint64_t)qx | ((uint64_t)qy << 32);
 #endif
         };
-        uint64_t a0; uint32_t nb, tt, item;
-        entry(0, a0, nb, tt, item);
-        issue(a0, nb);
+        uint64_t a0, aq; uint32_t nb, tt, item;
+        entry(0, a0, aq, nb, tt, item);
+        issue(a0, aq, nb);
         for (uint32_t i = 0; i < ng; i++) {
             TGSF_WAVE_SYNC();                                  // previous tile fully consumed
-            commit(a0, nb);
+            commit(a0, aq, nb);
             TGSF_WAVE_SYNC();
-            const uint64_t ca0 = a0; const uint32_t cnb = nb, ctt = tt, citem = item;
-            if (i + 1 < ng) { entry(i + 1, a0, nb, tt, item); issue(a0, nb); }   // in flight during the reduce
+            const uint64_t ca0 = a0, caq = aq; const uint32_t cnb = nb, ctt = tt, citem = item;
+            if (i + 1 < ng) { entry(i + 1, a0, aq, nb, tt, item); issue(a0, aq, nb); }   // in flight during the reduce
             if (ctt != t_acc || since >= 2048) {               // qs[c] carries 128*sum: stay below 2^32
                 if (t_acc != 0xFFFFFFFFu) flush(t_acc);
                 t_acc = ctt;
             }
             ++since;
-            const uint32_t sh = (uint32_t)(ca0 & 15u);
             const int nvalid = (int)cnb - (int)lane * kBin;     // bases of this lane's bin in the tile
             const uint32_t q4_before = qs[4];
             int nv = 0;
             if (nvalid > 0) {
                 nv = nvalid > kBin ? kBin : nvalid;
-                const uint32_t bo = sh + lane * kBin;
-                const uint32_t d0 = bo >> 2, bs = bo & 3u;
+                const uint32_t bos = (uint32_t)(ca0 & 15u) + lane * kBin, boq = (uint32_t)(caq & 15u) + lane * kBin;
+                const uint32_t ds = bos >> 2, bss = bos & 3u, dq = boq >> 2, bsq = boq & 3u;
                 const int ndw = (nv + 3) >> 2;
-                if (bs == 0) {
+                if ((bss | bsq) == 0) {
                     for (int k = 0; k < ndw; k++) {
-                        uint32_t q = Qd[d0 + k];
+                        uint32_t q = Qd[dq + k];
                         qor |= q;
-                        qc_accum4(S[d0 + k], q, cnt, qs);
+                        qc_accum4(S[ds + k], q, cnt, qs);
                     }
                 } else {
-                    uint32_t slo = S[d0], qlo = Qd[d0];
+                    // bytes past the item are zero in LDS; bytes before it never enter (the shift skips them)
+                    uint32_t slo = S[ds], qlo = Qd[dq];
                     for (int k = 0; k < ndw; k++) {
-                        uint32_t shi = S[d0 + k + 1], qhi = Qd[d0 + k + 1];
-                        uint32_t q = alignbyte(qhi, qlo, bs);
-                        // bytes past the item are zero in LDS; bytes before it never enter (bs skips them)
+                        const uint32_t shi = S[ds + k + 1], qhi = Qd[dq + k + 1];
+                        const uint32_t q = alignbyte(qhi, qlo, bsq);
                         qor |= q;
-                        qc_accum4(alignbyte(shi, slo, bs), q, cnt, qs);
+                        qc_accum4(alignbyte(shi, slo, bss), q, cnt, qs);
                         slo = shi; qlo = qhi;
                     }
                 }
@@ -607,13 +616,13 @@ TGSF_KERNEL k_end_tables(DevParams P, DevBatch B)
         atomicAdd(&acc[e][s][4][lane], 1u); atomicAdd(&acc[e][s][9][lane], q);
     };
     for (uint32_t i = gw; i < n; i += 2 * nw) {                 // two items in flight per wave
-        uint32_t L[2] = {0, 0}; uint64_t off[2] = {0, 0};
+        uint32_t L[2] = {0, 0}; uint64_t off[2] = {0, 0}, qof[2] = {0, 0};
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const uint32_t it = i + u * nw;
             if (it < n) {
-                if (CLEAN) { if (B.frag_flags[it] & TGSF_FF_PASS) { L[u] = B.frag_len[it]; off[u] = B.frag_off[it]; } }
-                else { L[u] = B.len[it]; off[u] = B.off[it]; }
+                if (CLEAN) { if (B.frag_flags[it] & TGSF_FF_PASS) { L[u] = B.frag_len[it]; off[u] = B.frag_off[it]; qof[u] = B.frag_qoff[it]; } }
+                else { L[u] = B.len[it]; off[u] = B.off[it]; qof[u] = B.qoff[it]; }
             }
         }
         for (uint32_t s = 0; s < slots; s++) {
@@ -625,8 +634,8 @@ TGSF_KERNEL k_end_tables(DevParams P, DevBatch B)
                 const uint32_t m = bc < L[u] ? bc : L[u];
                 on[u] = p < m;
                 if (on[u]) {
-                    b5[u] = B.seq[off[u] + p]; q5[u] = B.qual[off[u] + p];
-                    b3[u] = B.seq[off[u] + L[u] - 1 - p]; q3[u] = B.qual[off[u] + L[u] - 1 - p];   // :1554-1557
+                    b5[u] = B.seq[off[u] + p]; q5[u] = B.qual[qof[u] + p];
+                    b3[u] = B.seq[off[u] + L[u] - 1 - p]; q3[u] = B.qual[qof[u] + L[u] - 1 - p];   // :1554-1557
                 }
             }
 #pragma unroll
@@ -1155,6 +1164,7 @@ TGSF_KERNEL k_regions(DevParams P, DevBatch B)
                 const uint32_t f = fb + nf;
                 if (f < B.fcap) {
                     B.frag_off[f] = B.off[r] + (uint64_t)s;
+                    B.frag_qoff[f] = B.qoff[r] + (uint64_t)s;
                     B.frag_len[f] = (uint32_t)l;
                     B.frag_sum[f] = 0;
                     B.frag_read[f] = r;

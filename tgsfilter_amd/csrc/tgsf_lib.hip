@@ -51,6 +51,7 @@ struct tgsf_ctx {
     // internal input / output staging for tgsf_submit
     uint8_t *d_seq, *d_qual;
     uint64_t* d_off;
+    uint64_t* d_qoff;
     uint32_t* d_lenin;
     tgsf_read_result* d_out_reads;
     tgsf_fragment* d_out_frags;
@@ -313,6 +314,7 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     if (!e) e = dev_alloc(c, &c->d_seq, cap_bytes);
     if (!e) e = dev_alloc(c, &c->d_qual, cap_bytes);
     if (!e) e = dev_alloc(c, &c->d_off, n + 1);
+    if (!e) e = dev_alloc(c, &c->d_qoff, n + 1);
     if (!e) e = dev_alloc(c, &c->d_lenin, n);
     if (!e) e = dev_alloc(c, &B.len, n);
     if (!e) e = dev_alloc(c, &B.sumq, n);
@@ -331,8 +333,9 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     if (!e) e = dev_alloc(c, &B.tile_fill, (size_t)B.max_tiles + 2);
     if (!e) e = dev_alloc(c, &B.perm, nitems);
     B.work_cap = (uint32_t)std::min<uint64_t>(c->cap_bases / kTileBases + nitems + 16, 0x7FFFFFF0ull);
-    if (!e) e = dev_alloc(c, &B.work, (size_t)B.work_cap);
+    if (!e) e = dev_alloc(c, &B.work, 2 * (size_t)B.work_cap);
     if (!e) e = dev_alloc(c, &B.frag_off, (size_t)B.fcap);
+    if (!e) e = dev_alloc(c, &B.frag_qoff, (size_t)B.fcap);
     if (!e) e = dev_alloc(c, &B.frag_len, (size_t)B.fcap);
     if (!e) e = dev_alloc(c, &B.frag_sum, (size_t)B.fcap);
     if (!e) e = dev_alloc(c, &B.frag_read, (size_t)B.fcap);
@@ -406,6 +409,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     DevBatch B = c->B;
     const DevParams& P = c->P;
     B.seq = in->seq; B.qual = in->qual; B.off = in->offsets; B.len_in = in->lengths;
+    B.qoff = in->qual_offsets ? in->qual_offsets : in->offsets;
     B.n = in->n_reads; B.n_bytes = in->n_bytes;
     const uint32_t n = B.n;
     const int A = P.n_adapters;
@@ -524,6 +528,7 @@ static int check_batch(tgsf_ctx* c, const tgsf_batch_in* in)
     if (!in || !in->seq || !in->qual || !in->offsets) return fail(c, TGSF_E_INVALID, "null batch pointer");
     if (in->n_reads == 0) return fail(c, TGSF_E_INVALID, "empty batch");
     if (in->n_reads > c->cap_reads) return fail(c, TGSF_E_CAPACITY, "batch has %u reads, context was sized for %u", in->n_reads, c->cap_reads);
+    if (in->qual_offsets && !in->lengths) return fail(c, TGSF_E_INVALID, "qual_offsets requires explicit lengths");
     return TGSF_OK;
 }
 
@@ -576,21 +581,27 @@ extern "C" int tgsf_submit(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_batch_out*
     if (!out || !out->reads) return fail(c, TGSF_E_INVALID, "null output");
     const uint32_t n = in->n_reads;
     uint64_t span = in->n_bytes;
-    if (!span) span = in->lengths ? in->offsets[n - 1] + in->lengths[n - 1] : in->offsets[n];
+    if (!span) {
+        span = in->lengths ? in->offsets[n - 1] + in->lengths[n - 1] : in->offsets[n];
+        if (in->qual_offsets) span = std::max<uint64_t>(span, in->qual_offsets[n - 1] + in->lengths[n - 1]);
+    }
     if (span > c->cap_bases + 16ull * c->cap_reads) return fail(c, TGSF_E_CAPACITY, "batch spans %llu bytes, context was sized for %llu bases", (unsigned long long)span, (unsigned long long)c->cap_bases);
 #if !defined(TGSF_EMUL)
     (void)hipSetDevice(c->device);
 #endif
     rt_stream st = c->stream;
     int he = 0;
+    const bool one_buffer = in->qual == in->seq;            // raw FASTQ text: both streams are read in place
     he |= rt_h2d(c->d_seq, in->seq, span, st);
-    he |= rt_h2d(c->d_qual, in->qual, span, st);
+    if (!one_buffer) he |= rt_h2d(c->d_qual, in->qual, span, st);
     he |= rt_h2d(c->d_off, in->offsets, (size_t)(in->lengths ? n : n + 1) * 8, st);
     if (in->lengths) he |= rt_h2d(c->d_lenin, in->lengths, (size_t)n * 4, st);
+    if (in->qual_offsets) he |= rt_h2d(c->d_qoff, in->qual_offsets, (size_t)n * 8, st);
     if (he) return fail(c, TGSF_E_HIP, "host to device copy failed");
     tgsf_batch_in din = *in;
-    din.seq = c->d_seq; din.qual = c->d_qual; din.offsets = c->d_off;
+    din.seq = c->d_seq; din.qual = one_buffer ? c->d_seq : c->d_qual; din.offsets = c->d_off;
     din.lengths = in->lengths ? c->d_lenin : nullptr;
+    din.qual_offsets = in->qual_offsets ? c->d_qoff : nullptr;
     din.n_bytes = span;
     e = run_pipeline(c, &din, c->d_out_reads, c->d_out_frags, c->B.fcap, c->d_out_nfrags, st);
     if (e) return e;

@@ -3,8 +3,9 @@
 //
 // Replaces main (src/TGSFilter.cpp:2945-3332) and TGSFilterTask (:1755-2162): the reference moves one
 // read at a time as three std::string copies through lock-free queues to N worker threads; here reads
-// are packed once into 16-byte-aligned CSR batches, filtered on the GPU through the C ABI, and the kept
-// fragments are formatted straight from the batch buffers in input order (= the reference's -t 1 order).
+// are only INDEXED on the host (the mmap'ed FASTQ text itself is the batch buffer: sequence and quality
+// lines are read in place by the kernels), filtered on the GPU through the C ABI, and the kept
+// fragments are formatted straight from the input text in input order (= the reference's -t 1 order).
 #include <zlib.h>
 
 #include <algorithm>
@@ -29,11 +30,14 @@ using namespace host;
 
 namespace {
 
+// A batch is a slice [base, base+span) of the input text plus an index of its records: nothing is
+// copied on the host; the library reads sequence and quality lines in place (tgsf_batch_in.qual_offsets).
 struct Batch {
-    std::vector<uint8_t> seq, qual;
-    std::vector<uint64_t> off;
+    const char* base = nullptr;              // first byte of the slice (inside the mmap'ed input)
+    uint64_t span = 0;                       // bytes of the slice
+    std::vector<uint64_t> off, qoff;         // sequence / quality line of each read, relative to base
     std::vector<uint32_t> len;
-    std::vector<std::string_view> names;     // views into the (mmap'ed) input
+    std::vector<std::string_view> names;     // views into the input
     std::vector<tgsf_read_result> res;
     std::vector<tgsf_fragment> frags;
     uint32_t n_frags = 0;
@@ -205,7 +209,8 @@ int main(int argc, char** argv)
     }
 
     // ---- context ----
-    const uint64_t batch_bases = std::min<uint64_t>(1ull << 30, std::max<uint64_t>(in.size() / 2 + 4096, 1 << 16));
+    // batches are slices of the input text: sized in text bytes (about 2 bytes per base + headers)
+    const uint64_t batch_text = std::min<uint64_t>(2ull << 30, std::max<uint64_t>(in.size() / 2 + 4096, 1 << 16));
     const uint32_t batch_reads = 1u << 16;
     tgsf_params p;
     memset(&p, 0, sizeof p);
@@ -218,7 +223,7 @@ int main(int argc, char** argv)
     if (adapters.size() > TGSF_MAX_ADAPTERS) die("more than " + std::to_string(TGSF_MAX_ADAPTERS) + " adapter sequences");
     p.n_adapters = (int)adapters.size();
     for (size_t a = 0; a < adapters.size(); a++) { p.adapters[a] = adapters[a].data(); p.adapter_len[a] = (int)adapters[a].size(); }
-    p.max_batch_bases = batch_bases;
+    p.max_batch_bases = batch_text + (1 << 20);           // capacity is in buffer bytes: the text slice must fit
     p.max_batch_reads = batch_reads;
     p.max_read_len = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(in.size() / 2, 1024), 1u << 26);
     tgsf_ctx* ctx = nullptr;
@@ -235,14 +240,12 @@ int main(int argc, char** argv)
     Output out;
     if (!o.only_qc && !out.open(o)) return 1;
 
-    std::thread reader([&] {                                           // read_fastx, :1845-1870
+    std::thread reader([&] {                                           // read_fastx, :1845-1870 (index only)
         FastxReader rd(in.data(), in.size(), true);
         Record r;
-        const size_t cap = (size_t)batch_bases + 16 * (size_t)batch_reads + 4096;
         auto fresh = [&] {
             std::unique_ptr<Batch> nb(new Batch);
-            nb->seq.reserve(cap); nb->qual.reserve(cap);
-            nb->off.reserve(batch_reads); nb->len.reserve(batch_reads); nb->names.reserve(batch_reads);
+            nb->off.reserve(batch_reads); nb->qoff.reserve(batch_reads); nb->len.reserve(batch_reads); nb->names.reserve(batch_reads);
             return nb;
         };
         std::unique_ptr<Batch> b = fresh();
@@ -258,12 +261,14 @@ int main(int argc, char** argv)
         while (rd.next(r)) {
             const size_t L = r.seq.size();
             if (L > p.max_read_len) die("read longer than the supported maximum");
-            if (b->bases + L > batch_bases || b->names.size() >= batch_reads) flush();
-            const size_t o0 = (b->seq.size() + 15) & ~size_t(15);      // 16-byte aligned read starts
-            b->seq.resize(o0); b->qual.resize(o0);                       // pad (zero) up to the aligned start
-            b->seq.insert(b->seq.end(), r.seq.begin(), r.seq.end());     // one copy, no zero fill
-            b->qual.insert(b->qual.end(), r.qual.begin(), r.qual.end());
-            b->off.push_back(o0); b->len.push_back((uint32_t)L); b->names.push_back(r.name);
+            const char* rec_end = r.qual.data() + L;
+            if (!b->names.empty() && ((uint64_t)(rec_end - b->base) > batch_text || b->names.size() >= batch_reads)) flush();
+            if (b->names.empty()) b->base = r.name.data();
+            b->off.push_back((uint64_t)(r.seq.data() - b->base));
+            b->qoff.push_back((uint64_t)(r.qual.data() - b->base));
+            b->len.push_back((uint32_t)L); b->names.push_back(r.name);
+            b->span = (uint64_t)(rec_end - b->base);
+            if (b->span > p.max_batch_bases) die("record larger than a batch");
             b->bases += L;
             raw_bases += L; raw_lens.push_back((int)L);
         }
@@ -279,8 +284,12 @@ int main(int argc, char** argv)
             const double g0 = now_s();
             b->res.resize(b->names.size());
             b->frags.resize((size_t)(b->bases / (uint64_t)std::max(p.min_len, 1)) + b->names.size() + 16);
-            tgsf_batch_in bi{b->seq.data(), b->qual.data(), b->off.data(), b->len.data(), (uint32_t)b->names.size(), 0,
-                             (uint64_t)b->seq.size()};
+            const uint8_t* text = reinterpret_cast<const uint8_t*>(b->base);
+            tgsf_batch_in bi;
+            memset(&bi, 0, sizeof bi);
+            bi.seq = text; bi.qual = text;                             // one buffer: the FASTQ text itself
+            bi.offsets = b->off.data(); bi.qual_offsets = b->qoff.data(); bi.lengths = b->len.data();
+            bi.n_reads = (uint32_t)b->names.size(); bi.n_bytes = b->span;
             tgsf_batch_out bo{b->res.data(), b->frags.data(), (uint32_t)b->frags.size(), 0};
             if (tgsf_submit(ctx, &bi, &bo) != TGSF_OK) die(tgsf_last_error(ctx));
             t_gpu += now_s() - g0;
@@ -306,10 +315,10 @@ int main(int argc, char** argv)
                     rec += fastq_out ? '@' : '>';
                     append_name(rec, b->names[r], pass_num++);
                     rec += '\n';
-                    rec.append((const char*)b->seq.data() + b->off[r] + fr.start, (size_t)fr.len);
+                    rec.append(b->base + b->off[r] + fr.start, (size_t)fr.len);
                     if (fastq_out) {
                         rec += "\n+\n";
-                        rec.append((const char*)b->qual.data() + b->off[r] + fr.start, (size_t)fr.len);
+                        rec.append(b->base + b->qoff[r] + fr.start, (size_t)fr.len);
                     }
                     rec += '\n';
                     out.write(rec);
