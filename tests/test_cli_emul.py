@@ -21,3 +21,44 @@ def binary():
 @pytest.mark.parametrize("name", hostmodel.GOLDEN_CASES)
 def test_cli_golden(binary, golden_dir, name):
     cli_check.run_case(binary, golden_dir, name)
+
+
+def test_cli_gz_output_and_fasta(binary, golden_dir, tmp_path):
+    """-o *.fq.gz (per-record gzip members) inflates to the reference's output; -o *.fa keeps the bases."""
+    import gzip
+    import json
+    name = "ont_zoo"
+    cmd = json.load(open(os.path.join(golden_dir, name + ".cmd.json")))
+    ref_out = gzip.open(os.path.join(golden_dir, name + ".out.fq.gz"), "rb").read()
+    fin = tmp_path / "in.fq"
+    fin.write_bytes(gzip.open(os.path.join(golden_dir, name + ".in.fq.gz"), "rb").read())
+    fa = tmp_path / "ad.fa"
+    fa.write_text("".join(">a%d\n%s\n" % (i, a) for i, a in enumerate(cmd["adapters"])))
+    base = [binary, "-i", str(fin), "-a", str(fa)] + cmd["flags"].split()
+    subprocess.run(base + ["-o", str(tmp_path / "o.fq.gz")], check=True, capture_output=True)
+    assert gzip.open(tmp_path / "o.fq.gz", "rb").read() == ref_out
+    subprocess.run(base + ["-o", str(tmp_path / "o.fa")], check=True, capture_output=True)
+    ref_lines = ref_out.split(b"\n")
+    exp = b"".join(b">" + ref_lines[i][1:] + b"\n" + ref_lines[i + 1] + b"\n" for i in range(0, len(ref_lines) - 3, 4))
+    assert (tmp_path / "o.fa").read_bytes() == exp
+    # gz input
+    gz_in = tmp_path / "in2.fq.gz"
+    gz_in.write_bytes(open(os.path.join(golden_dir, name + ".in.fq.gz"), "rb").read())
+    subprocess.run([binary, "-i", str(gz_in), "-a", str(fa)] + cmd["flags"].split() + ["-o", str(tmp_path / "o2.fq")],
+                   check=True, capture_output=True)
+    assert (tmp_path / "o2.fq").read_bytes() == ref_out
+
+
+def test_cli_usage_and_errors(binary, tmp_path):
+    p = subprocess.run([binary], capture_output=True)
+    assert p.returncode == 1 and p.stdout.startswith(b"Usage: tgsfilter -i TGS.raw.fq.gz -x ont -o TGS.clean.fq.gz")
+    p = subprocess.run([binary, "-i", "/nonexistent.fq", "-x", "ont"], capture_output=True)
+    assert p.returncode != 0 and b"Error: Can't find this file for -i /nonexistent.fq" in p.stderr
+    f = tmp_path / "a.fq"
+    f.write_bytes(b"@r\nACGT\n+\nIIII\n")
+    p = subprocess.run([binary, "-i", str(f), "-z", "1"], capture_output=True)
+    assert p.returncode == 1 and b"Error: UnKnow argument -z" in p.stderr
+    p = subprocess.run([binary, "-i", str(f), "-l"], capture_output=True)
+    assert p.returncode == 1 and b"Error: Lack Argument for [ -l ]" in p.stderr
+    p = subprocess.run([binary, "-i", str(f), "-o", "x.fq"], capture_output=True)
+    assert b"Error: lack argument for the must: -x" in p.stderr

@@ -6,6 +6,8 @@
 // are only INDEXED on the host (the mmap'ed FASTQ text itself is the batch buffer: sequence and quality
 // lines are read in place by the kernels), filtered on the GPU through the C ABI, and the kept
 // fragments are formatted straight from the input text in input order (= the reference's -t 1 order).
+#include <sys/uio.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -88,32 +90,68 @@ public:
         if (o.out_file.empty()) f_ = stdout;
         else f_ = fopen(o.out_file.c_str(), "wb");
         if (!f_) { std::cerr << "Error: Failed to open file: " << o.out_file << std::endl; return false; }
-        setvbuf(f_, nullptr, _IOFBF, 8 << 20);
         if (gz_) {
+            setvbuf(f_, nullptr, _IOFBF, 8 << 20);
             memset(&z_, 0, sizeof z_);
             if (deflateInit2(&z_, o.comp_level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+        } else {
+            fflush(f_);
+            fd_ = fileno(f_);
         }
         return true;
     }
-    void write(const std::string& rec) {
-        if (!gz_) { fwrite(rec.data(), 1, rec.size(), f_); return; }
+    // Plain output: the pieces of a record (header, sequence, separator, qualities) are gathered with
+    // writev straight from the input text -- no intermediate record string.
+    void piece(const char* p, size_t n) {
+        if (!n) return;
+        if (gz_) { rec_.append(p, n); return; }
+        iov_.push_back({const_cast<char*>(p), n});
+        if (iov_.size() >= 1000) flush_iov();
+    }
+    // small generated text (":<n>" suffixes, separators that are not in the input)
+    void text(const std::string& t) {
+        if (gz_) { rec_ += t; return; }
+        if (pool_.size() + t.size() > pool_.capacity()) flush_iov();
+        const size_t o0 = pool_.size();
+        pool_ += t;
+        iov_.push_back({&pool_[o0], t.size()});
+    }
+    void end_record() {
+        if (!gz_) return;
         deflateReset(&z_);
-        zbuf_.resize(deflateBound(&z_, (uLong)rec.size()) + 64);
-        z_.next_in = (Bytef*)rec.data(); z_.avail_in = (uInt)rec.size();
+        zbuf_.resize(deflateBound(&z_, (uLong)rec_.size()) + 64);
+        z_.next_in = (Bytef*)rec_.data(); z_.avail_in = (uInt)rec_.size();
         z_.next_out = (Bytef*)zbuf_.data(); z_.avail_out = (uInt)zbuf_.size();
         deflate(&z_, Z_FINISH);
         fwrite(zbuf_.data(), 1, zbuf_.size() - z_.avail_out, f_);
+        rec_.clear();
+    }
+    void flush_iov() {
+        size_t i = 0;
+        while (i < iov_.size()) {
+            ssize_t w = writev(fd_, &iov_[i], (int)std::min<size_t>(iov_.size() - i, 1000));
+            if (w < 0) { std::cerr << "Error: write failed" << std::endl; exit(-1); }
+            size_t left = (size_t)w;
+            while (i < iov_.size() && left >= iov_[i].iov_len) { left -= iov_[i].iov_len; i++; }
+            if (left) { iov_[i].iov_base = (char*)iov_[i].iov_base + left; iov_[i].iov_len -= left; }
+        }
+        iov_.clear();
+        pool_.clear();
     }
     void close() {
-        if (gz_) deflateEnd(&z_);
+        if (gz_) deflateEnd(&z_); else flush_iov();
         if (f_ && f_ != stdout) fclose(f_); else if (f_) fflush(f_);
         f_ = nullptr;
     }
+    Output() { pool_.reserve(1 << 16); }
 private:
     FILE* f_ = nullptr;
+    int fd_ = -1;
     bool gz_ = false;
     z_stream z_;
     std::vector<char> zbuf_;
+    std::string rec_, pool_;
+    std::vector<iovec> iov_;
 };
 
 double now_s()
@@ -210,7 +248,7 @@ int main(int argc, char** argv)
 
     // ---- context ----
     // batches are slices of the input text: sized in text bytes (about 2 bytes per base + headers)
-    const uint64_t batch_text = std::min<uint64_t>(2ull << 30, std::max<uint64_t>(in.size() / 2 + 4096, 1 << 16));
+    const uint64_t batch_text = std::min<uint64_t>(512ull << 20, std::max<uint64_t>(in.size() / 4 + 4096, 1 << 16));
     const uint32_t batch_reads = 1u << 16;
     tgsf_params p;
     memset(&p, 0, sizeof p);
@@ -233,7 +271,7 @@ int main(int argc, char** argv)
     const double t_p0 = now_s();
 
     // ---- pipeline ----
-    Channel<std::unique_ptr<Batch>> to_gpu(2), to_writer(2);
+    Channel<std::unique_ptr<Batch>> to_gpu(3), to_writer(3);
     std::vector<int> raw_lens, clean_lens;
     uint64_t raw_bases = 0, clean_bases = 0;
     const bool fastq_out = o.out_type == 1;
@@ -300,7 +338,8 @@ int main(int argc, char** argv)
     });
 
     std::thread writer([&] {                                           // record formatting :2011-2053 + write_output :2095-2145
-        std::string rec;
+        const std::string lead(1, fastq_out ? '@' : '>'), nl("\n"), sep("\n+\n");
+        std::string name;
         for (;;) {
             std::unique_ptr<Batch> b = to_writer.get();
             if (!b) break;
@@ -311,21 +350,23 @@ int main(int argc, char** argv)
                 for (uint32_t f = rr.frag_begin; f < rr.frag_begin + rr.n_frags; f++) {
                     const tgsf_fragment& fr = b->frags[f];
                     if (!(fr.flags & TGSF_FF_PASS)) continue;
-                    rec.clear();
-                    rec += fastq_out ? '@' : '>';
-                    append_name(rec, b->names[r], pass_num++);
-                    rec += '\n';
-                    rec.append(b->base + b->off[r] + fr.start, (size_t)fr.len);
+                    out.text(lead);
+                    if (pass_num < 2) out.piece(b->names[r].data(), b->names[r].size());
+                    else { name.clear(); append_name(name, b->names[r], pass_num); out.text(name); }
+                    pass_num++;
+                    out.text(nl);
+                    out.piece(b->base + b->off[r] + fr.start, (size_t)fr.len);
                     if (fastq_out) {
-                        rec += "\n+\n";
-                        rec.append(b->base + b->qoff[r] + fr.start, (size_t)fr.len);
+                        out.text(sep);
+                        out.piece(b->base + b->qoff[r] + fr.start, (size_t)fr.len);
                     }
-                    rec += '\n';
-                    out.write(rec);
+                    out.text(nl);
+                    out.end_record();
                     clean_bases += (uint64_t)fr.len;
                     clean_lens.push_back(fr.len);
                 }
             }
+            if (!o.only_qc) out.flush_iov();                             // the batch (and its views) goes away
             t_write += now_s() - w0;
         }
     });

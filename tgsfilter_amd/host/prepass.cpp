@@ -156,6 +156,8 @@ PrepassResult run_prepass(Options& o, const InputBytes& in)
     int min_len = std::max(o.min_len, 2 * check_len);                   // :906-909
     const int max_seq = std::max(o.ad_num, o.bc_num);                   // :911-914
     std::vector<std::string> ends5, ends3;
+    const bool need5 = o.filter && (o.head_trim < 0 || o.adapter_file.empty());
+    const bool need3 = o.filter && (o.tail_trim < 0 || o.adapter_file.empty());
     int seq_num = 0, min_qc = 255, max_qc = 0;
     {
         FastxReader rd(in.data(), in.size(), o.in_type == 1);           // read_fastx, :949-982
@@ -165,8 +167,9 @@ PrepassResult run_prepass(Options& o, const InputBytes& in)
             if (L < min_len) continue;
             if (seq_num >= max_seq) break;
             seq_num++;
-            ends5.emplace_back(r.seq.substr(0, (size_t)check_len));
-            ends3.emplace_back(rev_comp(std::string(r.seq.substr((size_t)(L - check_len)))));
+            // the read ends are only looked at by the base-content check and the adapter search
+            if (need5) ends5.emplace_back(r.seq.substr(0, (size_t)check_len));
+            if (need3) ends3.emplace_back(rev_comp(std::string(r.seq.substr((size_t)(L - check_len)))));
             const std::string_view q = r.qual.substr(0, std::min((size_t)check_len, r.qual.size()));
             for (char c : q) { if (min_qc > c) min_qc = c; if (max_qc < c) max_qc = c; }
         }
