@@ -31,11 +31,15 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def gen_batch(torch, device, n_reads, seed, mean_len, max_len):
-    """Synthetic C2 batch built directly in HBM (generation is outside every timed region)."""
+def gen_batch(torch, device, n_reads, seed, mean_len, max_len, workload="ont"):
+    """Synthetic C2 (ont) / C3 (hifi) batch built directly in HBM (generation is outside every timed region)."""
     from tgsfilter_amd import synth
     rng = np.random.default_rng(seed)
-    lens = np.minimum(synth.ont_lengths(rng, n_reads, mean_len), max_len).astype(np.int64)
+    hifi = workload == "hifi"
+    if hifi:
+        lens = np.minimum(synth.hifi_lengths(rng, n_reads, mean_len, sd=mean_len / 6.0), max_len).astype(np.int64)
+    else:
+        lens = np.minimum(synth.ont_lengths(rng, n_reads, mean_len), max_len).astype(np.int64)
     padded = (lens + 15) // 16 * 16
     offsets = np.zeros(n_reads + 1, dtype=np.int64)
     np.cumsum(padded, out=offsets[1:])
@@ -44,7 +48,8 @@ def gen_batch(torch, device, n_reads, seed, mean_len, max_len):
     g.manual_seed(seed)
     seq = torch.empty(total, dtype=torch.uint8, device=device)
     qual = torch.empty(total, dtype=torch.uint8, device=device)
-    mq = torch.from_numpy(rng.choice(np.array([7, 9, 12, 14, 18], dtype=np.float32), n_reads)).to(device)
+    mq_set = np.array([30], dtype=np.float32) if hifi else np.array([7, 9, 12, 14, 18], dtype=np.float32)
+    mq = torch.from_numpy(rng.choice(mq_set, n_reads)).to(device)
     per_base_mq = torch.repeat_interleave(mq.to(torch.float16), torch.from_numpy(padded).to(device))
     lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=device)
     CH = 1 << 26
@@ -52,13 +57,22 @@ def gen_batch(torch, device, n_reads, seed, mean_len, max_len):
         e = min(total, s + CH)
         codes = torch.randint(0, 4, (e - s,), device=device, generator=g)
         seq[s:e] = lut[codes]
-        q = torch.randn(e - s, device=device, generator=g) * 4.0 + per_base_mq[s:e].float()
-        qual[s:e] = (q.round().clamp_(1, 50) + 33).to(torch.uint8)
+        q = torch.randn(e - s, device=device, generator=g) * (6.0 if hifi else 4.0) + per_base_mq[s:e].float()
+        qual[s:e] = (q.round().clamp_(2 if hifi else 1, 60 if hifi else 50) + 33).to(torch.uint8)
     del per_base_mq
     # rapid adapter at the 5' end of 80 % of reads (0-30 random bases before it, 10 % errors); 0.03 % middle
     idx, val = [], []
     for i in range(n_reads):
         L = int(lens[i])
+        if hifi:
+            # blunt adapter 5' in 0.27 %, 3' in 0.26 %, middle in 0.002 % of reads, 3 % errors (README ratios)
+            u = rng.random()
+            if u < 0.0027 + 0.0026 + 0.00002 and L > 2000:
+                a = synth.mutate(rng, synth.PACBIO_BLUNT, 0.03)
+                p = 0 if u < 0.0027 else (L - len(a) if u < 0.0053 else int(rng.integers(300, L - 300 - len(a))))
+                idx.append(np.arange(len(a), dtype=np.int64) + offsets[i] + p)
+                val.append(np.frombuffer(a, dtype=np.uint8))
+            continue
         if rng.random() < 0.80:
             a = synth.mutate(rng, synth.ONT_RAPID, 0.10)
             pre = int(rng.integers(0, 31))
@@ -130,7 +144,9 @@ def main():
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=65536, help="reads per step per GPU")
-    ap.add_argument("--mean-len", type=float, default=45000.0)
+    ap.add_argument("--mean-len", type=float, default=None)
+    ap.add_argument("--workload", choices=["ont", "hifi"], default="ont",
+                    help="ont = config C2 (the headline line); hifi = config C3 shape, for information")
     ap.add_argument("--max-len", type=int, default=2_000_000)
     ap.add_argument("--cpu-sample-reads", type=int, default=24000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -155,11 +171,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    flags = "-x ont -l 1000 -q 10 -5 0 -3 0"
-    batches = [gen_batch(torch, device, args.reads, 1000 * rank + b + 1, args.mean_len, args.max_len) for b in range(2)]
+    hifi = args.workload == "hifi"
+    if args.mean_len is None:
+        args.mean_len = 18000.0 if hifi else 45000.0
+    flags = "-x hifi -l 1000 -q 20 -5 0 -3 0" if hifi else "-x ont -l 1000 -q 10 -5 0 -3 0"
+    wl_adapters = [synth.PACBIO_BLUNT, synth.PACBIO_BLUNT_RC] if hifi else [synth.ONT_RAPID, synth.ONT_RAPID_RC]
+    batches = [gen_batch(torch, device, args.reads, 1000 * rank + b + 1, args.mean_len, args.max_len, args.workload)
+               for b in range(2)]
     max_bases = max(b["bases"] for b in batches)
     max_len = max(int(b["h_lens"].max()) for b in batches)
-    p = abi.make_params("ont", adapters=[synth.ONT_RAPID, synth.ONT_RAPID_RC], min_len=1000, min_q=10.0,
+    p = abi.make_params(args.workload, adapters=wl_adapters, min_len=1000, min_q=20.0 if hifi else 10.0,
                         head_trim=0, tail_trim=0, max_batch_bases=max_bases + 64, max_batch_reads=args.reads,
                         max_read_len=max_len)
     NS = max(1, args.streams)
@@ -289,11 +310,14 @@ def main():
         "dtype": "u8",
         "data": "synthetic",
         "config": {
-            "workload": "C2 (BASELINE.json configs[1]): synthetic ONT reads, lognormal lengths mean %.0f bp, "
-                        "%s, adapters ONT rapid + reverse complement; %d reads (%.2f Gbases) per step per GPU, "
-                        "inputs resident in HBM; the 4M-read job is %d such steps"
-                        % (args.mean_len, flags, args.reads, bases / args.steps / 1e9,
-                           int(np.ceil(4_000_000 / args.reads))),
+            "workload": ("C3 shape (BASELINE.json configs[2], for information): synthetic HiFi reads, N(%.0f, /6) bp, Q~N(30,6), "
+                         "%s, adapters PacBio blunt + reverse complement; %d reads (%.2f Gbases) per step per GPU, "
+                         "inputs resident in HBM" % (args.mean_len, flags, args.reads, bases / args.steps / 1e9)) if hifi else
+                        ("C2 (BASELINE.json configs[1]): synthetic ONT reads, lognormal lengths mean %.0f bp, "
+                         "%s, adapters ONT rapid + reverse complement; %d reads (%.2f Gbases) per step per GPU, "
+                         "inputs resident in HBM; the 4M-read job is %d such steps"
+                         % (args.mean_len, flags, args.reads, bases / args.steps / 1e9,
+                            int(np.ceil(4_000_000 / args.reads)))),
             "reads_per_step_per_gpu": args.reads,
             "parallelism": "reads sharded over %d GPU(s), one all-reduce of the tallies" % world,
             "batches_in_flight_per_gpu": NS,
@@ -318,7 +342,7 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(torch, batches[0], flags,
-                                               b">rapid\n" + synth.ONT_RAPID + b"\n", args.cpu_sample_reads)
+                                               b">ad\n" + wl_adapters[0] + b"\n", args.cpu_sample_reads)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
