@@ -77,8 +77,8 @@ typedef struct tgsf_params {
     int32_t  discard;         /* -D  discard reads with a middle adapter              */
     int32_t  filter;          /* Para_A24::Filter (0 with -F / --qc)                  */
     int32_t  only_qc;         /* --qc                                                 */
-    int32_t  min_repeat;      /* -p  MinRepeat; must be 0 (GetKmerCount is a "next" row) */
-    int32_t  kmer;            /* -k  Kmer (unused while min_repeat == 0)              */
+    int32_t  min_repeat;      /* -p  MinRepeat (0 disables the repeat gate)           */
+    int32_t  kmer;            /* -k  Kmer, 1..13 when min_repeat > 0 (GetKmerCount :1703-1753) */
     int32_t  qtype;           /* global qType: 33 or 64 (:80, :1042-1053)             */
     int32_t  n_adapters;      /* size of the global `adapters` set (:1324)            */
     const char* adapters[TGSF_MAX_ADAPTERS];     /* not NUL-terminated necessarily    */
@@ -133,7 +133,8 @@ typedef struct tgsf_read_result {
 } tgsf_read_result;
 
 /* tgsf_fragment.flags */
-#define TGSF_FF_PASS  0x01u   /* survived the post-split quality gate (:1995-2001) => emitted  */
+#define TGSF_FF_PASS    0x01u /* survived the post-split quality gate (:1995-2001) => emitted  */
+#define TGSF_FF_REPEAT  0x02u /* dropped by the repeat gate: GetKmerCount < -p (:1982-1989); no clean stats */
 
 /* one keep-region {start,len} of adapterMap (:1404-1431), ascending within a read */
 typedef struct tgsf_fragment {

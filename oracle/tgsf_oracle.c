@@ -394,6 +394,31 @@ static void adapter_map(const tgsf_params* p, const uint8_t* read, int L,
     free(regs.r); free(merged.r);
 }
 
+/* GetKmerCount, src/TGSFilter.cpp:1703-1753: (#k-mers) - (#distinct k-mers) of a fragment, k-mers as
+ * 2-bit codes A=0 C=1 G=2 T=3; any other byte (lower case, N) contributes 0 bits (:1722-1723). */
+static int u64_cmp(const void* a, const void* b)
+{
+    uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b;
+    return x < y ? -1 : x > y;
+}
+static int kmer_repeat(const uint8_t* seq, int len, int k)
+{
+    int total = len - k + 1;
+    if (total <= 0) return 0;
+    uint64_t* v = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)total);
+    uint64_t mask = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1ull), km = 0;
+    for (int i = 0; i < len; i++) {
+        uint64_t c = seq[i] == 'C' ? 1 : seq[i] == 'G' ? 2 : seq[i] == 'T' ? 3 : 0;
+        km = ((km << 2) | c) & mask;
+        if (i >= k - 1) v[i - k + 1] = km;
+    }
+    qsort(v, (size_t)total, sizeof(uint64_t), u64_cmp);
+    int distinct = 1;
+    for (int i = 1; i < total; i++) distinct += v[i] != v[i - 1];
+    free(v);
+    return total - distinct;
+}
+
 /* ------------------------------------------------------------------------- */
 /* filter_sequence for a batch, src/TGSFilter.cpp:1939-2061                    */
 /* ------------------------------------------------------------------------- */
@@ -401,7 +426,6 @@ static void adapter_map(const tgsf_params* p, const uint8_t* read, int L,
 int orc_filter_batch(const tgsf_params* p, const tgsf_batch_in* in, tgsf_batch_out* out,
                      uint64_t* ctr, uint32_t n_bins)
 {
-    if (p->min_repeat > 0) return TGSF_E_UNSUPPORTED;
     int bc = p->bc_len;
     uint64_t* drop = ctr + TGSF_CTR_DROPINFO;
     uint64_t* rows = ctr + TGSF_CTR_ROWS;
@@ -446,7 +470,14 @@ int orc_filter_batch(const tgsf_params* p, const tgsf_batch_in* in, tgsf_batch_o
                 int s = keep.r[f].s, fl = keep.r[f].e;                 /* rv holds {start,len} here */
                 if (nf >= out->frag_capacity) { free(keep.r); return TGSF_E_CAPACITY; }
                 tgsf_fragment* fr = &out->frags[nf++];
-                fr->read = r; fr->start = s; fr->len = fl; fr->flags = 0;
+                fr->read = r; fr->start = s; fr->len = fl; fr->flags = 0; fr->sum_q = 0;
+                if (p->min_repeat > 0) {                                                 /* :1982-1989 */
+                    if (kmer_repeat(seq + s, fl, p->kmer) < p->min_repeat) {
+                        drop[15]++; drop[16] += (uint64_t)fl;
+                        fr->flags |= TGSF_FF_REPEAT;
+                        continue;
+                    }
+                }
                 /* clean bin tables accumulate BEFORE the gate: :1994 */
                 uint64_t cs = calc_avg_quality(seq + s, qual + s, (uint64_t)fl, p->qtype,
                                                B[TGSF_B_CLEAN_QUAL], B[TGSF_B_CLEAN_CNT], &rows[1]);

@@ -107,3 +107,18 @@ def compare_batch_in_place(ctx: capi.Context, p: abi.Params, reads):
     seq, qual, offsets, lengths = synth.pack(reads)
     pk_r, pk_f, pk_ctr = orc.filter_batch(p, seq, qual, offsets, lengths, n_bins=ctx.n_bins)
     assert np.array_equal(pk_ctr, exp_ctr) and np.array_equal(pk_f, exp_f)
+
+
+def repeat_reads(seed=51, n=60):
+    """Random reads plus low-complexity (tandem repeat) reads: exercises both sides of the -p gate."""
+    reads = synth.make_reads(seed, n, "ont", mean_len=3000, zoo=True)
+    rng = np.random.default_rng(seed)
+    for i in range(12):
+        unit = bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, int(rng.integers(2, 60)))])
+        L = int(rng.integers(1500, 9000))
+        s = bytearray((unit * (L // len(unit) + 1))[:L])
+        for pos in rng.integers(0, L, L // 50):
+            s[int(pos)] = int(np.frombuffer(b"ACGTNa", dtype=np.uint8)[rng.integers(0, 6)])
+        q = bytes((rng.integers(12, 30, L) + 33).astype(np.uint8))
+        reads.append((b"rep%d" % i, bytes(s), q))
+    return reads

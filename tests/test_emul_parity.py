@@ -81,3 +81,14 @@ def test_emul_in_place_fastq_text(emul):
     ctx = capi.Context(p, 0, emul)
     parity.compare_batch_in_place(ctx, p, reads)
     ctx.close()
+
+
+@pytest.mark.parametrize("pval,k", [(300, 11), (40, 9), (2000, 12)])
+def test_emul_repeat_gate(emul, pval, k):
+    reads = parity.repeat_reads()
+    p = parity.sized(abi.make_params("ont", adapters=[synth.ONT_RAPID, synth.ONT_RAPID_RC], min_q=10.0,
+                                     min_repeat=pval, kmer=k), reads)
+    ctx = capi.Context(p, 0, emul)
+    res, frags, ctr = parity.compare_batch(ctx, p, reads)
+    assert (frags["flags"] & abi.FF_REPEAT).any() and (frags["flags"] & abi.FF_PASS).any()
+    ctx.close()

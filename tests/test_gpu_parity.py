@@ -142,3 +142,15 @@ def test_gpu_in_place_fastq_text():
     ctx = capi.Context(p, 0)
     parity.compare_batch_in_place(ctx, p, reads)
     ctx.close()
+
+
+@pytest.mark.parametrize("pval,k", [(300, 11), (40, 9), (2000, 12), (100, 13)])
+def test_gpu_repeat_gate(pval, k):
+    """-p/-k: GetKmerCount on the device (LDS bitmap partitions) against the oracle."""
+    reads = parity.repeat_reads(n=150)
+    p = parity.sized(abi.make_params("ont", adapters=[synth.ONT_RAPID, synth.ONT_RAPID_RC], min_q=10.0,
+                                     min_repeat=pval, kmer=k), reads)
+    ctx = capi.Context(p, 0)
+    res, frags, ctr = parity.compare_batch(ctx, p, reads)
+    assert (frags["flags"] & abi.FF_REPEAT).any()
+    ctx.close()

@@ -19,7 +19,7 @@ N_STAGES = 12
 OK, E_INVALID, E_NO_DEVICE, E_HIP, E_CAPACITY, E_UNSUPPORTED, E_DATA = 0, -1, -2, -3, -4, -5, -6
 
 RF_LOWQ, RF_AD5P, RF_AD3P, RF_ADMID, RF_DISCARDED = 0x01, 0x02, 0x04, 0x08, 0x10
-FF_PASS = 0x01
+FF_PASS, FF_REPEAT = 0x01, 0x02
 
 CTR_DROPINFO, CTR_RAW_DIFFQ, CTR_CLEAN_DIFFQ, CTR_ROWS, CTR_END_TABLES = 0, 17, 273, 529, 533
 (T_RAW5P_QUAL, T_RAW5P_CNT, T_RAW3P_QUAL, T_RAW3P_CNT,
@@ -96,7 +96,7 @@ _END_SIM = {"hifi": 0.9, "clr": 0.8, "ont": 0.75}
 def make_params(read_type: str = "ont", *, adapters=(), min_len=1000, max_len=2147483647,
                 min_q=10.0, max_q=255.0, bc_len=150, head_trim=0, tail_trim=0, end_len=150,
                 end_match_len=4, mid_match_len=35, extra_len=50, end_sim=None, mid_sim=None,
-                discard=False, filter=True, only_qc=False, qtype=33,
+                discard=False, filter=True, only_qc=False, qtype=33, min_repeat=0, kmer=11,
                 max_batch_bases=0, max_batch_reads=0, max_read_len=0) -> Params:
     """Para_A24 defaults as CODED (src/TGSFilter.cpp:129-171, e.g. -m defaults to 4)."""
     p = Params()
@@ -112,7 +112,7 @@ def make_params(read_type: str = "ont", *, adapters=(), min_len=1000, max_len=21
     if only_qc:
         filter = False                                                          # :409-411
     p.discard, p.filter, p.only_qc = int(bool(discard)), int(bool(filter)), int(bool(only_qc))
-    p.min_repeat, p.kmer, p.qtype = 0, 11, int(qtype)
+    p.min_repeat, p.kmer, p.qtype = int(min_repeat), int(kmer), int(qtype)
     ads = [bytes(a) for a in adapters]
     if len(ads) > MAX_ADAPTERS:
         raise ValueError("too many adapters")

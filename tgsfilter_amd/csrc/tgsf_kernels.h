@@ -179,6 +179,7 @@ TGSF_KERNEL k_frag_prepare(DevParams P, DevBatch B)
     const uint32_t nf = stored_frags(B);
     uint32_t rows = 0;
     for (uint32_t f = gtid(); f < nf; f += gsize()) {
+        if (B.frag_flags[f] & TGSF_FF_REPEAT) continue;        // dropped before CalcAvgQuality (:1982-1989)
         uint32_t L = B.frag_len[f];
         const uint32_t v = (L + kTileBases - 1) / kTileBases;
         if (use_lds) atomicAdd(&h[v], 1u); else atomicAdd(&B.tile_hist[v], 1u);
@@ -246,7 +247,7 @@ TGSF_KERNEL k_tile_scatter(DevBatch B)
         TGSF_BLOCK_SYNC();
         uint32_t L = 0, v = 0, local = 0;
         if (i < n) {
-            L = CLEAN ? B.frag_len[i] : B.len[i];
+            L = CLEAN ? ((B.frag_flags[i] & TGSF_FF_REPEAT) ? 0u : B.frag_len[i]) : B.len[i];
             v = (L + kTileBases - 1) / kTileBases;
             if (L && use_lds) local = atomicAdd(&h[v], 1u);
         }
@@ -1239,6 +1240,80 @@ TGSF_KERNEL k_regions(DevParams P, DevBatch B)
 }
 
 // ---------------------------------------------------------------------------
+// k_repeat: the repeat gate, GetKmerCount (src/TGSFilter.cpp:1703-1753, :1982-1989).
+// repeat = (#k-mers) - (#distinct k-mers) of a fragment; fragments below -p are dropped before any
+// clean statistics.  k-mers are 2-bit codes (A0 C1 G2 T3, every other byte 0).  One workgroup per
+// fragment; the 4^k-bit "seen" set lives in LDS as a bitmap of at most 2^20 bits (128 KB), so k = 11
+// takes 4 passes over the fragment, each pass owning the k-mers whose top bits equal the pass number;
+// "distinct" is counted from the values returned by the LDS atomic OR.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kRepBits = 1u << 20;
+TGSF_KERNEL k_repeat(DevParams P, DevBatch B)
+{
+    TGSF_SHARED uint32_t bm[kRepBits / 32];
+    TGSF_SHARED uint32_t distinct_s;
+    const int k = P.kmer;
+    const uint32_t space_log2 = 2u * (uint32_t)k;                      // k <= 13 -> <= 26 bits
+    const uint32_t part_log2 = space_log2 < 20u ? space_log2 : 20u;
+    const uint32_t passes = 1u << (space_log2 - part_log2);
+    const uint32_t part_words = ((1u << part_log2) + 31u) / 32u;
+    const uint32_t kmask = (1u << space_log2) - 1u;
+    const uint32_t nf = stored_frags(B);
+    uint64_t drop_n = 0, drop_b = 0;
+    for (uint32_t f = blockIdx.x; f < nf; f += gridDim.x) {
+        const int L = (int)B.frag_len[f];
+        const int total = L - k + 1;
+        const uint8_t* seq = B.seq + B.frag_off[f];
+        if (threadIdx.x == 0) distinct_s = 0;
+#if defined(TGSF_EMUL)
+        if (threadIdx.x != 0) continue;                                // emulation: one lane does the whole fragment
+        const int per = total > 0 ? total : 0, i0 = 0;
+#else
+        const int per = total > 0 ? (total + (int)blockDim.x - 1) / (int)blockDim.x : 0;
+        const int i0 = (int)threadIdx.x * per;
+#endif
+        int i1 = i0 + per;
+        if (i1 > total) i1 = total;
+        uint32_t mine = 0;
+        for (uint32_t pass = 0; pass < passes; pass++) {
+            TGSF_BLOCK_SYNC();
+            for (uint32_t w = TGSF_COOP_BEGIN; w < part_words; w += TGSF_COOP_STRIDE) bm[w] = 0;
+            TGSF_BLOCK_SYNC();
+            if (i0 < i1) {
+                uint32_t km = 0;
+                for (int j = i0; j < i0 + k - 1; j++) {                // the first k-1 bases of this lane's first k-mer
+                    const uint32_t c = seq[j];
+                    km = (km << 2) | (c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 0u);
+                }
+                for (int i = i0; i < i1; i++) {
+                    const uint32_t c = seq[i + k - 1];
+                    km = ((km << 2) | (c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 0u)) & kmask;
+                    if ((km >> part_log2) == pass) {
+                        const uint32_t idx = km & ((1u << part_log2) - 1u), bit = 1u << (idx & 31u);
+                        const uint32_t old = atomicOr(&bm[idx >> 5], bit);
+                        mine += (old & bit) ? 0u : 1u;
+                    }
+                }
+            }
+        }
+        if (mine) atomicAdd(&distinct_s, mine);
+        TGSF_BLOCK_SYNC();
+        if (threadIdx.x == 0) {
+            const int repeat = (total > 0 ? total : 0) - (int)distinct_s;
+            if (repeat < P.min_repeat) {                               // :1984-1988
+                B.frag_flags[f] |= TGSF_FF_REPEAT;
+                drop_n++; drop_b += (uint64_t)L;
+            }
+        }
+        TGSF_BLOCK_SYNC();
+    }
+    if (threadIdx.x == 0 && drop_n) {
+        atomicAdd((ull*)&B.ctr[TGSF_CTR_DROPINFO + 15], (ull)drop_n);
+        atomicAdd((ull*)&B.ctr[TGSF_CTR_DROPINFO + 16], (ull)drop_b);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // k_gate_frags: the post-split quality gate (src/TGSFilter.cpp:1995-2002).
 // ---------------------------------------------------------------------------
 TGSF_KERNEL k_gate_frags(DevParams P, DevBatch B)
@@ -1251,7 +1326,7 @@ TGSF_KERNEL k_gate_frags(DevParams P, DevBatch B)
     uint32_t erows = 0;
     for (uint32_t f0 = blockIdx.x * blockDim.x; f0 < nf; f0 += gsize()) {
         const uint32_t f = f0 + threadIdx.x;
-        if (f >= nf) continue;
+        if (f >= nf || (B.frag_flags[f] & TGSF_FF_REPEAT)) continue;
         const uint32_t L = B.frag_len[f];
         const double cm = mean_q(B.frag_sum[f], L);
         if (P.filter && q_fail(cm, P.min_q, P.max_q)) { lq_n++; lq_b += L; continue; }

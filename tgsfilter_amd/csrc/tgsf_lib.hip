@@ -222,8 +222,8 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
         return fail(nullptr, TGSF_E_INVALID, "tgsf_params.struct_size %u != %zu (ABI mismatch)", p->struct_size, sizeof(tgsf_params));
     if (p->n_adapters < 0 || p->n_adapters > TGSF_MAX_ADAPTERS)
         return fail(nullptr, TGSF_E_INVALID, "n_adapters %d outside [0,%d]", p->n_adapters, TGSF_MAX_ADAPTERS);
-    if (p->min_repeat > 0)
-        return fail(nullptr, TGSF_E_UNSUPPORTED, "-p/-k repeat filter (GetKmerCount) is not on this path yet");
+    if (p->min_repeat > 0 && (p->kmer < 1 || p->kmer > 13))
+        return fail(nullptr, TGSF_E_UNSUPPORTED, "-k %d: the repeat gate supports k-mer sizes 1..13 (4^k-bit set in LDS partitions)", p->kmer);
     if (p->qtype != 33 && p->qtype != 64) return fail(nullptr, TGSF_E_INVALID, "qtype must be 33 or 64");
     if (p->bc_len < 0 || p->bc_len > kMaxBcLen) return fail(nullptr, TGSF_E_INVALID, "bc_len (-e) outside [0,%d]", kMaxBcLen);
     if (p->filter && p->n_adapters > 0) {
@@ -286,6 +286,7 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     P.end_match_len = p->end_match_len; P.mid_match_len = p->mid_match_len; P.extra_len = p->extra_len;
     P.end_sim = p->end_sim; P.mid_sim = p->mid_sim; P.discard = p->discard; P.filter = p->filter;
     P.only_qc = p->only_qc; P.qtype = p->qtype; P.n_adapters = p->n_adapters;
+    P.min_repeat = p->min_repeat; P.kmer = p->kmer;
     c->cap_bases = p->max_batch_bases;
     c->cap_reads = p->max_batch_reads;
     c->max_read_len = p->max_read_len;
@@ -499,6 +500,8 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     TGSF_LAUNCH(k_regions<false>, gsmall, T, st, P, B);
     TGSF_LAUNCH_COOP(k_scan_u32, 1, 1024, st, B.nfr, (const uint32_t*)nullptr, n);
     TGSF_LAUNCH(k_regions<true>, gsmall, T, st, P, B);
+    if (P.min_repeat > 0 && !P.only_qc)
+        TGSF_LAUNCH(k_repeat, grid_cap(256u), 256, st, P, B);          // one workgroup per CU: 128 KB of LDS each
     STAGE_MARK();
     // -- clean stats over the fragments
     rt_memset(B.tile_hist, 0, tl, st);
