@@ -49,6 +49,16 @@ CASES = {
     "ont_auto": (dict(seed=16, n=1500, kind="ont", mean_len=1300), None, "-x ont -l 1000 -b 8"),
     "hifi_auto": (dict(seed=17, n=1200, kind="hifi", mean_len=1400, p5=0.5, p3=0.4), None, "-x hifi -l 1000 -b 8"),
     "qc_only": (dict(seed=18, n=64, kind="ont", mean_len=3000, zoo=True), None, "--qc"),
+    # repeat k-mer gate and length-ranked downsampling (config 5 flags)
+    "ont_repeat": (dict(seed=19, n=80, kind="ont", mean_len=4500, zoo=True, pmid=0.05),
+                   [synth.ONT_RAPID], "-x ont -l 1000 -q 10 -5 0 -3 0 -p 3 -k 11"),
+    "down_gd": (dict(seed=20, n=90, kind="ont", mean_len=3500, zoo=True, pmid=0.05),
+                [synth.ONT_RAPID], "-x ont -l 1000 -q 10 -5 0 -3 0 -g 40k -d 2"),
+    "down_r": (dict(seed=21, n=90, kind="ont", mean_len=3500, zoo=True, pmid=0.05),
+               [synth.ONT_RAPID], "-x ont -l 1000 -q 10 -5 0 -3 0 -r 17 -p 2"),
+    "down_R": (dict(seed=22, n=90, kind="hifi", mean_len=3000, p5=0.2, p3=0.2),
+               [synth.PACBIO_BLUNT], "-x hifi -l 1000 -q 20 -5 0 -3 0 -R 0.3"),
+    "down_F": (dict(seed=23, n=70, kind="ont", mean_len=3000), None, "-F -r 20"),
 }
 
 

@@ -18,7 +18,7 @@ def binary():
     return os.path.join(ROOT, "tests", "emul", "tgsfilter_emul")
 
 
-@pytest.mark.parametrize("name", hostmodel.GOLDEN_CASES)
+@pytest.mark.parametrize("name", hostmodel.GOLDEN_CASES + hostmodel.GOLDEN_CLI_ONLY)
 def test_cli_golden(binary, golden_dir, name):
     cli_check.run_case(binary, golden_dir, name)
 

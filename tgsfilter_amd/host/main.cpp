@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
@@ -44,6 +45,15 @@ struct Batch {
     std::vector<tgsf_fragment> frags;
     uint32_t n_frags = 0;
     uint64_t bases = 0;
+};
+
+// a kept fragment, addressed in the input text (used when a downsampling pass follows the filter pass)
+struct CleanRec {
+    std::string_view name;
+    int pass_num;
+    const char* seq;
+    const char* qual;
+    uint32_t len;
 };
 
 template <class T>
@@ -196,7 +206,6 @@ int main(int argc, char** argv)
     // rows of SURVEY 8(f) that are not built yet fail loudly instead of silently doing something else
     if (o.in_type == 2) die("BAM/SAM input is not supported by this build (SURVEY 8f-4)");
     if (o.in_type == 0) die("FASTA input (no qualities) is not supported by this build");
-    if (o.downsample || o.min_repeat > 0) die("downsampling (-g/-d/-r/-R) and the repeat filter (-p/-k) are not supported by this build (SURVEY 8f-3)");
 
     InputBytes in;
     if (!in.open(o.in_file)) return 1;
@@ -257,7 +266,7 @@ int main(int argc, char** argv)
     p.bc_len = o.bc_len; p.head_trim = o.head_trim < 0 ? 0 : o.head_trim; p.tail_trim = o.tail_trim < 0 ? 0 : o.tail_trim;
     p.end_len = o.end_len; p.end_match_len = o.end_match_len; p.mid_match_len = o.mid_match_len; p.extra_len = o.extra_len;
     p.end_sim = o.end_sim; p.mid_sim = o.mid_sim; p.discard = o.discard; p.filter = o.filter; p.only_qc = o.only_qc;
-    p.min_repeat = 0; p.kmer = o.kmer; p.qtype = pp.qtype ? pp.qtype : 33;
+    p.min_repeat = o.min_repeat; p.kmer = o.kmer; p.qtype = pp.qtype ? pp.qtype : 33;
     if (adapters.size() > TGSF_MAX_ADAPTERS) die("more than " + std::to_string(TGSF_MAX_ADAPTERS) + " adapter sequences");
     p.n_adapters = (int)adapters.size();
     for (size_t a = 0; a < adapters.size(); a++) { p.adapters[a] = adapters[a].data(); p.adapter_len[a] = (int)adapters[a].size(); }
@@ -277,8 +286,19 @@ int main(int argc, char** argv)
     const bool fastq_out = o.out_type == 1;
     Output out;
     if (!o.only_qc && !out.open(o)) return 1;
+    std::vector<CleanRec> clean_recs;                                  // only filled when downsampling follows
+    const bool run_filter_pass = o.filter || o.only_qc;                // :3061; with -F the input goes straight to downsampling
+    if (!run_filter_pass) {                                            // get_fastx_SeqLen, :2256-2269
+        FastxReader rd(in.data(), in.size(), true);
+        Record r;
+        while (rd.next(r)) {
+            clean_recs.push_back({r.name, 1, r.seq.data(), r.qual.data(), (uint32_t)r.seq.size()});
+            clean_bases += r.seq.size();
+        }
+    }
 
     std::thread reader([&] {                                           // read_fastx, :1845-1870 (index only)
+        if (!run_filter_pass) { to_gpu.put(nullptr); return; }
         FastxReader rd(in.data(), in.size(), true);
         Record r;
         auto fresh = [&] {
@@ -350,6 +370,13 @@ int main(int argc, char** argv)
                 for (uint32_t f = rr.frag_begin; f < rr.frag_begin + rr.n_frags; f++) {
                     const tgsf_fragment& fr = b->frags[f];
                     if (!(fr.flags & TGSF_FF_PASS)) continue;
+                    if (o.downsample) {                                // kept in memory instead of a tmp file (:3129-3137)
+                        clean_recs.push_back({b->names[r], pass_num++, b->base + b->off[r] + fr.start,
+                                              b->base + b->qoff[r] + fr.start, (uint32_t)fr.len});
+                        clean_bases += (uint64_t)fr.len;
+                        clean_lens.push_back(fr.len);
+                        continue;
+                    }
                     out.text(lead);
                     if (pass_num < 2) out.piece(b->names[r].data(), b->names[r].size());
                     else { name.clear(); append_name(name, b->names[r], pass_num); out.text(name); }
@@ -371,58 +398,141 @@ int main(int argc, char** argv)
         }
     });
     reader.join(); feeder.join(); writer.join();
-    if (!o.only_qc) out.close();
     t_pipe = now_s() - t_p0;
 
-    // ---- statistics, stderr, report: :3146-3235, :3285-3328 ----
+    // ---- downsampling: DownSampleTask, :2164-2568 ----
+    // keep the longest reads until the target is met (:2297-2344), then a QC-only pass over the kept reads
+    // (CalcAvgQuality / Get_5p/3p_base_qual again, :2436-2447) which also writes them, in input order.
+    uint64_t down_bases = 0;
+    std::vector<int> down_lens;
+    std::vector<uint64_t> down_t;
+    if (o.downsample) {
+        std::vector<uint32_t> order(clean_recs.size());
+        for (uint32_t i = 0; i < order.size(); i++) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return clean_recs[a].len > clean_recs[b].len; });
+        std::vector<char> keep(clean_recs.size(), 0);
+        uint64_t total = 0;
+        for (const CleanRec& c : clean_recs) total += c.len;
+        uint64_t desired = 0; int want_num = 0; bool by_size = true;
+        if (o.genome_size > 0 && o.desired_depth > 0) desired = o.genome_size * (uint64_t)o.desired_depth;
+        else if (o.desired_frac > 0) desired = (uint64_t)(o.desired_frac * total);        // float * uint64, :2322
+        else { by_size = false; want_num = o.desired_num; }
+        uint64_t added = 0; int added_num = 0;
+        for (uint32_t i : order) {
+            keep[i] = 1;
+            added += clean_recs[i].len; added_num++;
+            down_bases += clean_recs[i].len; down_lens.push_back((int)clean_recs[i].len);
+            if (by_size ? added >= desired : added_num >= want_num) break;
+        }
+        tgsf_params qp = p;
+        qp.filter = 0; qp.only_qc = 1; qp.n_adapters = 0; qp.min_repeat = 0;
+        qp.max_batch_bases = (1ull << 30); qp.max_batch_reads = 1u << 16;
+        tgsf_ctx* qctx = nullptr;
+        if (tgsf_create(&qp, o.device, &qctx) != TGSF_OK) die(tgsf_last_error(nullptr));
+        std::vector<uint8_t> bs, bq; std::vector<uint64_t> boff; std::vector<uint32_t> blen;
+        std::vector<tgsf_read_result> bres; std::vector<tgsf_fragment> bfr(16);
+        auto run = [&] {
+            if (blen.empty()) return;
+            bres.resize(blen.size());
+            bs.resize(bs.size() + 64); bq.resize(bq.size() + 64);
+            tgsf_batch_in bi; memset(&bi, 0, sizeof bi);
+            bi.seq = bs.data(); bi.qual = bq.data(); bi.offsets = boff.data(); bi.lengths = blen.data();
+            bi.n_reads = (uint32_t)blen.size(); bi.n_bytes = bs.size() - 64;
+            tgsf_batch_out bo{bres.data(), bfr.data(), (uint32_t)bfr.size(), 0};
+            if (tgsf_submit(qctx, &bi, &bo) != TGSF_OK) die(tgsf_last_error(qctx));
+            bs.clear(); bq.clear(); boff.clear(); blen.clear();
+        };
+        const std::string lead(1, fastq_out ? '@' : '>'), nl("\n"), sep("\n+\n");
+        std::string name;
+        for (size_t i = 0; i < clean_recs.size(); i++) {
+            if (!keep[i]) continue;
+            const CleanRec& c = clean_recs[i];
+            if (bs.size() + c.len > qp.max_batch_bases - (1u << 20) || blen.size() >= qp.max_batch_reads) run();
+            const size_t o0 = (bs.size() + 15) & ~size_t(15);
+            bs.resize(o0); bq.resize(o0);
+            bs.insert(bs.end(), c.seq, c.seq + c.len); bq.insert(bq.end(), c.qual, c.qual + c.len);
+            boff.push_back(o0); blen.push_back(c.len);
+            out.text(lead);
+            if (c.pass_num < 2) out.piece(c.name.data(), c.name.size());
+            else { name.clear(); append_name(name, c.name, c.pass_num); out.text(name); }
+            out.text(nl);
+            out.piece(c.seq, c.len);
+            if (fastq_out) { out.text(sep); out.piece(c.qual, c.len); }
+            out.text(nl);
+            out.end_record();
+        }
+        run();
+        uint64_t qnw = 0; int32_t qbc = 0; uint32_t qnb = 0;
+        tgsf_counters_len(qctx, &qnw, &qbc, &qnb);
+        down_t.resize(qnw);
+        if (tgsf_counters(qctx, down_t.data(), qnw) != TGSF_OK) die(tgsf_last_error(qctx));
+        tgsf_destroy(qctx);
+    }
+    if (!o.only_qc) out.close();
+
+    // ---- statistics, stderr, report: :3146-3235, :3240-3279, :3285-3328 ----
     uint64_t nw = 0; int32_t bc = 0; uint32_t nbins = 0;
     tgsf_counters_len(ctx, &nw, &bc, &nbins);
     std::vector<uint64_t> t(nw);
     if (tgsf_counters(ctx, t.data(), nw) != TGSF_OK) die(tgsf_last_error(ctx));
     tgsf_destroy(ctx);
-    if (raw_lens.empty()) die("no reads in the input");
-    auto tables = [&](bool clean) {
+    auto tables = [&](const std::vector<uint64_t>& v, bool clean) {
         SideTables s;
-        s.bin_qual = &t[tgsf_ctr_bin_table(clean ? TGSF_B_CLEAN_QUAL : TGSF_B_RAW_QUAL, bc, nbins)];
-        s.bin_cnt = &t[tgsf_ctr_bin_table(clean ? TGSF_B_CLEAN_CNT : TGSF_B_RAW_CNT, bc, nbins)];
-        s.bin_rows = t[TGSF_CTR_ROWS + (clean ? 1 : 0)];
-        s.q5 = &t[tgsf_ctr_end_table(clean ? TGSF_T_CLEAN5P_QUAL : TGSF_T_RAW5P_QUAL, bc)];
-        s.c5 = &t[tgsf_ctr_end_table(clean ? TGSF_T_CLEAN5P_CNT : TGSF_T_RAW5P_CNT, bc)];
-        s.q3 = &t[tgsf_ctr_end_table(clean ? TGSF_T_CLEAN3P_QUAL : TGSF_T_RAW3P_QUAL, bc)];
-        s.c3 = &t[tgsf_ctr_end_table(clean ? TGSF_T_CLEAN3P_CNT : TGSF_T_RAW3P_CNT, bc)];
-        s.end_rows = t[TGSF_CTR_ROWS + (clean ? 3 : 2)];
-        s.diff_qual = &t[clean ? TGSF_CTR_CLEAN_DIFFQ : TGSF_CTR_RAW_DIFFQ];
+        s.bin_qual = &v[tgsf_ctr_bin_table(clean ? TGSF_B_CLEAN_QUAL : TGSF_B_RAW_QUAL, bc, nbins)];
+        s.bin_cnt = &v[tgsf_ctr_bin_table(clean ? TGSF_B_CLEAN_CNT : TGSF_B_RAW_CNT, bc, nbins)];
+        s.bin_rows = v[TGSF_CTR_ROWS + (clean ? 1 : 0)];
+        s.q5 = &v[tgsf_ctr_end_table(clean ? TGSF_T_CLEAN5P_QUAL : TGSF_T_RAW5P_QUAL, bc)];
+        s.c5 = &v[tgsf_ctr_end_table(clean ? TGSF_T_CLEAN5P_CNT : TGSF_T_RAW5P_CNT, bc)];
+        s.q3 = &v[tgsf_ctr_end_table(clean ? TGSF_T_CLEAN3P_QUAL : TGSF_T_RAW3P_QUAL, bc)];
+        s.c3 = &v[tgsf_ctr_end_table(clean ? TGSF_T_CLEAN3P_CNT : TGSF_T_RAW3P_CNT, bc)];
+        s.end_rows = v[TGSF_CTR_ROWS + (clean ? 3 : 2)];
+        s.diff_qual = &v[clean ? TGSF_CTR_CLEAN_DIFFQ : TGSF_CTR_RAW_DIFFQ];
         return s;
     };
     SideStats raw, clean;
-    std::sort(raw_lens.begin(), raw_lens.end());
-    side_stats(bc, raw_lens, raw_bases, tables(false), raw);
     const int clean_num = (int)clean_lens.size();
-    if (!o.only_qc) {
-        if (clean_lens.empty()) die("no reads passed the filters");      // the reference dereferences an empty vector here (:3183)
-        std::sort(clean_lens.begin(), clean_lens.end());
-        side_stats(bc, clean_lens, clean_bases, tables(true), clean);
+    if (run_filter_pass) {
+        if (raw_lens.empty()) die("no reads in the input");
+        std::sort(raw_lens.begin(), raw_lens.end());
+        side_stats(bc, raw_lens, raw_bases, tables(t, false), raw);
+        if (!o.only_qc && !o.downsample) {
+            if (clean_lens.empty()) die("no reads passed the filters");  // the reference dereferences an empty vector here (:3183)
+            std::sort(clean_lens.begin(), clean_lens.end());
+            side_stats(bc, clean_lens, clean_bases, tables(t, true), clean);
+        }
+        const uint64_t* d = &t[TGSF_CTR_DROPINFO];
+        std::cerr << "INFO: " << raw_lens.size() << " reads with a total of " << raw_bases << " bases were input." << std::endl;
+        if (!o.only_qc) {
+            std::cerr << "INFO: " << d[0] << " reads were discarded with " << d[1] << " bases due to low quality." << std::endl;
+            std::cerr << "INFO: " << d[2] << " reads have adapter at 5', 3' and middle." << std::endl;
+            std::cerr << "INFO: " << d[3] << " reads have adapter at 5' and middle." << std::endl;
+            std::cerr << "INFO: " << d[4] << " reads have adapter at 3' and middle." << std::endl;
+            std::cerr << "INFO: " << d[5] << " reads have adapter at 5' and 3' end." << std::endl;
+            std::cerr << "INFO: " << d[6] << " reads only have adapter at middle." << std::endl;
+            std::cerr << "INFO: " << d[7] << " reads only have adapter at 5' end." << std::endl;
+            std::cerr << "INFO: " << d[8] << " reads only have adapter at 3' end." << std::endl;
+            std::cerr << "INFO: " << d[9] << " reads didn't have any adapter." << std::endl;
+            std::cerr << "INFO: " << d[10] << " bases were trimmed due to the adapter or base content bias." << std::endl;
+            std::cerr << "INFO: " << d[11] << " reads were discarded with " << d[12] << " bases due to the short length." << std::endl;
+            std::cerr << "INFO: " << d[13] << " reads were discarded with " << d[14] << " bases due to low quality after split." << std::endl;
+            if (o.min_repeat > 0)
+                std::cerr << "INFO: " << d[15] << " reads were discarded with " << d[16] << " bases due to short repeat length." << std::endl;
+            std::cerr << "INFO: " << clean_num << " reads with a total of " << clean_bases << " bases after filtering." << std::endl;
+            if (!o.downsample && !o.out_file.empty()) std::cerr << "INFO: Filtered reads were written to: " << o.out_file << "." << std::endl;
+        }
     }
-    const uint64_t* d = &t[TGSF_CTR_DROPINFO];
-    std::cerr << "INFO: " << raw_lens.size() << " reads with a total of " << raw_bases << " bases were input." << std::endl;
-    if (!o.only_qc) {
-        std::cerr << "INFO: " << d[0] << " reads were discarded with " << d[1] << " bases due to low quality." << std::endl;
-        std::cerr << "INFO: " << d[2] << " reads have adapter at 5', 3' and middle." << std::endl;
-        std::cerr << "INFO: " << d[3] << " reads have adapter at 5' and middle." << std::endl;
-        std::cerr << "INFO: " << d[4] << " reads have adapter at 3' and middle." << std::endl;
-        std::cerr << "INFO: " << d[5] << " reads have adapter at 5' and 3' end." << std::endl;
-        std::cerr << "INFO: " << d[6] << " reads only have adapter at middle." << std::endl;
-        std::cerr << "INFO: " << d[7] << " reads only have adapter at 5' end." << std::endl;
-        std::cerr << "INFO: " << d[8] << " reads only have adapter at 3' end." << std::endl;
-        std::cerr << "INFO: " << d[9] << " reads didn't have any adapter." << std::endl;
-        std::cerr << "INFO: " << d[10] << " bases were trimmed due to the adapter or base content bias." << std::endl;
-        std::cerr << "INFO: " << d[11] << " reads were discarded with " << d[12] << " bases due to the short length." << std::endl;
-        std::cerr << "INFO: " << d[13] << " reads were discarded with " << d[14] << " bases due to low quality after split." << std::endl;
-        std::cerr << "INFO: " << clean_num << " reads with a total of " << clean_bases << " bases after filtering." << std::endl;
-        if (!o.out_file.empty()) std::cerr << "INFO: Filtered reads were written to: " << o.out_file << "." << std::endl;
+    if (o.downsample) {                                                // :3240-3279
+        if (down_lens.empty()) die("no reads to downsample");
+        std::sort(down_lens.begin(), down_lens.end());
+        side_stats(bc, down_lens, down_bases, tables(down_t, false), clean);
+        clean.tab[8] = limit_decimals(std::round(clean.mean_qual * 1000) / 1000.0, 2);      // two places here, :3268
+        if (!o.filter)
+            std::cerr << "INFO: " << clean_recs.size() << " reads with a total of " << clean_bases << " bases were input." << std::endl;
+        std::cerr << "INFO: " << down_lens.size() << " reads with a total of " << down_bases << " bases after downsampling." << std::endl;
+        if (!o.out_file.empty()) std::cerr << "INFO: Downsampled reads were written to: " << o.out_file << "." << std::endl;
     }
     std::string qc = "1";                                              // fastq input
-    qc += o.only_qc ? "0" : "2";                                       // :3293-3299
+    qc += o.only_qc ? "0" : ((!o.filter && o.downsample) ? "1" : "2"); // :3293-3299
     std::ofstream ofs(html);
     write_report(ofs, qc, raw, clean);
     ofs.close();
