@@ -145,6 +145,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=65536, help="reads per step per GPU")
     ap.add_argument("--mean-len", type=float, default=None)
+    ap.add_argument("--min-repeat", type=int, default=0, help="-p of config C5 (with -k 11), for information")
     ap.add_argument("--workload", choices=["ont", "hifi"], default="ont",
                     help="ont = config C2 (the headline line); hifi = config C3 shape, for information")
     ap.add_argument("--max-len", type=int, default=2_000_000)
@@ -182,7 +183,7 @@ def main():
     max_len = max(int(b["h_lens"].max()) for b in batches)
     p = abi.make_params(args.workload, adapters=wl_adapters, min_len=1000, min_q=20.0 if hifi else 10.0,
                         head_trim=0, tail_trim=0, max_batch_bases=max_bases + 64, max_batch_reads=args.reads,
-                        max_read_len=max_len)
+                        max_read_len=max_len, min_repeat=args.min_repeat, kmer=11)
     NS = max(1, args.streams)
     ctxs = [capi.Context(p, local_rank) for _ in range(NS)]
     ctx = ctxs[0]

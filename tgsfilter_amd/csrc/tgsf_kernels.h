@@ -1245,9 +1245,18 @@ TGSF_KERNEL k_regions(DevParams P, DevBatch B)
 // clean statistics.  k-mers are 2-bit codes (A0 C1 G2 T3, every other byte 0).  One workgroup per
 // fragment; the 4^k-bit "seen" set lives in LDS as a bitmap of at most 2^20 bits (128 KB), so k = 11
 // takes 4 passes over the fragment, each pass owning the k-mers whose top bits equal the pass number;
-// "distinct" is counted from the values returned by the LDS atomic OR.
+// the LDS atomic ORs are fire-and-forget and "distinct" is the popcount of the bitmap after each pass.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kRepBits = 1u << 20;
+// 2-bit code of a base as GetKmerCount assigns it: exactly 'A' 'C' 'G' 'T' -> 0 1 2 3, any other byte 0
+// (:1709-1724).  Branch-free: (c>>1)&3 is A0 C1 T2 G3, x^(x>>1) swaps the last two; validity from a bit
+// mask over c - 'A'.
+TGSF_D uint32_t base_code(uint32_t c) {
+    const uint32_t v = c - 0x41u;
+    const uint32_t valid = (v < 20u ? 1u : 0u) & (0x80045u >> (v & 31u));
+    const uint32_t x = (c >> 1) & 3u;
+    return (x ^ (x >> 1)) & (0u - valid);
+}
 TGSF_KERNEL k_repeat(DevParams P, DevBatch B)
 {
     TGSF_SHARED uint32_t bm[kRepBits / 32];
@@ -1282,19 +1291,33 @@ TGSF_KERNEL k_repeat(DevParams P, DevBatch B)
             if (i0 < i1) {
                 uint32_t km = 0;
                 for (int j = i0; j < i0 + k - 1; j++) {                // the first k-1 bases of this lane's first k-mer
-                    const uint32_t c = seq[j];
-                    km = (km << 2) | (c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 0u);
+                    km = (km << 2) | base_code(seq[j]);
                 }
-                for (int i = i0; i < i1; i++) {
-                    const uint32_t c = seq[i + k - 1];
-                    km = ((km << 2) | (c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 0u)) & kmask;
+                auto feed = [&](uint32_t c) {                          // one base: extend the k-mer, mark it if this pass owns it
+                    km = ((km << 2) | base_code(c)) & kmask;
                     if ((km >> part_log2) == pass) {
-                        const uint32_t idx = km & ((1u << part_log2) - 1u), bit = 1u << (idx & 31u);
-                        const uint32_t old = atomicOr(&bm[idx >> 5], bit);
-                        mine += (old & bit) ? 0u : 1u;
+                        const uint32_t idx = km & ((1u << part_log2) - 1u);
+                        atomicOr(&bm[idx >> 5], 1u << (idx & 31u));     // result unused: a fire-and-forget ds_or
                     }
+                };
+                // bases [i0+k-1, i1+k-1): single bytes up to a 16-byte boundary, then 16 at a time
+                int b = i0 + k - 1;
+                const int bend = i1 + k - 1;
+                while (b < bend && ((uintptr_t)(seq + b) & 15u)) { feed(seq[b]); b++; }
+                while (b + 16 <= bend) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(seq + b);
+                    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        feed(d[q] & 0xFFu); feed((d[q] >> 8) & 0xFFu); feed((d[q] >> 16) & 0xFFu); feed(d[q] >> 24);
+                    }
+                    b += 16;
                 }
+                while (b < bend) { feed(seq[b]); b++; }
             }
+            // distinct k-mers of this partition = set bits of the bitmap
+            TGSF_BLOCK_SYNC();
+            for (uint32_t w = TGSF_COOP_BEGIN; w < part_words; w += TGSF_COOP_STRIDE) mine += popc32(bm[w]);
         }
         if (mine) atomicAdd(&distinct_s, mine);
         TGSF_BLOCK_SYNC();
