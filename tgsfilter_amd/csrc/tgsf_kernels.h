@@ -1243,11 +1243,13 @@ TGSF_KERNEL k_regions(DevParams P, DevBatch B)
 // k_repeat: the repeat gate, GetKmerCount (src/TGSFilter.cpp:1703-1753, :1982-1989).
 // repeat = (#k-mers) - (#distinct k-mers) of a fragment; fragments below -p are dropped before any
 // clean statistics.  k-mers are 2-bit codes (A0 C1 G2 T3, every other byte 0).  One workgroup per
-// fragment; the 4^k-bit "seen" set lives in LDS as a bitmap of at most 2^20 bits (128 KB), so k = 11
-// takes 4 passes over the fragment, each pass owning the k-mers whose top bits equal the pass number;
-// the LDS atomic ORs are fire-and-forget and "distinct" is the popcount of the bitmap after each pass.
+// fragment; the fragment is converted once per pass window into 2-bit codes held in LDS (16 per word), the
+// 4^k-bit "seen" set lives in LDS as a bitmap of at most 2^20 bits (128 KB), so k = 11 takes 4 passes,
+// each pass owning the k-mers whose top bits equal the pass number; the LDS atomic ORs are fire-and-forget
+// and "distinct" is the popcount of the bitmap after each pass.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kRepBits = 1u << 20;
+constexpr int kRepWin = 96 * 1024;                  // bases of a fragment held in LDS as 2-bit codes (24 KB)
 // 2-bit code of a base as GetKmerCount assigns it: exactly 'A' 'C' 'G' 'T' -> 0 1 2 3, any other byte 0
 // (:1709-1724).  Branch-free: (c>>1)&3 is A0 C1 T2 G3, x^(x>>1) swaps the last two; validity from a bit
 // mask over c - 'A'.
@@ -1259,7 +1261,8 @@ TGSF_D uint32_t base_code(uint32_t c) {
 }
 TGSF_KERNEL k_repeat(DevParams P, DevBatch B)
 {
-    TGSF_SHARED uint32_t bm[kRepBits / 32];
+    TGSF_SHARED uint32_t bm[kRepBits / 32];           // 128 KB: one partition of the 4^k-bit "seen" set
+    TGSF_SHARED uint32_t codes[kRepWin / 16 + 4];     // 24 KB: 16 bases per word, base i at bits 2*(i&15)
     TGSF_SHARED uint32_t distinct_s;
     const int k = P.kmer;
     const uint32_t space_log2 = 2u * (uint32_t)k;                      // k <= 13 -> <= 26 bits
@@ -1269,59 +1272,85 @@ TGSF_KERNEL k_repeat(DevParams P, DevBatch B)
     const uint32_t kmask = (1u << space_log2) - 1u;
     const uint32_t nf = stored_frags(B);
     uint64_t drop_n = 0, drop_b = 0;
+#if defined(TGSF_EMUL)
+    const uint32_t nthr = 1, tid = 0;                                  // emulation: one lane does the whole fragment
+    if (threadIdx.x != 0) return;
+#else
+    const uint32_t nthr = blockDim.x, tid = threadIdx.x;
+#endif
     for (uint32_t f = blockIdx.x; f < nf; f += gridDim.x) {
         const int L = (int)B.frag_len[f];
-        const int total = L - k + 1;
+        const int total = L - k + 1;                                   // number of k-mers
         const uint8_t* seq = B.seq + B.frag_off[f];
-        if (threadIdx.x == 0) distinct_s = 0;
-#if defined(TGSF_EMUL)
-        if (threadIdx.x != 0) continue;                                // emulation: one lane does the whole fragment
-        const int per = total > 0 ? total : 0, i0 = 0;
-#else
-        const int per = total > 0 ? (total + (int)blockDim.x - 1) / (int)blockDim.x : 0;
-        const int i0 = (int)threadIdx.x * per;
-#endif
-        int i1 = i0 + per;
-        if (i1 > total) i1 = total;
+        if (tid == 0) distinct_s = 0;
         uint32_t mine = 0;
         for (uint32_t pass = 0; pass < passes; pass++) {
             TGSF_BLOCK_SYNC();
-            for (uint32_t w = TGSF_COOP_BEGIN; w < part_words; w += TGSF_COOP_STRIDE) bm[w] = 0;
-            TGSF_BLOCK_SYNC();
-            if (i0 < i1) {
-                uint32_t km = 0;
-                for (int j = i0; j < i0 + k - 1; j++) {                // the first k-1 bases of this lane's first k-mer
-                    km = (km << 2) | base_code(seq[j]);
-                }
-                auto feed = [&](uint32_t c) {                          // one base: extend the k-mer, mark it if this pass owns it
-                    km = ((km << 2) | base_code(c)) & kmask;
-                    if ((km >> part_log2) == pass) {
-                        const uint32_t idx = km & ((1u << part_log2) - 1u);
-                        atomicOr(&bm[idx >> 5], 1u << (idx & 31u));     // result unused: a fire-and-forget ds_or
-                    }
-                };
-                // bases [i0+k-1, i1+k-1): single bytes up to a 16-byte boundary, then 16 at a time
-                int b = i0 + k - 1;
-                const int bend = i1 + k - 1;
-                while (b < bend && ((uintptr_t)(seq + b) & 15u)) { feed(seq[b]); b++; }
-                while (b + 16 <= bend) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(seq + b);
-                    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+            for (uint32_t w = tid; w < part_words; w += nthr) bm[w] = 0;
+            // windows of kRepWin bases (consecutive windows overlap by k-1 bases so every k-mer is seen once)
+            for (int w0 = 0; w0 < (total > 0 ? total : 0); w0 += kRepWin - (k - 1)) {
+                int wn = L - w0;                                       // bases in this window
+                if (wn > kRepWin) wn = kRepWin;
+                const int nk = wn - k + 1;                             // k-mers starting in this window
+                TGSF_BLOCK_SYNC();
+                // bases -> 2-bit codes, 16 per word
+                for (int g = (int)tid; g * 16 < wn; g += (int)nthr) {
+                    const int b0 = w0 + g * 16;
+                    const int nb = L - b0 < 16 ? L - b0 : 16;
+                    // 16 bases as five aligned dwords + funnel shifts (any alignment; bytes past the fragment
+                    // are read but masked out below)
+                    const uintptr_t a = (uintptr_t)(seq + b0);
+                    const uint32_t* w32 = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+                    const uint32_t bs = (uint32_t)(a & 3u);
+                    uint32_t wv[5];
+#pragma unroll
+                    for (int q = 0; q < 5; q++) wv[q] = (q < 4 || bs) ? w32[q] : 0u;
+                    uint32_t word = 0;
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        feed(d[q] & 0xFFu); feed((d[q] >> 8) & 0xFFu); feed((d[q] >> 16) & 0xFFu); feed(d[q] >> 24);
+                        const uint32_t d = alignbyte(wv[q + 1], wv[q], bs);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) word |= base_code((d >> (8 * r)) & 0xFFu) << (2 * (4 * q + r));
                     }
-                    b += 16;
+                    if (nb < 16) word &= (1u << (2 * nb)) - 1u;
+                    codes[g] = word;
                 }
-                while (b < bend) { feed(seq[b]); b++; }
+                TGSF_BLOCK_SYNC();
+                const int per = (nk + (int)nthr - 1) / (int)nthr;
+                const int i0 = (int)tid * per;
+                int i1 = i0 + per;
+                if (i1 > nk) i1 = nk;
+                if (i0 < i1) {
+                    auto code_at = [&](int i) { return (codes[i >> 4] >> (2 * (i & 15))) & 3u; };
+                    uint32_t km = 0;
+                    for (int j = i0; j < i0 + k - 1; j++) km = (km << 2) | code_at(j);
+                    auto feed = [&](uint32_t c) {                              // extend the k-mer by one code, mark it if this pass owns it
+                        km = ((km << 2) | c) & kmask;
+                        if ((km >> part_log2) == pass) {
+                            const uint32_t idx = km & ((1u << part_log2) - 1u);
+                            atomicOr(&bm[idx >> 5], 1u << (idx & 31u));         // result unused: a fire-and-forget ds_or
+                        }
+                    };
+                    // codes at positions [i0+k-1, i1+k-1): one LDS word feeds 16 k-mers
+                    int pos = i0 + k - 1;
+                    const int pend = i1 + k - 1;
+                    while (pos < pend && (pos & 15)) { feed(code_at(pos)); pos++; }
+                    while (pos + 16 <= pend) {
+                        uint32_t w = codes[pos >> 4];
+#pragma unroll
+                        for (int q = 0; q < 16; q++) { feed(w & 3u); w >>= 2; }
+                        pos += 16;
+                    }
+                    while (pos < pend) { feed(code_at(pos)); pos++; }
+                }
             }
             // distinct k-mers of this partition = set bits of the bitmap
             TGSF_BLOCK_SYNC();
-            for (uint32_t w = TGSF_COOP_BEGIN; w < part_words; w += TGSF_COOP_STRIDE) mine += popc32(bm[w]);
+            for (uint32_t w = tid; w < part_words; w += nthr) mine += popc32(bm[w]);
         }
         if (mine) atomicAdd(&distinct_s, mine);
         TGSF_BLOCK_SYNC();
-        if (threadIdx.x == 0) {
+        if (tid == 0) {
             const int repeat = (total > 0 ? total : 0) - (int)distinct_s;
             if (repeat < P.min_repeat) {                               // :1984-1988
                 B.frag_flags[f] |= TGSF_FF_REPEAT;
@@ -1330,7 +1359,7 @@ TGSF_KERNEL k_repeat(DevParams P, DevBatch B)
         }
         TGSF_BLOCK_SYNC();
     }
-    if (threadIdx.x == 0 && drop_n) {
+    if (tid == 0 && drop_n) {
         atomicAdd((ull*)&B.ctr[TGSF_CTR_DROPINFO + 15], (ull)drop_n);
         atomicAdd((ull*)&B.ctr[TGSF_CTR_DROPINFO + 16], (ull)drop_b);
     }
