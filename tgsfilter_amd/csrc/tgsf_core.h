@@ -117,8 +117,10 @@ TGSF_HD void bv_step(Bv<NW>& s, const uint64_t* eq, int hin_top, int Q) {
 // loop that contains 3-input ops issues in 4 cycles, so instruction COUNT is what
 // matters (measured: tools/valu_rates.hip):
 //   Xh | Pv  =  ((sum ^ Pv) | Eq) | Pv  =  sum | Pv | Eq          one v_or3 per half
-//   Pv & Xh  =  (Pv & ~sum) | (Eq & Pv) =  bfi(sum, t, Pv)         one v_bfi per half  (t = Eq & Pv <= Pv)
-//   Mv | ~u  =  bfi(u, Mv, ~0)                                      one v_bfi per half
+//   Pv & Xh  =  (Pv & ~sum) | (Eq & Pv) =  Pv & (Eq | ~sum)        one v_bitop3 per half
+//   Mv | ~u,  Mh' | ~x                                              one v_bfi / v_bitop3 per half
+//   Ph' & Xv =  Ph' & (Eq | Mv),   Xv | Ph' = Eq | Mv | Ph'        one v_bitop3 / v_or3 per half
+// (17 instructions per column: 2 and, 1 add64, 2 shift64, 12 three-input ops)
 // and the bottom-row value is not carried along: D[Q][j] is the sum of the
 // vertical deltas of column j, i.e. popcount(Pv) - popcount(Mv) (wildcard rows
 // contribute 0), evaluated only where it is needed.
@@ -131,17 +133,39 @@ TGSF_HD void hot_init(Hot& s, int Q) {
     s.p = (Q >= 64) ? ~0ull : (~0ull << (64 - Q));
     s.m = 0ull;
 }
+// any boolean function of three words in one instruction: bit i of the result is TT[a_i b_i c_i],
+// TT = f(0xF0, 0xCC, 0xAA) (v_bitop3_b32)
+template <int TT>
+TGSF_HD uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, TT);
+#else
+    uint32_t r = 0;
+    for (int i = 0; i < 32; i++) {
+        const int idx = (int)(((a >> i) & 1u) << 2 | ((b >> i) & 1u) << 1 | ((c >> i) & 1u));
+        r |= (uint32_t)((TT >> idx) & 1) << i;
+    }
+    return r;
+#endif
+}
 TGSF_HD void hot_step(Hot& s, uint64_t Eq) {
     const uint64_t Pv = s.p, Mv = s.m;
-    const uint64_t t = Eq & Pv;
-    const uint64_t sum = t + Pv;
-    const uint64_t u = sum | Pv | Eq;
-    uint64_t Ph = Mv | ~u;
-    uint64_t Mh = (sum & t) | (~sum & Pv);
-    Ph <<= 1; Mh <<= 1;
-    const uint64_t Xv = Eq | Mv;
-    s.p = Mh | ~(Xv | Ph);
-    s.m = Ph & Xv;
+    const uint64_t t = Eq & Pv;                          // 2 v_and
+    const uint64_t sum = t + Pv;                         // 1 v_lshl_add_u64
+    const uint64_t u = sum | Pv | Eq;                    // 2 v_or3           (= Xh | Pv)
+    uint64_t Ph = Mv | ~u;                               // 2 v_bfi
+    uint64_t Mh = (sum & t) | (~sum & Pv);               // 2 v_bfi           (= Pv & Xh)
+    Ph <<= 1; Mh <<= 1;                                  // 2 v_lshlrev_b64 (operands are register pairs)
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(Ph));                         // keep the shifted pair as is (else its high half is re-derived with a v_alignbit)
+#endif
+    const uint64_t x = Eq | Mv | Ph;                     // 2 v_or3           (= Xv | Ph')
+    s.p = Mh | ~x;                                       // 2 v_bfi
+    // Mv' = Ph' & (Eq | Mv) is one 3-input function per half; its result only feeds bitwise ops, so it
+    // does not need to sit in a register pair (the builtin's results do not)
+    const uint32_t nml = bitop3<0xE0>((uint32_t)Ph, (uint32_t)Eq, (uint32_t)Mv);
+    const uint32_t nmh = bitop3<0xE0>((uint32_t)(Ph >> 32), (uint32_t)(Eq >> 32), (uint32_t)(Mv >> 32));
+    s.m = ((uint64_t)nmh << 32) | nml;                   // 2 v_bitop3
 }
 TGSF_HD int hot_score(const Hot& s) { return (int)popc64(s.p) - (int)popc64(s.m); }
 
