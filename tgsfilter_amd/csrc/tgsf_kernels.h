@@ -31,6 +31,7 @@ extern thread_local Dim3 threadIdx, blockIdx, blockDim, gridDim;
 }
 using tgsf_emul::threadIdx; using tgsf_emul::blockIdx; using tgsf_emul::blockDim; using tgsf_emul::gridDim;
 #define TGSF_KERNEL static void
+#define TGSF_BOUNDS(threads, waves_per_simd)
 #define TGSF_SHARED static
 #define TGSF_BLOCK_SYNC() ((void)0)
 #define TGSF_WAVE_SYNC() ((void)0)
@@ -46,6 +47,7 @@ template <class T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; ret
 template <class T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 #else
 #define TGSF_KERNEL __global__ void
+#define TGSF_BOUNDS(threads, waves_per_simd) __launch_bounds__(threads, waves_per_simd)
 #define TGSF_SHARED __shared__
 #define TGSF_BLOCK_SYNC() __syncthreads()
 #define TGSF_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
@@ -326,8 +328,10 @@ TGSF_D int32_t wave_sum_i32(int32_t v) {
 #endif
 }
 
+// 51 KB of LDS per block already limits a CU to 3 blocks (3 waves per SIMD): take that register budget
+// (the 14 staging registers per stream plus the work-list words spill at the default 128).
 template <bool CLEAN>
-TGSF_KERNEL k_stats(DevParams P, DevBatch B)
+TGSF_KERNEL TGSF_BOUNDS(256, 3) k_stats(DevParams P, DevBatch B)
 {
     TGSF_SHARED uint4 lds[kStatsWaves][2][kTileChunks];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
