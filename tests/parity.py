@@ -122,3 +122,55 @@ def repeat_reads(seed=51, n=60):
         q = bytes((rng.integers(12, 30, L) + 33).astype(np.uint8))
         reads.append((b"rep%d" % i, bytes(s), q))
     return reads
+
+
+def clean_table_strategy(lib_path, mode, golden_dir):
+    """Both ways of tallying the clean bin tables (TGSF_CLEAN_TABLES=direct|difference, see k_clean_plan)
+    must give the oracle's tallies: trimmed / split / dropped / low-quality / repeat-dropped reads, -F,
+    in-place text, and two batches through one context (the per-batch raw table is reused)."""
+    old = os.environ.get("TGSF_CLEAN_TABLES")
+    os.environ["TGSF_CLEAN_TABLES"] = mode
+    try:
+        for name in ("ont_zoo", "hifi_zoo", "ont_discard"):
+            golden_case(lib_path, golden_dir, name)
+        ads = [synth.ONT_RAPID, synth.ONT_RAPID_RC]
+        # repeat gate + quality gates
+        reads = repeat_reads(seed=77, n=40)
+        p = sized(abi.make_params("ont", adapters=ads, min_q=10.0, min_repeat=300, kmer=11), reads)
+        ctx = capi.Context(p, 0, lib_path)
+        compare_batch(ctx, p, reads)
+        ctx.close()
+        # -F: nothing is trimmed, every read is kept whole
+        reads = synth.make_reads(31, 30, "hifi", mean_len=9000, zoo=True)
+        p = sized(abi.make_params("hifi", adapters=[synth.PACBIO_BLUNT], filter=0), reads)
+        ctx = capi.Context(p, 0, lib_path)
+        compare_batch(ctx, p, reads)
+        ctx.close()
+        # in-place text
+        reads = synth.make_reads(32, 30, "ont", mean_len=3000, zoo=True, pmid=0.1)
+        p = abi.make_params("ont", adapters=ads, min_q=9.0, head_trim=4)
+        p.max_batch_reads = len(reads)
+        p.max_batch_bases = 2 * sum(len(r[1]) for r in reads) + 64 * len(reads) + 4096
+        p.max_read_len = max(len(r[1]) for r in reads)
+        ctx = capi.Context(p, 0, lib_path)
+        compare_batch_in_place(ctx, p, reads)
+        ctx.close()
+        # two batches, one context: tallies accumulate
+        r1 = synth.make_reads(33, 24, "hifi", mean_len=12000, zoo=True)
+        r2 = synth.make_reads(34, 30, "hifi", mean_len=4000, zoo=True)
+        p = sized(abi.make_params("hifi", adapters=[synth.PACBIO_BLUNT, synth.PACBIO_BLUNT_RC], min_q=15.0), r1 + r2)
+        ctx = capi.Context(p, 0, lib_path)
+        exp = np.zeros(ctx.ctr_words, dtype=np.uint64)
+        for rd in (r1, r2):
+            seq, qual, offsets, lengths = synth.pack(rd)
+            ctx.submit(seq, qual, offsets[:-1].copy(), lengths)
+            orc.filter_batch(p, seq, qual, offsets, lengths, n_bins=ctx.n_bins, ctr=exp)
+        got = ctx.counters()
+        bad = np.nonzero(got != exp)[0]
+        assert bad.size == 0, f"tally words differ at {bad[:12]}"
+        ctx.close()
+    finally:
+        if old is None:
+            os.environ.pop("TGSF_CLEAN_TABLES", None)
+        else:
+            os.environ["TGSF_CLEAN_TABLES"] = old

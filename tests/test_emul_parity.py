@@ -92,3 +92,8 @@ def test_emul_repeat_gate(emul, pval, k):
     res, frags, ctr = parity.compare_batch(ctx, p, reads)
     assert (frags["flags"] & abi.FF_REPEAT).any() and (frags["flags"] & abi.FF_PASS).any()
     ctx.close()
+
+
+@pytest.mark.parametrize("mode", ["direct", "difference"])
+def test_emul_clean_table_strategy(emul, golden_dir, mode):
+    parity.clean_table_strategy(emul, mode, golden_dir)

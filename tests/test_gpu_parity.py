@@ -154,3 +154,19 @@ def test_gpu_repeat_gate(pval, k):
     res, frags, ctr = parity.compare_batch(ctx, p, reads)
     assert (frags["flags"] & abi.FF_REPEAT).any()
     ctx.close()
+
+
+@pytest.mark.parametrize("mode", ["direct", "difference"])
+def test_gpu_clean_table_strategy(golden_dir, mode):
+    parity.clean_table_strategy(None, mode, golden_dir)
+
+
+@pytest.mark.parametrize("mode", ["direct", "difference"])
+def test_gpu_clean_table_strategy_large(mode, monkeypatch):
+    """Thousands of reads: many waves mixing fragments to add with whole reads to take back out."""
+    monkeypatch.setenv("TGSF_CLEAN_TABLES", mode)
+    reads = synth.make_reads(91, 3000, "hifi", mean_len=7000, zoo=True)
+    p = parity.sized(abi.make_params("hifi", adapters=[synth.PACBIO_BLUNT, synth.PACBIO_BLUNT_RC], min_q=15.0), reads)
+    ctx = capi.Context(p, 0)
+    parity.compare_batch(ctx, p, reads)
+    ctx.close()

@@ -62,7 +62,8 @@ struct DevBatch {
     uint32_t* nfr;             // [n+1] fragments per read, scanned in place to frag_begin
     uint32_t* trimmed;         // [n]
 
-    // stats work lists (raw: items are reads; clean: items are fragments)
+    // stats work lists (raw: items are reads; clean: items are fragments [0,fcap) and, in the
+    // "difference" strategy, whole reads to take back out, numbered fcap + read)
     uint32_t* tile_hist;       // [max_tiles+2]
     uint32_t* tile_cnt;        // [max_tiles+2]  cnt[t] = #items with more than t tiles
     uint32_t* tile_base;       // [max_tiles+2]  exclusive prefix of cnt
@@ -81,6 +82,12 @@ struct DevBatch {
     int32_t*  frag_start;      // [fcap]
     uint32_t* frag_flags;      // [fcap]
     uint32_t  fcap;
+
+    // clean-table strategy of this batch (see k_clean_plan)
+    uint64_t* raw_tab;         // [2][n_bins*5] this batch's raw bin tallies: quality sums, then counts
+    uint32_t* whole;           // [n] 1 = the read is kept whole (one fragment == the read, not dropped)
+    uint64_t* plan;            // [4] {batch raw rows, -, bases to scan directly, bases to scan by difference}
+    uint32_t  clean_force;     // 0 = choose per batch, 1 = always direct, 2 = always by difference
 
     uint64_t* scratch;         // traceback columns, one region per wave: [column][word][lane]
     size_t    scratch_wave_words;

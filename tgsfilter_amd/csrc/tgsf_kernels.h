@@ -113,6 +113,32 @@ TGSF_D void set_status(const DevBatch& B, uint32_t code, uint32_t detail) {
 // fragments actually stored (the count may exceed the capacity: DS_FRAG_CAP)
 TGSF_D uint32_t stored_frags(const DevBatch& B) { uint32_t nf = B.nfr[B.n]; return nf < B.fcap ? nf : B.fcap; }
 
+// ---------------------------------------------------------------------------
+// The clean bin tables of a batch can be tallied two ways, both exact:
+//   direct      scan every surviving fragment;
+//   difference  clean += raw tallies of the batch - reads NOT kept whole + their fragments,
+//               because a read kept whole adds to the clean tables exactly what it added to the raw ones.
+// k_clean_plan counts the bases either way needs to scan; the cheaper one runs (difference must win by
+// a quarter: it also pays one more pass over the batch's table rows).  Valid after k_clean_plan.
+// ---------------------------------------------------------------------------
+TGSF_D bool clean_by_difference(const DevBatch& B) {
+    if (B.clean_force) return B.clean_force == 2;
+    const uint64_t direct = B.plan[2], diff = B.plan[3];
+    return diff + (diff >> 2) < direct;
+}
+// Items of a stats pass.  RAW: read i.  CLEAN: fragment i (< fcap), or read i - fcap to be taken back out.
+// Length 0 = not part of the pass.
+template <bool CLEAN>
+TGSF_D uint32_t stats_item_len(const DevBatch& B, uint32_t item, bool diff) {
+    if (!CLEAN) return B.len[item];
+    if (item >= B.fcap) return (diff && !B.whole[item - B.fcap]) ? B.len[item - B.fcap] : 0u;
+    if (B.frag_flags[item] & TGSF_FF_REPEAT) return 0u;          // dropped before CalcAvgQuality (:1982-1989)
+    if (diff && B.whole[B.frag_read[item]]) return 0u;
+    return B.frag_len[item];
+}
+// i-th candidate of the clean pass -> item number
+TGSF_D uint32_t clean_item(const DevBatch& B, uint32_t i, uint32_t nf) { return i < nf ? i : B.fcap + (i - nf); }
+
 TGSF_D uint32_t gtid() { return blockIdx.x * blockDim.x + threadIdx.x; }
 TGSF_D uint32_t gsize() { return gridDim.x * blockDim.x; }
 
@@ -163,6 +189,7 @@ TGSF_KERNEL k_prepare(DevParams P, DevBatch B, uint32_t max_read_len)
         erows = er > erows ? er : erows;
     }
     wave_max_u64(&B.ctr[TGSF_CTR_ROWS + 0], rows);
+    wave_max_u64(&B.plan[0], rows);
     wave_max_u64(&B.ctr[TGSF_CTR_ROWS + 2], erows);
     TGSF_BLOCK_SYNC();
     if (use_lds)
@@ -170,7 +197,51 @@ TGSF_KERNEL k_prepare(DevParams P, DevBatch B, uint32_t max_read_len)
             if (h[i]) atomicAdd(&B.tile_hist[i], h[i]);
 }
 
-// Items of the clean stats pass are the fragments (keep regions).
+// k_clean_plan: which reads are kept whole, and the bases each clean-table strategy would scan.
+TGSF_KERNEL k_clean_plan(DevParams P, DevBatch B)
+{
+    uint64_t direct = 0, diff = 0;
+    for (uint32_t r0 = blockIdx.x * blockDim.x; r0 < B.n; r0 += gsize()) {
+        const uint32_t r = r0 + threadIdx.x;
+        if (r >= B.n) continue;
+        const uint32_t L = B.len[r];
+        uint32_t f0 = B.nfr[r], f1 = B.nfr[r + 1];
+        if (f1 > B.fcap) f1 = B.fcap;
+        uint64_t kept = 0;
+        bool whole = false;
+        for (uint32_t f = f0; f < f1; f++) {
+            if (B.frag_flags[f] & TGSF_FF_REPEAT) continue;
+            kept += B.frag_len[f];
+            whole = (f1 - f0 == 1) && B.frag_len[f] == L && B.frag_start[f] == 0;
+        }
+        if (L == 0 || P.only_qc) whole = false;
+        B.whole[r] = whole ? 1u : 0u;
+        direct += kept;
+        if (!whole) diff += kept + L;
+    }
+    wave_add_u64(&B.plan[2], direct);
+    wave_add_u64(&B.plan[3], diff);
+}
+
+// ctr tables += this batch's raw tallies (rows the batch reached only).  The CLEAN instance is the
+// last user of raw_tab and leaves it zeroed for the next batch.
+template <bool CLEAN>
+TGSF_KERNEL k_fold_raw(DevParams P, DevBatch B)
+{
+    const bool add = !CLEAN || clean_by_difference(B);
+    uint64_t rows = B.plan[0];
+    if (rows > P.n_bins) rows = P.n_bins;
+    const size_t nw = (size_t)rows * 5, stride = (size_t)P.n_bins * 5;
+    uint64_t* tq = B.ctr + ctr_bin_table(CLEAN ? TGSF_B_CLEAN_QUAL : TGSF_B_RAW_QUAL, P.bc_len, P.n_bins);
+    uint64_t* tc = B.ctr + ctr_bin_table(CLEAN ? TGSF_B_CLEAN_CNT : TGSF_B_RAW_CNT, P.bc_len, P.n_bins);
+    for (size_t i = gtid(); i < nw; i += gsize()) {
+        const uint64_t q = B.raw_tab[i], c = B.raw_tab[stride + i];
+        if (add && (c | q)) { tq[i] += q; tc[i] += c; }
+        if (CLEAN && (c | q)) { B.raw_tab[i] = 0; B.raw_tab[stride + i] = 0; }
+    }
+}
+
+// Items of the clean stats pass: the fragments (keep regions), plus -- by difference -- the reads to take out.
 TGSF_KERNEL k_frag_prepare(DevParams P, DevBatch B)
 {
     TGSF_SHARED uint32_t h[kHistLds];
@@ -179,14 +250,19 @@ TGSF_KERNEL k_frag_prepare(DevParams P, DevBatch B)
     if (use_lds) for (uint32_t i = TGSF_COOP_BEGIN; i < nbuck; i += TGSF_COOP_STRIDE) h[i] = 0;
     TGSF_BLOCK_SYNC();
     const uint32_t nf = stored_frags(B);
+    const bool diff = clean_by_difference(B);
+    const uint32_t ni = nf + (diff ? B.n : 0u);
     uint32_t rows = 0;
-    for (uint32_t f = gtid(); f < nf; f += gsize()) {
-        if (B.frag_flags[f] & TGSF_FF_REPEAT) continue;        // dropped before CalcAvgQuality (:1982-1989)
-        uint32_t L = B.frag_len[f];
+    for (uint32_t i = gtid(); i < ni; i += gsize()) {
+        const uint32_t item = clean_item(B, i, nf);
+        if (i < nf && !(B.frag_flags[i] & TGSF_FF_REPEAT)) {
+            uint32_t rw = B.frag_len[i] / kBin + 1;
+            rows = rw > rows ? rw : rows;
+        }
+        const uint32_t L = stats_item_len<true>(B, item, diff);
+        if (!L) continue;
         const uint32_t v = (L + kTileBases - 1) / kTileBases;
         if (use_lds) atomicAdd(&h[v], 1u); else atomicAdd(&B.tile_hist[v], 1u);
-        uint32_t rw = L / kBin + 1;
-        rows = rw > rows ? rw : rows;
     }
     wave_max_u64(&B.ctr[TGSF_CTR_ROWS + 1], rows);
     TGSF_BLOCK_SYNC();
@@ -242,14 +318,17 @@ TGSF_KERNEL k_tile_scatter(DevBatch B)
     TGSF_SHARED uint32_t hb[kHistLds];
     const uint32_t nbuck = B.max_tiles + 2;
     const bool use_lds = nbuck <= kHistLds;
-    const uint32_t n = CLEAN ? stored_frags(B) : B.n;
+    const uint32_t nf = CLEAN ? stored_frags(B) : 0u;
+    const bool diff = CLEAN && clean_by_difference(B);
+    const uint32_t n = CLEAN ? nf + (diff ? B.n : 0u) : B.n;
     for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gsize()) {     // whole blocks stay in step
         const uint32_t i = i0 + threadIdx.x;
         if (use_lds) for (uint32_t k = TGSF_COOP_BEGIN; k < nbuck; k += TGSF_COOP_STRIDE) h[k] = 0;
         TGSF_BLOCK_SYNC();
-        uint32_t L = 0, v = 0, local = 0;
+        uint32_t L = 0, v = 0, local = 0, item = 0;
         if (i < n) {
-            L = CLEAN ? ((B.frag_flags[i] & TGSF_FF_REPEAT) ? 0u : B.frag_len[i]) : B.len[i];
+            item = CLEAN ? clean_item(B, i, nf) : i;
+            L = stats_item_len<CLEAN>(B, item, diff);
             v = (L + kTileBases - 1) / kTileBases;
             if (L && use_lds) local = atomicAdd(&h[v], 1u);
         }
@@ -261,7 +340,7 @@ TGSF_KERNEL k_tile_scatter(DevBatch B)
         if (L) {
             const uint32_t slot = use_lds ? B.tile_cnt[v] + hb[v] + local
                                           : B.tile_cnt[v] + atomicAdd(&B.tile_fill[v], 1u);
-            B.perm[slot] = i;
+            B.perm[slot] = item;
         }
         TGSF_BLOCK_SYNC();
     }
@@ -292,17 +371,16 @@ TGSF_KERNEL k_build_work(DevBatch B)
 {
     const uint32_t mt = B.max_tiles;
     const uint32_t W = B.tile_base[mt + 1];
-    const uint64_t* it_off = CLEAN ? B.frag_off : B.off;
-    const uint64_t* it_qoff = CLEAN ? B.frag_qoff : B.qoff;
-    const uint32_t* it_len = CLEAN ? B.frag_len : B.len;
     for (uint32_t w = gtid(); w < W && w < B.work_cap; w += gsize()) {
         const uint32_t t = find_owner(B.tile_base, mt + 1, w);
         const uint32_t item = B.perm[w - B.tile_base[t]];
-        const uint32_t L = it_len[item];
-        const uint64_t a0 = it_off[item] + (uint64_t)t * kTileBases;
+        const bool frag = CLEAN && item < B.fcap;
+        const uint32_t rd = CLEAN ? item - B.fcap : item;
+        const uint32_t L = frag ? B.frag_len[item] : B.len[rd];
+        const uint64_t a0 = (frag ? B.frag_off[item] : B.off[rd]) + (uint64_t)t * kTileBases;
         uint32_t nb = L - t * kTileBases;
         if (nb > (uint32_t)kTileBases) nb = kTileBases;
-        const uint64_t aq = it_qoff[item] + (uint64_t)t * kTileBases;
+        const uint64_t aq = (frag ? B.frag_qoff[item] : B.qoff[rd]) + (uint64_t)t * kTileBases;
         uint4 e, q;
         e.x = (uint32_t)a0; e.y = (uint32_t)(a0 >> 32); e.z = nb | (t << 13); e.w = item;
         q.x = (uint32_t)aq; q.y = (uint32_t)(aq >> 32); q.z = 0; q.w = 0;
@@ -344,10 +422,13 @@ TGSF_KERNEL TGSF_BOUNDS(256, 3) k_stats(DevParams P, DevBatch B)
     if (w1 > W) w1 = W;
     if (w0 >= w1) return;
 
-    uint64_t* tab_q = B.ctr + ctr_bin_table(CLEAN ? TGSF_B_CLEAN_QUAL : TGSF_B_RAW_QUAL, P.bc_len, P.n_bins);
-    uint64_t* tab_c = B.ctr + ctr_bin_table(CLEAN ? TGSF_B_CLEAN_CNT : TGSF_B_RAW_CNT, P.bc_len, P.n_bins);
+    // raw tallies go to the batch's own table first (k_fold_raw adds it to ctr, and to the clean tables
+    // when those are tallied by difference)
+    uint64_t* tab_q = CLEAN ? B.ctr + ctr_bin_table(TGSF_B_CLEAN_QUAL, P.bc_len, P.n_bins) : B.raw_tab;
+    uint64_t* tab_c = CLEAN ? B.ctr + ctr_bin_table(TGSF_B_CLEAN_CNT, P.bc_len, P.n_bins) : B.raw_tab + (size_t)P.n_bins * 5;
     uint64_t* it_sum = CLEAN ? B.frag_sum : B.sumq;
     const int64_t qt = P.qtype;
+    bool neg = false;                                  // accumulated tallies are to be taken OUT of the tables
 
     uint32_t cnt[4] = {0, 0, 0, 0}, qs[5] = {0, 0, 0, 0, 0}, call = 0, since = 0, qor = 0;
     uint32_t t_acc = 0xFFFFFFFFu;
@@ -360,12 +441,14 @@ TGSF_KERNEL TGSF_BOUNDS(256, 3) k_stats(DevParams P, DevBatch B)
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 if (cnt[c]) {
-                    atomicAdd((ull*)&tab_c[row + c], (ull)cnt[c]);
-                    atomicAdd((ull*)&tab_q[row + c], (ull)((int64_t)(qs[c] >> 7) - qt * (int64_t)cnt[c]));
+                    const int64_t dc = (int64_t)cnt[c], dq = (int64_t)(qs[c] >> 7) - qt * (int64_t)cnt[c];
+                    atomicAdd((ull*)&tab_c[row + c], (ull)(neg ? -dc : dc));
+                    atomicAdd((ull*)&tab_q[row + c], (ull)(neg ? -dq : dq));
                 }
             }
-            atomicAdd((ull*)&tab_c[row + 4], (ull)call);
-            atomicAdd((ull*)&tab_q[row + 4], (ull)((int64_t)qs[4] - qt * (int64_t)call));
+            const int64_t dc = (int64_t)call, dq = (int64_t)qs[4] - qt * (int64_t)call;
+            atomicAdd((ull*)&tab_c[row + 4], (ull)(neg ? -dc : dc));
+            atomicAdd((ull*)&tab_q[row + 4], (ull)(neg ? -dq : dq));
         }
         cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0;
         qs[0] = qs[1] = qs[2] = qs[3] = qs[4] = 0;
@@ -465,9 +548,11 @@ TGSF_KERNEL TGSF_BOUNDS(256, 3) k_stats(DevParams P, DevBatch B)
             TGSF_WAVE_SYNC();
             const uint64_t ca0 = a0, caq = aq; const uint32_t cnb = nb, ctt = tt, citem = item;
             if (i + 1 < ng) { entry(i + 1, a0, aq, nb, tt, item); issue(a0, aq, nb); }   // in flight during the reduce
-            if (ctt != t_acc || since >= 2048) {               // qs[c] carries 128*sum: stay below 2^32
+            const bool ineg = CLEAN && citem >= B.fcap;         // a read being taken back out
+            if (ctt != t_acc || ineg != neg || since >= 2048) { // qs[c] carries 128*sum: stay below 2^32
                 if (t_acc != 0xFFFFFFFFu) flush(t_acc);
                 t_acc = ctt;
+                neg = ineg;
             }
             ++since;
             const int nvalid = (int)cnb - (int)lane * kBin;     // bases of this lane's bin in the tile
@@ -500,7 +585,7 @@ TGSF_KERNEL TGSF_BOUNDS(256, 3) k_stats(DevParams P, DevBatch B)
             // sumQ of the item: sum over the tile of (qual - qType), two's complement in u64 (:1457-1458)
             const int32_t part = (int32_t)(qs[4] - q4_before) - (int32_t)qt * nv;
             const int32_t tot = wave_sum_i32(part);
-            if (wave_leader()) atomicAdd((ull*)&it_sum[citem], (ull)(int64_t)tot);
+            if (!ineg && wave_leader()) atomicAdd((ull*)&it_sum[citem], (ull)(int64_t)tot);
         }
     }
     if (t_acc != 0xFFFFFFFFu) flush(t_acc);
@@ -1378,12 +1463,14 @@ TGSF_KERNEL k_gate_frags(DevParams P, DevBatch B)
     for (uint32_t i = TGSF_COOP_BEGIN; i < (uint32_t)TGSF_N_QBINS; i += TGSF_COOP_STRIDE) hq[i] = 0;
     TGSF_BLOCK_SYNC();
     const uint32_t nf = stored_frags(B);
+    const bool diff = clean_by_difference(B);
     uint64_t lq_n = 0, lq_b = 0;
     uint32_t erows = 0;
     for (uint32_t f0 = blockIdx.x * blockDim.x; f0 < nf; f0 += gsize()) {
         const uint32_t f = f0 + threadIdx.x;
         if (f >= nf || (B.frag_flags[f] & TGSF_FF_REPEAT)) continue;
         const uint32_t L = B.frag_len[f];
+        if (diff && B.whole[B.frag_read[f]]) B.frag_sum[f] = B.sumq[B.frag_read[f]];   // not re-scanned
         const double cm = mean_q(B.frag_sum[f], L);
         if (P.filter && q_fail(cm, P.min_q, P.max_q)) { lq_n++; lq_b += L; continue; }
         if (!(cm >= 0.0 && cm < 256.0)) { set_status(B, DS_BAD_MEANQ, B.frag_read[f]); continue; }

@@ -311,7 +311,7 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     B.max_tiles = (c->max_read_len + kTileBases - 1) / kTileBases;
     uint64_t pool = c->cap_bases / 64 + 65536;
     B.pool_cap = (uint32_t)std::min<uint64_t>(pool, 1ull << 28);
-    const size_t nitems = std::max<size_t>(n, B.fcap);
+    const size_t nitems = n + (size_t)B.fcap;         // clean pass: fragments, and reads to take back out
     if (!e) e = dev_alloc(c, &c->d_seq, cap_bytes);
     if (!e) e = dev_alloc(c, &c->d_qual, cap_bytes);
     if (!e) e = dev_alloc(c, &c->d_off, n + 1);
@@ -333,7 +333,7 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     if (!e) e = dev_alloc(c, &B.tile_base, (size_t)B.max_tiles + 2);
     if (!e) e = dev_alloc(c, &B.tile_fill, (size_t)B.max_tiles + 2);
     if (!e) e = dev_alloc(c, &B.perm, nitems);
-    B.work_cap = (uint32_t)std::min<uint64_t>(c->cap_bases / kTileBases + nitems + 16, 0x7FFFFFF0ull);
+    B.work_cap = (uint32_t)std::min<uint64_t>(2 * (c->cap_bases / kTileBases) + nitems + 16, 0x7FFFFFF0ull);
     if (!e) e = dev_alloc(c, &B.work, 2 * (size_t)B.work_cap);
     if (!e) e = dev_alloc(c, &B.frag_off, (size_t)B.fcap);
     if (!e) e = dev_alloc(c, &B.frag_qoff, (size_t)B.fcap);
@@ -342,6 +342,14 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     if (!e) e = dev_alloc(c, &B.frag_read, (size_t)B.fcap);
     if (!e) e = dev_alloc(c, &B.frag_start, (size_t)B.fcap);
     if (!e) e = dev_alloc(c, &B.frag_flags, (size_t)B.fcap);
+    if (!e) e = dev_alloc(c, &B.raw_tab, 2 * (size_t)c->n_bins * 5);
+    if (!e) e = dev_alloc(c, &B.whole, n);
+    if (!e) e = dev_alloc(c, &B.plan, 4);
+    B.clean_force = p->only_qc ? 1u : 0u;
+    if (const char* f = getenv("TGSF_CLEAN_TABLES")) {      // test knob: "direct" | "difference"
+        if (!strcmp(f, "direct")) B.clean_force = 1;
+        else if (!strcmp(f, "difference") && !p->only_qc) B.clean_force = 2;
+    }
     {
         // traceback scratch: a window of the first location spans at most Q + k columns
         int maxcols = 1;
@@ -367,6 +375,7 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     }
     rt_memset(B.ctr, 0, c->ctr_words * 8, c->stream);
     rt_memset(B.status, 0, 16, c->stream);
+    rt_memset(B.raw_tab, 0, 2 * (size_t)c->n_bins * 5 * 8, c->stream);
     rt_sync(c->stream);
     *out = c;
     return TGSF_OK;
@@ -419,6 +428,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     const unsigned gsmall = grid_cap(std::min(blocks_for(n, T), 2048u));
     const unsigned gstats = grid_cap(768u);     // 3 blocks (12 waves) per CU on 256 CUs: LDS-limited
     const size_t tl = ((size_t)B.max_tiles + 2) * 4;
+    const unsigned gfold = grid_cap(std::min(blocks_for((uint64_t)P.n_bins * 5, T), 1024u));
     int stage = 0;
 #if !defined(TGSF_EMUL)
     if (c->profile && c->prof_pending == tgsf_ctx::kProfRing) { int e = harvest_profile(c, st); if (e) return e; }
@@ -438,6 +448,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     rt_memset(B.tile_hist, 0, tl, st);
     rt_memset(B.tile_fill, 0, tl, st);
     rt_memset(B.pool_n, 0, 4, st);
+    rt_memset(B.plan, 0, 32, st);
     TGSF_LAUNCH(k_prepare, gsmall, T, st, P, B, c->max_read_len);
     TGSF_LAUNCH_COOP(k_tile_scan, 1, 1024, st, B);
     TGSF_LAUNCH(k_tile_scatter<false>, gsmall, T, st, B);
@@ -446,6 +457,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     STAGE_MARK();
     // -- raw stats
     TGSF_LAUNCH(k_stats<false>, gstats, 64 * kStatsWaves, st, P, B);
+    TGSF_LAUNCH(k_fold_raw<false>, gfold, T, st, P, B);
     STAGE_MARK();
     TGSF_LAUNCH(k_gate_reads, gsmall, T, st, P, B);
     STAGE_MARK();
@@ -506,7 +518,9 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     // -- clean stats over the fragments
     rt_memset(B.tile_hist, 0, tl, st);
     rt_memset(B.tile_fill, 0, tl, st);
-    const unsigned gfr = grid_cap(std::min(blocks_for(B.fcap, T), 2048u));
+    const unsigned gfr = grid_cap(std::min(blocks_for((uint64_t)B.fcap + n, T), 2048u));
+    TGSF_LAUNCH(k_clean_plan, gsmall, T, st, P, B);
+    TGSF_LAUNCH(k_fold_raw<true>, gfold, T, st, P, B);
     TGSF_LAUNCH(k_frag_prepare, gfr, T, st, P, B);
     TGSF_LAUNCH_COOP(k_tile_scan, 1, 1024, st, B);
     TGSF_LAUNCH(k_tile_scatter<true>, gfr, T, st, B);
@@ -660,6 +674,7 @@ extern "C" int tgsf_reset_counters(tgsf_ctx* c)
 {
     if (!c) return TGSF_E_INVALID;
     int he = rt_memset(c->B.ctr, 0, c->ctr_words * 8, c->stream);
+    if (!he) he = rt_memset(c->B.raw_tab, 0, 2 * (size_t)c->n_bins * 5 * 8, c->stream);
     if (!he) he = rt_sync(c->stream);
     return he ? fail(c, TGSF_E_HIP, "memset failed") : TGSF_OK;
 }
