@@ -151,7 +151,7 @@ def main():
     ap.add_argument("--max-len", type=int, default=2_000_000)
     ap.add_argument("--cpu-sample-reads", type=int, default=24000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="batches in flight per GPU (one context + one HIP stream each); >1 overlaps the "
                          "HBM-bound stats kernels of one batch with the VALU-bound adapter scan of another")
     args = ap.parse_args()

@@ -32,7 +32,7 @@ class TgsfError(RuntimeError):
 
 
 def load(path: str | None = None):
-    path = path or DEFAULT_LIB
+    path = path or os.environ.get("TGSF_LIB") or DEFAULT_LIB
     if path in _LIBS:
         return _LIBS[path]
     if not os.path.exists(path):

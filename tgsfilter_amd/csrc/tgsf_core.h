@@ -220,19 +220,48 @@ TGSF_HD int win_start(const uint64_t* peq_rev, int Q, const uint8_t* t, int end,
 // of all 4 quality bytes.  Quality bytes must be < 128.
 // ---------------------------------------------------------------------------
 TGSF_HD void qc_accum4(uint32_t s, uint32_t q, uint32_t* cnt /*[4]*/, uint32_t* qs /*[5]*/) {
-    const uint32_t x = s & 0xDFDFDFDFu;          // fold lower case onto upper case
-    const uint32_t x7 = x & 0x7F7F7F7Fu;
+    const uint32_t x7 = s & 0x5F5F5F5Fu;         // fold lower case onto upper case, drop bit 7
     const uint32_t K[4] = {0x41414141u, 0x54545454u, 0x47474747u, 0x43434343u};   // A T G C
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        uint32_t t = x7 ^ K[c];
-        uint32_t nz = (t + 0x7F7F7F7Fu) | x;     // bit 7 of each byte: byte differs from K[c]
-        uint32_t m = ~nz & 0x80808080u;          // 0x80 where the base is of class c
+        const uint32_t nz = ((x7 ^ K[c]) + 0x7F7F7F7Fu) | s;   // bit 7 of each byte: byte differs from K[c]
+        const uint32_t m = ~nz & 0x80808080u;                   // 0x80 where the base is of class c
         cnt[c] += popc32(m);
         qs[c] = udot4(q, m, qs[c]);
     }
     qs[4] = udot4(q, 0x01010101u, qs[4]);
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// The same tallies with the class constants held in VGPRs, so that (x7 ^ K) + 0x7F7F7F7F is one
+// v_xad_u32 (a VOP3 instruction reads one scalar at most): 4 instructions per class and dword.
+struct QcConsts { uint32_t k[4]; };
+__device__ __forceinline__ QcConsts qc_consts() {
+    QcConsts c;
+    asm volatile("v_mov_b32 %0, 0x41414141" : "=v"(c.k[0]));
+    asm volatile("v_mov_b32 %0, 0x54545454" : "=v"(c.k[1]));
+    asm volatile("v_mov_b32 %0, 0x47474747" : "=v"(c.k[2]));
+    asm volatile("v_mov_b32 %0, 0x43434343" : "=v"(c.k[3]));
+    return c;
+}
+__device__ __forceinline__ void qc_accum4(const QcConsts& kc, uint32_t s, uint32_t q, uint32_t* cnt, uint32_t* qs) {
+    const uint32_t x7 = s & 0x5F5F5F5Fu;
+    const uint32_t c7f = 0x7F7F7F7Fu;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        uint32_t t;
+        asm("v_xad_u32 %0, %1, %2, %3" : "=v"(t) : "v"(x7), "v"(kc.k[c]), "s"(c7f));
+        const uint32_t m = ~(t | s) & 0x80808080u;
+        cnt[c] += popc32(m);
+        qs[c] = udot4(q, m, qs[c]);
+    }
+    qs[4] = udot4(q, 0x01010101u, qs[4]);
+}
+#else
+struct QcConsts { int unused; };
+TGSF_HD QcConsts qc_consts() { return QcConsts{0}; }
+TGSF_HD void qc_accum4(const QcConsts&, uint32_t s, uint32_t q, uint32_t* cnt, uint32_t* qs) { qc_accum4(s, q, cnt, qs); }
+#endif
 
 // mean-quality gate: src/TGSFilter.cpp:1478 (double(sumQ)/len), :1947 (compare
 // against float thresholds promoted to double).  sum is the uint64 accumulator.

@@ -429,6 +429,7 @@ TGSF_KERNEL TGSF_BOUNDS(256, 3) k_stats(DevParams P, DevBatch B)
     uint64_t* it_sum = CLEAN ? B.frag_sum : B.sumq;
     const int64_t qt = P.qtype;
     bool neg = false;                                  // accumulated tallies are to be taken OUT of the tables
+    const QcConsts kc = qc_consts();
 
     uint32_t cnt[4] = {0, 0, 0, 0}, qs[5] = {0, 0, 0, 0, 0}, call = 0, since = 0, qor = 0;
     uint32_t t_acc = 0xFFFFFFFFu;
@@ -563,21 +564,43 @@ TGSF_KERNEL TGSF_BOUNDS(256, 3) k_stats(DevParams P, DevBatch B)
                 const uint32_t bos = (uint32_t)(ca0 & 15u) + lane * kBin, boq = (uint32_t)(caq & 15u) + lane * kBin;
                 const uint32_t ds = bos >> 2, bss = bos & 3u, dq = boq >> 2, bsq = boq & 3u;
                 const int ndw = (nv + 3) >> 2;
+                // A full bin (every tile but an item's last) runs a fixed 25 dwords, unrolled by 5: LDS reads
+                // with immediate offsets, no per-dword loop bookkeeping.
                 if ((bss | bsq) == 0) {
-                    for (int k = 0; k < ndw; k++) {
-                        uint32_t q = Qd[dq + k];
-                        qor |= q;
-                        qc_accum4(S[ds + k], q, cnt, qs);
+                    if (nv == kBin) {
+#pragma unroll 5
+                        for (int k = 0; k < kBin / 4; k++) {
+                            const uint32_t q = Qd[dq + k];
+                            qor |= q;
+                            qc_accum4(kc, S[ds + k], q, cnt, qs);
+                        }
+                    } else {
+                        for (int k = 0; k < ndw; k++) {
+                            const uint32_t q = Qd[dq + k];
+                            qor |= q;
+                            qc_accum4(kc, S[ds + k], q, cnt, qs);
+                        }
                     }
                 } else {
                     // bytes past the item are zero in LDS; bytes before it never enter (the shift skips them)
                     uint32_t slo = S[ds], qlo = Qd[dq];
-                    for (int k = 0; k < ndw; k++) {
-                        const uint32_t shi = S[ds + k + 1], qhi = Qd[dq + k + 1];
-                        const uint32_t q = alignbyte(qhi, qlo, bsq);
-                        qor |= q;
-                        qc_accum4(alignbyte(shi, slo, bss), q, cnt, qs);
-                        slo = shi; qlo = qhi;
+                    if (nv == kBin) {
+#pragma unroll 5
+                        for (int k = 0; k < kBin / 4; k++) {
+                            const uint32_t shi = S[ds + k + 1], qhi = Qd[dq + k + 1];
+                            const uint32_t q = alignbyte(qhi, qlo, bsq);
+                            qor |= q;
+                            qc_accum4(kc, alignbyte(shi, slo, bss), q, cnt, qs);
+                            slo = shi; qlo = qhi;
+                        }
+                    } else {
+                        for (int k = 0; k < ndw; k++) {
+                            const uint32_t shi = S[ds + k + 1], qhi = Qd[dq + k + 1];
+                            const uint32_t q = alignbyte(qhi, qlo, bsq);
+                            qor |= q;
+                            qc_accum4(kc, alignbyte(shi, slo, bss), q, cnt, qs);
+                            slo = shi; qlo = qhi;
+                        }
                     }
                 }
                 call += (uint32_t)nv;
@@ -984,8 +1007,13 @@ TGSF_D void push_candidate(const DevBatch& B, uint32_t r, int pos, int score, in
     B.pool[idx] = c;
 }
 
+#if defined(TGSF_MID_MAXW) && !defined(TGSF_EMUL)
+#define TGSF_MID_OCC __attribute__((amdgpu_waves_per_eu(1, TGSF_MID_MAXW)))
+#else
+#define TGSF_MID_OCC
+#endif
 template <int AT>
-TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
+TGSF_KERNEL TGSF_MID_OCC k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
 {
     TGSF_SHARED uint64_t eqt[256][AT];
     // per lane and adapter: up to 4 columns that tie the lane's best value so far (slow path only)
@@ -995,9 +1023,10 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
         eqt[sym][j] = (int)j < na ? P.peq_top[(size_t)(a0 + j) * 256 + sym] : 0ull;
     }
     TGSF_BLOCK_SYNC();
-    const uint32_t g = gtid();
     const uint32_t total = B.seg_cnt[B.n];
-    if (g >= total) return;
+    // grid-stride over segments: the host may launch fewer workgroups than segments / 256 to leave part
+    // of every CU to the HBM-bound kernels of the batch on the other stream (this kernel is VALU-bound)
+    for (uint32_t g = gtid(); g < total; g += gsize()) {
     const uint32_t r = find_owner(B.seg_cnt, B.n, g);
     const uint32_t seg = g - B.seg_cnt[r];
     const int L = (int)B.len[r];
@@ -1116,6 +1145,7 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
     while (c < c1) { step_all(mid[c]); if (c >= c0) check_col(c); c++; }
 #pragma unroll
     for (int j = 0; j < AT; j++) flush_ties(j);
+    }
 }
 
 // adapters of 65..128 bp: two-word standard layout, one adapter per pass
@@ -1125,8 +1155,8 @@ TGSF_KERNEL k_mid_scan2(DevParams P, DevBatch B, int a)
     for (uint32_t i = TGSF_COOP_BEGIN; i < 512u; i += TGSF_COOP_STRIDE)
         eqt[i >> 1][i & 1] = P.peq_fwd[(size_t)a * 512 + i];
     TGSF_BLOCK_SYNC();
-    const uint32_t g = gtid();
     const uint32_t total = B.seg_cnt[B.n];
+    const uint32_t g = gtid();
     if (g >= total) return;
     const uint32_t r = find_owner(B.seg_cnt, B.n, g);
     const uint32_t seg = g - B.seg_cnt[r];

@@ -46,6 +46,7 @@ struct tgsf_ctx {
     // capacities
     uint64_t cap_bases;
     uint32_t cap_reads, max_read_len, n_bins;
+    unsigned stats_grid = 768, mid_grid = 0;   // tuning knobs (TGSF_STATS_GRID, TGSF_MID_GRID; 0 = one lane per segment)
     uint64_t ctr_words;
     int scratch_cols;
     // internal input / output staging for tgsf_submit
@@ -69,6 +70,8 @@ struct tgsf_ctx {
     int prof_pending;
     hipStream_t aux;                      // end-window / end-table kernels overlap the middle scan here
     hipEvent_t ev_fork, ev_join;
+    hipStream_t hp;                       // optional high-priority stream for the HBM-bound stats kernels (TGSF_STATS_PRIO=1)
+    hipEvent_t ev_hp[2];
 #endif
     uint32_t h_status[4];
 };
@@ -208,6 +211,8 @@ extern "C" void tgsf_destroy(tgsf_ctx* c)
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->aux) (void)hipStreamDestroy(c->aux);
+    if (c->hp) (void)hipStreamDestroy(c->hp);
+    for (int i = 0; i < 2; i++) if (c->ev_hp[i]) (void)hipEventDestroy(c->ev_hp[i]);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
 #endif
     for (void* p : c->allocs) rt_free(p);
@@ -257,6 +262,7 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     memset(c->ev, 0, sizeof c->ev);
     memset(c->ev_aux, 0, sizeof c->ev_aux);
     c->aux = nullptr; c->ev_fork = c->ev_join = nullptr;
+    c->hp = nullptr; c->ev_hp[0] = c->ev_hp[1] = nullptr;
     int ndev = 0;
     hipError_t he = hipGetDeviceCount(&ndev);
     if (he != hipSuccess || ndev <= 0) {
@@ -274,6 +280,17 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
         (he = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess ||
         (he = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) {
         tgsf_destroy(c); return fail(nullptr, TGSF_E_HIP, "auxiliary stream: %s", hipGetErrorString(he));
+    }
+    if (const char* e = getenv("TGSF_STATS_PRIO")) {
+        if (atoi(e) > 0) {
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);       // hi = numerically lowest = greatest priority
+            if ((he = hipStreamCreateWithPriority(&c->hp, hipStreamNonBlocking, hi)) != hipSuccess ||
+                (he = hipEventCreateWithFlags(&c->ev_hp[0], hipEventDisableTiming)) != hipSuccess ||
+                (he = hipEventCreateWithFlags(&c->ev_hp[1], hipEventDisableTiming)) != hipSuccess) {
+                tgsf_destroy(c); return fail(nullptr, TGSF_E_HIP, "priority stream: %s", hipGetErrorString(he));
+            }
+        }
     }
 #else
     c->stream = nullptr; c->own_stream = false;
@@ -294,6 +311,8 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     P.n_bins = c->n_bins;
     c->ctr_words = tgsf_ctr_len(p->bc_len, c->n_bins);
     P.seg_cols = kSegCols;
+    if (const char* e = getenv("TGSF_STATS_GRID")) { int v = atoi(e); if (v >= 1 && v <= 65536) c->stats_grid = (unsigned)v; }
+    if (const char* e = getenv("TGSF_MID_GRID")) { int v = atoi(e); if (v >= 1) c->mid_grid = (unsigned)v; }
     if (const char* e = getenv("TGSF_SEG_COLS")) { int v = atoi(e); if (v >= 256 && v <= 65536) P.seg_cols = v & ~15; }   // tuning knob
 
     int e = build_tables(c);
@@ -426,7 +445,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     const unsigned T = 256;
     c->last_stream = st;
     const unsigned gsmall = grid_cap(std::min(blocks_for(n, T), 2048u));
-    const unsigned gstats = grid_cap(768u);     // 3 blocks (12 waves) per CU on 256 CUs: LDS-limited
+    const unsigned gstats = grid_cap(c->stats_grid);   // 3 blocks (12 waves) per CU on 256 CUs: LDS-limited
     const size_t tl = ((size_t)B.max_tiles + 2) * 4;
     const unsigned gfold = grid_cap(std::min(blocks_for((uint64_t)P.n_bins * 5, T), 1024u));
     int stage = 0;
@@ -456,7 +475,14 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     TGSF_LAUNCH(k_build_work<false>, gwork, T, st, B);
     STAGE_MARK();
     // -- raw stats
-    TGSF_LAUNCH(k_stats<false>, gstats, 64 * kStatsWaves, st, P, B);
+    rt_stream ss = st;
+#if !defined(TGSF_EMUL)
+    if (c->hp) { ss = c->hp; (void)hipEventRecord(c->ev_hp[0], st); (void)hipStreamWaitEvent(ss, c->ev_hp[0], 0); }
+#endif
+    TGSF_LAUNCH(k_stats<false>, gstats, 64 * kStatsWaves, ss, P, B);
+#if !defined(TGSF_EMUL)
+    if (c->hp) { (void)hipEventRecord(c->ev_hp[1], ss); (void)hipStreamWaitEvent(st, c->ev_hp[1], 0); }
+#endif
     TGSF_LAUNCH(k_fold_raw<false>, gfold, T, st, P, B);
     STAGE_MARK();
     TGSF_LAUNCH(k_gate_reads, gsmall, T, st, P, B);
@@ -489,16 +515,17 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
         // upper bound of the segment count, known on the host: no device round trip
         const uint64_t max_segs = in->n_bytes / (uint64_t)P.seg_cols + 2ull * n + 1;
         const unsigned gseg = blocks_for(max_segs, T);
+        const unsigned gmid = c->mid_grid ? std::min(gseg, c->mid_grid) : gseg;
         int a = 0;
         while (a < A) {
             if (P.Q[a] > 64) { TGSF_LAUNCH(k_mid_scan2, gseg, T, st, P, B, a); a++; continue; }
             int na = 0;
             while (a + na < A && na < 4 && P.Q[a + na] <= 64) na++;
             switch (na) {
-            case 1: TGSF_LAUNCH(k_mid_scan1<1>, gseg, T, st, P, B, a, na); break;
-            case 2: TGSF_LAUNCH(k_mid_scan1<2>, gseg, T, st, P, B, a, na); break;
-            case 3: TGSF_LAUNCH(k_mid_scan1<3>, gseg, T, st, P, B, a, na); break;
-            default: TGSF_LAUNCH(k_mid_scan1<4>, gseg, T, st, P, B, a, na); break;
+            case 1: TGSF_LAUNCH(k_mid_scan1<1>, gmid, T, st, P, B, a, na); break;
+            case 2: TGSF_LAUNCH(k_mid_scan1<2>, gmid, T, st, P, B, a, na); break;
+            case 3: TGSF_LAUNCH(k_mid_scan1<3>, gmid, T, st, P, B, a, na); break;
+            default: TGSF_LAUNCH(k_mid_scan1<4>, gmid, T, st, P, B, a, na); break;
             }
             a += na;
         }
@@ -525,7 +552,13 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     TGSF_LAUNCH_COOP(k_tile_scan, 1, 1024, st, B);
     TGSF_LAUNCH(k_tile_scatter<true>, gfr, T, st, B);
     TGSF_LAUNCH(k_build_work<true>, gwork, T, st, B);
-    TGSF_LAUNCH(k_stats<true>, gstats, 64 * kStatsWaves, st, P, B);
+#if !defined(TGSF_EMUL)
+    if (c->hp) { (void)hipEventRecord(c->ev_hp[0], st); (void)hipStreamWaitEvent(ss, c->ev_hp[0], 0); }
+#endif
+    TGSF_LAUNCH(k_stats<true>, gstats, 64 * kStatsWaves, ss, P, B);
+#if !defined(TGSF_EMUL)
+    if (c->hp) { (void)hipEventRecord(c->ev_hp[1], ss); (void)hipStreamWaitEvent(st, c->ev_hp[1], 0); }
+#endif
     STAGE_MARK();
     TGSF_LAUNCH(k_gate_frags, gfr, T, st, P, B);
     if (P.bc_len > 0) TGSF_LAUNCH(k_end_tables<true>, grid_cap(128u), 64 * kEndWaves, st, P, B);
