@@ -16,8 +16,12 @@ def run_case(binary: str, golden_dir: str, name: str):
     ref_err = open(os.path.join(golden_dir, name + ".stderr.txt")).read()
     ref_html = json.load(open(os.path.join(golden_dir, name + ".html.json")))
     with tempfile.TemporaryDirectory() as td:
-        fin = os.path.join(td, "in.fq")
-        open(fin, "wb").write(gzip.open(os.path.join(golden_dir, name + ".in.fq.gz"), "rb").read())
+        fmt = cmd.get("in_format", "fq")
+        fin = os.path.join(td, "in." + fmt)
+        if fmt == "bam":
+            open(fin, "wb").write(open(os.path.join(golden_dir, name + ".in.bam"), "rb").read())
+        else:
+            open(fin, "wb").write(gzip.open(os.path.join(golden_dir, name + ".in." + fmt + ".gz"), "rb").read())
         args = [binary, "-i", fin, "-t", "1"] + cmd["flags"].split()
         qc = "--qc" in cmd["flags"]
         if not qc:

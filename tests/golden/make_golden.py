@@ -3,7 +3,8 @@
 
 Run in the build container only (needs oracle/_ref/tgsfilter_ref, i.e. `make -C oracle ref`,
 which compiles the reference from /root/reference where it lies).  The outputs are data:
-  <case>.in.fq.gz      seeded synthetic input (tgsfilter_amd/synth.py)
+  <case>.in.fq.gz      seeded synthetic input (tgsfilter_amd/synth.py); .in.bam / .in.sam.gz for the
+                       BAM / SAM cases (written by tests/bamio.py from the same generator)
   <case>.out.fq.gz     the reference's clean FASTQ with -t 1 (byte-deterministic, input order)
   <case>.stderr.txt    the reference's stderr (INFO: lines = counters, resolved parameters)
   <case>.html.json     the <table> rows and the `var data = {...}` object of the HTML report
@@ -59,7 +60,31 @@ CASES = {
     "down_R": (dict(seed=22, n=90, kind="hifi", mean_len=3000, p5=0.2, p3=0.2),
                [synth.PACBIO_BLUNT], "-x hifi -l 1000 -q 20 -5 0 -3 0 -R 0.3"),
     "down_F": (dict(seed=23, n=70, kind="ont", mean_len=3000), None, "-F -r 20"),
+    # unaligned BAM / SAM input (the reference reads them through htslib); a few bases are
+    # IUPAC / odd characters, which its 4-bit round trip turns into NUL or N
+    "hifi_bam": (dict(seed=24, n=60, kind="hifi", mean_len=3000, zoo=True, p5=0.2, p3=0.2, pmid=0.05),
+                 [synth.PACBIO_BLUNT], "-x hifi -l 1000 -q 20 -5 0 -3 0", "bam"),
+    "ont_sam": (dict(seed=25, n=60, kind="ont", mean_len=3000, zoo=True, pmid=0.05),
+                [synth.ONT_RAPID], "-x ont -l 1000 -q 10 -5 0 -3 0", "sam"),
+    "hifi_bam_auto": (dict(seed=26, n=700, kind="hifi", mean_len=1400, p5=0.5, p3=0.4), None, "-x hifi -l 1000 -b 8", "bam"),
 }
+
+IN_EXT = {"fq": "in.fq", "bam": "in.bam", "sam": "in.sam"}
+
+
+def odd_bases(reads, seed):
+    """Sprinkle IUPAC codes, '=', digits and other characters over a few reads (SAM/BAM cases)."""
+    rng = np.random.default_rng(seed)
+    odd = np.frombuffer(b"RYKMSWBDHVU=.x0123nacgt", dtype=np.uint8)
+    out = []
+    for i, (name, s, q) in enumerate(reads):
+        if i % 4 == 1:
+            b = bytearray(s)
+            for pos in rng.integers(0, len(b), max(1, len(b) // 300)):
+                b[int(pos)] = int(odd[rng.integers(0, len(odd))])
+            s = bytes(b)
+        out.append((name, s, q))
+    return out
 
 
 def html_slices(html: str):
@@ -70,12 +95,20 @@ def html_slices(html: str):
     return {"table_rows": table, "data": m.group(1) if m else None}
 
 
-def run_case(name, kwargs, adapters, flags):
+def run_case(name, kwargs, adapters, flags, fmt="fq"):
     reads = synth.make_reads(**kwargs)
     with tempfile.TemporaryDirectory() as td:
-        fin = os.path.join(td, "in.fq")
+        fin = os.path.join(td, IN_EXT[fmt])
         fout = os.path.join(td, "out.fq")
-        synth.write_fastq(fin, reads)
+        if fmt == "fq":
+            synth.write_fastq(fin, reads)
+        else:
+            from tests import bamio
+            reads = odd_bases(reads, kwargs["seed"])
+            if fmt == "bam":
+                bamio.write_bam(fin, reads, block=0x4000)
+            else:
+                bamio.write_sam(fin, reads)
         cmd = [REF_BIN, "-i", fin, "-t", "1"] + flags.split()
         if "--qc" not in flags:
             cmd += ["-o", fout]
@@ -91,15 +124,18 @@ def run_case(name, kwargs, adapters, flags):
         htmlname = os.path.join(td, "out.html" if "--qc" not in flags else "in.html")
         html = open(htmlname, encoding="utf-8", errors="replace").read() if os.path.exists(htmlname) else ""
         raw = open(fin, "rb").read()
-    with gzip.GzipFile(os.path.join(HERE, name + ".in.fq.gz"), "wb", mtime=0) as f:
-        f.write(raw)
+    if fmt == "bam":
+        open(os.path.join(HERE, name + ".in.bam"), "wb").write(raw)        # already BGZF-compressed
+    else:
+        with gzip.GzipFile(os.path.join(HERE, name + "." + IN_EXT[fmt] + ".gz"), "wb", mtime=0) as f:
+            f.write(raw)
     with gzip.GzipFile(os.path.join(HERE, name + ".out.fq.gz"), "wb", mtime=0) as f:
         f.write(out)
     open(os.path.join(HERE, name + ".stderr.txt"), "w").write(stderr)
     json.dump(html_slices(html), open(os.path.join(HERE, name + ".html.json"), "w"), indent=0)
     json.dump({"flags": flags, "adapters": [a.decode() for a in adapters] if adapters else None,
                "synth": kwargs if "adapter" not in kwargs else {**kwargs, "adapter": kwargs["adapter"].decode()},
-               "returncode": p.returncode},
+               "returncode": p.returncode, "in_format": fmt},
               open(os.path.join(HERE, name + ".cmd.json"), "w"), indent=1)
     print(name, "rc", p.returncode, "in", len(raw), "out", len(out))
     print("   ", "\n    ".join(l for l in stderr.splitlines() if "reads" in l or "adapter" in l or "trim" in l))
@@ -155,8 +191,8 @@ def edlib_vectors(n=600, seed=7):
 
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for name, (kw, ad, fl) in CASES.items():
+    for name, case in CASES.items():
         if not only or name in only:
-            run_case(name, kw, ad, fl)
+            run_case(name, *case)
     if not only or "edlib" in only:
         edlib_vectors()

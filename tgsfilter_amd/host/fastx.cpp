@@ -1,5 +1,7 @@
 #include "fastx.h"
 
+#include "bam.h"
+
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -21,8 +23,19 @@ InputBytes::~InputBytes()
     if (map_) munmap(map_, map_len_);
 }
 
-bool InputBytes::open(const std::string& path)
+bool InputBytes::open(const std::string& path, bool sam_or_bam)
 {
+    if (sam_or_bam) {
+        InputBytes raw;
+        if (!raw.open_plain(path)) { std::cerr << "Error: Failed to open file: " << path << std::endl; return false; }
+        std::string err;
+        if (!decode_sam_or_bam(raw.data(), raw.size(), owned_, err)) {
+            std::cerr << "Error: " << err << " (" << path << ")" << std::endl;
+            exit(-1);
+        }
+        data_ = owned_.data(); size_ = owned_.size();
+        return true;
+    }
     if (ends_with(path, ".gz")) {
         gzFile g = gzopen(path.c_str(), "rb");          // multi-member gzip is handled by zlib (:632-639)
         if (!g) { std::cerr << "Failed to open file: " << path << std::endl; return false; }
@@ -35,15 +48,21 @@ bool InputBytes::open(const std::string& path)
         data_ = owned_.data(); size_ = owned_.size();
         return true;
     }
+    if (!open_plain(path)) { std::cerr << "Failed to open file: " << path << std::endl; return false; }
+    return true;
+}
+
+bool InputBytes::open_plain(const std::string& path)
+{
     const int fd = ::open(path.c_str(), O_RDONLY);
-    if (fd < 0) { std::cerr << "Failed to open file: " << path << std::endl; return false; }
+    if (fd < 0) return false;
     struct stat st;
     if (fstat(fd, &st) != 0) { close(fd); return false; }
     size_ = (size_t)st.st_size;
     if (size_ == 0) { close(fd); data_ = ""; return true; }
     void* m = mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd, 0);
     close(fd);
-    if (m == MAP_FAILED) { std::cerr << "Failed to open file: " << path << std::endl; return false; }
+    if (m == MAP_FAILED) return false;
     madvise(m, size_, MADV_SEQUENTIAL);
     map_ = m; map_len_ = size_;
     data_ = static_cast<const char*>(m);

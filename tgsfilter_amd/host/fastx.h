@@ -2,7 +2,8 @@
 // (FastxReader, src/TGSFilter.cpp:521-782): strict 4-line FASTQ / 2-line FASTA, "\r\n" tolerated
 // (:666-668), header = everything after '@'/'>' (:709, :748), up to 5 (FASTQ) / 3 (FASTA) lines are
 // tried for a header (:689-698, :732-737), the stream ENDS at the first malformed record (:700-723).
-// Input is a flat byte range: plain files are mmap'ed, .gz files are inflated into memory (zlib).
+// Input is a flat byte range: plain files are mmap'ed, .gz files are inflated into memory (zlib),
+// SAM/BAM files are decoded into FASTQ text in memory (bam.h).
 #pragma once
 #include <cstddef>
 #include <string>
@@ -14,10 +15,13 @@ namespace host {
 class InputBytes {
 public:
     ~InputBytes();
-    bool open(const std::string& path);         // prints "Failed to open file: <path>" on failure (:564)
+    // prints "Failed to open file: <path>" on failure (:564).  sam_or_bam: the file is SAM/BAM (by name, as the
+    // reference decides) and is decoded to FASTQ text in memory (bam.h).
+    bool open(const std::string& path, bool sam_or_bam = false);
     const char* data() const { return data_; }
     size_t size() const { return size_; }
 private:
+    bool open_plain(const std::string& path);   // mmap, no message
     const char* data_ = nullptr;
     size_t size_ = 0;
     void* map_ = nullptr;

@@ -204,11 +204,10 @@ int main(int argc, char** argv)
     }
     if (o.in_type == 0 && o.out_type == 1) { std::cerr << "Error: Fasta format input file can't output fastq format file" << std::endl; return 1; }
     // rows of SURVEY 8(f) that are not built yet fail loudly instead of silently doing something else
-    if (o.in_type == 2) die("BAM/SAM input is not supported by this build (SURVEY 8f-4)");
     if (o.in_type == 0) die("FASTA input (no qualities) is not supported by this build");
 
     InputBytes in;
-    if (!in.open(o.in_file)) return 1;
+    if (!in.open(o.in_file, o.in_type == 2)) return 1;            // SAM/BAM: decoded to FASTQ text (read_bam, :1872-1917)
 
     // ---- pre-pass, :3058-3126 ----
     PrepassResult pp = run_prepass(o, in);
