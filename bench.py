@@ -291,11 +291,21 @@ def main():
     alg_bytes = 2.0 * (bases / args.steps) + 32.0 * (reads / args.steps)    # 2 B/base + 32 B/read
     achieved = alg_bytes / t_dom / 1e9 if t_dom > 0 else 0.0
     traffic = None
+    valu = None
     tj = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tj):
         tr = json.load(open(tj))
-        if tr.get("reads_per_step") == args.reads:
+        if tr.get("reads_per_step") == args.reads and args.workload == "ont":
             traffic = tr.get("mid_scan_hbm_bytes_per_launch")
+            vi, va = tr.get("mid_scan_valu_insts_per_launch"), tr.get("valu_insts_per_batch_all_kernels")
+            if vi and va and t_dom > 0:
+                # a wave64 VALU instruction holds its SIMD for 4 cycles; 256 CUs x 4 SIMDs
+                valu = {"kernel_valu_insts_per_launch": vi, "kernel_issue_cycles_per_simd": vi * 4 / 1024,
+                        "kernel_min_clock_ghz_if_valu_only": vi * 4 / 1024 / t_dom / 1e9,
+                        "pipeline_valu_insts_per_batch": va, "pipeline_issue_cycles_per_simd": va * 4 / 1024,
+                        "note": "SQ_INSTS_VALU from profiles/ (PMC pass of the same command): the dominant kernel "
+                                "issues VALU instructions back to back for its whole duration -- the pipeline is "
+                                "VALU-issue bound, the HBM fraction above is what that leaves"}
 
     out = {
         "metric": "filtered Gbases/sec (end-to-end, excl. gzip I/O)",
@@ -327,6 +337,7 @@ def main():
             "bound": "hbm", "kernel": "k_mid_scan1<2> (Myers infix scan, stage 'mid_scan')",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
+            "valu_issue": valu,
             "measured": "HIP events on the launch stream around every stage (inside libtgsf); kernel durations "
                         "of %d single-stream steps run right after the timed region (the GPU is not shared with "
                         "another batch); 'timed_region_stage_ms' are the same events inside the timed region with "

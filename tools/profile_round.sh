@@ -1,0 +1,67 @@
+#!/bin/bash
+# All the rocprofv3 passes behind profiles/: kernel-trace stats for the default bench line and for one batch
+# in flight, and the PMC passes (one per counter set, with --kernel-trace only).  Run on the GPU box:
+#   tools/profile_round.sh <tag>     -> gpurun_out/prof_<tag>/*.csv|json  (copy what is to be judged to profiles/)
+tag=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/prof_$tag
+rm -rf $O; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+python3 $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_default -- python3 $R/bench.py --no-cpu-baseline > $O/kt_default.json 2> $O/kt_default.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_single -- python3 $R/bench.py --no-cpu-baseline --streams 1 > $O/kt_single.json 2> $O/kt_single.err
+B="python3 $R/bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $B > $O/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $B > $O/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_tcc -- $B > $O/pmc_tcc.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES --output-format csv -d $O/pmc_sq -- $B > $O/pmc_sq.log 2>&1
+python3 - "$O" "$tag" <<'PY'
+import csv, glob, collections, json, os, sys
+O, tag = sys.argv[1], sys.argv[2]
+def short(n): return n.split("(")[0].replace("void ", "").strip()
+# ---- kernel stats ----
+for run in ("kt_default", "kt_single"):
+    rows = []
+    for fn in glob.glob(O + "/" + run + "/**/*kernel_stats.csv", recursive=True):
+        rows += list(csv.DictReader(open(fn)))
+    rows = [r for r in rows if "tgsf::" in r["Name"]]
+    tot = sum(float(r["TotalDurationNs"]) for r in rows) or 1.0
+    with open(O + "/%s_%s_kernel_stats.csv" % (tag, run), "w") as o:
+        o.write("Name,Calls,TotalDurationNs,AverageNs,PctOfTgsf,MinNs,MaxNs\n")
+        for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
+            o.write('"%s",%s,%s,%s,%.2f,%s,%s\n' % (r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"],
+                                                  100 * float(r["TotalDurationNs"]) / tot, r["MinNs"], r["MaxNs"]))
+# ---- PMC ----
+def pmc(run):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(collections.Counter)
+    for fn in glob.glob(O + "/" + run + "/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(fn)):
+            k = short(row["Kernel_Name"])
+            if not k.startswith("tgsf::"): continue
+            agg[k][row["Counter_Name"]] += float(row["Counter_Value"]); n[k][row["Counter_Name"]] += 1
+    return {k: {c: v / n[k][c] for c, v in d.items()} for k, d in agg.items()}
+fetch, write, tcc, sq = pmc("pmc_fetch"), pmc("pmc_write"), pmc("pmc_tcc"), pmc("pmc_sq")
+kernels = sorted(set(fetch) | set(write) | set(tcc), key=lambda k: -tcc.get(k, {}).get("TCC_EA0_RDREQ_sum", 0))
+with open(O + "/%s_pmc_hbm_traffic.csv" % tag, "w") as o:
+    o.write("kernel,FETCH_SIZE_KB,WRITE_SIZE_KB,TCC_EA0_RDREQ,TCC_HIT,TCC_MISS,read_bytes_corrected,write_bytes\n")
+    for k in kernels:
+        f = fetch.get(k, {}).get("FETCH_SIZE", 0.0); w = write.get(k, {}).get("WRITE_SIZE", 0.0); t = tcc.get(k, {})
+        o.write("%s,%.0f,%.0f,%.0f,%.0f,%.0f,%.0f,%.0f\n" % (k, f, w, t.get("TCC_EA0_RDREQ_sum", 0), t.get("TCC_HIT_sum", 0),
+                                                         t.get("TCC_MISS_sum", 0), t.get("TCC_EA0_RDREQ_sum", 0) * 128, w * 1024))
+with open(O + "/%s_pmc_valu.csv" % tag, "w") as o:
+    cols = ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAVES"]
+    o.write("kernel," + ",".join(cols) + "\n")
+    for k, d in sorted(sq.items(), key=lambda kv: -kv[1].get("SQ_INSTS_VALU", 0)):
+        o.write(k + "," + ",".join("%.0f" % d.get(c, 0) for c in cols) + "\n")
+b = json.load(open(O + "/kt_single.json"))
+def hbm(k):
+    return tcc.get(k, {}).get("TCC_EA0_RDREQ_sum", 0) * 128 + write.get(k, {}).get("WRITE_SIZE", 0) * 1024
+json.dump({"reads_per_step": b["config"]["reads_per_step_per_gpu"],
+           "mid_scan_hbm_bytes_per_launch": hbm("tgsf::k_mid_scan1<2>"),
+           "stats_raw_hbm_bytes_per_launch": hbm("tgsf::k_stats<false>"),
+           "mid_scan_valu_insts_per_launch": sq.get("tgsf::k_mid_scan1<2>", {}).get("SQ_INSTS_VALU"),
+           "valu_insts_per_batch_all_kernels": sum(d.get("SQ_INSTS_VALU", 0) for d in sq.values()),
+           "source": "profiles/%s_pmc_hbm_traffic.csv (TCC_EA0_RDREQ_sum*128 + WRITE_SIZE*1024) and %s_pmc_valu.csv" % (tag, tag)},
+          open(O + "/traffic.json", "w"), indent=1)
+PY
+ls $O
