@@ -31,6 +31,7 @@ extern thread_local Dim3 threadIdx, blockIdx, blockDim, gridDim;
 }
 using tgsf_emul::threadIdx; using tgsf_emul::blockIdx; using tgsf_emul::blockDim; using tgsf_emul::gridDim;
 #define TGSF_KERNEL static void
+#define TGSF_INLINE_LAMBDA
 #define TGSF_BOUNDS(threads, waves_per_simd)
 #define TGSF_SHARED static
 #define TGSF_BLOCK_SYNC() ((void)0)
@@ -47,6 +48,7 @@ template <class T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; ret
 template <class T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 #else
 #define TGSF_KERNEL __global__ void
+#define TGSF_INLINE_LAMBDA __attribute__((always_inline))
 #define TGSF_BOUNDS(threads, waves_per_simd) __launch_bounds__(threads, waves_per_simd)
 #define TGSF_SHARED __shared__
 #define TGSF_BLOCK_SYNC() __syncthreads()
@@ -396,6 +398,14 @@ TGSF_D uint32_t wave_bcast(uint32_t v, uint32_t src_lane) {
     return (uint32_t)__shfl((int)v, (int)src_lane, 64);
 #endif
 }
+// lane src_lane's value as a wave-uniform (scalar) value; src_lane must be wave-uniform
+TGSF_D uint32_t wave_pick(uint32_t v, uint32_t src_lane) {
+#if defined(TGSF_EMUL)
+    (void)src_lane; return v;
+#else
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src_lane);
+#endif
+}
 TGSF_D int32_t wave_sum_i32(int32_t v) {
 #if defined(TGSF_EMUL)
     return v;
@@ -458,20 +468,24 @@ TGSF_KERNEL TGSF_BOUNDS(256, 3) k_stats(DevParams P, DevBatch B)
 
     // register staging of one tile: chunk c = lane + 64*k of each stream.  The two streams may sit at
     // different alignments (raw FASTQ text: seq and qual of a read are different lines of one buffer).
-    uint4 rs[kLaneChunks], rq[kLaneChunks];
-    auto issue = [&](uint64_t a0, uint64_t aq, uint32_t nb) {
+#if !defined(TGSF_EMUL)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // plain vector values: stay in registers
+    u32x4 rs[kLaneChunks], rq[kLaneChunks];
+#endif
+    // (a0, aq, nb are wave-uniform -- read with v_readlane from the work list -- so the chunk addresses are a
+    // scalar base plus a per-lane offset.  Loads are not predicated: past the tile's last data chunk the
+    // offset is clamped to that chunk (a line already being fetched) and the register is simply not stored.)
+    auto issue = [&](uint64_t a0, uint64_t aq, uint32_t nb) TGSF_INLINE_LAMBDA {
 #if !defined(TGSF_EMUL)
         const uint32_t shs = (uint32_t)(a0 & 15u), shq = (uint32_t)(aq & 15u);
         const uint8_t* ps = B.seq + (a0 - shs);
         const uint8_t* pq = B.qual + (aq - shq);
-        const uint32_t ends = shs + nb, endq = shq + nb;
+        const uint32_t lasts = (shs + nb - 1u) & ~15u, lastq = (shq + nb - 1u) & ~15u;   // nb >= 1
 #pragma unroll
         for (int k = 0; k < kLaneChunks; k++) {
             const uint32_t cb = (lane + 64u * k) * 16u;
-            uint4 z = {0, 0, 0, 0};
-            rs[k] = z; rq[k] = z;
-            if (cb < ends) rs[k] = *reinterpret_cast<const uint4*>(ps + cb);
-            if (cb < endq) rq[k] = *reinterpret_cast<const uint4*>(pq + cb);
+            rs[k] = *reinterpret_cast<const u32x4*>(ps + (cb < lasts ? cb : lasts));
+            rq[k] = *reinterpret_cast<const u32x4*>(pq + (cb < lastq ? cb : lastq));
         }
 #else
         (void)a0; (void)aq; (void)nb;
@@ -485,23 +499,23 @@ TGSF_KERNEL TGSF_BOUNDS(256, 3) k_stats(DevParams P, DevBatch B)
             p[d] &= kb >= 4 ? 0xFFFFFFFFu : (kb <= 0 ? 0u : ((1u << (8 * kb)) - 1u));
         }
     };
-    auto commit = [&](uint64_t a0, uint64_t aq, uint32_t nb) {
+    auto commit = [&](uint64_t a0, uint64_t aq, uint32_t nb) TGSF_INLINE_LAMBDA {
         const uint32_t shs = (uint32_t)(a0 & 15u), shq = (uint32_t)(aq & 15u);
         const uint32_t ends = shs + nb, endq = shq + nb;
         const uint32_t nchs = (ends + 15u) / 16u + 1u, nchq = (endq + 15u) / 16u + 1u;   // + one all-zero guard chunk
 #if !defined(TGSF_EMUL)
+        // data chunks as loaded, then the bytes from the end of the tile to the end of the guard chunk are
+        // zeroed in LDS by byte stores of lanes 0..31 (LDS operations of one wave complete in order)
 #pragma unroll
         for (int k = 0; k < kLaneChunks; k++) {
-            const uint32_t c = lane + 64u * k, cb = c * 16u;
-            if (c < nchs) {
-                if (cb < ends && cb + 16u > ends) mask_tail(rs[k], ends - cb);
-                lds[wave][0][c] = rs[k];
-            }
-            if (c < nchq) {
-                if (cb < endq && cb + 16u > endq) mask_tail(rq[k], endq - cb);
-                lds[wave][1][c] = rq[k];
-            }
+            const uint32_t c = lane + 64u * k;
+            if (c + 1u < nchs) *reinterpret_cast<u32x4*>(&lds[wave][0][c]) = rs[k];
+            if (c + 1u < nchq) *reinterpret_cast<u32x4*>(&lds[wave][1][c]) = rq[k];
         }
+        uint8_t* bs = reinterpret_cast<uint8_t*>(&lds[wave][0][0]);
+        uint8_t* bq = reinterpret_cast<uint8_t*>(&lds[wave][1][0]);
+        if (ends + lane < nchs * 16u) bs[ends + lane] = 0;
+        if (endq + lane < nchq * 16u) bq[endq + lane] = 0;
 #else
         // emulation: one lane at a time, so every emulated lane stages the whole tile
         for (uint32_t c = 0; c < nchs; c++) {
@@ -533,9 +547,9 @@ TGSF_KERNEL TGSF_BOUNDS(256, 3) k_stats(DevParams P, DevBatch B)
             a0 = (uint64_t)e.x | ((uint64_t)e.y << 32); nb = e.z & 0x1FFFu; tt = e.z >> 13; item = e.w;
             aq = (uint64_t)q.x | ((uint64_t)q.y << 32);
 #else
-            const uint32_t x = wave_bcast(me.x, i), y = wave_bcast(me.y, i), z = wave_bcast(me.z, i);
-            const uint32_t qx = wave_bcast(mq.x, i), qy = wave_bcast(mq.y, i);
-            item = wave_bcast(me.w, i);
+            const uint32_t x = wave_pick(me.x, i), y = wave_pick(me.y, i), z = wave_pick(me.z, i);
+            const uint32_t qx = wave_pick(mq.x, i), qy = wave_pick(mq.y, i);
+            item = wave_pick(me.w, i);
             a0 = (uint64_t)x | ((uint64_t)y << 32); nb = z & 0x1FFFu; tt = z >> 13;
             aq = (uint64_t)qx | ((uint64_t)qy << 32);
 #endif
