@@ -167,6 +167,18 @@ TGSF_HD void hot_step(Hot& s, uint64_t Eq) {
     const uint32_t nmh = bitop3<0xE0>((uint32_t)(Ph >> 32), (uint32_t)(Eq >> 32), (uint32_t)(Mv >> 32));
     s.m = ((uint64_t)nmh << 32) | nml;                   // 2 v_bitop3
 }
+// popcount(x) + acc as two accumulating v_bcnt_u32_b32 (the compiler adds acc separately when popcount(x)
+// has another use)
+TGSF_HD int popc64_acc(uint64_t x, int acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"((uint32_t)x), "v"(acc));
+    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(r) : "v"((uint32_t)(x >> 32)));
+    return r;
+#else
+    return (int)popc64(x) + acc;
+#endif
+}
 TGSF_HD int hot_score(const Hot& s) { return (int)popc64(s.p) - (int)popc64(s.m); }
 
 // ---------------------------------------------------------------------------

@@ -1057,6 +1057,7 @@ TGSF_KERNEL TGSF_MID_OCC k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
 
     Hot st[AT];
     int lim[AT];              // best bottom-row value seen so far in the owned columns (k+1: none yet)
+    int lim3[AT];             // lim + 3: the every-4th-column test
     int ntie[AT];             // buffered columns attaining it
     int wu = 0;
 #pragma unroll
@@ -1065,12 +1066,13 @@ TGSF_KERNEL TGSF_MID_OCC k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
         const bool on = j < na && ML >= P.Q[a] && P.k_mid[a] >= 0;    // :1237 tsmLen >= qLen
         hot_init(st[j], j < na ? P.Q[a] : 1);
         lim[j] = on ? P.k_mid[a] + 1 : -1000;
+        lim3[j] = lim[j] + 3;
         ntie[j] = 0;
         if (on) { int w = P.Q[a] + P.k_mid[a]; wu = w > wu ? w : wu; }
     }
     int c = c0 - wu;
     if (c < 0) c = 0;
-    else if (c > 0) { int al = c - (int)((amid + (uint64_t)c) & 63u); c = al > 0 ? al : c; }  // longer warm-up, 64-B aligned
+    else if (c > 0) { int al = c - (int)((amid + (uint64_t)c) & 15u); c = al > 0 ? al : c; }  // warm-up starts 16-B aligned
 
     auto step_all = [&](uint32_t byte) {
 #pragma unroll
@@ -1085,7 +1087,7 @@ TGSF_KERNEL TGSF_MID_OCC k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
         ntie[j] = 0;
     };
     auto note = [&](int j, int sc, int col) {
-        if (sc < lim[j]) { lim[j] = sc; ntie[j] = 0; }            // strictly better: older ties are void
+        if (sc < lim[j]) { lim[j] = sc; lim3[j] = sc + 3; ntie[j] = 0; }   // strictly better: older ties are void
         if (sc == lim[j]) {                                          // lim <= k here (init k+1 is never equalled... see below)
             if (ntie[j] == 4) flush_ties(j);
             ties[j][ntie[j]++] = col;
@@ -1117,19 +1119,20 @@ TGSF_KERNEL TGSF_MID_OCC k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
 #pragma unroll
             for (int j = 0; j < AT; j++) h3[j] = st[j];
             step_all(d[k] >> 24);
-            int s4[AT];
+            // value <= lim + 3  <=>  popcount(Pv) <= popcount(Mv) + (lim + 3): two accumulating v_bcnt per side
             bool any = false;
 #pragma unroll
-            for (int j = 0; j < AT; j++) { s4[j] = hot_score(st[j]); any |= (s4[j] <= lim[j] + 3); }
+            for (int j = 0; j < AT; j++) any |= (popc64_acc(st[j].p, 0) <= popc64_acc(st[j].m, lim3[j]));
             if (any && own) {
 #pragma unroll
                 for (int j = 0; j < AT; j++) {
+                    const int s4j = hot_score(st[j]);
                     const int cc = cc0 + 4 * k;
                     const int s1 = hot_score(h1[j]), s2 = hot_score(h2[j]), s3 = hot_score(h3[j]);
                     if (s1 < lim[j] || (s1 == lim[j] && ntie[j] > 0)) note(j, s1, cc);
                     if (s2 < lim[j] || (s2 == lim[j] && ntie[j] > 0)) note(j, s2, cc + 1);
                     if (s3 < lim[j] || (s3 == lim[j] && ntie[j] > 0)) note(j, s3, cc + 2);
-                    if (s4[j] < lim[j] || (s4[j] == lim[j] && ntie[j] > 0)) note(j, s4[j], cc + 3);
+                    if (s4j < lim[j] || (s4j == lim[j] && ntie[j] > 0)) note(j, s4j, cc + 3);
                 }
             }
         }
@@ -1142,13 +1145,15 @@ TGSF_KERNEL TGSF_MID_OCC k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
     while (c < c1 && ((amid + (uint64_t)c) & 15u)) { step_all(mid[c]); if (c >= c0) check_col(c); c++; }
     // 64 bytes per lane per fetch: a 128-byte line is touched by two fetch groups only
     // (16-byte fetches were re-fetching evicted lines: 2.1x the bytes, see profiles/).
+    // The first group of a lane stops at the next 64-byte boundary, every later one covers a whole one.
     while (c + 16 <= c1) {
         const uint4* p4 = reinterpret_cast<const uint4*>(mid + c);
+        const int room = 4 - (int)(((amid + (uint64_t)c) >> 4) & 3u);      // 16-B chunks up to the boundary
         uint4 v0 = p4[0], v1 = v0, v2 = v0, v3 = v0;
         int nq = 1;
-        if (c + 32 <= c1) { v1 = p4[1]; nq = 2; }
-        if (c + 48 <= c1) { v2 = p4[2]; nq = 3; }
-        if (c + 64 <= c1) { v3 = p4[3]; nq = 4; }
+        if (room >= 2 && c + 32 <= c1) { v1 = p4[1]; nq = 2; }
+        if (room >= 3 && c + 48 <= c1) { v2 = p4[2]; nq = 3; }
+        if (room >= 4 && c + 64 <= c1) { v3 = p4[3]; nq = 4; }
 #pragma unroll 1
         for (int q = 0; q < nq; q++) {
             chunk16(v0, c, c >= c0);
