@@ -151,6 +151,8 @@ def main():
     ap.add_argument("--max-len", type=int, default=2_000_000)
     ap.add_argument("--cpu-sample-reads", type=int, default=24000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for validation)")
+    ap.add_argument("--share-gpu", action="store_true", help="validation on a 1-GPU box: every rank uses device 0")
     ap.add_argument("--streams", type=int, default=3,
                     help="batches in flight per GPU (one context + one HIP stream each); >1 overlaps the "
                          "HBM-bound stats kernels of one batch with the VALU-bound adapter scan of another")
@@ -166,11 +168,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.share_gpu:                      # validation on a 1-GPU box: all ranks on device 0, gloo for the exchange
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    xdev = device if args.backend == "nccl" else torch.device("cpu")       # where the exchanged tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     hifi = args.workload == "hifi"
     if args.mean_len is None:
@@ -181,6 +189,12 @@ def main():
                for b in range(2)]
     max_bases = max(b["bases"] for b in batches)
     max_len = max(int(b["h_lens"].max()) for b in batches)
+    if world > 1:
+        # the tally vector is sized by max_read_len (rows of the per-position tables): every rank must build
+        # the same layout, or the one all-reduce of the job would mix up words
+        mm = torch.tensor([max_bases, max_len], dtype=torch.int64, device=xdev)
+        dist.all_reduce(mm, op=dist.ReduceOp.MAX)
+        max_bases, max_len = int(mm[0].item()), int(mm[1].item())
     p = abi.make_params(args.workload, adapters=wl_adapters, min_len=1000, min_q=20.0 if hifi else 10.0,
                         head_trim=0, tail_trim=0, max_batch_bases=max_bases + 64, max_batch_reads=args.reads,
                         max_read_len=max_len, min_repeat=args.min_repeat, kmer=11)
@@ -236,7 +250,7 @@ def main():
     if world > 1:
         # the job's only exchange: sum the tally vector over ranks (the 4 "rows used" words are maxima)
         all_wait()
-        total_ctr = tdist.allreduce_counters(all_counters(), device=device)
+        total_ctr = tdist.allreduce_counters(all_counters(), device=xdev if args.backend == "nccl" else None)
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
@@ -246,10 +260,10 @@ def main():
 
     # max over ranks of the elapsed time; sum of the bases
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        tt = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        bb = torch.tensor([bases, reads], dtype=torch.int64, device=device)
+        bb = torch.tensor([bases, reads], dtype=torch.int64, device=xdev)
         dist.all_reduce(bb, op=dist.ReduceOp.SUM)
         bases_all, reads_all = int(bb[0].item()), int(bb[1].item())
     else:

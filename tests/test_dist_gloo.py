@@ -61,3 +61,32 @@ def test_two_rank_shard_and_allreduce(tmp_path):
         assert np.array_equal(got, eres[name]), name
     got_frags = np.concatenate([pp["frags"][["start", "len", "flags", "sum_q"]] for pp in parts])
     assert np.array_equal(got_frags, efrags[["start", "len", "flags", "sum_q"]])
+
+
+MISMATCH_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["TGSF_ROOT"])
+import torch.distributed as dist
+from tgsfilter_amd import dist as tdist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+try:
+    tdist.allreduce_counters(np.zeros(2000 + 100 * rank, dtype=np.uint64))   # layouts differ between the ranks
+    code = 1
+except ValueError as e:
+    code = 0 if "differ in length" in str(e) else 2
+dist.destroy_process_group()
+sys.exit(code)
+'''
+
+
+def test_allreduce_refuses_mismatched_layouts(tmp_path):
+    """Ranks that built their contexts with different max_read_len hold tally vectors of different lengths:
+    the exchange must refuse (on every rank) instead of summing words that mean different things."""
+    script = tmp_path / "worker.py"
+    script.write_text(MISMATCH_WORKER)
+    env = dict(os.environ, TGSF_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29612", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(2)]
+    for pr in procs:
+        assert pr.wait(timeout=300) == 0

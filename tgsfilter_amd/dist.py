@@ -42,6 +42,12 @@ def allreduce_counters(ctr: np.ndarray, device=None, group=None) -> np.ndarray:
     t = torch.from_numpy(np.ascontiguousarray(ctr, dtype=np.uint64).view(np.int64).copy())
     if device is not None:
         t = t.to(device)
+    # every rank must hold the same layout (same bc_len and max_read_len at tgsf_create): check before summing
+    n = torch.tensor([t.numel(), -t.numel()], dtype=torch.int64, device=t.device)
+    dist.all_reduce(n, op=dist.ReduceOp.MAX, group=group)
+    if int(n[0].item()) != -int(n[1].item()):
+        raise ValueError("tally vectors differ in length across ranks (%d here, %d..%d over the job): create every "
+                         "context with the same bc_len and max_read_len" % (t.numel(), -int(n[1].item()), int(n[0].item())))
     rows = t[abi.CTR_ROWS:abi.CTR_ROWS + 4].clone()
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     dist.all_reduce(rows, op=dist.ReduceOp.MAX, group=group)
