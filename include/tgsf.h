@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TGSF_ABI_VERSION 1
+#define TGSF_ABI_VERSION 2
 #define TGSF_MAX_ADAPTERS 32      /* adapters.size(): 2 or 4 in practice (src/TGSFilter.cpp:3105-3125) */
 #define TGSF_MAX_ADAPTER_LEN 128  /* two 64-row blocks; library adapters are 22..64 bp (:2970-2991) */
 #define TGSF_N_DROPINFO 17        /* DropInfo row, src/TGSFilter.cpp:1776 */
@@ -87,6 +87,13 @@ typedef struct tgsf_params {
     uint64_t max_batch_bases; /* largest sum of read lengths of one batch            */
     uint32_t max_batch_reads; /* largest number of reads of one batch                */
     uint32_t max_read_len;    /* longest read ever submitted (sizes the bin tables)  */
+    /* FASTA input (records without qualities, src/TGSFilter.cpp:1954-1958, :2005-2009): tgsf_batch_in.qual is
+     * ignored (may be NULL); the tallies are those of Get_base_counts (:1577-1606), Get_5p_base_counts
+     * (:1608-1640, where a lower-case 'g' is not counted as G) and Get_3p_base_counts (:1642-1678, where a
+     * lower-case 't' is not counted as T): counts only, all quality sums, sum_q and both DiffQual
+     * histograms stay 0; there is no quality gate. */
+    int32_t  no_qual;
+    int32_t  reserved;
 } tgsf_params;
 
 /*

@@ -245,6 +245,37 @@ static void end_tables(const uint8_t* seq, const uint8_t* qual, uint64_t len, in
     }
 }
 
+/* Count-only variants for records without qualities (FASTA input):
+ * Get_base_counts :1577-1606, Get_5p_base_counts :1608-1640, Get_3p_base_counts :1642-1678.
+ * As coded, the 5' variant tests 'G' twice (a lower-case g only reaches column 4) and the 3' variant tests
+ * 'T' twice (same for a lower-case t). */
+static void base_counts(const uint8_t* seq, uint64_t len, uint64_t* tab_cnt, uint64_t* rows_used)
+{
+    uint64_t rows = len / TGSF_BIN_WIDTH + 1;
+    if (rows > *rows_used) *rows_used = rows;
+    for (uint64_t i = 0; i < len; i++) {
+        uint64_t row = i / TGSF_BIN_WIDTH;
+        int c = base_column(seq[i]);
+        if (c < 4) tab_cnt[row * 5 + c]++;
+        tab_cnt[row * 5 + 4]++;
+    }
+}
+static void end_counts(const uint8_t* seq, uint64_t len, int bc_len, uint64_t* c5, uint64_t* c3, uint64_t* rows_used)
+{
+    uint64_t n = (uint64_t)(bc_len < 0 ? 0 : bc_len);
+    if (n > len) n = len;
+    if (n > *rows_used) *rows_used = n;
+    for (uint64_t i = 0; i < n; i++) {
+        int c = seq[i] == 'g' ? 4 : base_column(seq[i]);               /* :1629 */
+        if (c < 4) c5[i * 5 + c]++;
+        c5[i * 5 + 4]++;
+        uint64_t j = len - 1 - i;
+        c = seq[j] == 't' ? 4 : base_column(seq[j]);                   /* :1667 */
+        if (c < 4) c3[i * 5 + c]++;
+        c3[i * 5 + 4]++;
+    }
+}
+
 /* ------------------------------------------------------------------------- */
 /* adapter search + region logic                                              */
 /* ------------------------------------------------------------------------- */
@@ -438,7 +469,7 @@ int orc_filter_batch(const tgsf_params* p, const tgsf_batch_in* in, tgsf_batch_o
         uint64_t off = in->offsets[r];
         uint64_t len64 = in->lengths ? in->lengths[r] : in->offsets[r + 1] - off;
         const uint8_t* seq = in->seq + off;
-        const uint8_t* qual = in->qual + (in->qual_offsets ? in->qual_offsets[r] : off);
+        const uint8_t* qual = p->no_qual ? seq : in->qual + (in->qual_offsets ? in->qual_offsets[r] : off);
         tgsf_read_result* rr = &out->reads[r];
         memset(rr, 0, sizeof(*rr));
         rr->frag_begin = nf;
@@ -446,19 +477,24 @@ int orc_filter_batch(const tgsf_params* p, const tgsf_batch_in* in, tgsf_batch_o
         if (len64 / TGSF_BIN_WIDTH + 1 > n_bins) return TGSF_E_CAPACITY;
         int L = (int)len64;
 
-        /* raw stats, always: :1942-1945 */
-        uint64_t sum = calc_avg_quality(seq, qual, len64, p->qtype, B[TGSF_B_RAW_QUAL], B[TGSF_B_RAW_CNT], &rows[0]);
-        double mean = (double)sum / (double)len64;                     /* :1478 */
-        rr->sum_q = sum;
-        if (!(mean >= 0.0 && mean < 256.0)) return TGSF_E_DATA;        /* the reference indexes out of bounds here */
-        ctr[TGSF_CTR_RAW_DIFFQ + (int)mean] += len64;                  /* :1943 */
-        end_tables(seq, qual, len64, p->qtype, bc, T[TGSF_T_RAW5P_QUAL], T[TGSF_T_RAW5P_CNT],
-                   T[TGSF_T_RAW3P_QUAL], T[TGSF_T_RAW3P_CNT], &rows[2]);
-        if (p->filter) {                                               /* :1946-1953 */
-            if (mean < (double)p->min_q || mean > (double)p->max_q) {
-                drop[0]++; drop[1] += len64;
-                rr->flags |= TGSF_RF_LOWQ;
-                continue;
+        if (p->no_qual) {                                              /* :1954-1958 rawQualLen == 0 */
+            base_counts(seq, len64, B[TGSF_B_RAW_CNT], &rows[0]);
+            end_counts(seq, len64, bc, T[TGSF_T_RAW5P_CNT], T[TGSF_T_RAW3P_CNT], &rows[2]);
+        } else {
+            /* raw stats, always: :1942-1945 */
+            uint64_t sum = calc_avg_quality(seq, qual, len64, p->qtype, B[TGSF_B_RAW_QUAL], B[TGSF_B_RAW_CNT], &rows[0]);
+            double mean = (double)sum / (double)len64;                     /* :1478 */
+            rr->sum_q = sum;
+            if (!(mean >= 0.0 && mean < 256.0)) return TGSF_E_DATA;        /* the reference indexes out of bounds here */
+            ctr[TGSF_CTR_RAW_DIFFQ + (int)mean] += len64;                  /* :1943 */
+            end_tables(seq, qual, len64, p->qtype, bc, T[TGSF_T_RAW5P_QUAL], T[TGSF_T_RAW5P_CNT],
+                       T[TGSF_T_RAW3P_QUAL], T[TGSF_T_RAW3P_CNT], &rows[2]);
+            if (p->filter) {                                               /* :1946-1953 */
+                if (mean < (double)p->min_q || mean > (double)p->max_q) {
+                    drop[0]++; drop[1] += len64;
+                    rr->flags |= TGSF_RF_LOWQ;
+                    continue;
+                }
             }
         }
         region_vec keep = {0, 0, 0};
@@ -477,6 +513,12 @@ int orc_filter_batch(const tgsf_params* p, const tgsf_batch_in* in, tgsf_batch_o
                         fr->flags |= TGSF_FF_REPEAT;
                         continue;
                     }
+                }
+                if (p->no_qual) {                                                        /* :2005-2009 */
+                    base_counts(seq + s, (uint64_t)fl, B[TGSF_B_CLEAN_CNT], &rows[1]);
+                    end_counts(seq + s, (uint64_t)fl, bc, T[TGSF_T_CLEAN5P_CNT], T[TGSF_T_CLEAN3P_CNT], &rows[3]);
+                    fr->flags |= TGSF_FF_PASS;
+                    continue;
                 }
                 /* clean bin tables accumulate BEFORE the gate: :1994 */
                 uint64_t cs = calc_avg_quality(seq + s, qual + s, (uint64_t)fl, p->qtype,

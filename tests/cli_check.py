@@ -25,7 +25,7 @@ def run_case(binary: str, golden_dir: str, name: str):
         args = [binary, "-i", fin, "-t", "1"] + cmd["flags"].split()
         qc = "--qc" in cmd["flags"]
         if not qc:
-            args += ["-o", os.path.join(td, "out.fq")]
+            args += ["-o", os.path.join(td, "out.fa" if fmt == "fa" else "out.fq")]
         if cmd["adapters"]:
             fa = os.path.join(td, "adapters.fa")
             with open(fa, "w") as f:
@@ -35,7 +35,7 @@ def run_case(binary: str, golden_dir: str, name: str):
         p = subprocess.run(args, capture_output=True, cwd=td)
         err = p.stderr.decode().replace(td + "/", "")
         assert p.returncode == 0, err
-        out = open(os.path.join(td, "out.fq"), "rb").read() if not qc else b""
+        out = open(os.path.join(td, "out.fa" if fmt == "fa" else "out.fq"), "rb").read() if not qc else b""
         html = open(os.path.join(td, "in.html" if qc else "out.html"), encoding="utf-8").read()
     assert out == ref_out, "output FASTQ differs from the reference's"
 

@@ -67,9 +67,30 @@ CASES = {
     "ont_sam": (dict(seed=25, n=60, kind="ont", mean_len=3000, zoo=True, pmid=0.05),
                 [synth.ONT_RAPID], "-x ont -l 1000 -q 10 -5 0 -3 0", "sam"),
     "hifi_bam_auto": (dict(seed=26, n=700, kind="hifi", mean_len=1400, p5=0.5, p3=0.4), None, "-x hifi -l 1000 -b 8", "bam"),
+    # FASTA input (records without qualities): count-only tallies, soft-masked stretches at the read ends
+    "ont_fasta": (dict(seed=27, n=80, kind="ont", mean_len=3500, zoo=True, pmid=0.05),
+                  [synth.ONT_RAPID], "-x ont -l 1000 -5 0 -3 0", "fa"),
+    "hifi_fasta_auto": (dict(seed=28, n=700, kind="hifi", mean_len=1400, p5=0.5, p3=0.4), None, "-x hifi -l 1000 -b 8", "fa"),
+    "fasta_down": (dict(seed=29, n=70, kind="ont", mean_len=3000, zoo=True, pmid=0.05),
+                   [synth.ONT_RAPID], "-x ont -l 1000 -5 4 -3 0 -r 15 -p 2", "fa"),
 }
 
-IN_EXT = {"fq": "in.fq", "bam": "in.bam", "sam": "in.sam"}
+IN_EXT = {"fq": "in.fq", "bam": "in.bam", "sam": "in.sam", "fa": "in.fa"}
+
+
+def soft_mask(reads, seed):
+    """Lower-case stretches over both ends and the middle of every other read (FASTA cases)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i, (name, s, q) in enumerate(reads):
+        b = bytearray(s)
+        if i % 2 == 0:
+            for lo, hi in ((0, 60), (len(b) - 60, len(b)), (len(b) // 2, len(b) // 2 + 80)):
+                for k in range(max(lo, 0), min(hi, len(b))):
+                    if rng.random() < 0.7 and chr(b[k]).isalpha():
+                        b[k] |= 0x20
+        out.append((name, bytes(b), q))
+    return out
 
 
 def odd_bases(reads, seed):
@@ -99,9 +120,13 @@ def run_case(name, kwargs, adapters, flags, fmt="fq"):
     reads = synth.make_reads(**kwargs)
     with tempfile.TemporaryDirectory() as td:
         fin = os.path.join(td, IN_EXT[fmt])
-        fout = os.path.join(td, "out.fq")
+        fout = os.path.join(td, "out.fa" if fmt == "fa" else "out.fq")
         if fmt == "fq":
             synth.write_fastq(fin, reads)
+        elif fmt == "fa":
+            with open(fin, "wb") as f:
+                for rname, sq, _ in soft_mask(reads, kwargs["seed"]):
+                    f.write(b">" + rname + b"\n" + sq + b"\n")
         else:
             from tests import bamio
             reads = odd_bases(reads, kwargs["seed"])

@@ -174,3 +174,34 @@ def clean_table_strategy(lib_path, mode, golden_dir):
             os.environ.pop("TGSF_CLEAN_TABLES", None)
         else:
             os.environ["TGSF_CLEAN_TABLES"] = old
+
+
+def no_qual_batch(lib_path, mode=None):
+    """Records without qualities (FASTA input, tgsf_params.no_qual): count-only tallies incl. the reference's
+    lower-case quirks at the read ends, no quality gate, adapter trimming as usual."""
+    old = os.environ.get("TGSF_CLEAN_TABLES")
+    if mode:
+        os.environ["TGSF_CLEAN_TABLES"] = mode
+    try:
+        rng = np.random.default_rng(5)
+        reads = []
+        for i, (name, s, q) in enumerate(synth.make_reads(41, 60, "ont", mean_len=3000, zoo=True, pmid=0.1)):
+            b = bytearray(s)
+            if i % 2 == 0:                                 # soft-masked stretches over both ends and the middle
+                for lo, hi in ((0, 40), (len(b) - 40, len(b)), (len(b) // 2, len(b) // 2 + 60)):
+                    for k in range(max(lo, 0), min(hi, len(b))):
+                        if rng.random() < 0.7:
+                            b[k] = b[k] | 0x20 if chr(b[k]).isalpha() else b[k]
+            reads.append((name, bytes(b), q))
+        p = sized(abi.make_params("ont", adapters=[synth.ONT_RAPID, synth.ONT_RAPID_RC], min_q=10.0, head_trim=3,
+                                  no_qual=True), reads)
+        ctx = capi.Context(p, 0, lib_path)
+        res, frags, ctr = compare_batch(ctx, p, reads)
+        assert not (res["flags"] & abi.RF_LOWQ).any() and (res["sum_q"] == 0).all() and (frags["sum_q"] == 0).all()
+        assert ctr[abi.CTR_RAW_DIFFQ:abi.CTR_RAW_DIFFQ + 512].sum() == 0
+        ctx.close()
+    finally:
+        if old is None:
+            os.environ.pop("TGSF_CLEAN_TABLES", None)
+        else:
+            os.environ["TGSF_CLEAN_TABLES"] = old

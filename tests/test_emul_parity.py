@@ -97,3 +97,8 @@ def test_emul_repeat_gate(emul, pval, k):
 @pytest.mark.parametrize("mode", ["direct", "difference"])
 def test_emul_clean_table_strategy(emul, golden_dir, mode):
     parity.clean_table_strategy(emul, mode, golden_dir)
+
+
+@pytest.mark.parametrize("mode", [None, "direct", "difference"])
+def test_emul_no_qual(emul, mode):
+    parity.no_qual_batch(emul, mode)

@@ -170,3 +170,8 @@ def test_gpu_clean_table_strategy_large(mode, monkeypatch):
     ctx = capi.Context(p, 0)
     parity.compare_batch(ctx, p, reads)
     ctx.close()
+
+
+@pytest.mark.parametrize("mode", [None, "direct", "difference"])
+def test_gpu_no_qual(mode):
+    parity.no_qual_batch(None, mode)

@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_ADAPTERS = 32
 MAX_ADAPTER_LEN = 128
 N_DROPINFO = 17
@@ -44,6 +44,7 @@ class Params(C.Structure):
         ("max_batch_bases", C.c_uint64),
         ("max_batch_reads", C.c_uint32),
         ("max_read_len", C.c_uint32),
+        ("no_qual", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -97,7 +98,7 @@ def make_params(read_type: str = "ont", *, adapters=(), min_len=1000, max_len=21
                 min_q=10.0, max_q=255.0, bc_len=150, head_trim=0, tail_trim=0, end_len=150,
                 end_match_len=4, mid_match_len=35, extra_len=50, end_sim=None, mid_sim=None,
                 discard=False, filter=True, only_qc=False, qtype=33, min_repeat=0, kmer=11,
-                max_batch_bases=0, max_batch_reads=0, max_read_len=0) -> Params:
+                max_batch_bases=0, max_batch_reads=0, max_read_len=0, no_qual=False) -> Params:
     """Para_A24 defaults as CODED (src/TGSFilter.cpp:129-171, e.g. -m defaults to 4)."""
     p = Params()
     p.struct_size = C.sizeof(Params)
@@ -123,4 +124,5 @@ def make_params(read_type: str = "ont", *, adapters=(), min_len=1000, max_len=21
         p.adapter_len[i] = len(a)
     p.max_batch_bases, p.max_batch_reads, p.max_read_len = (
         int(max_batch_bases), int(max_batch_reads), int(max_read_len))
+    p.no_qual = int(bool(no_qual))
     return p

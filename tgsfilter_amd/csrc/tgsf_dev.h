@@ -12,6 +12,7 @@ struct DevParams {
     int bc_len, head_trim, tail_trim, end_len, end_match_len, mid_match_len, extra_len;
     float end_sim, mid_sim;
     int discard, filter, only_qc, qtype;
+    int no_qual;               // records without qualities (FASTA): count-only tallies, no quality gate
     int min_repeat, kmer;             // -p / -k: repeat gate (GetKmerCount), 0 = off
     int n_adapters;
     int max_nw;                       // 1 if every adapter is <= 64 bp, else 2

@@ -485,7 +485,8 @@ TGSF_KERNEL TGSF_BOUNDS(256, 3) k_stats(DevParams P, DevBatch B)
         for (int k = 0; k < kLaneChunks; k++) {
             const uint32_t cb = (lane + 64u * k) * 16u;
             rs[k] = *reinterpret_cast<const u32x4*>(ps + (cb < lasts ? cb : lasts));
-            rq[k] = *reinterpret_cast<const u32x4*>(pq + (cb < lastq ? cb : lastq));
+            if (P.no_qual) { const uint32_t w = (uint32_t)P.qtype * 0x01010101u; rq[k] = u32x4{w, w, w, w}; }   // q - qType = 0
+            else rq[k] = *reinterpret_cast<const u32x4*>(pq + (cb < lastq ? cb : lastq));
         }
 #else
         (void)a0; (void)aq; (void)nb;
@@ -527,7 +528,11 @@ TGSF_KERNEL TGSF_BOUNDS(256, 3) k_stats(DevParams P, DevBatch B)
         for (uint32_t c = 0; c < nchq; c++) {
             uint4 v = {0, 0, 0, 0};
             const uint32_t cb = c * 16u;
-            if (cb < endq) { v = *reinterpret_cast<const uint4*>(B.qual + (aq - shq) + cb); if (cb + 16u > endq) mask_tail(v, endq - cb); }
+            if (cb < endq) {
+                if (P.no_qual) { const uint32_t w = (uint32_t)P.qtype * 0x01010101u; v = uint4{w, w, w, w}; }
+                else v = *reinterpret_cast<const uint4*>(B.qual + (aq - shq) + cb);
+                if (cb + 16u > endq) mask_tail(v, endq - cb);
+            }
             lds[wave][1][c] = v;
         }
 #endif
@@ -646,10 +651,10 @@ TGSF_KERNEL k_gate_reads(DevParams P, DevBatch B)
             const double mq = mean_q(B.sumq[r], L);
             if (!(mq >= 0.0 && mq < 256.0)) { set_status(B, DS_BAD_MEANQ, r); }
             else {
-                atomicAdd(&hq[(int)mq], (ull)L);                          // :1943
+                if (!P.no_qual) atomicAdd(&hq[(int)mq], (ull)L);          // :1943 (records with qualities only, :1941)
                 uint32_t segs = 0;
                 if (P.filter) {
-                    if (q_fail(mq, P.min_q, P.max_q)) {
+                    if (!P.no_qual && q_fail(mq, P.min_q, P.max_q)) {
                         B.flags[r] = TGSF_RF_LOWQ;
                         lowq_reads++; lowq_bases += L;
                     } else {
@@ -738,7 +743,9 @@ TGSF_KERNEL k_end_tables(DevParams P, DevBatch B)
     for (uint32_t i = TGSF_COOP_BEGIN; i < 2u * (kMaxBcLen / 64) * 10u * 64u; i += TGSF_COOP_STRIDE) flat[i] = 0;
     TGSF_BLOCK_SYNC();
     auto add = [&](uint32_t e, uint32_t s, uint32_t b, uint32_t q) {
-        const int c = base_col(b);
+        int c = base_col(b);
+        // count-only variants as coded: 'g' is not a G at the 5' end (:1629), 't' is not a T at the 3' end (:1667)
+        if (P.no_qual && b == (e ? (uint32_t)'t' : (uint32_t)'g')) c = 4;
         if (c < 4) { atomicAdd(&acc[e][s][c][lane], 1u); atomicAdd(&acc[e][s][5 + c][lane], q); }
         atomicAdd(&acc[e][s][4][lane], 1u); atomicAdd(&acc[e][s][9][lane], q);
     };
@@ -761,8 +768,10 @@ TGSF_KERNEL k_end_tables(DevParams P, DevBatch B)
                 const uint32_t m = bc < L[u] ? bc : L[u];
                 on[u] = p < m;
                 if (on[u]) {
-                    b5[u] = B.seq[off[u] + p]; q5[u] = B.qual[qof[u] + p];
-                    b3[u] = B.seq[off[u] + L[u] - 1 - p]; q3[u] = B.qual[qof[u] + L[u] - 1 - p];   // :1554-1557
+                    b5[u] = B.seq[off[u] + p];
+                    b3[u] = B.seq[off[u] + L[u] - 1 - p];                                          // :1554-1557
+                    if (P.no_qual) q5[u] = q3[u] = (uint32_t)P.qtype;
+                    else { q5[u] = B.qual[qof[u] + p]; q3[u] = B.qual[qof[u] + L[u] - 1 - p]; }
                 }
             }
 #pragma unroll
@@ -1521,9 +1530,11 @@ TGSF_KERNEL k_gate_frags(DevParams P, DevBatch B)
         const uint32_t L = B.frag_len[f];
         if (diff && B.whole[B.frag_read[f]]) B.frag_sum[f] = B.sumq[B.frag_read[f]];   // not re-scanned
         const double cm = mean_q(B.frag_sum[f], L);
-        if (P.filter && q_fail(cm, P.min_q, P.max_q)) { lq_n++; lq_b += L; continue; }
-        if (!(cm >= 0.0 && cm < 256.0)) { set_status(B, DS_BAD_MEANQ, B.frag_read[f]); continue; }
-        atomicAdd(&hq[(int)cm], (ull)L);                                  // :2002
+        if (!P.no_qual) {                                                 // :1992 rawQualLen > 0
+            if (P.filter && q_fail(cm, P.min_q, P.max_q)) { lq_n++; lq_b += L; continue; }
+            if (!(cm >= 0.0 && cm < 256.0)) { set_status(B, DS_BAD_MEANQ, B.frag_read[f]); continue; }
+            atomicAdd(&hq[(int)cm], (ull)L);                              // :2002
+        }
         B.frag_flags[f] = TGSF_FF_PASS;
         uint32_t er = (uint32_t)P.bc_len < L ? (uint32_t)P.bc_len : L;
         erows = er > erows ? er : erows;

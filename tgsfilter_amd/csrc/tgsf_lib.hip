@@ -303,6 +303,7 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     P.end_match_len = p->end_match_len; P.mid_match_len = p->mid_match_len; P.extra_len = p->extra_len;
     P.end_sim = p->end_sim; P.mid_sim = p->mid_sim; P.discard = p->discard; P.filter = p->filter;
     P.only_qc = p->only_qc; P.qtype = p->qtype; P.n_adapters = p->n_adapters;
+    P.no_qual = p->no_qual ? 1 : 0;
     P.min_repeat = p->min_repeat; P.kmer = p->kmer;
     c->cap_bases = p->max_batch_bases;
     c->cap_reads = p->max_batch_reads;
@@ -575,7 +576,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
 
 static int check_batch(tgsf_ctx* c, const tgsf_batch_in* in)
 {
-    if (!in || !in->seq || !in->qual || !in->offsets) return fail(c, TGSF_E_INVALID, "null batch pointer");
+    if (!in || !in->seq || (!in->qual && !c->P.no_qual) || !in->offsets) return fail(c, TGSF_E_INVALID, "null batch pointer");
     if (in->n_reads == 0) return fail(c, TGSF_E_INVALID, "empty batch");
     if (in->n_reads > c->cap_reads) return fail(c, TGSF_E_CAPACITY, "batch has %u reads, context was sized for %u", in->n_reads, c->cap_reads);
     if (in->qual_offsets && !in->lengths) return fail(c, TGSF_E_INVALID, "qual_offsets requires explicit lengths");
@@ -615,7 +616,7 @@ extern "C" int tgsf_submit_device(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_bat
     int e = check_batch(c, in);
     if (e) return e;
     if (!out || !out->reads) return fail(c, TGSF_E_INVALID, "null output");
-    if (((uintptr_t)in->seq & 15u) || ((uintptr_t)in->qual & 15u)) return fail(c, TGSF_E_INVALID, "seq/qual device pointers must be 16-byte aligned");
+    if (((uintptr_t)in->seq & 15u) || (!c->P.no_qual && ((uintptr_t)in->qual & 15u))) return fail(c, TGSF_E_INVALID, "seq/qual device pointers must be 16-byte aligned");
 #if !defined(TGSF_EMUL)
     (void)hipSetDevice(c->device);
 #endif
@@ -641,7 +642,7 @@ extern "C" int tgsf_submit(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_batch_out*
 #endif
     rt_stream st = c->stream;
     int he = 0;
-    const bool one_buffer = in->qual == in->seq;            // raw FASTQ text: both streams are read in place
+    const bool one_buffer = in->qual == in->seq || c->P.no_qual;   // raw FASTQ text: both streams are read in place (no_qual: none)
     he |= rt_h2d(c->d_seq, in->seq, span, st);
     if (!one_buffer) he |= rt_h2d(c->d_qual, in->qual, span, st);
     he |= rt_h2d(c->d_off, in->offsets, (size_t)(in->lengths ? n : n + 1) * 8, st);

@@ -204,7 +204,7 @@ int main(int argc, char** argv)
     }
     if (o.in_type == 0 && o.out_type == 1) { std::cerr << "Error: Fasta format input file can't output fastq format file" << std::endl; return 1; }
     // rows of SURVEY 8(f) that are not built yet fail loudly instead of silently doing something else
-    if (o.in_type == 0) die("FASTA input (no qualities) is not supported by this build");
+    const bool fasta_in = o.in_type == 0;                              // records without qualities: count-only tallies, no Q gate
 
     InputBytes in;
     if (!in.open(o.in_file, o.in_type == 2)) return 1;            // SAM/BAM: decoded to FASTQ text (read_bam, :1872-1917)
@@ -219,7 +219,7 @@ int main(int argc, char** argv)
         std::cerr << "INFO: trim 5' end length: " << o.head_trim << std::endl;
         std::cerr << "INFO: trim 3' end length: " << o.tail_trim << std::endl;
         std::cerr << "INFO: min output reads length: " << o.min_len << std::endl;
-        std::cerr << "INFO: min Phred average quality score: " << o.min_q << std::endl;
+        if (!fasta_in) std::cerr << "INFO: min Phred average quality score: " << o.min_q << std::endl;     // :3074-3076
         auto add = [&](const std::string& a) { if (std::find(adapters.begin(), adapters.end(), a) == adapters.end()) adapters.push_back(a); };
         if (!o.adapter_file.empty()) {                                 // Get_adapters, :2923-2942
             InputBytes af;
@@ -266,6 +266,7 @@ int main(int argc, char** argv)
     p.end_len = o.end_len; p.end_match_len = o.end_match_len; p.mid_match_len = o.mid_match_len; p.extra_len = o.extra_len;
     p.end_sim = o.end_sim; p.mid_sim = o.mid_sim; p.discard = o.discard; p.filter = o.filter; p.only_qc = o.only_qc;
     p.min_repeat = o.min_repeat; p.kmer = o.kmer; p.qtype = pp.qtype ? pp.qtype : 33;
+    p.no_qual = fasta_in ? 1 : 0;
     if (adapters.size() > TGSF_MAX_ADAPTERS) die("more than " + std::to_string(TGSF_MAX_ADAPTERS) + " adapter sequences");
     p.n_adapters = (int)adapters.size();
     for (size_t a = 0; a < adapters.size(); a++) { p.adapters[a] = adapters[a].data(); p.adapter_len[a] = (int)adapters[a].size(); }
@@ -288,7 +289,7 @@ int main(int argc, char** argv)
     std::vector<CleanRec> clean_recs;                                  // only filled when downsampling follows
     const bool run_filter_pass = o.filter || o.only_qc;                // :3061; with -F the input goes straight to downsampling
     if (!run_filter_pass) {                                            // get_fastx_SeqLen, :2256-2269
-        FastxReader rd(in.data(), in.size(), true);
+        FastxReader rd(in.data(), in.size(), !fasta_in);
         Record r;
         while (rd.next(r)) {
             clean_recs.push_back({r.name, 1, r.seq.data(), r.qual.data(), (uint32_t)r.seq.size()});
@@ -298,7 +299,7 @@ int main(int argc, char** argv)
 
     std::thread reader([&] {                                           // read_fastx, :1845-1870 (index only)
         if (!run_filter_pass) { to_gpu.put(nullptr); return; }
-        FastxReader rd(in.data(), in.size(), true);
+        FastxReader rd(in.data(), in.size(), !fasta_in);
         Record r;
         auto fresh = [&] {
             std::unique_ptr<Batch> nb(new Batch);
@@ -318,11 +319,11 @@ int main(int argc, char** argv)
         while (rd.next(r)) {
             const size_t L = r.seq.size();
             if (L > p.max_read_len) die("read longer than the supported maximum");
-            const char* rec_end = r.qual.data() + L;
+            const char* rec_end = (fasta_in ? r.seq.data() : r.qual.data()) + L;
             if (!b->names.empty() && ((uint64_t)(rec_end - b->base) > batch_text || b->names.size() >= batch_reads)) flush();
             if (b->names.empty()) b->base = r.name.data();
             b->off.push_back((uint64_t)(r.seq.data() - b->base));
-            b->qoff.push_back((uint64_t)(r.qual.data() - b->base));
+            b->qoff.push_back(fasta_in ? b->off.back() : (uint64_t)(r.qual.data() - b->base));
             b->len.push_back((uint32_t)L); b->names.push_back(r.name);
             b->span = (uint64_t)(rec_end - b->base);
             if (b->span > p.max_batch_bases) die("record larger than a batch");
@@ -449,7 +450,8 @@ int main(int argc, char** argv)
             if (bs.size() + c.len > qp.max_batch_bases - (1u << 20) || blen.size() >= qp.max_batch_reads) run();
             const size_t o0 = (bs.size() + 15) & ~size_t(15);
             bs.resize(o0); bq.resize(o0);
-            bs.insert(bs.end(), c.seq, c.seq + c.len); bq.insert(bq.end(), c.qual, c.qual + c.len);
+            bs.insert(bs.end(), c.seq, c.seq + c.len);
+            if (!fasta_in) bq.insert(bq.end(), c.qual, c.qual + c.len); else bq.resize(bs.size());
             boff.push_back(o0); blen.push_back(c.len);
             out.text(lead);
             if (c.pass_num < 2) out.piece(c.name.data(), c.name.size());
@@ -530,7 +532,7 @@ int main(int argc, char** argv)
         std::cerr << "INFO: " << down_lens.size() << " reads with a total of " << down_bases << " bases after downsampling." << std::endl;
         if (!o.out_file.empty()) std::cerr << "INFO: Downsampled reads were written to: " << o.out_file << "." << std::endl;
     }
-    std::string qc = "1";                                              // fastq input
+    std::string qc = fasta_in ? "0" : "1";                             // :3286-3291
     qc += o.only_qc ? "0" : ((!o.filter && o.downsample) ? "1" : "2"); // :3293-3299
     std::ofstream ofs(html);
     write_report(ofs, qc, raw, clean);
