@@ -10,7 +10,7 @@ import subprocess
 import tempfile
 
 
-def run_case(binary: str, golden_dir: str, name: str):
+def run_case(binary: str, golden_dir: str, name: str, extra_args=()):
     cmd = json.load(open(os.path.join(golden_dir, name + ".cmd.json")))
     ref_out = gzip.open(os.path.join(golden_dir, name + ".out.fq.gz"), "rb").read()
     ref_err = open(os.path.join(golden_dir, name + ".stderr.txt")).read()
@@ -22,7 +22,7 @@ def run_case(binary: str, golden_dir: str, name: str):
             open(fin, "wb").write(open(os.path.join(golden_dir, name + ".in.bam"), "rb").read())
         else:
             open(fin, "wb").write(gzip.open(os.path.join(golden_dir, name + ".in." + fmt + ".gz"), "rb").read())
-        args = [binary, "-i", fin, "-t", "1"] + cmd["flags"].split()
+        args = [binary, "-i", fin, "-t", "1"] + cmd["flags"].split() + list(extra_args)
         qc = "--qc" in cmd["flags"]
         if not qc:
             args += ["-o", os.path.join(td, "out.fa" if fmt == "fa" else "out.fq")]

@@ -49,6 +49,13 @@ def test_cli_gz_output_and_fasta(binary, golden_dir, tmp_path):
     assert (tmp_path / "o2.fq").read_bytes() == ref_out
 
 
+@pytest.mark.parametrize("name", ["ont_zoo", "hifi_auto", "down_r"])
+def test_cli_several_devices(binary, golden_dir, name):
+    """--devices a,b,c: one context and feeder thread per entry (here three on the same device), batches
+    re-sequenced by the writer, tallies merged on the host: everything equals the single-context run."""
+    cli_check.run_case(binary, golden_dir, name, extra_args=["--devices", "0,0,0"])
+
+
 def test_cli_usage_and_errors(binary, tmp_path):
     p = subprocess.run([binary], capture_output=True)
     assert p.returncode == 1 and p.stdout.startswith(b"Usage: tgsfilter -i TGS.raw.fq.gz -x ont -o TGS.clean.fq.gz")

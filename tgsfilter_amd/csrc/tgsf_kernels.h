@@ -33,7 +33,7 @@ using tgsf_emul::threadIdx; using tgsf_emul::blockIdx; using tgsf_emul::blockDim
 #define TGSF_KERNEL static void
 #define TGSF_INLINE_LAMBDA
 #define TGSF_BOUNDS(threads, waves_per_simd)
-#define TGSF_SHARED static
+#define TGSF_SHARED static thread_local      /* contexts may run on several host threads at once */
 #define TGSF_BLOCK_SYNC() ((void)0)
 #define TGSF_WAVE_SYNC() ((void)0)
 // cooperative loops: every emulated thread performs all iterations (idempotent fills)

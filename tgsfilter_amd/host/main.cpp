@@ -19,6 +19,7 @@
 #include <deque>
 #include <fstream>
 #include <iostream>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -45,6 +46,7 @@ struct Batch {
     std::vector<tgsf_fragment> frags;
     uint32_t n_frags = 0;
     uint64_t bases = 0;
+    uint64_t id = 0;                         // position in the input: the writer puts batches back in order
 };
 
 // a kept fragment, addressed in the input text (used when a downsampling pass follows the filter pass)
@@ -273,14 +275,19 @@ int main(int argc, char** argv)
     p.max_batch_bases = batch_text + (1 << 20);           // capacity is in buffer bytes: the text slice must fit
     p.max_batch_reads = batch_reads;
     p.max_read_len = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(in.size() / 2, 1024), 1u << 26);
-    tgsf_ctx* ctx = nullptr;
+    // one context (and one feeder thread) per device of --devices; batches are dealt to whichever feeder is
+    // free, the writer re-sequences them, the tallies are merged at the end (host side)
+    if (o.devices.empty()) o.devices.push_back(o.device);
+    std::vector<tgsf_ctx*> ctxs(o.devices.size(), nullptr);
     const double t_c0 = now_s();
-    if (tgsf_create(&p, o.device, &ctx) != TGSF_OK) die(tgsf_last_error(nullptr));
+    for (size_t d = 0; d < ctxs.size(); d++)
+        if (tgsf_create(&p, o.devices[d], &ctxs[d]) != TGSF_OK) die(tgsf_last_error(nullptr));
+    tgsf_ctx* ctx = ctxs[0];
     t_create = now_s() - t_c0;
     const double t_p0 = now_s();
 
     // ---- pipeline ----
-    Channel<std::unique_ptr<Batch>> to_gpu(3), to_writer(3);
+    Channel<std::unique_ptr<Batch>> to_gpu(2 + o.devices.size()), to_writer(2 + o.devices.size());
     std::vector<int> raw_lens, clean_lens;
     uint64_t raw_bases = 0, clean_bases = 0;
     const bool fastq_out = o.out_type == 1;
@@ -298,7 +305,7 @@ int main(int argc, char** argv)
     }
 
     std::thread reader([&] {                                           // read_fastx, :1845-1870 (index only)
-        if (!run_filter_pass) { to_gpu.put(nullptr); return; }
+        if (!run_filter_pass) { for (size_t d = 0; d < ctxs.size(); d++) to_gpu.put(nullptr); return; }
         FastxReader rd(in.data(), in.size(), !fasta_in);
         Record r;
         auto fresh = [&] {
@@ -309,9 +316,11 @@ int main(int argc, char** argv)
         std::unique_ptr<Batch> b = fresh();
         const double t0 = now_s();
         double waited = 0;
+        uint64_t next_id = 0;
         auto flush = [&] {
             if (b->names.empty()) return;
             const double w0 = now_s();
+            b->id = next_id++;
             to_gpu.put(std::move(b));
             waited += now_s() - w0;
             b = fresh();
@@ -331,11 +340,12 @@ int main(int argc, char** argv)
             raw_bases += L; raw_lens.push_back((int)L);
         }
         flush();
-        to_gpu.put(nullptr);
+        for (size_t d = 0; d < ctxs.size(); d++) to_gpu.put(nullptr);       // one end marker per feeder
         t_parse = now_s() - t0 - waited;
     });
 
-    std::thread feeder([&] {                                           // filter_sequence, :1919-2064, one batch per call
+    std::mutex gpu_time_m;
+    auto feed = [&](tgsf_ctx* fctx) {                                  // filter_sequence, :1919-2064, one batch per call
         for (;;) {
             std::unique_ptr<Batch> b = to_gpu.get();
             if (!b) break;
@@ -349,20 +359,33 @@ int main(int argc, char** argv)
             bi.offsets = b->off.data(); bi.qual_offsets = b->qoff.data(); bi.lengths = b->len.data();
             bi.n_reads = (uint32_t)b->names.size(); bi.n_bytes = b->span;
             tgsf_batch_out bo{b->res.data(), b->frags.data(), (uint32_t)b->frags.size(), 0};
-            if (tgsf_submit(ctx, &bi, &bo) != TGSF_OK) die(tgsf_last_error(ctx));
-            t_gpu += now_s() - g0;
+            if (tgsf_submit(fctx, &bi, &bo) != TGSF_OK) die(tgsf_last_error(fctx));
+            { std::lock_guard<std::mutex> l(gpu_time_m); t_gpu += now_s() - g0; }
             b->n_frags = bo.n_frags;
             to_writer.put(std::move(b));
         }
         to_writer.put(nullptr);
-    });
+    };
+    std::vector<std::thread> feeders;
+    for (tgsf_ctx* c : ctxs) feeders.emplace_back(feed, c);
 
     std::thread writer([&] {                                           // record formatting :2011-2053 + write_output :2095-2145
         const std::string lead(1, fastq_out ? '@' : '>'), nl("\n"), sep("\n+\n");
         std::string name;
+        std::map<uint64_t, std::unique_ptr<Batch>> held;               // batches that arrived ahead of their turn
+        uint64_t want = 0;
+        size_t open_feeders = ctxs.size();
         for (;;) {
-            std::unique_ptr<Batch> b = to_writer.get();
-            if (!b) break;
+            std::unique_ptr<Batch> b;
+            auto it = held.find(want);
+            if (it != held.end()) { b = std::move(it->second); held.erase(it); }
+            else {
+                if (open_feeders == 0) break;
+                b = to_writer.get();
+                if (!b) { open_feeders--; continue; }
+                if (b->id != want) { const uint64_t id = b->id; held[id] = std::move(b); continue; }
+            }
+            want++;
             const double w0 = now_s();
             for (size_t r = 0; r < b->names.size(); r++) {
                 int pass_num = 1;
@@ -397,7 +420,9 @@ int main(int argc, char** argv)
             t_write += now_s() - w0;
         }
     });
-    reader.join(); feeder.join(); writer.join();
+    reader.join();
+    for (std::thread& f : feeders) f.join();
+    writer.join();
     t_pipe = now_s() - t_p0;
 
     // ---- downsampling: DownSampleTask, :2164-2568 ----
@@ -428,7 +453,7 @@ int main(int argc, char** argv)
         qp.filter = 0; qp.only_qc = 1; qp.n_adapters = 0; qp.min_repeat = 0;
         qp.max_batch_bases = (1ull << 30); qp.max_batch_reads = 1u << 16;
         tgsf_ctx* qctx = nullptr;
-        if (tgsf_create(&qp, o.device, &qctx) != TGSF_OK) die(tgsf_last_error(nullptr));
+        if (tgsf_create(&qp, o.devices[0], &qctx) != TGSF_OK) die(tgsf_last_error(nullptr));
         std::vector<uint8_t> bs, bq; std::vector<uint64_t> boff; std::vector<uint32_t> blen;
         std::vector<tgsf_read_result> bres; std::vector<tgsf_fragment> bfr(16);
         auto run = [&] {
@@ -474,9 +499,15 @@ int main(int argc, char** argv)
     // ---- statistics, stderr, report: :3146-3235, :3240-3279, :3285-3328 ----
     uint64_t nw = 0; int32_t bc = 0; uint32_t nbins = 0;
     tgsf_counters_len(ctx, &nw, &bc, &nbins);
-    std::vector<uint64_t> t(nw);
-    if (tgsf_counters(ctx, t.data(), nw) != TGSF_OK) die(tgsf_last_error(ctx));
-    tgsf_destroy(ctx);
+    std::vector<uint64_t> t(nw, 0), part(nw);
+    for (tgsf_ctx* c : ctxs) {                                         // sums; the four "rows used" words are maxima
+        if (tgsf_counters(c, part.data(), nw) != TGSF_OK) die(tgsf_last_error(c));
+        uint64_t rows[4];
+        for (int k = 0; k < 4; k++) rows[k] = std::max(t[TGSF_CTR_ROWS + k], part[TGSF_CTR_ROWS + k]);
+        for (uint64_t i = 0; i < nw; i++) t[i] += part[i];
+        for (int k = 0; k < 4; k++) t[TGSF_CTR_ROWS + k] = rows[k];
+        tgsf_destroy(c);
+    }
     auto tables = [&](const std::vector<uint64_t>& v, bool clean) {
         SideTables s;
         s.bin_qual = &v[tgsf_ctr_bin_table(clean ? TGSF_B_CLEAN_QUAL : TGSF_B_RAW_QUAL, bc, nbins)];

@@ -143,6 +143,14 @@ int parse_args(int argc, char** argv, Options& o)
         {"c", [&](const char* v) { o.comp_level = atoi(v); return 0; }},
         {"t", [&](const char* v) { o.n_thread = atoi(v); return 0; }},
         {"device", [&](const char* v) { o.device = atoi(v); return 0; }},
+        {"devices", [&](const char* v) {                      // not in the reference: batches are dealt to several GPUs
+             o.devices.clear();
+             for (const char* c = v; *c;) {
+                 o.devices.push_back(atoi(c));
+                 while (*c && *c != ',') c++;
+                 if (*c == ',') c++;
+             }
+             return 0; }},
     };
     std::map<std::string, std::function<void()>> switches = {
         {"A", [&] { o.only_adapters = true; }},

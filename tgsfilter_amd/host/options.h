@@ -3,6 +3,7 @@
 #pragma once
 #include <cstdint>
 #include <string>
+#include <vector>
 
 namespace host {
 
@@ -42,6 +43,7 @@ struct Options {
     bool out_gz = false;
     // this build only
     int device = 0;                   // --device <n>
+    std::vector<int> devices;         // --devices a,b,...: one context + feeder thread per entry (default: {device})
 };
 
 int print_usage();
