@@ -209,10 +209,16 @@ void tgsf_destroy(tgsf_ctx* ctx);
 
 /*
  * Filter one batch held in HOST memory: H2D, run the kernels, D2H of results.
- * Synchronous variant of the worker loop body (:1939-2061) for n_reads reads.
- * Counters accumulate inside the context.
+ * The worker loop body (:1939-2061) for n_reads reads.  Counters accumulate inside the context.
+ *
+ * tgsf_submit_async only enqueues the work on the context's stream and returns; `in`, `out` and every
+ * buffer they point to must stay valid and untouched until tgsf_wait(ctx) returns, which completes the
+ * batch: out->n_frags is set, the fragment records are copied, asynchronous errors are reported.  One
+ * batch may be pending per context; several contexts overlap each other's copies and kernels (copies are
+ * only asynchronous from pinned host memory).  tgsf_submit = tgsf_submit_async + tgsf_wait.
  */
 int tgsf_submit(tgsf_ctx* ctx, const tgsf_batch_in* in, tgsf_batch_out* out);
+int tgsf_submit_async(tgsf_ctx* ctx, const tgsf_batch_in* in, tgsf_batch_out* out);
 
 /*
  * Same, but every pointer in `in` and `out` is a DEVICE pointer already
@@ -225,7 +231,8 @@ int tgsf_submit(tgsf_ctx* ctx, const tgsf_batch_in* in, tgsf_batch_out* out);
 int tgsf_submit_device(tgsf_ctx* ctx, const tgsf_batch_in* in, tgsf_batch_out* out,
                        uint32_t* d_n_frags, void* hip_stream);
 
-/* Block until everything submitted on this context has finished; report async errors. */
+/* Block until everything submitted on this context has finished; complete a pending tgsf_submit_async
+ * batch; report async errors. */
 int tgsf_wait(tgsf_ctx* ctx);
 
 /* Number of uint64 words tgsf_counters() writes, and the table geometry. */

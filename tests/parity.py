@@ -205,3 +205,30 @@ def no_qual_batch(lib_path, mode=None):
             os.environ.pop("TGSF_CLEAN_TABLES", None)
         else:
             os.environ["TGSF_CLEAN_TABLES"] = old
+
+
+def async_two_contexts(lib_path):
+    """tgsf_submit_async on two contexts, then tgsf_wait on both: each batch equals the oracle's result; a second
+    submit on a context with a batch pending is refused."""
+    ads = [synth.ONT_RAPID, synth.ONT_RAPID_RC]
+    r1 = synth.make_reads(61, 40, "ont", mean_len=3000, zoo=True, pmid=0.1)
+    r2 = synth.make_reads(62, 50, "ont", mean_len=2500, zoo=True, pmid=0.1)
+    p = sized(abi.make_params("ont", adapters=ads, min_q=9.0), r1 + r2)
+    c1, c2 = capi.Context(p, 0, lib_path), capi.Context(p, 0, lib_path)
+    packs = [synth.pack(r1), synth.pack(r2)]
+    for c, (seq, qual, off, ln) in zip((c1, c2), packs):
+        c.submit_async(seq, qual, off[:-1].copy(), ln)
+    seq, qual, off, ln = packs[0]
+    pend = c1._pending
+    try:
+        c1.submit_async(seq, qual, off[:-1].copy(), ln)
+        raise AssertionError("second pending batch was accepted")
+    except capi.TgsfError as e:
+        assert e.code == -1
+    c1._pending = pend
+    for c, (seq, qual, off, ln) in zip((c1, c2), packs):
+        got_r, got_f = c.wait_result()
+        exp_r, exp_f, exp_ctr = orc.filter_batch(p, seq, qual, off, ln, n_bins=c.n_bins)
+        assert np.array_equal(got_r, exp_r) and np.array_equal(got_f, exp_f)
+        assert np.array_equal(c.counters(), exp_ctr)
+        c.close()

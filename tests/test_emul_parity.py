@@ -102,3 +102,7 @@ def test_emul_clean_table_strategy(emul, golden_dir, mode):
 @pytest.mark.parametrize("mode", [None, "direct", "difference"])
 def test_emul_no_qual(emul, mode):
     parity.no_qual_batch(emul, mode)
+
+
+def test_emul_submit_async(emul):
+    parity.async_two_contexts(emul)

@@ -175,3 +175,7 @@ def test_gpu_clean_table_strategy_large(mode, monkeypatch):
 @pytest.mark.parametrize("mode", [None, "direct", "difference"])
 def test_gpu_no_qual(mode):
     parity.no_qual_batch(None, mode)
+
+
+def test_gpu_submit_async():
+    parity.async_two_contexts(None)

@@ -19,7 +19,8 @@ DEFAULT_LIB = os.path.join(_HERE, "libtgsf.so")
 _LIBS = {}
 
 SYMBOLS = [
-    "tgsf_abi_version", "tgsf_create", "tgsf_destroy", "tgsf_submit", "tgsf_submit_device", "tgsf_wait",
+    "tgsf_abi_version", "tgsf_create", "tgsf_destroy", "tgsf_submit", "tgsf_submit_async", "tgsf_submit_device",
+    "tgsf_wait",
     "tgsf_counters_len", "tgsf_counters", "tgsf_counters_device", "tgsf_reset_counters", "tgsf_profile",
     "tgsf_stage_times", "tgsf_stage_name", "tgsf_align_windows", "tgsf_last_error",
 ]
@@ -45,6 +46,7 @@ def load(path: str | None = None):
     L.tgsf_destroy.argtypes = [vp]
     L.tgsf_destroy.restype = None
     L.tgsf_submit.argtypes = [vp, C.POINTER(abi.BatchIn), C.POINTER(abi.BatchOut)]
+    L.tgsf_submit_async.argtypes = [vp, C.POINTER(abi.BatchIn), C.POINTER(abi.BatchOut)]
     L.tgsf_submit_device.argtypes = [vp, C.POINTER(abi.BatchIn), C.POINTER(abi.BatchOut), vp, vp]
     L.tgsf_wait.argtypes = [vp]
     L.tgsf_counters_len.argtypes = [vp, C.POINTER(u64), C.POINTER(i32), C.POINTER(u32)]
@@ -97,6 +99,11 @@ class Context:
     # ---- host-buffer path -------------------------------------------------
     def submit(self, seq, qual, offsets, lengths=None, frag_capacity=None, qual_offsets=None):
         """Filter one CSR batch held in host memory; returns (reads, frags) structured arrays."""
+        self.submit_async(seq, qual, offsets, lengths, frag_capacity, qual_offsets)
+        return self.wait_result()
+
+    def submit_async(self, seq, qual, offsets, lengths=None, frag_capacity=None, qual_offsets=None):
+        """Enqueue one host batch (tgsf_submit_async); wait_result() completes it and returns the arrays."""
         seq = np.ascontiguousarray(seq, dtype=np.uint8)
         qual = np.ascontiguousarray(qual, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
@@ -118,7 +125,19 @@ class Context:
                          lengths.ctypes.data if lengths is not None else None, n, 0, seq.size,
                          qual_offsets.ctypes.data if qual_offsets is not None else None)
         bo = abi.BatchOut(reads.ctypes.data, frags.ctypes.data, frag_capacity, 0)
-        self._chk(self.lib.tgsf_submit(self.h, C.byref(bi), C.byref(bo)))
+        # everything the library may still read or write stays referenced until wait_result()
+        self._pending = (reads, frags, bi, bo, seq, qual, offsets, lengths, qual_offsets)
+        rc = self.lib.tgsf_submit_async(self.h, C.byref(bi), C.byref(bo))
+        if rc != 0:
+            self._pending = None
+            self._chk(rc)
+
+    def wait_result(self):
+        pend, self._pending = self._pending, None
+        if pend is None:
+            raise RuntimeError("no batch pending")
+        self._chk(self.lib.tgsf_wait(self.h))
+        reads, frags, _, bo = pend[:4]
         return reads, frags[:bo.n_frags].copy()
 
     # ---- device-resident path (pointers already in HBM) --------------------

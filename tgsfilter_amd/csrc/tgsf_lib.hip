@@ -74,6 +74,9 @@ struct tgsf_ctx {
     hipEvent_t ev_hp[2];
 #endif
     uint32_t h_status[4];
+    // batch enqueued by tgsf_submit_async, completed by tgsf_wait
+    tgsf_batch_out* pend_out = nullptr;
+    uint32_t pend_nf = 0;
 };
 
 static int fail(tgsf_ctx* c, int code, const char* fmt, ...)
@@ -600,13 +603,32 @@ static int check_status(tgsf_ctx* c)
     }
 }
 
+static int finish_pending(tgsf_ctx* c)
+{
+    tgsf_batch_out* out = c->pend_out;
+    if (!out) return TGSF_OK;
+    c->pend_out = nullptr;
+    const uint32_t nf = c->pend_nf;
+    out->n_frags = nf;
+    if (nf > out->frag_capacity || (nf && !out->frags))
+        return fail(c, TGSF_E_CAPACITY, "batch produced %u fragments, caller provided room for %u", nf, out->frag_capacity);
+    if (nf) {
+        int he = rt_d2h(out->frags, c->d_out_frags, (size_t)nf * sizeof(tgsf_fragment), c->stream);
+        if (!he) he = rt_sync(c->stream);
+        if (he) return fail(c, TGSF_E_HIP, "device to host copy failed");
+    }
+    return TGSF_OK;
+}
+
 extern "C" int tgsf_wait(tgsf_ctx* c)
 {
     if (!c) return TGSF_E_INVALID;
     int e = rt_d2h(c->h_status, c->B.status, 16, c->stream);
     if (!e) e = rt_sync(c->stream);
-    if (e) return fail(c, TGSF_E_HIP, "stream synchronize failed: %s", rt_errstr(e));
-    return check_status(c);
+    if (e) { c->pend_out = nullptr; return fail(c, TGSF_E_HIP, "stream synchronize failed: %s", rt_errstr(e)); }
+    e = check_status(c);
+    if (e) { c->pend_out = nullptr; return e; }
+    return finish_pending(c);
 }
 
 extern "C" int tgsf_submit_device(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_batch_out* out,
@@ -624,9 +646,10 @@ extern "C" int tgsf_submit_device(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_bat
     return run_pipeline(c, in, out->reads, out->frags, out->frags ? out->frag_capacity : 0u, d_n_frags, st);
 }
 
-extern "C" int tgsf_submit(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_batch_out* out)
+extern "C" int tgsf_submit_async(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_batch_out* out)
 {
     if (!c) return TGSF_E_INVALID;
+    if (c->pend_out) return fail(c, TGSF_E_INVALID, "a batch is already pending on this context: call tgsf_wait first");
     int e = check_batch(c, in);
     if (e) return e;
     if (!out || !out->reads) return fail(c, TGSF_E_INVALID, "null output");
@@ -656,21 +679,18 @@ extern "C" int tgsf_submit(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_batch_out*
     din.n_bytes = span;
     e = run_pipeline(c, &din, c->d_out_reads, c->d_out_frags, c->B.fcap, c->d_out_nfrags, st);
     if (e) return e;
-    uint32_t nf = 0;
-    he |= rt_d2h(&nf, c->d_out_nfrags, 4, st);
+    c->pend_nf = 0;
+    he |= rt_d2h(&c->pend_nf, c->d_out_nfrags, 4, st);
     he |= rt_d2h(out->reads, c->d_out_reads, (size_t)n * sizeof(tgsf_read_result), st);
     if (he) return fail(c, TGSF_E_HIP, "device to host copy failed");
-    e = tgsf_wait(c);
-    if (e) return e;
-    out->n_frags = nf;
-    if (nf > out->frag_capacity || (nf && !out->frags))
-        return fail(c, TGSF_E_CAPACITY, "batch produced %u fragments, caller provided room for %u", nf, out->frag_capacity);
-    if (nf) {
-        he = rt_d2h(out->frags, c->d_out_frags, (size_t)nf * sizeof(tgsf_fragment), st);
-        if (!he) he = rt_sync(st);
-        if (he) return fail(c, TGSF_E_HIP, "device to host copy failed");
-    }
+    c->pend_out = out;
     return TGSF_OK;
+}
+
+extern "C" int tgsf_submit(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_batch_out* out)
+{
+    const int e = tgsf_submit_async(c, in, out);
+    return e ? e : tgsf_wait(c);
 }
 
 // ---------------------------------------------------------------------------
