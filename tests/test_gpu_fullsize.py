@@ -1,0 +1,117 @@
+"""-m gpu: BASELINE.json-sized batches (C2 shape: 45-kb ONT reads, tens of thousands of them, resident in HBM)
+checked through size-independent properties -- the oracle cannot run that much -- plus an oracle spot check
+of a slice of the same batch:
+  * the result does not depend on how the middle scan is cut into segments (TGSF_SEG_COLS),
+  * nor on how the clean tables are tallied (TGSF_CLEAN_TABLES),
+  * permuting the reads of a batch permutes the per-read results and leaves the tallies unchanged,
+  * every read lands in exactly one class, bases are conserved (kept + trimmed + dropped = input)."""
+import os
+
+import numpy as np
+import pytest
+
+from tgsfilter_amd import abi, capi, synth
+
+pytestmark = pytest.mark.gpu
+N_READS = 32768
+
+
+@pytest.fixture(scope="module")
+def batch():
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    b = bench.gen_batch(torch, dev, N_READS, 7, 45000.0, 2_000_000, "ont")
+    b["torch"], b["dev"] = torch, dev
+    return b
+
+
+def run(batch, env=None, perm=None):
+    torch, dev = batch["torch"], batch["dev"]
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        n = batch["n"]
+        p = abi.make_params("ont", adapters=[synth.ONT_RAPID, synth.ONT_RAPID_RC], min_len=1000, min_q=10.0,
+                            head_trim=0, tail_trim=0, max_batch_bases=batch["bases"] + 64, max_batch_reads=n,
+                            max_read_len=int(batch["h_lens"].max()))
+        ctx = capi.Context(p, 0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    off, ln = batch["offsets"], batch["lengths"]
+    if perm is not None:
+        pt = torch.from_numpy(perm).to(dev)
+        off, ln = off[pt].contiguous(), ln[pt].contiguous()
+    fcap = batch["bases"] // 1000 + n + 16
+    d_reads = torch.empty(n * 32, dtype=torch.uint8, device=dev)
+    d_frags = torch.zeros(fcap * 24, dtype=torch.uint8, device=dev)
+    d_nf = torch.zeros(4, dtype=torch.int32, device=dev)
+    ctx.submit_device(batch["seq"].data_ptr(), batch["qual"].data_ptr(), off.data_ptr(), ln.data_ptr(), n,
+                      batch["n_bytes"], d_reads.data_ptr(), d_frags.data_ptr(), fcap, d_nf.data_ptr(),
+                      torch.cuda.current_stream().cuda_stream)
+    ctx.wait()
+    nf = int(d_nf[0].item())
+    reads = d_reads.cpu().numpy().view(abi.READ_RESULT_DTYPE)
+    frags = d_frags.cpu().numpy().view(abi.FRAGMENT_DTYPE)[:nf].copy()
+    ctr = ctx.counters()
+    ctx.close()
+    return reads, frags, ctr
+
+
+def same(a, b):
+    return all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_full_size_segmenting_invariance(batch):
+    ref = run(batch)
+    for sc in ("512", "4096"):
+        assert same(ref, run(batch, {"TGSF_SEG_COLS": sc})), sc
+
+
+def test_full_size_clean_table_strategy_invariance(batch):
+    a = run(batch, {"TGSF_CLEAN_TABLES": "direct"})
+    b = run(batch, {"TGSF_CLEAN_TABLES": "difference"})
+    assert same(a, b)
+
+
+def test_full_size_permutation(batch):
+    reads, frags, ctr = run(batch)
+    perm = np.random.default_rng(3).permutation(batch["n"]).astype(np.int64)
+    preads, pfrags, pctr = run(batch, perm=perm)
+    assert np.array_equal(ctr, pctr)
+    for name in ("sum_q", "flags", "n_frags", "trimmed"):
+        assert np.array_equal(preads[name], reads[name][perm]), name
+    # fragments of read perm[i] in the permuted run == fragments of that read in the original run
+    for i in np.random.default_rng(4).integers(0, batch["n"], 2000):
+        a = pfrags[preads["frag_begin"][i]:preads["frag_begin"][i] + preads["n_frags"][i]]
+        r = perm[i]
+        b = frags[reads["frag_begin"][r]:reads["frag_begin"][r] + reads["n_frags"][r]]
+        assert np.array_equal(a[["start", "len", "flags", "sum_q"]], b[["start", "len", "flags", "sum_q"]])
+
+
+def test_full_size_conservation_and_oracle_slice(batch):
+    from oracle import orc
+    reads, frags, ctr = run(batch)
+    n, lens = batch["n"], batch["h_lens"].astype(np.int64)
+    drop = ctr[abi.CTR_DROPINFO:abi.CTR_DROPINFO + 17].astype(np.int64)
+    assert drop[0] + drop[2:10].sum() == n                       # one class per read
+    kept = frags["len"][(frags["flags"] & abi.FF_PASS) != 0].astype(np.int64).sum()
+    # input bases = low-Q reads + trimmed + too-short/too-long fragments + low-Q fragments + kept
+    assert lens.sum() == drop[1] + drop[10] + drop[12] + drop[14] + kept
+    assert int(ctr[abi.CTR_RAW_DIFFQ:abi.CTR_RAW_DIFFQ + 256].sum()) == lens.sum()
+    # oracle on the first 150 reads: per-read records must agree
+    m = 150
+    end = int(batch["h_offsets"][m])
+    seq = batch["seq"][:end].cpu().numpy()
+    qual = batch["qual"][:end].cpu().numpy()
+    p = abi.make_params("ont", adapters=[synth.ONT_RAPID, synth.ONT_RAPID_RC], min_len=1000, min_q=10.0,
+                        head_trim=0, tail_trim=0, max_read_len=int(lens.max()))
+    er, ef, _ = orc.filter_batch(p, seq, qual, batch["h_offsets"][:m].astype(np.uint64), batch["h_lens"][:m].astype(np.uint32))
+    for name in ("sum_q", "flags", "n_frags", "trimmed"):
+        assert np.array_equal(reads[name][:m], er[name]), name
+    nf = int(er["n_frags"].sum())
+    assert np.array_equal(frags[["start", "len", "flags", "sum_q"]][:nf], ef[["start", "len", "flags", "sum_q"]])

@@ -171,7 +171,7 @@ static std::string json_array(const std::vector<T>& v)
 template <class T>
 static int max_y(const std::vector<T>& v, int m = 0)
 {
-    for (const T& x : v) if (x > m) m = (int)x;       // int maxY compared/assigned like getMaxY (report.cpp:508-546)
+    for (const T& x : v) if ((long long)x > (long long)m) m = (int)x;       // int maxY compared/assigned like getMaxY (report.cpp:508-546)
     return m;
 }
 
