@@ -1030,13 +1030,8 @@ TGSF_D void push_candidate(const DevBatch& B, uint32_t r, int pos, int score, in
     B.pool[idx] = c;
 }
 
-#if defined(TGSF_MID_MAXW) && !defined(TGSF_EMUL)
-#define TGSF_MID_OCC __attribute__((amdgpu_waves_per_eu(1, TGSF_MID_MAXW)))
-#else
-#define TGSF_MID_OCC
-#endif
 template <int AT>
-TGSF_KERNEL TGSF_MID_OCC k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
+TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
 {
     TGSF_SHARED uint64_t eqt[256][AT];
     // per lane and adapter: up to 4 columns that tie the lane's best value so far (slow path only)
