@@ -1,0 +1,62 @@
+"""Seeded parameter / input fuzzing shared by the emulation (CPU) and GPU suites: random command-line-level
+parameters inside the supported domain, random read sets, full comparison with the oracle."""
+from __future__ import annotations
+
+import numpy as np
+
+from tests import parity
+from tgsfilter_amd import abi, capi, synth
+
+LIB_ADAPTERS = [synth.ONT_RAPID, synth.ONT_RAPID_RC, synth.PACBIO_BLUNT, synth.PACBIO_BLUNT_RC,
+                b"AATGTACTTCGTTCAGTTACGTATTGCT", b"AGCAATACGTAACTGAACGAAGTACATT",
+                b"GGCGTCTGCTTGGGTGTTTAACCTTTTTGTCAGAGAGGTTCCAAGTCAGAGAGGTTCCT",
+                b"CTTGCGGGCGGCGGACTCTCCTCTGAAGATAGAGCGACAGGCAAG"]
+
+
+def random_case(seed: int, n_reads: int):
+    rng = np.random.default_rng(seed)
+    kind = "ont" if rng.random() < 0.6 else "hifi"
+    na = int(rng.choice([1, 2, 2, 3, 4]))
+    ads = [LIB_ADAPTERS[i] for i in rng.choice(len(LIB_ADAPTERS), na, replace=False)]
+    planted = ads[0] if rng.random() < 0.8 else None
+    reads = synth.make_reads(int(rng.integers(1, 1 << 30)), n_reads, kind, mean_len=float(rng.choice([800, 2500, 6000])),
+                             zoo=bool(rng.random() < 0.7), pmid=float(rng.choice([0.0, 0.05, 0.3])),
+                             **({"adapter": planted} if planted else {}))
+    end_len = int(rng.choice([150, 60, 300]))
+    kw = dict(
+        adapters=ads,
+        min_len=int(rng.choice([100, 500, 1000, 2000])),
+        max_len=int(rng.choice([2147483647, 2147483647, 5000])),
+        min_q=float(rng.choice([0.0, 7.0, 10.0, 20.0])),
+        max_q=float(rng.choice([255.0, 255.0, 25.0])),
+        bc_len=int(rng.choice([150, 64, 1, 200])),
+        head_trim=int(rng.choice([0, 0, 5, 40])),
+        tail_trim=int(rng.choice([0, 0, 7, 33])),
+        end_len=end_len,
+        end_match_len=int(rng.choice([4, 8, 15])),
+        mid_match_len=int(rng.choice([35, 20, 25])),
+        extra_len=int(rng.choice([50, 0, 10])),
+        end_sim=float(rng.choice([0.75, 0.8, 0.9])),
+        mid_sim=float(rng.choice([0.9, 0.95, 0.8])),
+        discard=bool(rng.random() < 0.25),
+        filter=bool(rng.random() < 0.9),
+        qtype=33,
+    )
+    if rng.random() < 0.2:
+        kw.update(min_repeat=int(rng.choice([50, 400])), kmer=int(rng.choice([7, 11, 12])))
+    if rng.random() < 0.15:
+        kw.update(no_qual=True)
+    return kind, reads, kw
+
+
+def run_case(lib_path, seed: int, n_reads: int):
+    kind, reads, kw = random_case(seed, n_reads)
+    p = parity.sized(abi.make_params(kind, **kw), reads)
+    ctx = capi.Context(p, 0, lib_path)
+    try:
+        parity.compare_batch(ctx, p, reads, align=int(np.random.default_rng(seed).choice([1, 16])),
+                             explicit_lengths=True)
+    except AssertionError as e:
+        raise AssertionError("fuzz seed %d (%s, %s): %s" % (seed, kind, {k: v for k, v in kw.items() if k != "adapters"}, e))
+    finally:
+        ctx.close()
