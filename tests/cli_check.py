@@ -61,3 +61,61 @@ def _first_diff(a, b):
         if a[i] != b[i]:
             return "var data differs at %d: ...%r vs ...%r" % (i, a[max(0, i - 60):i + 60], b[max(0, i - 60):i + 60])
     return "var data lengths differ: %d vs %d" % (len(a), len(b))
+
+
+def _run(binary, td, sub, fin, flags, adapters):
+    """One run of `binary` in its own sub-directory; returns (returncode, output bytes, stderr text, html text)."""
+    d = os.path.join(td, sub)
+    os.makedirs(d)
+    qc = "--qc" in flags
+    fasta = fin.endswith(".fa")
+    out = os.path.join(d, "out.fa" if fasta else "out.fq")
+    args = [binary, "-i", fin, "-t", "1"] + flags
+    if not qc:
+        args += ["-o", out]
+    if adapters:
+        fa = os.path.join(d, "adapters.fa")
+        with open(fa, "w") as f:
+            for i, a in enumerate(adapters):
+                f.write(">a%d\n%s\n" % (i, a.decode()))
+        args += ["-a", fa]
+    p = subprocess.run(args, capture_output=True, cwd=d)
+    err = p.stderr.decode().replace(d + "/", "").replace(os.path.dirname(fin) + "/", "")
+    data = open(out, "rb").read() if (not qc and os.path.exists(out)) else b""
+    hname = os.path.join(os.path.dirname(fin), os.path.basename(fin).rsplit(".", 1)[0] + ".html") if qc else os.path.join(d, "out.html")
+    html = open(hname, encoding="utf-8", errors="replace").read() if os.path.exists(hname) else ""
+    return p.returncode, data, err, html
+
+
+def compare_live(binary, ref_binary, reads, flags, adapters, fasta=False):
+    """Run the reference binary and ours on the same freshly written input: output file, INFO lines and the
+    report's table / data object must be identical."""
+    from tgsfilter_amd import synth
+    with tempfile.TemporaryDirectory() as td:
+        fin = os.path.join(td, "in.fa" if fasta else "in.fq")
+        if fasta:
+            with open(fin, "wb") as f:
+                for name, s, _ in reads:
+                    f.write(b">" + name + b"\n" + s + b"\n")
+        else:
+            synth.write_fastq(fin, reads)
+        rc_r, out_r, err_r, html_r = _run(ref_binary, td, "ref", fin, flags, adapters)
+        rc_o, out_o, err_o, html_o = _run(binary, td, "own", fin, flags, adapters)
+    if rc_r != 0:
+        # parameter sets the reference itself cannot finish (e.g. nothing passes the filters: it dereferences an
+        # empty vector, src/TGSFilter.cpp:3183): this side must refuse too, there is nothing else to compare
+        assert rc_o != 0, "the reference failed (%s) but tgsfilter succeeded" % err_r[-300:]
+        return "both failed"
+    assert rc_o == 0, "tgsfilter failed: " + err_o
+    assert out_o == out_r, "output differs from the reference's (flags %s)" % flags
+
+    def info(text):
+        lines = [l for l in text.splitlines() if l.startswith("INFO:") or l.startswith("Warning:")]
+        ad = sorted(l.split(":", 2)[2] for l in lines if l.startswith("INFO: input adapter"))
+        rest = [l for l in lines if not l.startswith("INFO: input adapter") and not l.startswith("Warning: reset -t")]
+        return ad, rest
+    assert info(err_o) == info(err_r), "stderr differs (flags %s):\n%s\n---- reference:\n%s" % (flags, err_o, err_r)
+    rows = lambda h: re.findall(r"<tr>.*?</tr>", h, flags=re.S)
+    assert rows(html_o) == rows(html_r)
+    data = lambda h: (re.search(r"var data = (\{.*?\})\n</script>", h, flags=re.S) or [None, ""])[1].strip()
+    assert data(html_o) == data(html_r), _first_diff(data(html_o), data(html_r))

@@ -1,0 +1,73 @@
+"""The command line against the REFERENCE BINARY run side by side on freshly generated inputs and random flag
+sets (oracle/_ref/tgsfilter_ref: compiled from the reference where it lies, by `make -C oracle ref`; it travels
+to the GPU box with the repo).  Complements the committed goldens: nothing here was seen when the code was written.
+CPU: through the emulation build of the CLI (small inputs).  GPU (-m gpu): the real binary."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import cli_check
+from tgsfilter_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref", "tgsfilter_ref")
+
+
+def case(seed, n):
+    rng = np.random.default_rng(seed)
+    kind = "ont" if rng.random() < 0.6 else "hifi"
+    fasta = rng.random() < 0.15
+    reads = synth.make_reads(int(rng.integers(1, 1 << 30)), n, kind, mean_len=float(rng.choice([1500, 3000, 5000])),
+                             zoo=bool(rng.random() < 0.7), pmid=float(rng.choice([0.0, 0.05, 0.2])))
+    flags = ["-x", kind, "-l", str(int(rng.choice([500, 1000, 2000])))]
+    if rng.random() < 0.5 and not fasta:
+        flags += ["-q", str(int(rng.choice([7, 10, 13]) if kind == "ont" else rng.choice([15, 20, 28])))]
+    if rng.random() < 0.3 and not fasta:
+        flags += ["-Q", str(int(rng.choice([16, 30]) if kind == "ont" else rng.choice([33, 45])))]
+    if rng.random() < 0.3:
+        flags += ["-L", str(int(rng.choice([4000, 9000])))]
+    if rng.random() < 0.6:
+        flags += ["-5", str(int(rng.choice([0, 0, 6, 25]))), "-3", str(int(rng.choice([0, 0, 9])))]
+    else:
+        flags += ["-b", str(int(rng.choice([2, 8]))), "-n", "500"]
+    if rng.random() < 0.3:
+        flags += ["-E", str(int(rng.choice([100, 250])))]
+    if rng.random() < 0.3:
+        flags += ["-e", str(int(rng.choice([80, 150, 220])))]
+    if rng.random() < 0.3:
+        flags += ["-m", str(int(rng.choice([6, 12]))), "-M", str(int(rng.choice([25, 30])))]
+    if rng.random() < 0.3:
+        flags += ["-T", str(int(rng.choice([0, 20])))]
+    if rng.random() < 0.3:
+        flags += ["-s", str(float(rng.choice([0.8, 0.85]))), "-S", str(float(rng.choice([0.85, 0.92])))]
+    if rng.random() < 0.2:
+        flags += ["-D"]
+    if rng.random() < 0.2:
+        flags += ["-p", str(int(rng.choice([2, 40]))), "-k", str(int(rng.choice([9, 11])))]
+    if rng.random() < 0.2:
+        flags += ["-r", str(int(rng.integers(3, n)))]
+    adapters = None
+    if rng.random() < 0.7:
+        adapters = [synth.ONT_RAPID if kind == "ont" else synth.PACBIO_BLUNT]
+    return reads, flags, adapters, fasta
+
+
+needs_ref = pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/tgsfilter_ref not built (make -C oracle ref)")
+
+
+@needs_ref
+@pytest.mark.parametrize("seed", range(300, 312))
+def test_cli_live_emul(seed):
+    import subprocess
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tgsfilter_amd", "host"), "emul"], check=True)
+    reads, flags, adapters, fasta = case(seed, 60)
+    cli_check.compare_live(os.path.join(ROOT, "tests", "emul", "tgsfilter_emul"), REF, reads, flags, adapters, fasta)
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(300, 340))
+def test_cli_live_gpu(seed):
+    reads, flags, adapters, fasta = case(seed, 400)
+    cli_check.compare_live(os.path.join(ROOT, "tgsfilter_amd", "bin", "tgsfilter"), REF, reads, flags, adapters, fasta)

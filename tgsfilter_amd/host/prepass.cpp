@@ -196,6 +196,11 @@ PrepassResult run_prepass(Options& o, const InputBytes& in)
     if (o.filter) {                                                     // :926-945
         if (o.head_trim < 0) R.trim5p = check_base_content(ends5, check_len, seq_num, o.end_bias);
         if (o.tail_trim < 0) R.trim3p = check_base_content(ends3, check_len, seq_num, o.end_bias);
+        // :1135-1137 clamps trim5p to -e BEFORE the result of the running check is stored, and the 5' and the 3'
+        // check run as two threads (:930-936): what the clamp sees is the 5' result when the 3' thread gets there
+        // after the 5' thread has stored it -- the order observed in practice (the 5' thread starts first).  So the
+        // 5' trim is clamped exactly when both checks run; the 3' trim never is.
+        if (o.head_trim < 0 && o.tail_trim < 0 && R.trim5p > o.bc_len) R.trim5p = o.bc_len;
         if (o.adapter_file.empty()) {
             adapter_search(o, ends5, R.adapter5p, R.depth5p);
             adapter_search(o, ends3, R.adapter3p, R.depth3p);
