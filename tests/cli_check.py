@@ -63,13 +63,12 @@ def _first_diff(a, b):
     return "var data lengths differ: %d vs %d" % (len(a), len(b))
 
 
-def _run(binary, td, sub, fin, flags, adapters):
+def _run(binary, td, sub, fin, flags, adapters, out_name="out.fq"):
     """One run of `binary` in its own sub-directory; returns (returncode, output bytes, stderr text, html text)."""
     d = os.path.join(td, sub)
     os.makedirs(d)
     qc = "--qc" in flags
-    fasta = fin.endswith(".fa")
-    out = os.path.join(d, "out.fa" if fasta else "out.fq")
+    out = os.path.join(d, out_name)
     args = [binary, "-i", fin, "-t", "1"] + flags
     if not qc:
         args += ["-o", out]
@@ -81,26 +80,51 @@ def _run(binary, td, sub, fin, flags, adapters):
         args += ["-a", fa]
     p = subprocess.run(args, capture_output=True, cwd=d)
     err = p.stderr.decode().replace(d + "/", "").replace(os.path.dirname(fin) + "/", "")
-    data = open(out, "rb").read() if (not qc and os.path.exists(out)) else b""
-    hname = os.path.join(os.path.dirname(fin), os.path.basename(fin).rsplit(".", 1)[0] + ".html") if qc else os.path.join(d, "out.html")
+    data = b""
+    if not qc and os.path.exists(out):
+        data = open(out, "rb").read()
+        if out.endswith(".gz"):
+            data = gzip.decompress(data) if data else b""
+    in_prefix = os.path.basename(fin)
+    for ext in (".gz", ".fq", ".fa", ".bam", ".sam"):
+        if in_prefix.endswith(ext):
+            in_prefix = in_prefix[:-len(ext)]
+    out_prefix = out_name[:-3] if out_name.endswith(".gz") else out_name
+    out_prefix = out_prefix.rsplit(".", 1)[0]
+    hname = os.path.join(os.path.dirname(fin), in_prefix + ".html") if qc else os.path.join(d, out_prefix + ".html")
     html = open(hname, encoding="utf-8", errors="replace").read() if os.path.exists(hname) else ""
+    if qc and os.path.exists(hname):
+        os.remove(hname)
     return p.returncode, data, err, html
 
 
-def compare_live(binary, ref_binary, reads, flags, adapters, fasta=False):
+def compare_live(binary, ref_binary, reads, flags, adapters, fasta=False, in_fmt=None, out_name=None):
     """Run the reference binary and ours on the same freshly written input: output file, INFO lines and the
-    report's table / data object must be identical."""
+    report's table / data object must be identical.  in_fmt: fq | fq.gz | fa | bam | sam."""
     from tgsfilter_amd import synth
+    in_fmt = in_fmt or ("fa" if fasta else "fq")
+    out_name = out_name or ("out.fa" if in_fmt == "fa" else "out.fq")
     with tempfile.TemporaryDirectory() as td:
-        fin = os.path.join(td, "in.fa" if fasta else "in.fq")
-        if fasta:
+        fin = os.path.join(td, "in." + in_fmt)
+        if in_fmt == "fa":
             with open(fin, "wb") as f:
                 for name, s, _ in reads:
                     f.write(b">" + name + b"\n" + s + b"\n")
+        elif in_fmt == "bam":
+            from tests import bamio
+            bamio.write_bam(fin, reads, block=0x8000)
+        elif in_fmt == "sam":
+            from tests import bamio
+            bamio.write_sam(fin, reads)
+        elif in_fmt == "fq.gz":
+            synth.write_fastq(fin[:-3], reads)
+            with open(fin[:-3], "rb") as f, gzip.open(fin, "wb", compresslevel=1) as g:
+                g.write(f.read())
+            os.remove(fin[:-3])
         else:
             synth.write_fastq(fin, reads)
-        rc_r, out_r, err_r, html_r = _run(ref_binary, td, "ref", fin, flags, adapters)
-        rc_o, out_o, err_o, html_o = _run(binary, td, "own", fin, flags, adapters)
+        rc_r, out_r, err_r, html_r = _run(ref_binary, td, "ref", fin, flags, adapters, out_name)
+        rc_o, out_o, err_o, html_o = _run(binary, td, "own", fin, flags, adapters, out_name)
     if rc_r != 0:
         # parameter sets the reference itself cannot finish (e.g. nothing passes the filters: it dereferences an
         # empty vector, src/TGSFilter.cpp:3183): this side must refuse too, there is nothing else to compare

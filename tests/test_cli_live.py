@@ -31,10 +31,13 @@ def case(seed, n):
         flags += ["-5", str(int(rng.choice([0, 0, 6, 25]))), "-3", str(int(rng.choice([0, 0, 9])))]
     else:
         flags += ["-b", str(int(rng.choice([2, 8]))), "-n", "500"]
+    # With automatic trims and a check length above -e the reference is not deterministic (its 3' base-content
+    # thread clamps whatever the 5' thread has stored by then, src/TGSFilter.cpp:1135-1137): keep -E <= -e there.
+    auto_trims = "-b" in flags
     if rng.random() < 0.3:
-        flags += ["-E", str(int(rng.choice([100, 250])))]
+        flags += ["-E", str(int(rng.choice([100, 140]) if auto_trims else rng.choice([100, 250])))]
     if rng.random() < 0.3:
-        flags += ["-e", str(int(rng.choice([80, 150, 220])))]
+        flags += ["-e", str(int(rng.choice([150, 220]) if auto_trims else rng.choice([80, 150, 220])))]
     if rng.random() < 0.3:
         flags += ["-m", str(int(rng.choice([6, 12]))), "-M", str(int(rng.choice([25, 30])))]
     if rng.random() < 0.3:
@@ -44,13 +47,43 @@ def case(seed, n):
     if rng.random() < 0.2:
         flags += ["-D"]
     if rng.random() < 0.2:
-        flags += ["-p", str(int(rng.choice([2, 40]))), "-k", str(int(rng.choice([9, 11])))]
+        flags += ["-p", str(int(rng.choice([2, 5]))), "-k", str(int(rng.choice([9, 11])))]
     if rng.random() < 0.2:
         flags += ["-r", str(int(rng.integers(3, n)))]
     adapters = None
     if rng.random() < 0.7:
         adapters = [synth.ONT_RAPID if kind == "ont" else synth.PACBIO_BLUNT]
     return reads, flags, adapters, fasta
+
+
+def case2(seed, n):
+    """Wider surface: input formats (gz, SAM, BAM, FASTA), output forms (-f, .gz), --qc, -F, -A-less downsampling."""
+    rng = np.random.default_rng(seed)
+    reads, flags, adapters, fasta = case(seed + 7919, n)
+    in_fmt = "fa" if fasta else str(rng.choice(["fq", "fq", "fq.gz", "bam", "sam"]))
+    if in_fmt in ("bam", "sam"):
+        reads = [(name.split()[0], s, q) for name, s, q in reads]
+    out_name = "out.fa" if in_fmt == "fa" else "out.fq"
+    u = rng.random()
+    if u < 0.1:
+        flags = ["--qc"]
+        adapters = None
+    elif u < 0.2:
+        flags = ["-F", "-r", str(int(rng.integers(3, n)))]
+        adapters = None
+    elif u < 0.3 and "-r" not in flags:
+        flags += ["-R", str(float(rng.choice([0.2, 0.5])))]
+    elif u < 0.4 and "-r" not in flags:
+        flags += ["-g", str(int(rng.choice([20, 60]))) + "k", "-d", str(int(rng.choice([2, 5])))]
+    v = rng.random()
+    if v < 0.15 and in_fmt != "fa":
+        flags += ["-f"]
+        out_name = "out.fa"
+    elif v < 0.3:
+        out_name += ".gz"
+        if rng.random() < 0.5:
+            flags += ["-c", str(int(rng.choice([1, 6, 9])))]
+    return reads, flags, adapters, in_fmt, out_name
 
 
 needs_ref = pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/tgsfilter_ref not built (make -C oracle ref)")
@@ -71,3 +104,20 @@ def test_cli_live_emul(seed):
 def test_cli_live_gpu(seed):
     reads, flags, adapters, fasta = case(seed, 400)
     cli_check.compare_live(os.path.join(ROOT, "tgsfilter_amd", "bin", "tgsfilter"), REF, reads, flags, adapters, fasta)
+
+
+@needs_ref
+@pytest.mark.parametrize("seed", range(700, 716))
+def test_cli_live_formats_emul(seed):
+    reads, flags, adapters, in_fmt, out_name = case2(seed, 60)
+    cli_check.compare_live(os.path.join(ROOT, "tests", "emul", "tgsfilter_emul"), REF, reads, flags, adapters,
+                           in_fmt=in_fmt, out_name=out_name)
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(700, 740))
+def test_cli_live_formats_gpu(seed):
+    reads, flags, adapters, in_fmt, out_name = case2(seed, 300)
+    cli_check.compare_live(os.path.join(ROOT, "tgsfilter_amd", "bin", "tgsfilter"), REF, reads, flags, adapters,
+                           in_fmt=in_fmt, out_name=out_name)

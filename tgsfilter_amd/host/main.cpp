@@ -451,6 +451,10 @@ int main(int argc, char** argv)
         }
         tgsf_params qp = p;
         qp.filter = 0; qp.only_qc = 1; qp.n_adapters = 0; qp.min_repeat = 0;
+        // The reference's second pass re-reads what the filter pass wrote (:3129-3137): after a FASTA output
+        // (-f, or FASTA input) the records carry no qualities, so this pass takes the count-only tallies.
+        const bool down_no_qual = fasta_in || (run_filter_pass && !fastq_out);
+        qp.no_qual = down_no_qual ? 1 : 0;
         qp.max_batch_bases = (1ull << 30); qp.max_batch_reads = 1u << 16;
         tgsf_ctx* qctx = nullptr;
         if (tgsf_create(&qp, o.devices[0], &qctx) != TGSF_OK) die(tgsf_last_error(nullptr));
@@ -476,7 +480,7 @@ int main(int argc, char** argv)
             const size_t o0 = (bs.size() + 15) & ~size_t(15);
             bs.resize(o0); bq.resize(o0);
             bs.insert(bs.end(), c.seq, c.seq + c.len);
-            if (!fasta_in) bq.insert(bq.end(), c.qual, c.qual + c.len); else bq.resize(bs.size());
+            if (!down_no_qual) bq.insert(bq.end(), c.qual, c.qual + c.len); else bq.resize(bs.size());
             boff.push_back(o0); blen.push_back(c.len);
             out.text(lead);
             if (c.pass_num < 2) out.piece(c.name.data(), c.name.size());
