@@ -23,6 +23,8 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
+#include <unordered_set>
 
 #include "fastx.h"
 #include "options.h"
@@ -432,23 +434,38 @@ int main(int argc, char** argv)
     std::vector<int> down_lens;
     std::vector<uint64_t> down_t;
     if (o.downsample) {
-        std::vector<uint32_t> order(clean_recs.size());
-        for (uint32_t i = 0; i < order.size(); i++) order[i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return clean_recs[a].len > clean_recs[b].len; });
-        std::vector<char> keep(clean_recs.size(), 0);
+        // Selection as the reference makes it (:2297-2344), container for container, so that ties at the cut fall
+        // the same way when both programs are built with the same standard library: lengths keyed by record name
+        // in an unordered_map filled in write order (:2105, :2267; a repeated name keeps its last length), handed
+        // over by copy (:3142, :2169), listed in the map's iteration order, std::sort by length (descending),
+        // names taken from the top; the second pass keeps every record whose name was taken (:2356).
+        auto full_name = [&](const CleanRec& c) {
+            std::string nm;
+            append_name(nm, c.name, c.pass_num);
+            return nm;
+        };
+        std::unordered_map<std::string, int> seq_lens;
         uint64_t total = 0;
-        for (const CleanRec& c : clean_recs) total += c.len;
+        for (const CleanRec& c : clean_recs) { seq_lens[full_name(c)] = (int)c.len; total += c.len; }
+        const std::unordered_map<std::string, int> handed(seq_lens), task_lens(handed);
+        std::vector<std::pair<std::string, int>> vec(task_lens.begin(), task_lens.end());
+        std::sort(vec.begin(), vec.end(), [](const std::pair<std::string, int>& a, const std::pair<std::string, int>& b) {
+            return a.second > b.second;
+        });
         uint64_t desired = 0; int want_num = 0; bool by_size = true;
         if (o.genome_size > 0 && o.desired_depth > 0) desired = o.genome_size * (uint64_t)o.desired_depth;
         else if (o.desired_frac > 0) desired = (uint64_t)(o.desired_frac * total);        // float * uint64, :2322
         else { by_size = false; want_num = o.desired_num; }
+        std::unordered_set<std::string> chosen;
         uint64_t added = 0; int added_num = 0;
-        for (uint32_t i : order) {
-            keep[i] = 1;
-            added += clean_recs[i].len; added_num++;
-            down_bases += clean_recs[i].len; down_lens.push_back((int)clean_recs[i].len);
+        for (const auto& pr : vec) {
+            chosen.insert(pr.first);
+            added += (uint64_t)pr.second; added_num++;
+            down_bases += (uint64_t)pr.second; down_lens.push_back(pr.second);
             if (by_size ? added >= desired : added_num >= want_num) break;
         }
+        std::vector<char> keep(clean_recs.size(), 0);
+        for (size_t i = 0; i < clean_recs.size(); i++) keep[i] = chosen.count(full_name(clean_recs[i])) ? 1 : 0;
         tgsf_params qp = p;
         qp.filter = 0; qp.only_qc = 1; qp.n_adapters = 0; qp.min_repeat = 0;
         // The reference's second pass re-reads what the filter pass wrote (:3129-3137): after a FASTA output

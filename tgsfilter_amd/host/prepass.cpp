@@ -5,6 +5,8 @@
 #include <cstring>
 #include <iostream>
 #include <thread>
+#include <unordered_map>
+#include <vector>
 
 #include "tgsf.h"
 
@@ -114,8 +116,9 @@ static void adapter_search(const Options& o, const std::vector<std::string>& end
     tgsf_ctx* ctx = nullptr;
     if (tgsf_create(&p, o.device, &ctx) != TGSF_OK) { std::cerr << "Error: " << tgsf_last_error(nullptr) << std::endl; exit(-1); }
 
-    std::vector<long long> score(22, 0);
-    std::vector<char> hit(22, 0);
+    // totals per adapter in the reference's own container (:1150, :1171): the winner among equal totals is
+    // whatever its iteration order and std::sort make of it, reproduced here by using the same ones
+    std::unordered_map<int, int> maps;
     std::vector<uint8_t> buf; std::vector<uint64_t> off; std::vector<uint32_t> len; std::vector<uint8_t> aid;
     std::vector<int32_t> kk, res, eds;
     for (size_t b = 0; b < ends.size(); b += per_call) {
@@ -134,18 +137,16 @@ static void adapter_search(const Options& o, const std::vector<std::string>& end
             std::cerr << "Error: " << tgsf_last_error(ctx) << std::endl; exit(-1);
         }
         for (uint32_t i = 0; i < n; i++)
-            if (res[(size_t)i * 4 + 1] > 0) {                           // numAln > 0, :1170
-                score[aid[i]] += res[(size_t)i * 4 + 2] - res[(size_t)i * 4 + 0];   // mlen = alignmentLength - editDistance
-                hit[aid[i]] = 1;
-            }
+            if (res[(size_t)i * 4 + 1] > 0)                             // numAln > 0, :1170 (problems are read-major, as :1156-1158)
+                maps[(int)aid[i]] += res[(size_t)i * 4 + 2] - res[(size_t)i * 4 + 0];   // mlen = alignmentLength - editDistance
     }
     tgsf_destroy(ctx);
-    // the adapter with the largest total (ties: the reference's order is that of an unordered_map; lowest index here)
-    int best = -1;
-    for (int a = 0; a < 22; a++) if (hit[a] && (best < 0 || score[a] > score[best])) best = a;
-    if (best < 0) return;
+    std::vector<std::pair<int, int>> vec(maps.begin(), maps.end());     // :1179-1182
+    std::sort(vec.begin(), vec.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.second > b.second; });
+    if (vec.empty()) return;
+    const int best = vec.front().first;
     const std::string cand = kAdapterLib[best];
-    const float mean_dep = (float)score[best] / (float)cand.size();     // :1189
+    const float mean_dep = (float)maps[best] / (float)cand.size();      // :1189
     if (mean_dep >= 2 * min_sim) { adapter = cand; depth = mean_dep; }  // :1193
 }
 
