@@ -63,11 +63,11 @@ def _first_diff(a, b):
     return "var data lengths differ: %d vs %d" % (len(a), len(b))
 
 
-def _run(binary, td, sub, fin, flags, adapters, out_name="out.fq"):
+def _run(binary, td, sub, fin, flags, adapters, out_name="out.fq", to_stdout=False):
     """One run of `binary` in its own sub-directory; returns (returncode, output bytes, stderr text, html text)."""
     d = os.path.join(td, sub)
     os.makedirs(d)
-    qc = "--qc" in flags
+    qc = "--qc" in flags or to_stdout          # no -o: the report is named after the input
     out = os.path.join(d, out_name)
     args = [binary, "-i", fin, "-t", "1"] + flags
     if not qc:
@@ -80,7 +80,7 @@ def _run(binary, td, sub, fin, flags, adapters, out_name="out.fq"):
         args += ["-a", fa]
     p = subprocess.run(args, capture_output=True, cwd=d)
     err = p.stderr.decode().replace(d + "/", "").replace(os.path.dirname(fin) + "/", "")
-    data = b""
+    data = p.stdout if to_stdout else b""
     if not qc and os.path.exists(out):
         data = open(out, "rb").read()
         if out.endswith(".gz"):
@@ -98,7 +98,7 @@ def _run(binary, td, sub, fin, flags, adapters, out_name="out.fq"):
     return p.returncode, data, err, html
 
 
-def compare_live(binary, ref_binary, reads, flags, adapters, fasta=False, in_fmt=None, out_name=None):
+def compare_live(binary, ref_binary, reads, flags, adapters, fasta=False, in_fmt=None, out_name=None, to_stdout=False):
     """Run the reference binary and ours on the same freshly written input: output file, INFO lines and the
     report's table / data object must be identical.  in_fmt: fq | fq.gz | fa | bam | sam."""
     from tgsfilter_amd import synth
@@ -123,8 +123,8 @@ def compare_live(binary, ref_binary, reads, flags, adapters, fasta=False, in_fmt
             os.remove(fin[:-3])
         else:
             synth.write_fastq(fin, reads)
-        rc_r, out_r, err_r, html_r = _run(ref_binary, td, "ref", fin, flags, adapters, out_name)
-        rc_o, out_o, err_o, html_o = _run(binary, td, "own", fin, flags, adapters, out_name)
+        rc_r, out_r, err_r, html_r = _run(ref_binary, td, "ref", fin, flags, adapters, out_name, to_stdout)
+        rc_o, out_o, err_o, html_o = _run(binary, td, "own", fin, flags, adapters, out_name, to_stdout)
     if rc_r != 0:
         # parameter sets the reference itself cannot finish (e.g. nothing passes the filters: it dereferences an
         # empty vector, src/TGSFilter.cpp:3183): this side must refuse too, there is nothing else to compare

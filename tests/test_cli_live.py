@@ -121,3 +121,14 @@ def test_cli_live_formats_gpu(seed):
     reads, flags, adapters, in_fmt, out_name = case2(seed, 300)
     cli_check.compare_live(os.path.join(ROOT, "tgsfilter_amd", "bin", "tgsfilter"), REF, reads, flags, adapters,
                            in_fmt=in_fmt, out_name=out_name)
+
+
+@needs_ref
+@pytest.mark.parametrize("seed", range(5000, 5008))
+def test_cli_live_stdout_and_adapters_only_emul(seed):
+    """No -o (records on stdout, report named after the input) and -A (adapter identification only)."""
+    binary = os.path.join(ROOT, "tests", "emul", "tgsfilter_emul")
+    reads, flags, adapters, fasta = case(seed, 80)
+    if "-r" not in flags:
+        cli_check.compare_live(binary, REF, reads, flags, adapters, fasta, to_stdout=True)
+    cli_check.compare_live(binary, REF, reads, flags + ["-A"], None, fasta)
