@@ -98,7 +98,8 @@ def _run(binary, td, sub, fin, flags, adapters, out_name="out.fq", to_stdout=Fal
     return p.returncode, data, err, html
 
 
-def compare_live(binary, ref_binary, reads, flags, adapters, fasta=False, in_fmt=None, out_name=None, to_stdout=False):
+def compare_live(binary, ref_binary, reads, flags, adapters, fasta=False, in_fmt=None, out_name=None, to_stdout=False,
+                 raw_input=None):
     """Run the reference binary and ours on the same freshly written input: output file, INFO lines and the
     report's table / data object must be identical.  in_fmt: fq | fq.gz | fa | bam | sam."""
     from tgsfilter_amd import synth
@@ -106,7 +107,9 @@ def compare_live(binary, ref_binary, reads, flags, adapters, fasta=False, in_fmt
     out_name = out_name or ("out.fa" if in_fmt == "fa" else "out.fq")
     with tempfile.TemporaryDirectory() as td:
         fin = os.path.join(td, "in." + in_fmt)
-        if in_fmt == "fa":
+        if raw_input is not None:
+            open(fin, "wb").write(raw_input)
+        elif in_fmt == "fa":
             with open(fin, "wb") as f:
                 for name, s, _ in reads:
                     f.write(b">" + name + b"\n" + s + b"\n")

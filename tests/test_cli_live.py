@@ -132,3 +132,41 @@ def test_cli_live_stdout_and_adapters_only_emul(seed):
     if "-r" not in flags:
         cli_check.compare_live(binary, REF, reads, flags, adapters, fasta, to_stdout=True)
     cli_check.compare_live(binary, REF, reads, flags + ["-A"], None, fasta)
+
+
+def case3(seed, n):
+    """Unusual but valid FASTQ texts: headers with blanks and tabs, repeated names, blank lines before records,
+    Phred+64 qualities.  (Texts the reference itself cannot read -- CR LF line ends, a last line without a
+    newline: it reads out of bounds there -- are accepted here and are not part of the comparison.)"""
+    rng = np.random.default_rng(seed)
+    reads, flags, adapters, _ = case(seed, n)
+    mode = int(rng.choice([0, 1, 5, 6]))
+    out = bytearray()
+    for i, (name, s, q) in enumerate(reads):
+        nm = name
+        if mode == 0:
+            nm = name + b" runid=abc\tch=5"
+        if mode == 1 and i % 7 == 3:
+            nm = b"dup"
+        if mode == 6:
+            q = bytes(min(126, c + 31) for c in q)
+        rec = b"@" + nm + b"\n" + s + b"\n+\n" + q + b"\n"
+        if mode == 5 and i % 9 == 4:
+            rec = b"\n" + rec
+        out += rec
+    return bytes(out), flags, adapters
+
+
+@needs_ref
+@pytest.mark.parametrize("seed", range(6000, 6010))
+def test_cli_live_unusual_text_emul(seed):
+    raw, flags, adapters = case3(seed, 60)
+    cli_check.compare_live(os.path.join(ROOT, "tests", "emul", "tgsfilter_emul"), REF, None, flags, adapters, raw_input=raw)
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(6000, 6030))
+def test_cli_live_unusual_text_gpu(seed):
+    raw, flags, adapters = case3(seed, 300)
+    cli_check.compare_live(os.path.join(ROOT, "tgsfilter_amd", "bin", "tgsfilter"), REF, None, flags, adapters, raw_input=raw)
