@@ -15,3 +15,16 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_collection_finish(session):
+    """A GPU session that also uses torch (tests/test_gpu_fullsize.py builds its batches with it): torch ships its
+    own HIP runtime and must bring the device up BEFORE libtgsf.so binds the system one, or its later
+    initialisation finds no device.  Nothing is touched in a session without selected GPU tests."""
+    if any(item.get_closest_marker("gpu") for item in session.items):
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:
+            pass

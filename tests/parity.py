@@ -232,3 +232,72 @@ def async_two_contexts(lib_path):
         assert np.array_equal(got_r, exp_r) and np.array_equal(got_f, exp_f)
         assert np.array_equal(c.counters(), exp_ctr)
         c.close()
+
+
+def align_windows_random(lib_path, n, seed=9, golden_dir=None):
+    """tgsf_align_windows against edlib itself where oracle/_ref/libedlib_ref.so exists (compiled from the
+    reference's include/edlib.cpp), else against the oracle's DP restatement: random adapters of 20..128 bp,
+    windows of 5..400 bp with planted mutated copies, homopolymers and Ns, assorted k."""
+    import ctypes as C
+    ref_so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libedlib_ref.so")
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    adapters = [synth.ONT_RAPID, synth.PACBIO_BLUNT, b"AATGTACTTCGTTCAGTTACGTATTGCT", b"GCAATACGTAACTGAACGAAGT"]
+    adapters += [bytes(acgt[rng.integers(0, 4, int(L))]) for L in (20, 33, 64, 65, 90, 127, 128)]
+    p = abi.make_params("ont", adapters=adapters, max_batch_bases=1 << 22, max_batch_reads=4096, max_read_len=4096)
+    ctx = capi.Context(p, 0, lib_path)
+    buf, off, ln, aid, ks, trip = bytearray(), [], [], [], [], []
+    for i in range(n):
+        a = int(rng.integers(0, len(adapters)))
+        q = adapters[a]
+        Q = len(q)
+        T = int(rng.integers(5, 40)) if i % 9 == 0 else int(rng.integers(40, 400))
+        t = bytearray(acgt[rng.integers(0, 4, T)].tobytes())
+        if i % 11 == 5:
+            t = bytearray(b"T" * T)
+        for _ in range(int(rng.integers(0, 3))):
+            m = synth.mutate(rng, q, float(rng.choice([0.0, 0.05, 0.15, 0.3])))
+            if rng.random() < 0.3:
+                m = m[int(rng.integers(0, len(m))):]
+            pos = int(rng.integers(0, T))
+            t[pos:pos + len(m)] = m
+        if i % 13 == 7:
+            t[int(rng.integers(0, len(t)))] = ord("N")
+        t = bytes(t[:400])
+        k = max(1, int(rng.choice([Q - 3, Q - 14, Q - 34, Q // 3, Q // 8 + 1])))
+        k = min(k, Q - 1)
+        off.append(len(buf)); ln.append(len(t)); aid.append(a); ks.append(k); trip.append((q, t, k))
+        buf += t
+    res, ends = ctx.align_windows(bytes(buf), off, ln, aid, ks)
+    ctx.close()
+    if os.path.exists(ref_so):
+        class Cfg(C.Structure):
+            _fields_ = [("k", C.c_int), ("mode", C.c_int), ("task", C.c_int), ("eq", C.c_void_p), ("neq", C.c_int)]
+
+        class Res(C.Structure):
+            _fields_ = [("status", C.c_int), ("editDistance", C.c_int), ("endLocations", C.POINTER(C.c_int)),
+                        ("startLocations", C.POINTER(C.c_int)), ("numLocations", C.c_int),
+                        ("alignment", C.POINTER(C.c_ubyte)), ("alignmentLength", C.c_int), ("alphabetLength", C.c_int)]
+        lib = C.CDLL(ref_so)
+        lib.edlibAlign.restype = Res
+        lib.edlibAlign.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, Cfg]
+        lib.edlibFreeAlignResult.argtypes = [Res]
+
+        def truth(q, t, k):
+            r = lib.edlibAlign(q, len(q), t, len(t), Cfg(k, 2, 2, None, 0))
+            n_ = r.numLocations
+            out = (r.editDistance, n_, r.alignmentLength, r.startLocations[0] if n_ else -1,
+                   r.endLocations[0] if n_ else -1, r.endLocations[n_ - 1] if n_ else -1)
+            lib.edlibFreeAlignResult(r)
+            return out
+    else:
+        def truth(q, t, k):
+            ed, n_, starts, ends_, alen = orc.align_hw(q, t, k)
+            return (ed, n_, alen, starts[0] if n_ else -1, ends_[0] if n_ else -1, ends_[-1] if n_ else -1)
+    bad = []
+    for i, (q, t, k) in enumerate(trip):
+        got = (int(res[i, 0]), int(res[i, 1]), int(res[i, 2]), int(res[i, 3]), int(ends[i, 0]), int(ends[i, 1]))
+        exp = truth(q, t, k)
+        if got != exp:
+            bad.append((i, q, t, k, got, exp))
+    assert not bad, "%d of %d alignments differ, first: %s" % (len(bad), n, bad[0])

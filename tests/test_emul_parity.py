@@ -106,3 +106,7 @@ def test_emul_no_qual(emul, mode):
 
 def test_emul_submit_async(emul):
     parity.async_two_contexts(emul)
+
+
+def test_emul_align_windows_random(emul):
+    parity.align_windows_random(emul, 1500)

@@ -179,3 +179,8 @@ def test_gpu_no_qual(mode):
 
 def test_gpu_submit_async():
     parity.async_two_contexts(None)
+
+
+def test_gpu_align_windows_random():
+    parity.align_windows_random(None, 4000)
+    parity.align_windows_random(None, 4000, seed=10)
