@@ -56,6 +56,15 @@ def test_cli_several_devices(binary, golden_dir, name):
     cli_check.run_case(binary, golden_dir, name, extra_args=["--devices", "0,0,0"])
 
 
+@pytest.mark.parametrize("name,block", [("ont_zoo", "1000"), ("hifi_auto", "4096"), ("ont_fasta", "777"), ("down_r", "100000")])
+def test_cli_parallel_line_scan(binary, golden_dir, name, block, monkeypatch):
+    """Newlines located ahead of the parser by several threads, block by block (tiny blocks here: lines span
+    many of them): same records, same everything."""
+    monkeypatch.setenv("TGSF_SCAN_THREADS", "3")
+    monkeypatch.setenv("TGSF_SCAN_BLOCK", block)
+    cli_check.run_case(binary, golden_dir, name)
+
+
 def test_cli_usage_and_errors(binary, tmp_path):
     p = subprocess.run([binary], capture_output=True)
     assert p.returncode == 1 and p.stdout.startswith(b"Usage: tgsfilter -i TGS.raw.fq.gz -x ont -o TGS.clean.fq.gz")

@@ -9,7 +9,10 @@
 #include <zlib.h>
 
 #include <cstring>
+#include <algorithm>
+#include <cstdlib>
 #include <iostream>
+#include <thread>
 
 namespace host {
 
@@ -69,10 +72,59 @@ bool InputBytes::open_plain(const std::string& path)
     return true;
 }
 
+int FastxReader::scan_threads_from_env(int dflt)
+{
+    const char* e = getenv("TGSF_SCAN_THREADS");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? std::min(v, 64) : dflt;
+}
+
+void FastxReader::scan_block(const char* from)
+{
+    static const size_t kBlock = [] {                      // TGSF_SCAN_BLOCK: test knob (block edges on small inputs)
+        const char* e = getenv("TGSF_SCAN_BLOCK");
+        const size_t v = e ? (size_t)strtoull(e, nullptr, 10) : 0;
+        return v ? v : (size_t)(256u << 20);
+    }();
+    block_begin_ = from;
+    block_end_ = (size_t)(end_ - from) > kBlock ? from + kBlock : end_;
+    const int T = scan_threads_;
+    std::vector<std::vector<const char*>> part((size_t)T);
+    std::vector<std::thread> th;
+    const size_t per = ((size_t)(block_end_ - block_begin_) + (size_t)T - 1) / (size_t)T;
+    for (int t = 0; t < T; t++)
+        th.emplace_back([&, t] {
+            const char* a = block_begin_ + std::min(per * (size_t)t, (size_t)(block_end_ - block_begin_));
+            const char* b = block_begin_ + std::min(per * (size_t)(t + 1), (size_t)(block_end_ - block_begin_));
+            while (a < b) {
+                const char* q = static_cast<const char*>(memchr(a, '\n', (size_t)(b - a)));
+                if (!q) break;
+                part[(size_t)t].push_back(q);
+                a = q + 1;
+            }
+        });
+    for (std::thread& x : th) x.join();
+    nl_.clear();
+    for (const auto& v : part) nl_.insert(nl_.end(), v.begin(), v.end());
+    nl_at_ = 0;
+}
+
+const char* FastxReader::next_newline(const char* from)
+{
+    if (scan_threads_ <= 1) return static_cast<const char*>(memchr(from, '\n', (size_t)(end_ - from)));
+    for (;;) {
+        if (from >= end_) return nullptr;
+        if (!block_begin_ || from < block_begin_ || from >= block_end_) scan_block(from);
+        while (nl_at_ < nl_.size() && nl_[nl_at_] < from) nl_at_++;
+        if (nl_at_ < nl_.size()) return nl_[nl_at_];
+        from = block_end_;                 // none left in this block: the line runs on into the next one
+    }
+}
+
 std::string_view FastxReader::line()
 {
     if (p_ >= end_) { done_ = true; return {}; }
-    const char* nl = static_cast<const char*>(memchr(p_, '\n', (size_t)(end_ - p_)));
+    const char* nl = next_newline(p_);
     const char* e = nl ? nl : end_;          // a last line without '\n' is still a line here (the reference reads out of bounds)
     size_t n = (size_t)(e - p_);
     if (n > 0 && e[-1] == '\r') n--;         // :666-668

@@ -306,9 +306,10 @@ int main(int argc, char** argv)
         }
     }
 
+    const int scan_threads = std::max(1, std::min(o.n_thread, 8));
     std::thread reader([&] {                                           // read_fastx, :1845-1870 (index only)
         if (!run_filter_pass) { for (size_t d = 0; d < ctxs.size(); d++) to_gpu.put(nullptr); return; }
-        FastxReader rd(in.data(), in.size(), !fasta_in);
+        FastxReader rd(in.data(), in.size(), !fasta_in, scan_threads);
         Record r;
         auto fresh = [&] {
             std::unique_ptr<Batch> nb(new Batch);

@@ -161,7 +161,7 @@ PrepassResult run_prepass(Options& o, const InputBytes& in)
     const bool need3 = o.filter && (o.tail_trim < 0 || o.adapter_file.empty());
     int seq_num = 0, min_qc = 255, max_qc = 0;
     {
-        FastxReader rd(in.data(), in.size(), o.in_type != 0);           // read_fastx / read_bam, :949-1040
+        FastxReader rd(in.data(), in.size(), o.in_type != 0, std::max(1, std::min(o.n_thread, 8)));           // read_fastx / read_bam, :949-1040
         Record r;
         while (rd.next(r)) {
             const int L = (int)r.seq.size();
