@@ -201,6 +201,13 @@ typedef struct tgsf_ctx tgsf_ctx;
 int tgsf_abi_version(void);
 
 /*
+ * Optional: bring the HIP runtime up on `device` and load the library's kernels (first use costs a few
+ * tenths of a second).  Thread-safe; a host program can call it from a helper thread while it is still
+ * reading its parameters, so that tgsf_create and the first batch do not pay for it.
+ */
+int tgsf_prepare_device(int device);
+
+/*
  * Create a context on HIP device `device`.  Replaces the construction of
  * TGSFilterTask (:1757-1790: the accumulator rows) for one "worker" = one GPU.
  */

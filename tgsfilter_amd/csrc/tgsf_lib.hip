@@ -199,6 +199,53 @@ static int build_tables(tgsf_ctx* c)
 // ---------------------------------------------------------------------------
 extern "C" int tgsf_abi_version(void) { return TGSF_ABI_VERSION; }
 
+#if !defined(TGSF_EMUL)
+__global__ void k_noop(int* p) { if (p) *p = 0; }
+#endif
+extern "C" int tgsf_prepare_device(int device)
+{
+#if !defined(TGSF_EMUL)
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return TGSF_E_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return TGSF_E_HIP;
+    hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, 0, (int*)nullptr);      // loads the code object
+    if (hipDeviceSynchronize() != hipSuccess) return TGSF_E_HIP;
+    // every kernel is resolved on its first launch: run a miniature batch (two 50-bp adapters, the usual
+    // configuration) through the whole pipeline once
+    {
+        static const char a0[] = "GTTTTCGCATTTATCGTGAAACGCTTTCGCGTTTTTCGTGCGCCGCTTCA";
+        static const char a1[] = "TGAAGCGGCGCACGAAAAACGCGAAAGCGTTTCACGATAAATGCGAAAAC";
+        tgsf_params p;
+        memset(&p, 0, sizeof p);
+        p.struct_size = sizeof p;
+        p.min_len = 100; p.max_len = 2147483647; p.min_q = 0; p.max_q = 255; p.bc_len = 150;
+        p.end_len = 150; p.end_match_len = 4; p.mid_match_len = 35; p.extra_len = 50;
+        p.end_sim = 0.75f; p.mid_sim = 0.9f; p.filter = 1; p.qtype = 33; p.kmer = 11;
+        p.n_adapters = 2; p.adapters[0] = a0; p.adapters[1] = a1; p.adapter_len[0] = p.adapter_len[1] = 50;
+        p.max_batch_bases = 1 << 16; p.max_batch_reads = 16; p.max_read_len = 1 << 14;
+        tgsf_ctx* c = nullptr;
+        if (tgsf_create(&p, device, &c) == TGSF_OK) {
+            std::vector<uint8_t> seq(8192), qual(8192, (uint8_t)'5');
+            for (size_t i = 0; i < seq.size(); i++) seq[i] = "ACGT"[(i * 2654435761u >> 13) & 3];
+            memcpy(&seq[4096 + 1000], a0, 50);
+            const uint64_t off[2] = {0, 4096};
+            const uint32_t len[2] = {3000, 4000};
+            tgsf_read_result res[2];
+            tgsf_fragment fr[64];
+            tgsf_batch_in in;
+            memset(&in, 0, sizeof in);
+            in.seq = seq.data(); in.qual = qual.data(); in.offsets = off; in.lengths = len; in.n_reads = 2; in.n_bytes = seq.size();
+            tgsf_batch_out out{res, fr, 64, 0};
+            (void)tgsf_submit(c, &in, &out);
+            tgsf_destroy(c);
+        }
+    }
+#else
+    (void)device;
+#endif
+    return TGSF_OK;
+}
+
 extern "C" const char* tgsf_last_error(tgsf_ctx* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
 
 extern "C" void tgsf_destroy(tgsf_ctx* c)
