@@ -171,3 +171,42 @@ def test_cli_live_unusual_text_emul(seed):
 def test_cli_live_unusual_text_gpu(seed):
     raw, flags, adapters = case3(seed, 300)
     cli_check.compare_live(os.path.join(ROOT, "tgsfilter_amd", "bin", "tgsfilter"), REF, None, flags, adapters, raw_input=raw)
+
+
+def long_reads(lengths, seed=11):
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    reads = []
+    for i, L in enumerate(lengths):
+        s = bytearray(acgt[rng.integers(0, 4, L)].tobytes())
+        for k in range(int(rng.integers(0, 4))):
+            a = synth.mutate(rng, synth.ONT_RAPID if k % 2 else synth.ONT_RAPID_RC, 0.08)
+            if L > 3000:
+                p = int(rng.integers(200, L - 200 - len(a)))
+                s[p:p + len(a)] = a
+        if i % 2 == 0 and L > 1000:
+            a = synth.mutate(rng, synth.ONT_RAPID, 0.1)
+            s[10:10 + len(a)] = a
+        q = (np.clip(np.rint(rng.normal(14, 4, L)), 1, 50) + 33).astype(np.uint8).tobytes()
+        reads.append((b"long%d" % i, bytes(s), q))
+    return reads
+
+
+LONG_FLAGS = [["-x", "ont", "-l", "1000", "-q", "10", "-5", "0", "-3", "0"], ["-x", "ont", "-l", "500", "-5", "3", "-3", "2", "-D"],
+              ["-x", "ont", "-l", "1000", "-M", "25", "-S", "0.8", "-T", "10"], ["-x", "ont", "-l", "1000", "-p", "3", "-k", "11", "-r", "4"]]
+
+
+@needs_ref
+@pytest.mark.parametrize("flags", LONG_FLAGS[:2])
+def test_cli_live_long_reads_emul(flags):
+    """Records larger than the default text slice of a small file, tile / segment edge lengths."""
+    reads = long_reads([300_000, 123_457, 6400 * 3, 6400 * 3 + 1, 6399, 6401, 102_400, 99])
+    cli_check.compare_live(os.path.join(ROOT, "tests", "emul", "tgsfilter_emul"), REF, reads, flags, [synth.ONT_RAPID])
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", LONG_FLAGS)
+def test_cli_live_long_reads_gpu(flags):
+    reads = long_reads([2_000_000, 1_234_567, 700_001, 350_000, 6400 * 3, 6400 * 3 + 1, 6399, 6401, 102_400, 99])
+    cli_check.compare_live(os.path.join(ROOT, "tgsfilter_amd", "bin", "tgsfilter"), REF, reads, flags, [synth.ONT_RAPID])

@@ -279,9 +279,11 @@ int main(int argc, char** argv)
     if (adapters.size() > TGSF_MAX_ADAPTERS) die("more than " + std::to_string(TGSF_MAX_ADAPTERS) + " adapter sequences");
     p.n_adapters = (int)adapters.size();
     for (size_t a = 0; a < adapters.size(); a++) { p.adapters[a] = adapters[a].data(); p.adapter_len[a] = (int)adapters[a].size(); }
-    p.max_batch_bases = batch_text + (1 << 20);           // capacity is in buffer bytes: the text slice must fit
     p.max_batch_reads = batch_reads;
     p.max_read_len = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(in.size() / 2, 1024), 1u << 26);
+    // capacity is in buffer bytes: a text slice must fit, and so must one record of the longest read on its own
+    // (header + two lines of max_read_len)
+    p.max_batch_bases = std::max<uint64_t>(batch_text, 2ull * p.max_read_len + (1u << 16)) + (1 << 20);
     // one context (and one feeder thread) per device of --devices; batches are dealt to whichever feeder is
     // free, the writer re-sequences them, the tallies are merged at the end (host side)
     if (warm.joinable()) warm.join();
