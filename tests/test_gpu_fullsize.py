@@ -115,3 +115,39 @@ def test_full_size_conservation_and_oracle_slice(batch):
         assert np.array_equal(reads[name][:m], er[name]), name
     nf = int(er["n_frags"].sum())
     assert np.array_equal(frags[["start", "len", "flags", "sum_q"]][:nf], ef[["start", "len", "flags", "sum_q"]])
+
+
+def test_full_size_concurrent_contexts(batch):
+    """Three contexts on three streams filter the same batch at the same time, twice each (what bench.py does):
+    every one must produce the single-context result; tallies double."""
+    torch, dev = batch["torch"], batch["dev"]
+    ref_reads, ref_frags, ref_ctr = run(batch)
+    n = batch["n"]
+    p = abi.make_params("ont", adapters=[synth.ONT_RAPID, synth.ONT_RAPID_RC], min_len=1000, min_q=10.0,
+                        head_trim=0, tail_trim=0, max_batch_bases=batch["bases"] + 64, max_batch_reads=n,
+                        max_read_len=int(batch["h_lens"].max()))
+    fcap = batch["bases"] // 1000 + n + 16
+    ctxs = [capi.Context(p, 0) for _ in range(3)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    outs = [(torch.empty(n * 32, dtype=torch.uint8, device=dev), torch.zeros(fcap * 24, dtype=torch.uint8, device=dev),
+             torch.zeros(4, dtype=torch.int32, device=dev)) for _ in range(3)]
+    torch.cuda.synchronize()
+    for rep in range(2):
+        for c, st, (r, f, nf) in zip(ctxs, streams, outs):
+            c.submit_device(batch["seq"].data_ptr(), batch["qual"].data_ptr(), batch["offsets"].data_ptr(),
+                            batch["lengths"].data_ptr(), n, batch["n_bytes"], r.data_ptr(), f.data_ptr(), fcap,
+                            nf.data_ptr(), st.cuda_stream)
+    for c in ctxs:
+        c.wait()
+    torch.cuda.synchronize()
+    for c, (r, f, nf) in zip(ctxs, outs):
+        reads = r.cpu().numpy().view(abi.READ_RESULT_DTYPE)
+        k = int(nf[0].item())
+        frags = f.cpu().numpy().view(abi.FRAGMENT_DTYPE)[:k]
+        assert np.array_equal(reads, ref_reads) and np.array_equal(frags, ref_frags)
+        ctr = c.counters()
+        rows = slice(abi.CTR_ROWS, abi.CTR_ROWS + 4)
+        exp = ref_ctr * np.uint64(2)
+        exp[rows] = ref_ctr[rows]
+        assert np.array_equal(ctr, exp)
+        c.close()
