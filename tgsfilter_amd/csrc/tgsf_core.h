@@ -182,49 +182,6 @@ TGSF_HD int popc64_acc(uint64_t x, int acc) {
 TGSF_HD int hot_score(const Hot& s) { return (int)popc64(s.p) - (int)popc64(s.m); }
 
 // ---------------------------------------------------------------------------
-// Infix scan of a short window (read ends; single alignments for the pre-pass).
-// ---------------------------------------------------------------------------
-struct WinScan {
-    int best;        // min over columns of D[Q][j] if <= kk, else -1
-    int first_end;   // first / last column (0-based) attaining it
-    int last_end;
-    int n;           // number of such columns
-};
-
-template <int NW>
-TGSF_HD WinScan win_scan(const uint64_t* peq /*[256][NW]*/, int Q, const uint8_t* t, int T, int kk) {
-    Bv<NW> s;
-    bv_init(s, Q);
-    WinScan r;
-    r.best = -1; r.first_end = r.last_end = -1; r.n = 0;
-    int cur = kk + 1;
-    for (int j = 0; j < T; j++) {
-        bv_step<NW>(s, peq + (size_t)t[j] * NW, 0, Q);
-        if (s.score < cur) { cur = s.score; r.first_end = j; r.n = 0; }
-        if (s.score == cur && cur <= kk) { r.last_end = j; r.n++; }
-    }
-    if (cur <= kk) r.best = cur;
-    return r;
-}
-
-// startLocations[i]: longest suffix t[s..end] whose global distance to the adapter
-// equals `best` (edlib.cpp:246-255, "taking last location").  peq_rev is the Peq
-// table of the reversed adapter.
-template <int NW>
-TGSF_HD int win_start(const uint64_t* peq_rev, int Q, const uint8_t* t, int end, int best) {
-    Bv<NW> s;
-    bv_init(s, Q);
-    int maxl = end + 1;
-    if (maxl > Q + best) maxl = Q + best;
-    int best_l = 1;
-    for (int l = 1; l <= maxl; l++) {
-        bv_step<NW>(s, peq_rev + (size_t)t[end - (l - 1)] * NW, 1, Q);
-        if (s.score == best) best_l = l;
-    }
-    return end - best_l + 1;
-}
-
-// ---------------------------------------------------------------------------
 // QC columns for 4 bases at a time (SWAR).  s: 4 sequence bytes, q: 4 quality
 // bytes (already masked to the valid ones; invalid bytes are 0 in both).
 // cnt[c] += #bases of class c; qs[c] += 128 * sum of their quality bytes
