@@ -72,6 +72,7 @@ struct tgsf_ctx {
     hipEvent_t ev_fork, ev_join;
     hipStream_t hp;                       // optional high-priority stream for the HBM-bound stats kernels (TGSF_STATS_PRIO=1)
     hipEvent_t ev_hp[2];
+    bool side_mid = false;                // TGSF_BIG_LOWPRIO=1: stats AND scan kernels on a lowest-priority side stream
 #endif
     uint32_t h_status[4];
     // batch enqueued by tgsf_submit_async, completed by tgsf_wait
@@ -331,11 +332,15 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
         (he = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) {
         tgsf_destroy(c); return fail(nullptr, TGSF_E_HIP, "auxiliary stream: %s", hipGetErrorString(he));
     }
-    if (const char* e = getenv("TGSF_STATS_PRIO")) {
-        if (atoi(e) > 0) {
+    {
+        const char* e1 = getenv("TGSF_STATS_PRIO");      // experiment knobs, see tools/sweep_overlap.sh
+        const char* e2 = getenv("TGSF_BIG_LOWPRIO");
+        const bool hi_stats = e1 && atoi(e1) > 0, low_big = e2 && atoi(e2) > 0;
+        if (hi_stats || low_big) {
             int lo = 0, hi = 0;
             (void)hipDeviceGetStreamPriorityRange(&lo, &hi);       // hi = numerically lowest = greatest priority
-            if ((he = hipStreamCreateWithPriority(&c->hp, hipStreamNonBlocking, hi)) != hipSuccess ||
+            c->side_mid = low_big;
+            if ((he = hipStreamCreateWithPriority(&c->hp, hipStreamNonBlocking, low_big ? lo : hi)) != hipSuccess ||
                 (he = hipEventCreateWithFlags(&c->ev_hp[0], hipEventDisableTiming)) != hipSuccess ||
                 (he = hipEventCreateWithFlags(&c->ev_hp[1], hipEventDisableTiming)) != hipSuccess) {
                 tgsf_destroy(c); return fail(nullptr, TGSF_E_HIP, "priority stream: %s", hipGetErrorString(he));
@@ -567,19 +572,26 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
         const uint64_t max_segs = in->n_bytes / (uint64_t)P.seg_cols + 2ull * n + 1;
         const unsigned gseg = blocks_for(max_segs, T);
         const unsigned gmid = c->mid_grid ? std::min(gseg, c->mid_grid) : gseg;
+        rt_stream ms = st;
+#if !defined(TGSF_EMUL)
+        if (c->hp && c->side_mid) { ms = c->hp; (void)hipEventRecord(c->ev_hp[0], st); (void)hipStreamWaitEvent(ms, c->ev_hp[0], 0); }
+#endif
         int a = 0;
         while (a < A) {
-            if (P.Q[a] > 64) { TGSF_LAUNCH(k_mid_scan2, gseg, T, st, P, B, a); a++; continue; }
+            if (P.Q[a] > 64) { TGSF_LAUNCH(k_mid_scan2, gseg, T, ms, P, B, a); a++; continue; }
             int na = 0;
             while (a + na < A && na < 4 && P.Q[a + na] <= 64) na++;
             switch (na) {
-            case 1: TGSF_LAUNCH(k_mid_scan1<1>, gmid, T, st, P, B, a, na); break;
-            case 2: TGSF_LAUNCH(k_mid_scan1<2>, gmid, T, st, P, B, a, na); break;
-            case 3: TGSF_LAUNCH(k_mid_scan1<3>, gmid, T, st, P, B, a, na); break;
-            default: TGSF_LAUNCH(k_mid_scan1<4>, gmid, T, st, P, B, a, na); break;
+            case 1: TGSF_LAUNCH(k_mid_scan1<1>, gmid, T, ms, P, B, a, na); break;
+            case 2: TGSF_LAUNCH(k_mid_scan1<2>, gmid, T, ms, P, B, a, na); break;
+            case 3: TGSF_LAUNCH(k_mid_scan1<3>, gmid, T, ms, P, B, a, na); break;
+            default: TGSF_LAUNCH(k_mid_scan1<4>, gmid, T, ms, P, B, a, na); break;
             }
             a += na;
         }
+#if !defined(TGSF_EMUL)
+        if (c->hp && c->side_mid) { (void)hipEventRecord(c->ev_hp[1], ms); (void)hipStreamWaitEvent(st, c->ev_hp[1], 0); }
+#endif
     }
     STAGE_MARK();
     if (P.filter && A > 0) TGSF_LAUNCH(k_mid_resolve, blocks_for((uint64_t)n * A, 64), 64, st, P, B);

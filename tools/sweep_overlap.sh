@@ -1,11 +1,14 @@
 #!/bin/bash
-# Sweep of the co-scheduling knobs (priority stream for the HBM-bound stats kernels, their grid,
-# batches in flight).  Prints Gbases/s per combination.
+# Sweep of the co-scheduling knobs: a high-priority side stream for the HBM-bound stats kernels (TGSF_STATS_PRIO),
+# a lowest-priority side stream for the stats AND scan kernels so that the small latency-bound kernels of the
+# other batches are dispatched first (TGSF_BIG_LOWPRIO), the stats grid, batches in flight.
 out=${1:-gpurun_out/sweep_overlap.txt}
 : > $out
-for st in 2 3; do
-for pr in 0 1; do
-for sg in 768 512 256; do
-  v=$(TGSF_STATS_PRIO=$pr TGSF_STATS_GRID=$sg python bench.py --steps 16 --warmup 3 --streams $st --no-cpu-baseline 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(round(d["value"],1), round(d["ms_per_step"],3), {k:round(v,2) for k,v in d["roofline"]["timed_region_stage_ms"].items() if k in ("stats_raw","mid_scan","stats_clean")})')
-  echo "streams=$st prio=$pr stats_grid=$sg -> $v" >> $out
-done; done; done
+for st in 2 3 4; do
+for mode in none big_low stats_hi; do
+  case $mode in none) e="";; big_low) e="TGSF_BIG_LOWPRIO=1";; stats_hi) e="TGSF_STATS_PRIO=1";; esac
+  for rep in 1 2; do
+  v=$(env $e python bench.py --steps 24 --warmup 4 --streams $st --no-cpu-baseline 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(round(d["value"],1), round(d["ms_per_step"],3))')
+  echo "streams=$st mode=$mode -> $v" >> $out
+  done
+done; done
