@@ -1,16 +1,19 @@
 // tgsf_kernels.h -- the HIP kernels of the per-read filtering hot path (gfx950, wave64).
 //
-// Pipeline per batch (all on one stream, no host round trip):
+// Pipeline per batch (one stream plus an auxiliary one for the end kernels, no host round trip):
 //   k_prepare        lengths, per-read state, stats-tile histogram
-//   k_tile_scan/k_tile_scatter   counting sort of items by tile count (work list of k_stats)
-//   k_stats<raw>     CalcAvgQuality on every read: 100-bp bin tables + sumQ          [HBM-bound]
+//   k_tile_scan/k_tile_scatter/k_build_work   counting sort of items by tile count, work list of k_stats
+//   k_stats<raw>     CalcAvgQuality on every read: 100-bp bin tables (per batch) + sumQ   [HBM/VALU]
+//   k_fold_raw       batch tables -> job tables (raw; clean too when tallied by difference)
 //   k_gate_reads     mean-Q gate, rawDiffQual, middle-scan segment counts
-//   k_end_tables<raw>   Get_5p/3p_base_qual
-//   k_end_windows    GetEditDistance 5'/3' windows (edlib HW/PATH semantics)
+//   k_end_tables<raw>   Get_5p/3p_base_qual                                  (auxiliary stream)
+//   k_end_windows    GetEditDistance 5'/3' windows (edlib HW/PATH semantics) (auxiliary stream)
 //   k_scan_u32       exclusive scan (segment bases)
 //   k_mid_scan*      GetEditDistance middle: Myers infix scan, 1 lane = 1024 columns  [VALU-bound, dominant]
 //   k_mid_resolve    start locations + path of the first location + similarity gates
 //   k_regions<count|emit>   adapterMap: merge drop regions, keep regions, DropInfo
+//   k_repeat         GetKmerCount gate (-p/-k), only when asked for
+//   k_clean_plan     reads kept whole; which way the clean tables are cheaper to tally
 //   k_frag_prepare + sort + k_stats<clean> + k_gate_frags + k_end_tables<clean>
 //   k_finalize       tgsf_read_result / tgsf_fragment records
 //
