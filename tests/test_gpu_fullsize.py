@@ -1,4 +1,4 @@
-"""-m gpu: BASELINE.json-sized batches (C2 shape: 45-kb ONT reads, tens of thousands of them, resident in HBM)
+"""-m gpu: BASELINE.json-sized batches (C2 shape: 131 072 ONT reads of 45 kb = the batch bench.py times, resident in HBM)
 checked through size-independent properties -- the oracle cannot run that much -- plus an oracle spot check
 of a slice of the same batch:
   * the result does not depend on how the middle scan is cut into segments (TGSF_SEG_COLS),
@@ -13,7 +13,7 @@ import pytest
 from tgsfilter_amd import abi, capi, synth
 
 pytestmark = pytest.mark.gpu
-N_READS = 32768
+N_READS = 131072        # the batch bench.py times (5.9 Gbases)
 
 
 @pytest.fixture(scope="module")
