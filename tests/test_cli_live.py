@@ -54,6 +54,12 @@ def case(seed, n):
     adapters = None
     if rng.random() < 0.7:
         adapters = [synth.ONT_RAPID if kind == "ont" else synth.PACBIO_BLUNT]
+        if rng.random() < 0.35:                      # several adapters (passes of up to 4), one of them two words long
+            extra = [b"AATGTACTTCGTTCAGTTACGTATTGCT", b"GCAATACGTAACTGAACGAAGT",
+                     b"GGCGTCTGCTTGGGTGTTTAACCTTTTTGTCAGAGAGGTTCCAAGTCAGAGAGGTTCCTACGTTGCAATCGGATCCGATTACGGATCAAGT",
+                     b"CTTGCGGGCGGCGGACTCTCCTCTGAAGATAGAGCGACAGGCAAG"]
+            for i in rng.choice(len(extra), int(rng.integers(1, 3)), replace=False):
+                adapters.append(extra[int(i)])
     return reads, flags, adapters, fasta
 
 
