@@ -141,8 +141,8 @@ def cpu_baseline(torch, batch, flags, adapter_fa, sample_reads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reads", type=int, default=131072, help="reads per step per GPU")
     ap.add_argument("--mean-len", type=float, default=None)
     ap.add_argument("--min-repeat", type=int, default=0, help="-p of config C5 (with -k 11), for information")
