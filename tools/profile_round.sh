@@ -16,29 +16,47 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write --
 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_tcc -- $B > $O/pmc_tcc.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES --output-format csv -d $O/pmc_sq -- $B > $O/pmc_sq.log 2>&1
 python3 - "$O" "$tag" <<'PY'
-import csv, glob, collections, json, os, sys
+import csv, glob, collections, json, os, statistics, sys
 O, tag = sys.argv[1], sys.argv[2]
 def short(n): return n.split("(")[0].replace("void ", "").strip()
-# ---- kernel stats ----
+def real_dispatches(rows, grid_key):
+    """tgsf dispatches in dispatch order, without the miniature warm-up batch of tgsf_prepare_device
+    (its k_prepare runs one workgroup; it ends with its k_finalize)."""
+    rows = sorted((r for r in rows if "tgsf::" in r["Kernel_Name"]), key=lambda r: int(r["Dispatch_Id"]))
+    out, mini, seen = [], False, set()
+    for r in rows:
+        k = short(r["Kernel_Name"])
+        key = (r["Dispatch_Id"])
+        if k == "tgsf::k_prepare" and key not in seen:
+            mini = int(float(r[grid_key])) <= 256
+        seen.add(key)
+        if not mini and k != "tgsf::k_noop":
+            out.append(r)
+        if mini and k == "tgsf::k_finalize":
+            mini = False
+    return out
+# ---- kernel stats (from the per-dispatch trace) ----
 for run in ("kt_default", "kt_single"):
     rows = []
-    for fn in glob.glob(O + "/" + run + "/**/*kernel_stats.csv", recursive=True):
+    for fn in glob.glob(O + "/" + run + "/**/*kernel_trace.csv", recursive=True):
         rows += list(csv.DictReader(open(fn)))
-    rows = [r for r in rows if "tgsf::" in r["Name"]]
-    tot = sum(float(r["TotalDurationNs"]) for r in rows) or 1.0
+    by = collections.defaultdict(list)
+    for r in real_dispatches(rows, "Grid_Size_X"):
+        by[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    tot = sum(sum(v) for v in by.values()) or 1
     with open(O + "/%s_%s_kernel_stats.csv" % (tag, run), "w") as o:
         o.write("Name,Calls,TotalDurationNs,AverageNs,PctOfTgsf,MinNs,MaxNs\n")
-        for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
-            o.write('"%s",%s,%s,%s,%.2f,%s,%s\n' % (r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"],
-                                                  100 * float(r["TotalDurationNs"]) / tot, r["MinNs"], r["MaxNs"]))
+        for name, v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
+            o.write('"%s",%d,%d,%.3f,%.2f,%d,%d\n' % (name, len(v), sum(v), sum(v) / len(v), 100.0 * sum(v) / tot, min(v), max(v)))
 # ---- PMC ----
 def pmc(run):
-    agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(collections.Counter)
+    rows = []
     for fn in glob.glob(O + "/" + run + "/**/*counter_collection.csv", recursive=True):
-        for row in csv.DictReader(open(fn)):
-            k = short(row["Kernel_Name"])
-            if not k.startswith("tgsf::"): continue
-            agg[k][row["Counter_Name"]] += float(row["Counter_Value"]); n[k][row["Counter_Name"]] += 1
+        rows += list(csv.DictReader(open(fn)))
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(collections.Counter)
+    for row in real_dispatches(rows, "Grid_Size"):
+        k = short(row["Kernel_Name"])
+        agg[k][row["Counter_Name"]] += float(row["Counter_Value"]); n[k][row["Counter_Name"]] += 1
     return {k: {c: v / n[k][c] for c, v in d.items()} for k, d in agg.items()}
 fetch, write, tcc, sq = pmc("pmc_fetch"), pmc("pmc_write"), pmc("pmc_tcc"), pmc("pmc_sq")
 kernels = sorted(set(fetch) | set(write) | set(tcc), key=lambda k: -tcc.get(k, {}).get("TCC_EA0_RDREQ_sum", 0))
