@@ -199,7 +199,6 @@ def main():
                         head_trim=0, tail_trim=0, max_batch_bases=max_bases + 64, max_batch_reads=args.reads,
                         max_read_len=max_len, min_repeat=args.min_repeat, kmer=11)
     NS = max(1, args.streams)
-    capi.load().tgsf_prepare_device(local_rank)       # set-up, like context creation: runtime up, kernels loaded
     ctxs = [capi.Context(p, local_rank) for _ in range(NS)]
     ctx = ctxs[0]
     fcap = max_bases // 1000 + args.reads + 16
