@@ -11,6 +11,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -106,8 +107,8 @@ public:
         if (!f_) { std::cerr << "Error: Failed to open file: " << o.out_file << std::endl; return false; }
         if (gz_) {
             setvbuf(f_, nullptr, _IOFBF, 8 << 20);
-            memset(&z_, 0, sizeof z_);
-            if (deflateInit2(&z_, o.comp_level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+            level_ = o.comp_level;
+            gz_threads_ = std::max(1, std::min(o.n_thread, 32));
         } else {
             fflush(f_);
             fd_ = fileno(f_);
@@ -118,13 +119,13 @@ public:
     // writev straight from the input text -- no intermediate record string.
     void piece(const char* p, size_t n) {
         if (!n) return;
-        if (gz_) { rec_.append(p, n); return; }
+        if (gz_) { gzbuf_.append(p, n); return; }
         iov_.push_back({const_cast<char*>(p), n});
         if (iov_.size() >= 1000) flush_iov();
     }
     // small generated text (":<n>" suffixes, separators that are not in the input)
     void text(const std::string& t) {
-        if (gz_) { rec_ += t; return; }
+        if (gz_) { gzbuf_ += t; return; }
         if (pool_.size() + t.size() > pool_.capacity()) flush_iov();
         const size_t o0 = pool_.size();
         pool_ += t;
@@ -132,15 +133,52 @@ public:
     }
     void end_record() {
         if (!gz_) return;
-        deflateReset(&z_);
-        zbuf_.resize(deflateBound(&z_, (uLong)rec_.size()) + 64);
-        z_.next_in = (Bytef*)rec_.data(); z_.avail_in = (uInt)rec_.size();
-        z_.next_out = (Bytef*)zbuf_.data(); z_.avail_out = (uInt)zbuf_.size();
-        deflate(&z_, Z_FINISH);
-        fwrite(zbuf_.data(), 1, zbuf_.size() - z_.avail_out, f_);
-        rec_.clear();
+        ends_.push_back(gzbuf_.size());
+        if (gzbuf_.size() >= (256u << 20)) flush_gz();
+    }
+    // One gzip member per record, as the reference writes them (:786-812, compressed by its worker threads):
+    // the records gathered since the last flush are split into byte-balanced runs, each run is compressed
+    // member by member on its own thread, and the runs are written in order.
+    void flush_gz() {
+        if (ends_.empty()) return;
+        const size_t nrec = ends_.size();
+        const int T = (int)std::min<size_t>((size_t)gz_threads_, nrec);
+        std::vector<std::vector<char>> outv((size_t)T);
+        std::vector<size_t> cut((size_t)T + 1, nrec);
+        cut[0] = 0;
+        for (int t = 1; t < T; t++) {
+            const size_t target = gzbuf_.size() / (size_t)T * (size_t)t;
+            cut[(size_t)t] = (size_t)(std::lower_bound(ends_.begin(), ends_.end(), target) - ends_.begin());
+        }
+        std::atomic<bool> bad{false};
+        auto work = [&](int t) {
+            z_stream z;
+            memset(&z, 0, sizeof z);
+            if (deflateInit2(&z, level_, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad = true; return; }
+            std::vector<char>& o = outv[(size_t)t];
+            for (size_t r = cut[(size_t)t]; r < cut[(size_t)t + 1]; r++) {
+                const size_t b = r ? ends_[r - 1] : 0, n = ends_[r] - b;
+                deflateReset(&z);
+                const size_t at = o.size(), room = deflateBound(&z, (uLong)n) + 64;
+                o.resize(at + room);
+                z.next_in = (Bytef*)(gzbuf_.data() + b); z.avail_in = (uInt)n;
+                z.next_out = (Bytef*)(o.data() + at); z.avail_out = (uInt)room;
+                if (deflate(&z, Z_FINISH) != Z_STREAM_END) bad = true;
+                o.resize(at + room - z.avail_out);
+            }
+            deflateEnd(&z);
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; t++) th.emplace_back(work, t);
+        work(0);
+        for (std::thread& x : th) x.join();
+        if (bad) { std::cerr << "Error: compression failed" << std::endl; exit(-1); }
+        for (const auto& o : outv) if (!o.empty() && fwrite(o.data(), 1, o.size(), f_) != o.size()) { std::cerr << "Error: write failed" << std::endl; exit(-1); }
+        gzbuf_.clear();
+        ends_.clear();
     }
     void flush_iov() {
+        if (gz_) { flush_gz(); return; }
         size_t i = 0;
         while (i < iov_.size()) {
             ssize_t w = writev(fd_, &iov_[i], (int)std::min<size_t>(iov_.size() - i, 1000));
@@ -153,7 +191,7 @@ public:
         pool_.clear();
     }
     void close() {
-        if (gz_) deflateEnd(&z_); else flush_iov();
+        flush_iov();
         if (f_ && f_ != stdout) fclose(f_); else if (f_) fflush(f_);
         f_ = nullptr;
     }
@@ -162,9 +200,9 @@ private:
     FILE* f_ = nullptr;
     int fd_ = -1;
     bool gz_ = false;
-    z_stream z_;
-    std::vector<char> zbuf_;
-    std::string rec_, pool_;
+    int level_ = 6, gz_threads_ = 1;
+    std::string gzbuf_, pool_;              // gz: the records since the last flush, back to back
+    std::vector<size_t> ends_;              // ... and where each of them ends
     std::vector<iovec> iov_;
 };
 
