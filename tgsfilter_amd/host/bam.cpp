@@ -2,8 +2,11 @@
 
 #include <zlib.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstring>
+#include <thread>
 
 namespace host {
 
@@ -26,8 +29,70 @@ struct Nt16 {
     }
 };
 
+int worker_count()
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(hw ? hw - 1 : 1u, 16u));
+}
+
+template <class F>
+void parallel_for(size_t n, F f)            // f(begin, end) on contiguous ranges
+{
+    const size_t T = std::min<size_t>((size_t)worker_count(), std::max<size_t>(n, 1));
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < T; t++) th.emplace_back([=] { f(n * t / T, n * (t + 1) / T); });
+    f(0, n / T);
+    for (std::thread& x : th) x.join();
+}
+
+// BGZF: every gzip member carries its own size in a 'BC' extra subfield and its uncompressed size in the
+// trailer, so the members can be located without inflating and inflated independently.
+struct BgzfBlock { size_t at, payload, clen; uint32_t usize; size_t out; };
+bool bgzf_index(const unsigned char* p, size_t n, std::vector<BgzfBlock>& blocks)
+{
+    size_t at = 0, out = 0;
+    while (at < n) {
+        if (n - at < 18 || p[at] != 0x1f || p[at + 1] != 0x8b || p[at + 2] != 8 || !(p[at + 3] & 4)) return false;
+        const size_t xlen = (size_t)p[at + 10] | ((size_t)p[at + 11] << 8);
+        if (n - at < 12 + xlen + 8) return false;
+        size_t bsize = 0;
+        for (size_t x = at + 12; x + 4 <= at + 12 + xlen;) {
+            const size_t slen = (size_t)p[x + 2] | ((size_t)p[x + 3] << 8);
+            if (p[x] == 'B' && p[x + 1] == 'C' && slen == 2 && x + 6 <= at + 12 + xlen) bsize = ((size_t)p[x + 4] | ((size_t)p[x + 5] << 8)) + 1;
+            x += 4 + slen;
+        }
+        if (bsize < 12 + xlen + 8 || at + bsize > n) return false;
+        const unsigned char* tr = p + at + bsize - 8;
+        const uint32_t usize = (uint32_t)tr[4] | ((uint32_t)tr[5] << 8) | ((uint32_t)tr[6] << 16) | ((uint32_t)tr[7] << 24);
+        blocks.push_back({at, at + 12 + xlen, bsize - 12 - xlen - 8, usize, out});
+        out += usize;
+        at += bsize;
+    }
+    return true;
+}
+
 bool inflate_members(const char* data, size_t size, std::vector<char>& out, std::string& err)
 {
+    std::vector<BgzfBlock> blocks;
+    if (bgzf_index(reinterpret_cast<const unsigned char*>(data), size, blocks)) {
+        out.resize(blocks.empty() ? 0 : blocks.back().out + blocks.back().usize);
+        std::atomic<bool> bad{false};
+        parallel_for(blocks.size(), [&](size_t b0, size_t b1) {
+            z_stream z;
+            memset(&z, 0, sizeof z);
+            if (inflateInit2(&z, -15) != Z_OK) { bad = true; return; }
+            for (size_t b = b0; b < b1; b++) {
+                inflateReset(&z);
+                z.next_in = (Bytef*)(data + blocks[b].payload); z.avail_in = (uInt)blocks[b].clen;
+                z.next_out = (Bytef*)(out.data() + blocks[b].out); z.avail_out = blocks[b].usize;
+                const int rc = blocks[b].usize || blocks[b].clen > 2 ? inflate(&z, Z_FINISH) : Z_STREAM_END;
+                if (rc != Z_STREAM_END || z.avail_out != 0) bad = true;
+            }
+            inflateEnd(&z);
+        });
+        if (bad) { err = "error while decompressing"; return false; }
+        return true;
+    }
     z_stream z;
     memset(&z, 0, sizeof z);
     if (inflateInit2(&z, 15 + 16) != Z_OK) { err = "zlib init failed"; return false; }
@@ -45,7 +110,7 @@ bool inflate_members(const char* data, size_t size, std::vector<char>& out, std:
         out.insert(out.end(), chunk.data(), chunk.data() + (chunk.size() - z.avail_out));
         if (rc == Z_STREAM_END) {
             if (z.avail_in == 0 && left == 0) break;
-            inflateReset(&z);                                   // next BGZF block / gzip member
+            inflateReset(&z);                                   // next gzip member
         } else if (rc != Z_OK) { inflateEnd(&z); err = "error while decompressing"; return false; }
     }
     inflateEnd(&z);
@@ -80,7 +145,10 @@ bool decode_bam(const unsigned char* p, size_t n, std::vector<char>& text, std::
         if (!need((size_t)l_name + 4)) { err = "truncated BAM reference list"; return false; }
         at += (size_t)l_name + 4;
     }
-    std::string seq, qual;
+    // records are located first (each carries its size), then decoded side by side into their places
+    struct Rec { const unsigned char* r; uint32_t name_len, l_seq; size_t o_seq, o_qual, out; };
+    std::vector<Rec> recs;
+    size_t out = text.size();
     while (need(4)) {
         const uint32_t block = le32(p + at); at += 4;
         if (block < 32 || !need(block)) break;                   // sam_read1 < 0 ends the reference's loop silently
@@ -94,16 +162,33 @@ bool decode_bam(const unsigned char* p, size_t n, std::vector<char>& text, std::
         const char* name = reinterpret_cast<const char*>(r + o_name);
         const size_t nlen = strnlen(name, l_read_name);
         if (l_seq == 0) { err = "BAM record without a sequence: " + std::string(name, nlen); return false; }
-        seq.resize(l_seq); qual.resize(l_seq);
-        for (uint32_t i = 0; i < l_seq; i++) {
-            const unsigned char b = r[o_seq + (i >> 1)];
-            seq[i] = kBase[(i & 1) ? (b & 15) : (b >> 4)];
-            const unsigned char q = (unsigned char)(r[o_qual + i] + 33);
-            if (q == '\n') { err = "unsupported quality value in " + std::string(name, nlen); return false; }
-            qual[i] = (char)q;
-        }
-        emit(text, name, nlen, seq, qual);
+        recs.push_back({r, (uint32_t)nlen, l_seq, o_seq, o_qual, out});
+        out += 1 + nlen + 1 + l_seq + 3 + l_seq + 1;            // @name\n SEQ \n+\n QUAL \n
     }
+    text.resize(out);
+    std::atomic<int> bad_q{-1};
+    parallel_for(recs.size(), [&](size_t a, size_t b) {
+        for (size_t i = a; i < b; i++) {
+            const Rec& rc = recs[i];
+            char* o = text.data() + rc.out;
+            *o++ = '@';
+            memcpy(o, rc.r + 32, rc.name_len); o += rc.name_len;
+            *o++ = '\n';
+            const unsigned char* sq = rc.r + rc.o_seq;
+            for (uint32_t k = 0; k < rc.l_seq; k++) { const unsigned char by = sq[k >> 1]; o[k] = kBase[(k & 1) ? (by & 15) : (by >> 4)]; }
+            o += rc.l_seq;
+            *o++ = '\n'; *o++ = '+'; *o++ = '\n';
+            const unsigned char* ql = rc.r + rc.o_qual;
+            for (uint32_t k = 0; k < rc.l_seq; k++) {
+                const unsigned char q = (unsigned char)(ql[k] + 33);
+                if (q == '\n') bad_q = (int)i;
+                o[k] = (char)q;
+            }
+            o += rc.l_seq;
+            *o++ = '\n';
+        }
+    });
+    if (bad_q >= 0) { err = "unsupported quality value in " + std::string(reinterpret_cast<const char*>(recs[(size_t)bad_q].r + 32), recs[(size_t)bad_q].name_len); return false; }
     return true;
 }
 

@@ -37,24 +37,24 @@ public:
     // that many threads (finding the newlines is all the work of indexing long reads); the records are then
     // assembled from the lines exactly as without it.
     FastxReader(const char* data, size_t size, bool fastq, int scan_threads = 1)
-        : p_(data), end_(data + size), fastq_(fastq), scan_threads_(scan_threads_from_env(scan_threads)) {}
+        : p_(data), end_(data + size), scan_threads_(scan_threads_from_env(scan_threads)), fastq_(fastq) {}
     static int scan_threads_from_env(int dflt);   // TGSF_SCAN_THREADS overrides (test knob)
     bool next(Record& r);        // false: end of input (or first malformed record, after the reference's message)
 private:
     std::string_view line();     // "" at end of input (then done_ is set, like getLine :676-680)
     const char* next_newline(const char* from);   // first '\n' in [from, end_), or nullptr
     void scan_block(const char* from);
-    int scan_threads_ = 1;
-    std::vector<const char*> nl_;                 // newlines of the current block, ascending
-    size_t nl_at_ = 0;
-    const char* block_begin_ = nullptr;
-    const char* block_end_ = nullptr;
     bool next_fastq(Record& r);
     bool next_fasta(Record& r);
     const char* p_;
     const char* end_;
+    int scan_threads_ = 1;
     bool fastq_;
     bool done_ = false;
+    std::vector<const char*> nl_;                 // newlines of the current block, ascending
+    size_t nl_at_ = 0;
+    const char* block_begin_ = nullptr;
+    const char* block_end_ = nullptr;
 };
 
 }  // namespace host
