@@ -216,3 +216,22 @@ def test_cli_live_long_reads_emul(flags):
 def test_cli_live_long_reads_gpu(flags):
     reads = long_reads([2_000_000, 1_234_567, 700_001, 350_000, 6400 * 3, 6400 * 3 + 1, 6399, 6401, 102_400, 99])
     cli_check.compare_live(os.path.join(ROOT, "tgsfilter_amd", "bin", "tgsfilter"), REF, reads, flags, [synth.ONT_RAPID])
+
+
+@needs_ref
+def test_cli_live_bgzipped_fastq_emul():
+    """A bgzip'ed FASTQ (BGZF members, inflated side by side here) and a plain multi-member .gz."""
+    import gzip
+    import io
+    from tests import bamio
+    reads, flags, adapters, _ = case(321, 80)
+    buf = io.BytesIO()
+    for name, s, q in reads:
+        buf.write(b"@" + name + b"\n" + s + b"\n+\n" + q + b"\n")
+    text = buf.getvalue()
+    binary = os.path.join(ROOT, "tests", "emul", "tgsfilter_emul")
+    cli_check.compare_live(binary, REF, None, flags, adapters, in_fmt="fq.gz", raw_input=bamio.bgzf(text, block=0x3000))
+    half = len(text) // 2
+    cut = text.index(b"\n@", half) + 1
+    two = gzip.compress(text[:cut], 1) + gzip.compress(text[cut:], 6)
+    cli_check.compare_live(binary, REF, None, flags, adapters, in_fmt="fq.gz", raw_input=two)

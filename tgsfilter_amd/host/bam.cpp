@@ -230,6 +230,11 @@ bool decode_sam(const char* p, size_t n, std::vector<char>& text, std::string& e
 
 }  // namespace
 
+bool inflate_gzip(const char* data, size_t size, std::vector<char>& out, std::string& err)
+{
+    return inflate_members(data, size, out, err);
+}
+
 bool decode_sam_or_bam(const char* data, size_t size, std::vector<char>& text, std::string& err)
 {
     std::vector<char> plain;

@@ -17,4 +17,8 @@ namespace host {
 // Appends "@name\nSEQ\n+\nQUAL\n" per record to `text`.  Returns false (message in `err`) on malformed input.
 bool decode_sam_or_bam(const char* data, size_t size, std::vector<char>& text, std::string& err);
 
+// gzip -> bytes: any series of gzip members (zlib); BGZF members (bgzip, BAM) are located from their 'BC'
+// fields and inflated side by side on several threads.
+bool inflate_gzip(const char* data, size_t size, std::vector<char>& out, std::string& err);
+
 }  // namespace host

@@ -39,15 +39,14 @@ bool InputBytes::open(const std::string& path, bool sam_or_bam)
         data_ = owned_.data(); size_ = owned_.size();
         return true;
     }
-    if (ends_with(path, ".gz")) {
-        gzFile g = gzopen(path.c_str(), "rb");          // multi-member gzip is handled by zlib (:632-639)
-        if (!g) { std::cerr << "Failed to open file: " << path << std::endl; return false; }
-        gzbuffer(g, 1 << 20);
-        std::vector<char> chunk(8 << 20);
-        int n;
-        while ((n = gzread(g, chunk.data(), (unsigned)chunk.size())) > 0) owned_.insert(owned_.end(), chunk.data(), chunk.data() + n);
-        if (n < 0) { std::cerr << "Error: Error encountered while decompressing file: " << path << std::endl; exit(-1); }
-        gzclose(g);
+    if (ends_with(path, ".gz")) {                       // multi-member gzip is fine (:632-639); bgzip'ed files inflate in parallel
+        InputBytes raw;
+        if (!raw.open_plain(path)) { std::cerr << "Failed to open file: " << path << std::endl; return false; }
+        std::string err;
+        if (!inflate_gzip(raw.data(), raw.size(), owned_, err)) {
+            std::cerr << "Error: Error encountered while decompressing file: " << path << std::endl;
+            exit(-1);
+        }
         data_ = owned_.data(); size_ = owned_.size();
         return true;
     }
