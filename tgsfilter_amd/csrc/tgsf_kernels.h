@@ -495,6 +495,7 @@ TGSF_KERNEL TGSF_BOUNDS(256, 3) k_stats(DevParams P, DevBatch B)
         (void)a0; (void)aq; (void)nb;
 #endif
     };
+#if defined(TGSF_EMUL)
     auto mask_tail = [](uint4& v, uint32_t keep) {          // keep the first `keep` (1..15) bytes
         uint32_t* p = reinterpret_cast<uint32_t*>(&v);
 #pragma unroll
@@ -503,6 +504,7 @@ TGSF_KERNEL TGSF_BOUNDS(256, 3) k_stats(DevParams P, DevBatch B)
             p[d] &= kb >= 4 ? 0xFFFFFFFFu : (kb <= 0 ? 0u : ((1u << (8 * kb)) - 1u));
         }
     };
+#endif
     auto commit = [&](uint64_t a0, uint64_t aq, uint32_t nb) TGSF_INLINE_LAMBDA {
         const uint32_t shs = (uint32_t)(a0 & 15u), shq = (uint32_t)(aq & 15u);
         const uint32_t ends = shs + nb, endq = shq + nb;

@@ -532,6 +532,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     STAGE_MARK();
     // -- raw stats
     rt_stream ss = st;
+    (void)ss;
 #if !defined(TGSF_EMUL)
     if (c->hp) { ss = c->hp; (void)hipEventRecord(c->ev_hp[0], st); (void)hipStreamWaitEvent(ss, c->ev_hp[0], 0); }
 #endif
@@ -551,6 +552,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     if (c->profile) (void)hipEventRecord(evx[0], ax);
 #else
     rt_stream ax = st;
+    (void)ax;
 #endif
     if (P.bc_len > 0) TGSF_LAUNCH(k_end_tables<false>, grid_cap(128u), 64 * kEndWaves, ax, P, B);
 #if !defined(TGSF_EMUL)
@@ -573,6 +575,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
         const unsigned gseg = blocks_for(max_segs, T);
         const unsigned gmid = c->mid_grid ? std::min(gseg, c->mid_grid) : gseg;
         rt_stream ms = st;
+        (void)ms;
 #if !defined(TGSF_EMUL)
         if (c->hp && c->side_mid) { ms = c->hp; (void)hipEventRecord(c->ev_hp[0], st); (void)hipStreamWaitEvent(ms, c->ev_hp[0], 0); }
 #endif
