@@ -1066,7 +1066,8 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
 
     Hot st[AT];
     int lim[AT];              // best bottom-row value seen so far in the owned columns (k+1: none yet)
-    int lim3[AT];             // lim + 3: the every-4th-column test
+    int lim3[AT];             // the every-4th-column test: lim + 2 while nothing is recorded yet (only a value
+                              // BELOW lim counts then), lim + 3 afterwards (ties count too)
     int ntie[AT];             // buffered columns attaining it
     int wu = 0;
 #pragma unroll
@@ -1075,7 +1076,7 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
         const bool on = j < na && ML >= P.Q[a] && P.k_mid[a] >= 0;    // :1237 tsmLen >= qLen
         hot_init(st[j], j < na ? P.Q[a] : 1);
         lim[j] = on ? P.k_mid[a] + 1 : -1000;
-        lim3[j] = lim[j] + 3;
+        lim3[j] = lim[j] + 2;
         ntie[j] = 0;
         if (on) { int w = P.Q[a] + P.k_mid[a]; wu = w > wu ? w : wu; }
     }
