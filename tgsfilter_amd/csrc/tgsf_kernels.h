@@ -1082,7 +1082,12 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
     }
     int c = c0 - wu;
     if (c < 0) c = 0;
-    else if (c > 0) { int al = c - (int)((amid + (uint64_t)c) & 15u); c = al > 0 ? al : c; }  // warm-up starts 16-B aligned
+    else if (c > 0) {
+        // The 16-column body needs a 16-byte aligned start.  A few columns short of the boundary above are
+        // cheaper to take one by one; otherwise the warm-up is lengthened down to the boundary below.
+        const int mis = (int)((amid + (uint64_t)c) & 15u);
+        if (mis && 16 - mis > 7) { const int al = c - mis; c = al > 0 ? al : c; }
+    }
 
     auto step_all = [&](uint32_t byte) {
 #pragma unroll
