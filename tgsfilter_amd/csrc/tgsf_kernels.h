@@ -1138,7 +1138,7 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
             bool any = false;
 #pragma unroll
             for (int j = 0; j < AT; j++) any |= (popc64_acc(st[j].p, 0) <= popc64_acc(st[j].m, lim3[j]));
-            if (any && own) {
+            if (__builtin_expect(any && own, 0)) {          // a few % of the tests: keep this code out of the hot loop
 #pragma unroll
                 for (int j = 0; j < AT; j++) {
                     const int s4j = hot_score(st[j]);
