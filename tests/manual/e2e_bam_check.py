@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Wall time with an unaligned BAM input against the reference, same box: tools/e2e_bam_check.py [n_reads]"""
+"""Wall time with an unaligned BAM input against the reference, same box: tests/manual/e2e_bam_check.py [n_reads]"""
 import os, subprocess, sys, tempfile, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tests import bamio  # noqa: E402
 from tgsfilter_amd import synth  # noqa: E402

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """End-to-end wall time of the command line (FASTQ file in, FASTQ file out, tmpfs) against the reference
-binary on the same box: tools/e2e_cli_bench.py [n_reads] [mean_len].  Also checks that both wrote the
+binary on the same box: tests/manual/e2e_cli_bench.py [n_reads] [mean_len].  Also checks that both wrote the
 same multiset of records (the reference's order is nondeterministic with -t > 1)."""
 import hashlib
 import os
@@ -11,7 +11,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tgsfilter_amd import synth  # noqa: E402
 

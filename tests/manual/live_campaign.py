@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """One-off campaign: many seeds of tests/test_cli_live.py's generators, the real CLI against the reference binary
-(both must be built).  tools/live_campaign.py <first> <last> <reads> [binary]"""
+(both must be built).  tests/manual/live_campaign.py <first> <last> <reads> [binary]"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tests import cli_check  # noqa: E402
 from tests.test_cli_live import REF, case, case2  # noqa: E402

@@ -18,7 +18,7 @@ def case(seed, n):
     rng = np.random.default_rng(seed)
     kind = "ont" if rng.random() < 0.6 else "hifi"
     fasta = rng.random() < 0.15
-    scale = float(os.environ.get("TGSF_LIVE_LEN_SCALE", "1"))          # campaigns with long reads (tools/live_campaign.py)
+    scale = float(os.environ.get("TGSF_LIVE_LEN_SCALE", "1"))          # campaigns with long reads (tests/manual/live_campaign.py)
     reads = synth.make_reads(int(rng.integers(1, 1 << 30)), n, kind, mean_len=scale * float(rng.choice([1500, 3000, 5000])),
                              zoo=bool(rng.random() < 0.7), pmid=float(rng.choice([0.0, 0.05, 0.2])))
     flags = ["-x", kind, "-l", str(int(rng.choice([500, 1000, 2000])))]
