@@ -157,6 +157,10 @@ def main():
                     help="batches in flight per GPU (one context + one HIP stream each); >1 overlaps the "
                          "HBM-bound stats kernels of one batch with the VALU-bound adapter scan of another")
     args = ap.parse_args()
+    # stdout carries exactly one line, the result: whatever libraries print there meanwhile goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -369,7 +373,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(torch, batches[0], flags,
                                                b">ad\n" + wl_adapters[0] + b"\n", args.cpu_sample_reads)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 
