@@ -1,6 +1,8 @@
 #!/bin/bash
 out=gpurun_out/sweep_seg.txt; : > $out
-for sc in 512 1024 1536 2048 3072 4096 8192; do
-  v=$(TGSF_SEG_COLS=$sc python bench.py --steps 16 --warmup 3 --streams 3 --no-cpu-baseline 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(round(d["value"],1), round(d["ms_per_step"],3), round(d["roofline"]["stage_ms_per_step"]["mid_scan"],3))')
+for sc in 768 1024 1280 1536 2048; do
+  for rep in 1 2; do
+  v=$(TGSF_SEG_COLS=$sc python bench.py --no-cpu-baseline 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(round(d["value"],1), round(d["ms_per_step"],3), round(d["roofline"]["stage_ms_per_step"]["mid_scan"],3))')
   echo "seg_cols=$sc -> $v" >> $out
+  done
 done
