@@ -107,7 +107,7 @@ def test_cli_live_emul(seed):
 
 @needs_ref
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(300, 340))
+@pytest.mark.parametrize("seed", range(300, 324))
 def test_cli_live_gpu(seed):
     reads, flags, adapters, fasta = case(seed, 400)
     cli_check.compare_live(os.path.join(ROOT, "tgsfilter_amd", "bin", "tgsfilter"), REF, reads, flags, adapters, fasta)
@@ -123,7 +123,7 @@ def test_cli_live_formats_emul(seed):
 
 @needs_ref
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(700, 740))
+@pytest.mark.parametrize("seed", range(700, 724))
 def test_cli_live_formats_gpu(seed):
     reads, flags, adapters, in_fmt, out_name = case2(seed, 300)
     cli_check.compare_live(os.path.join(ROOT, "tgsfilter_amd", "bin", "tgsfilter"), REF, reads, flags, adapters,
@@ -173,7 +173,7 @@ def test_cli_live_unusual_text_emul(seed):
 
 @needs_ref
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(6000, 6030))
+@pytest.mark.parametrize("seed", range(6000, 6016))
 def test_cli_live_unusual_text_gpu(seed):
     raw, flags, adapters = case3(seed, 300)
     cli_check.compare_live(os.path.join(ROOT, "tgsfilter_amd", "bin", "tgsfilter"), REF, None, flags, adapters, raw_input=raw)
