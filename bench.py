@@ -1,23 +1,32 @@
 #!/usr/bin/env python3
-"""bench.py -- filtered Gbases/s of the per-read filtering hot path on N x MI355X.
+"""bench.py -- filtered Gbases/s of TGSFilter's per-read filtering path on N x MI355X.
 
-Contract (see the driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is
-launched by torch.distributed.run, one rank per GPU.  A step = one pass of the hot path over one
-batch of synthetic ONT reads (config C2 of BASELINE.json: lognormal lengths, mean 45 kb,
-`-x ont -l 1000 -q 10`, ONT rapid adapter + reverse complement) that is already resident in HBM.
-Reads shard across ranks with no data-path collective; the only exchange is one all-reduce
-(RCCL) of the tally vector at the end of the job, inside the timed region.
+Contract (see the driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
+torch.distributed.run, one rank per GPU.
 
-Rank 0 prints ONE JSON line with the throughput, the roofline of the dominant kernel (middle
-adapter scan, timed with HIP events on the launch stream inside the library) and -- at N = 1 --
-the reference's own CPU path (oracle/_ref/tgsfilter_ref -t <cores>) timed on this box's host cores
-on a bounded sample of the same workload.
+HEADLINE (`value`): the END-TO-END metric of BASELINE.json / SURVEY 8(d) -- input bases / wall seconds of the
+whole command line (tgsfilter_amd/bin/tgsfilter) on a FASTQ text file of config C2's shape held on tmpfs:
+process start, library load, index, pre-pass, H2D, kernels, D2H of reads and fragments, formatting, output file
+written and closed, report written.  A step = one whole run of the command line over that file; W warm-up runs,
+K timed runs.  The reference binary (oracle/_ref/tgsfilter_ref -t <cores>) runs on the SAME file with the SAME
+flags and the SAME sink in the same bench run: that is `cpu_baseline`; the two output files are compared as
+multisets of records (the reference's order is nondeterministic with -t > 1) and the INFO counters line by line.
+Both sinks SURVEY 8(d) allows are measured (a tmpfs file -- the headline -- and /dev/null), see `e2e`.
+
+`kernel_path`: the device-resident figure (batches already in HBM, tgsf_submit_device), kept separate; the
+`roofline` block is measured on it with HIP events on the launch stream inside the library.
+
+N > 1: the end-to-end runs use `--devices 0..N-1` (rank 0 drives the command line; one feeder set per GPU, tallies
+merged once); the kernel path runs the FIXED C4 job (31 batches = 4.06 M reads) dealt over the ranks -- strong
+scaling -- with ONE all-reduce (RCCL) of the tally vector inside the timed region.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -29,8 +38,130 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+CLI = os.path.join(ROOT, "tgsfilter_amd", "bin", "tgsfilter")
+REF = os.path.join(ROOT, "oracle", "_ref", "tgsfilter_ref")
+FQ_MULTISET = os.path.join(ROOT, "tools", "fq_multiset")
 
 
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def kernel_source_hash():
+    """Identifies the kernel sources a profile was taken with (profiles/traffic.json is stamped with it)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "tgsfilter_amd", "csrc")
+    for fn in ("tgsf_core.h", "tgsf_dev.h", "tgsf_kernels.h", "tgsf_lib.hip"):
+        h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# end-to-end leg: the command line on a FASTQ file (no GPU is touched by THIS process before it is over)
+# ---------------------------------------------------------------------------------------------------------
+def info_lines(stderr_text):
+    # the set of -a adapters is an unordered_set in the reference: its listing order is not part of the comparison
+    lines = [l for l in stderr_text.splitlines() if l.startswith("INFO: ") and "written to" not in l]
+    ads = sorted(l.split(":", 2)[2] for l in lines if l.startswith("INFO: input adapter"))
+    return ads + [l for l in lines if not l.startswith("INFO: input adapter")]
+
+
+def multiset(path):
+    if not os.path.exists(FQ_MULTISET):
+        subprocess.run(["gcc", "-O2", "-o", FQ_MULTISET, FQ_MULTISET + ".c"], check=True)
+    return subprocess.run([FQ_MULTISET, path], capture_output=True, check=True).stdout.decode().split()
+
+
+def run_cmd(cmd, env=None):
+    t0 = time.perf_counter()
+    p = subprocess.run(cmd, capture_output=True, env=env)
+    dt = time.perf_counter() - t0
+    if p.returncode != 0:
+        raise SystemExit("command failed (%d): %s\n%s" % (p.returncode, " ".join(cmd), p.stderr.decode()[-3000:]))
+    return dt, p.stderr.decode()
+
+
+def e2e_leg(args, n_gpus):
+    from tgsfilter_amd import synth
+    if not os.path.exists(CLI):
+        raise SystemExit("bench.py: %s is missing -- run __graft_entry__.build() (there is no fallback path)" % CLI)
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    n_reads = args.e2e_reads
+    need = n_reads * 92_000 * 2.3                     # input + two outputs
+    free = shutil.disk_usage(shm or tempfile.gettempdir()).free
+    if need > 0.6 * free:
+        n_reads = max(2000, int(n_reads * 0.6 * free / need))
+        log("bench: only %.0f GB free on the staging file system: end-to-end file reduced to %d reads" % (free / 1e9, n_reads))
+    td = tempfile.mkdtemp(prefix="tgsf_bench_", dir=shm)
+    res = {}
+    try:
+        fq = os.path.join(td, "c2.fq")
+        t0 = time.perf_counter()
+        bases, nbytes = synth.write_ont_fastq(fq, n_reads, seed=2)
+        log("bench: %d reads / %.2f Gbases / %.2f GB of FASTQ text written to %s in %.1f s"
+            % (n_reads, bases / 1e9, nbytes / 1e9, fq, time.perf_counter() - t0))
+        fa = os.path.join(td, "rapid.fa")
+        open(fa, "wb").write(b">rapid\n" + synth.ONT_RAPID + b"\n")
+        flags = ["-x", "ont", "-l", "1000", "-q", "10", "-5", "0", "-3", "0", "-a", fa]
+        cores = max(1, min((os.cpu_count() or 2) - 1, 32))      # the reference clamps -t to min(hw-1, 32), :488-499
+        devs = ",".join(str(d) for d in range(n_gpus))
+        null_out = os.path.join(td, "null.fq")                  # the suffix decides the format: a symlink to /dev/null
+        os.symlink("/dev/null", null_out)
+        env = dict(os.environ, TGSF_TIMING="1")
+
+        def ours(out):
+            if os.path.isfile(out) and not os.path.islink(out):
+                os.remove(out)             # dropping the previous run's GBs of tmpfs pages is not part of a run
+            return run_cmd([CLI, "-i", fq, "-o", out, "-t", str(cores), "--devices", devs] + flags, env)
+
+        def theirs(out):
+            if os.path.isfile(out) and not os.path.islink(out):
+                os.remove(out)
+            return run_cmd([REF, "-i", fq, "-o", out, "-t", str(cores)] + flags)
+
+        sinks = {}
+        for sink, out_o, out_r, k in (("tmpfs_file", os.path.join(td, "ours.fq"), os.path.join(td, "ref.fq"), args.steps),
+                                      ("dev_null", null_out, null_out, min(args.steps, 3))):
+            for _ in range(args.warmup):
+                ours(out_o)
+            walls, err = [], ""
+            for _ in range(k):
+                dt, err = ours(out_o)
+                walls.append(dt)
+            s = {"runs": k, "wall_s": walls, "wall_s_mean": sum(walls) / len(walls), "gbases_per_s": bases * len(walls) / sum(walls) / 1e9,
+                 "timing": [l for l in err.splitlines() if l.startswith("TIMING")][-1:]}
+            s["info"] = info_lines(err)
+            if os.path.exists(REF) and not args.no_cpu_baseline:
+                dt, rerr = theirs(out_r)
+                s["reference_wall_s"] = dt
+                s["reference_gbases_per_s"] = bases / dt / 1e9
+                s["speedup_vs_reference"] = s["gbases_per_s"] / (bases / dt / 1e9)
+                s["same_counters"] = info_lines(rerr) == s["info"]
+                if not s["same_counters"]:
+                    raise SystemExit("bench: INFO counters differ from the reference's:\n%s\n---\n%s" % ("\n".join(s["info"]), "\n".join(info_lines(rerr))))
+                if sink == "tmpfs_file":
+                    a, b = multiset(out_o), multiset(out_r)
+                    s["same_output_multiset"] = a == b
+                    s["output_records"], s["output_bytes"] = int(a[0]), int(a[3])
+                    if a != b:
+                        raise SystemExit("bench: output differs from the reference's (records sum xor bytes): %s vs %s" % (a, b))
+            del s["info"]
+            sinks[sink] = s
+            log("bench: e2e %s: %s" % (sink, json.dumps({k2: v for k2, v in s.items() if k2 != "timing"})))
+            for o_ in (out_o, out_r):
+                if os.path.isfile(o_) and not os.path.islink(o_):
+                    os.remove(o_)
+        res = {"reads": n_reads, "bases": bases, "fastq_bytes": nbytes, "flags": " ".join(flags[:-1]) + " rapid.fa", "threads": cores,
+               "devices": devs, "staging": "synthetic FASTQ text written to tmpfs (%s) by tgsfilter_amd/synth.write_ont_fastq before timing; "
+               "read by both programs through the page cache" % (shm or "tmp"), "sinks": sinks}
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------------
+# kernel path: batches resident in HBM
+# ---------------------------------------------------------------------------------------------------------
 def gen_batch(torch, device, n_reads, seed, mean_len, max_len, workload="ont"):
     """Synthetic C2 (ont) / C3 (hifi) batch built directly in HBM (generation is outside every timed region)."""
     from tgsfilter_amd import synth
@@ -91,130 +222,72 @@ def gen_batch(torch, device, n_reads, seed, mean_len, max_len, workload="ont"):
                 n=n_reads, n_bytes=total, bases=int(lens.sum()), h_lens=lens, h_offsets=offsets)
 
 
-def cpu_baseline(torch, batch, flags, adapter_fa, sample_reads):
-    """The reference's own CPU path on this box's host cores, on a bounded sample of the batch."""
-    ref = os.path.join(ROOT, "oracle", "_ref", "tgsfilter_ref")
-    n = min(sample_reads, batch["n"])
-    lens, offs = batch["h_lens"][:n], batch["h_offsets"][:n + 1]
-    end = int(offs[n])
-    seq = batch["seq"][:end].cpu().numpy()
-    qual = batch["qual"][:end].cpu().numpy()
-    bases = int(lens.sum())
-    cores = max(1, min((os.cpu_count() or 2) - 1, 32))     # the reference clamps -t to min(hw-1, 32)
-    if os.path.exists(ref):
-        tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
-        with tempfile.TemporaryDirectory(dir=tmpdir) as td:
-            fq = os.path.join(td, "sample.fq")
-            with open(fq, "wb") as f:
-                for i in range(n):
-                    o, L = int(offs[i]), int(lens[i])
-                    f.write(b"@r%d\n" % i)
-                    f.write(seq[o:o + L].tobytes())
-                    f.write(b"\n+\n")
-                    f.write(qual[o:o + L].tobytes())
-                    f.write(b"\n")
-            fa = os.path.join(td, "adapters.fa")
-            open(fa, "wb").write(adapter_fa)
-            cmd = [ref, "-i", fq, "-o", os.path.join(td, "out.fq"), "-a", fa, "-t", str(cores)] + flags.split()
-            t0 = time.perf_counter()
-            p = subprocess.run(cmd, capture_output=True)
-            dt = time.perf_counter() - t0
-        if p.returncode == 0:
-            return {"value": bases / dt / 1e9, "unit": "Gbases/s", "cores": cores, "kind": "reference",
-                    "sample": "%d reads / %.1f Mbases of the step-0 batch as uncompressed FASTQ on tmpfs, "
-                              "tgsfilter_ref -t %d %s, wall %.2f s" % (n, bases / 1e6, cores, flags, dt)}
-    # no reference binary on this box: the single-threaded C restatement on a smaller sample
+def oracle_slice_check(torch, batch, p_kwargs, workload, reads_rec, frags_rec, m=256, seed=11):
+    """A random slice of the batch through the oracle (the checker, never the thing measured): the per-read records
+    and the fragments the HIP path produced for those reads must be identical."""
     from oracle import orc
-    from tgsfilter_amd import abi, synth
-    m = min(n, 64)
-    end = int(offs[m])
-    p = abi.make_params("ont", adapters=[synth.ONT_RAPID, synth.ONT_RAPID_RC], min_q=10.0,
-                        max_read_len=int(lens[:m].max()))
-    t0 = time.perf_counter()
-    orc.filter_batch(p, seq[:end], qual[:end], offs[:m].astype(np.uint64), lens[:m].astype(np.uint32))
-    dt = time.perf_counter() - t0
-    b = int(lens[:m].sum())
-    return {"value": b / dt / 1e9, "unit": "Gbases/s", "cores": 1, "kind": "port",
-            "sample": "%d reads / %.1f Mbases, oracle/liborc.so (plain DP restatement), wall %.2f s" % (m, b / 1e6, dt)}
+    from tgsfilter_amd import abi
+    rng = np.random.default_rng(seed)
+    pick = np.sort(rng.choice(batch["n"], size=min(m, batch["n"]), replace=False))
+    lens = batch["h_lens"][pick]
+    offs = np.zeros(len(pick) + 1, dtype=np.int64)
+    np.cumsum((lens + 15) // 16 * 16, out=offs[1:])
+    seq = np.zeros(int(offs[-1]), dtype=np.uint8)
+    qual = np.zeros(int(offs[-1]), dtype=np.uint8)
+    for j, i in enumerate(pick):
+        o, L = int(batch["h_offsets"][i]), int(lens[j])
+        seq[offs[j]:offs[j] + L] = batch["seq"][o:o + L].cpu().numpy()
+        qual[offs[j]:offs[j] + L] = batch["qual"][o:o + L].cpu().numpy()
+    p = abi.make_params(workload, max_read_len=int(lens.max()), **p_kwargs)
+    er, ef, _ = orc.filter_batch(p, seq, qual, offs[:-1].astype(np.uint64), lens.astype(np.uint32))
+    got = reads_rec[pick]
+    for name in ("sum_q", "flags", "n_frags", "trimmed"):
+        assert np.array_equal(got[name], er[name]), "oracle slice: read field %s differs" % name
+    k = 0
+    for j in range(len(pick)):
+        fb, nf = int(got["frag_begin"][j]), int(got["n_frags"][j])
+        for name in ("start", "len", "flags", "sum_q"):
+            assert np.array_equal(frags_rec[name][fb:fb + nf], ef[name][k:k + nf]), "oracle slice: fragment field %s differs" % name
+        k += nf
+    return len(pick), int(lens.sum())
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--reads", type=int, default=131072, help="reads per step per GPU")
-    ap.add_argument("--mean-len", type=float, default=None)
-    ap.add_argument("--min-repeat", type=int, default=0, help="-p of config C5 (with -k 11), for information")
-    ap.add_argument("--workload", choices=["ont", "hifi"], default="ont",
-                    help="ont = config C2 (the headline line); hifi = config C3 shape, for information")
-    ap.add_argument("--max-len", type=int, default=2_000_000)
-    ap.add_argument("--cpu-sample-reads", type=int, default=24000)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for validation)")
-    ap.add_argument("--share-gpu", action="store_true", help="validation on a 1-GPU box: every rank uses device 0")
-    ap.add_argument("--streams", type=int, default=3,
-                    help="batches in flight per GPU (one context + one HIP stream each); >1 overlaps the "
-                         "HBM-bound stats kernels of one batch with the VALU-bound adapter scan of another")
-    args = ap.parse_args()
-    # stdout carries exactly one line, the result: whatever libraries print there meanwhile goes to stderr
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
-
-    import torch
-    import torch.distributed as dist
+def kernel_leg(args, torch, dist, world, rank, local_rank, device, xdev, host_group):
     from tgsfilter_amd import abi, capi, synth
     from tgsfilter_amd import dist as tdist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    if args.share_gpu:                      # validation on a 1-GPU box: all ranks on device 0, gloo for the exchange
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    xdev = device if args.backend == "nccl" else torch.device("cpu")       # where the exchanged tensors live
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
-
     hifi = args.workload == "hifi"
-    if args.mean_len is None:
-        args.mean_len = 18000.0 if hifi else 45000.0
+    mean_len = args.mean_len or (18000.0 if hifi else 45000.0)
     flags = "-x hifi -l 1000 -q 20 -5 0 -3 0" if hifi else "-x ont -l 1000 -q 10 -5 0 -3 0"
     wl_adapters = [synth.PACBIO_BLUNT, synth.PACBIO_BLUNT_RC] if hifi else [synth.ONT_RAPID, synth.ONT_RAPID_RC]
-    batches = [gen_batch(torch, device, args.reads, 1000 * rank + b + 1, args.mean_len, args.max_len, args.workload)
-               for b in range(2)]
+    # every rank builds the SAME two batches (same seeds): the fixed job is steps x these batches, dealt over ranks
+    batches = [gen_batch(torch, device, args.reads, b + 1, mean_len, args.max_len, args.workload) for b in range(2)]
     max_bases = max(b["bases"] for b in batches)
     max_len = max(int(b["h_lens"].max()) for b in batches)
-    if world > 1:
-        # the tally vector is sized by max_read_len (rows of the per-position tables): every rank must build
-        # the same layout, or the one all-reduce of the job would mix up words
-        mm = torch.tensor([max_bases, max_len], dtype=torch.int64, device=xdev)
-        dist.all_reduce(mm, op=dist.ReduceOp.MAX)
-        max_bases, max_len = int(mm[0].item()), int(mm[1].item())
-    p = abi.make_params(args.workload, adapters=wl_adapters, min_len=1000, min_q=20.0 if hifi else 10.0,
-                        head_trim=0, tail_trim=0, max_batch_bases=max_bases + 64, max_batch_reads=args.reads,
-                        max_read_len=max_len, min_repeat=args.min_repeat, kmer=11)
+    p_kwargs = dict(adapters=wl_adapters, min_len=1000, min_q=20.0 if hifi else 10.0, head_trim=0, tail_trim=0,
+                    min_repeat=args.min_repeat, kmer=args.kmer)
+    p = abi.make_params(args.workload, max_batch_bases=max_bases + 64, max_batch_reads=args.reads, max_read_len=max_len, **p_kwargs)
     NS = max(1, args.streams)
     ctxs = [capi.Context(p, local_rank) for _ in range(NS)]
-    ctx = ctxs[0]
+    if world > 1:
+        tdist.check_layout(ctxs[0].ctr_words)            # setup: same tally layout on every rank
     fcap = max_bases // 1000 + args.reads + 16
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=device) for _ in range(NS - 1)]
+    # every context gets a stream of its own (never torch's null stream: the library's streams are non-blocking,
+    # nothing orders the null stream against them)
+    streams = [torch.cuda.Stream(device=device) for _ in range(NS)]
     outs = [dict(reads=torch.empty(args.reads * 32, dtype=torch.uint8, device=device),
                  frags=torch.empty(fcap * 24, dtype=torch.uint8, device=device),
                  nfr=torch.zeros(4, dtype=torch.int32, device=device),
-                 h_reads=torch.empty(args.reads * 32, dtype=torch.uint8).pin_memory()) for _ in range(NS)]
+                 h_reads=torch.empty(args.reads * 32, dtype=torch.uint8).pin_memory(),
+                 h_frags=torch.empty(fcap * 24, dtype=torch.uint8).pin_memory()) for _ in range(NS)]
+    # fixed job: K steps in all; rank r takes steps r, r + world, ...
+    K = args.kernel_steps if world == 1 else args.job_steps
+    W = args.kernel_warmup
+    my_steps = list(range(rank, K, world))
+    state = {"NS": NS}
 
-    def step(i):
+    def step(i, j):
         b = batches[i % 2]
-        k = i % NS if NS > 1 else 0
+        k = j % state["NS"]
         o = outs[k]
         with torch.cuda.stream(streams[k]):
             ctxs[k].submit_device(b["seq"].data_ptr(), b["qual"].data_ptr(), b["offsets"].data_ptr(),
@@ -223,57 +296,51 @@ def main():
             o["h_reads"].copy_(o["reads"], non_blocking=True)   # the per-read records go back to the host every step
         return b["bases"], b["n"]
 
-    ctr_words = ctx.ctr_words
-
-    def all_wait():
-        for c in ctxs:
-            c.wait()
-
-    def all_counters():
-        return tdist.merge_counters([c.counters() for c in ctxs])
+    def sync_streams():
+        for s in streams:
+            s.synchronize()
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            dist.barrier(group=host_group)
 
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    all_wait()
+    for i in range(W):
+        step(i, i)
+    sync_streams()
     for c in ctxs:
+        c.wait()
         c.reset_counters()
         c.profile(True)
-    barrier()
     torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
     bases = reads = 0
-    for i in range(args.steps):
-        b, n = step(i)
+    for j, i in enumerate(my_steps):
+        b, n = step(i, j)
         bases += b
         reads += n
+    sync_streams()                                   # every submit stream is idle before the tallies are read
+    for c in ctxs:
+        c.wait()
+    total_ctr = tdist.merge_counters([c.counters() for c in ctxs])
     if world > 1:
-        # the job's only exchange: sum the tally vector over ranks (the 4 "rows used" words are maxima)
-        all_wait()
-        total_ctr = tdist.allreduce_counters(all_counters(), device=xdev if args.backend == "nccl" else None)
+        # the job's only exchange: ONE sum all-reduce of the tally vector (RCCL over xGMI)
+        total_ctr = tdist.allreduce_counters(total_ctr, rank, world, device=xdev)
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    all_wait()
-    if world == 1:
-        total_ctr = all_counters()
 
-    # max over ranks of the elapsed time; sum of the bases
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=xdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=host_group)
         dt = float(tt.item())
-        bb = torch.tensor([bases, reads], dtype=torch.int64, device=xdev)
-        dist.all_reduce(bb, op=dist.ReduceOp.SUM)
+        bb = torch.tensor([bases, reads], dtype=torch.int64)
+        dist.all_reduce(bb, op=dist.ReduceOp.SUM, group=host_group)
         bases_all, reads_all = int(bb[0].item()), int(bb[1].item())
     else:
         bases_all, reads_all = bases, reads
 
-    # sanity: every read was classified exactly once (low-Q, or one of the 8 adapter classes)
+    # sanity: every read was classified exactly once (low-Q, or one of the 8 adapter classes) ...
     drop = total_ctr[:17]
     assert int(drop[0]) + int(drop[2:10].sum()) == reads_all, (drop, reads_all)
 
@@ -286,96 +353,193 @@ def main():
                 st[k] = st.get(k, 0.0) + v
         return {k: v / max(nbat, 1) for k, v in st.items() if v > 0}, nbat
 
-    # kernel durations inside the timed region (with --streams > 1 kernels of different batches
-    # share the GPU, so a kernel's elapsed time is longer than its cost) ...
     timed_stage_ms, _ = harvest()
-    # ... and the same kernels with the GPU to themselves: a few more steps on ONE stream, timed with
-    # the same HIP events on the launch stream.  The roofline figures use these exclusive durations.
+    # the same kernels with the GPU to themselves: a few more steps on ONE stream, same HIP events
     for c in ctxs:
         c.profile(False)
-    NS_saved, nprof = NS, 4
+    nprof = 4
     ctxs[0].profile(True)
-    NS = 1
+    state["NS"] = 1
     for i in range(nprof):
-        step(i)
-    torch.cuda.synchronize()
+        step(i, 0)
+    sync_streams()
     ctxs[0].wait()
     excl_stage_ms, _ = harvest()
-    NS = NS_saved
+    state["NS"] = NS
+    # ... and a random slice of batch 0 agrees with the oracle, record for record
+    oracle_note = None
+    if rank == 0 and not args.no_oracle_check and args.min_repeat == 0:
+        with torch.cuda.stream(streams[0]):
+            step(0, 0)
+            outs[0]["h_frags"].copy_(outs[0]["frags"], non_blocking=True)
+        streams[0].synchronize()
+        ctxs[0].wait()
+        rr = outs[0]["h_reads"].numpy().view(abi.READ_RESULT_DTYPE)
+        ff = outs[0]["h_frags"].numpy().view(abi.FRAGMENT_DTYPE)
+        t1 = time.perf_counter()
+        n_chk, b_chk = oracle_slice_check(torch, batches[0], p_kwargs, args.workload, rr, ff)
+        oracle_note = "%d random reads (%.1f Mbases) of batch 0: per-read records and fragments identical to oracle/ (%.1f s)" % (
+            n_chk, b_chk / 1e6, time.perf_counter() - t1)
+
     dom = "mid_scan"
-    t_dom = excl_stage_ms[dom] / 1e3                       # seconds per launch of the dominant kernel
-    # stages 'end_tables_raw' and 'end_windows' run on the library's auxiliary stream beside 'mid_scan'
+    t_dom = excl_stage_ms[dom] / 1e3
     t_all = sum(v for k, v in excl_stage_ms.items() if k not in ("end_tables_raw", "end_windows")) / 1e3
-    alg_bytes = 2.0 * (bases / args.steps) + 32.0 * (reads / args.steps)    # 2 B/base + 32 B/read
-    achieved = alg_bytes / t_dom / 1e9 if t_dom > 0 else 0.0
-    traffic = None
-    valu = None
+    steps_mine = max(len(my_steps), 1)
+    alg_bytes = 2.0 * (bases / steps_mine) + 32.0 * (reads / steps_mine)    # 2 B/base + 32 B/read
+    contract = alg_bytes / t_dom / 1e9 if t_dom > 0 else 0.0
+    traffic, valu, stale = None, None, None
     tj = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tj):
         tr = json.load(open(tj))
-        if tr.get("reads_per_step") == args.reads and args.workload == "ont":
+        stale = tr.get("kernel_source_hash") != kernel_source_hash()
+        if not stale and tr.get("reads_per_step") == args.reads and args.workload == "ont":
             traffic = tr.get("mid_scan_hbm_bytes_per_launch")
             vi, va = tr.get("mid_scan_valu_insts_per_launch"), tr.get("valu_insts_per_batch_all_kernels")
             if vi and va and t_dom > 0:
-                # a wave64 VALU instruction holds its SIMD for 4 cycles; 256 CUs x 4 SIMDs
                 valu = {"kernel_valu_insts_per_launch": vi, "kernel_issue_cycles_per_simd": vi * 4 / 1024,
                         "kernel_min_clock_ghz_if_valu_only": vi * 4 / 1024 / t_dom / 1e9,
-                        "pipeline_valu_insts_per_batch": va, "pipeline_issue_cycles_per_simd": va * 4 / 1024,
-                        "note": "SQ_INSTS_VALU from profiles/ (PMC pass of the same command): the dominant kernel "
-                                "issues VALU instructions back to back for its whole duration -- the pipeline is "
-                                "VALU-issue bound, the HBM fraction above is what that leaves"}
-
-    out = {
-        "metric": "filtered Gbases/sec (end-to-end, excl. gzip I/O)",
-        "value": bases_all / dt / 1e9,
-        "unit": "Gbases/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "u8",
-        "data": "synthetic",
-        "config": {
-            "workload": ("C3 shape (BASELINE.json configs[2], for information): synthetic HiFi reads, N(%.0f, /6) bp, Q~N(30,6), "
-                         "%s, adapters PacBio blunt + reverse complement; %d reads (%.2f Gbases) per step per GPU, "
-                         "inputs resident in HBM" % (args.mean_len, flags, args.reads, bases / args.steps / 1e9)) if hifi else
-                        ("C2 (BASELINE.json configs[1]): synthetic ONT reads, lognormal lengths mean %.0f bp, "
-                         "%s, adapters ONT rapid + reverse complement; %d reads (%.2f Gbases) per step per GPU, "
-                         "inputs resident in HBM; the 4M-read job is %d such steps"
-                         % (args.mean_len, flags, args.reads, bases / args.steps / 1e9,
-                            int(np.ceil(4_000_000 / args.reads)))),
-            "reads_per_step_per_gpu": args.reads,
-            "parallelism": "reads sharded over %d GPU(s), one all-reduce of the tallies" % world,
-            "batches_in_flight_per_gpu": NS,
+                        "pipeline_valu_insts_per_batch": va, "source": tr.get("source")}
+    roofline = {
+        # the scan issues VALU instructions back to back for its whole duration: it is VALU-issue bound, and the HBM
+        # fractions below are what that leaves (named, so that none of them is mistaken for another)
+        "bound": "valu", "kernel": "k_mid_scan1<2> (Myers infix scan, stage 'mid_scan')",
+        "achieved": contract, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": contract / HBM_PEAK_GBS,
+        "traffic": traffic, "stale_profile": stale,
+        "fractions_of_hbm_peak": {
+            "dominant_kernel_contract": contract / HBM_PEAK_GBS,                      # (2 B/base + 32 B/read) / scan time
+            "pipeline": (alg_bytes / t_all / 1e9 / HBM_PEAK_GBS) if t_all > 0 else 0.0,  # same bytes / sum of kernel time
+            "dominant_kernel_actual_hbm": (traffic / t_dom / 1e9 / HBM_PEAK_GBS) if traffic and t_dom > 0 else None,  # PMC bytes / scan time
+            "whole_job": (2.0 * bases_all / world + 32.0 * reads_all / world) / dt / 1e9 / HBM_PEAK_GBS,
         },
-        "roofline": {
-            "bound": "hbm", "kernel": "k_mid_scan1<2> (Myers infix scan, stage 'mid_scan')",
-            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic,
-            "valu_issue": valu,
-            "measured": "HIP events on the launch stream around every stage (inside libtgsf); kernel durations "
-                        "of %d single-stream steps run right after the timed region (the GPU is not shared with "
-                        "another batch); 'timed_region_stage_ms' are the same events inside the timed region with "
-                        "%d batches in flight" % (nprof, NS),
-            "algorithmic_bytes_per_launch": alg_bytes,
-            "kernel_ms": excl_stage_ms[dom],
-            "pipeline_achieved": alg_bytes / t_all / 1e9 if t_all > 0 else 0.0,
-            "pipeline_frac": (alg_bytes / t_all / 1e9 / HBM_PEAK_GBS) if t_all > 0 else 0.0,
-            "whole_job_frac": (2.0 * bases_all / world + 32.0 * reads_all / world) / dt / 1e9 / HBM_PEAK_GBS,
-            "stage_ms_per_step": excl_stage_ms,
-            "timed_region_stage_ms": timed_stage_ms,
-        },
+        "valu_issue": valu,
+        "measured": "HIP events on the launch stream around every stage (inside libtgsf); kernel durations of %d "
+                    "single-stream steps run right after the timed region; 'timed_region_stage_ms' are the same events "
+                    "inside the timed region with %d batches in flight; traffic/valu_issue come from the PMC passes in "
+                    "profiles/ and are reported only while profiles/traffic.json carries the hash of today's kernel "
+                    "sources (stale_profile says so)" % (nprof, NS),
+        "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": excl_stage_ms[dom],
+        "sum_kernel_ms": t_all * 1e3,
+        "stage_ms_per_step": excl_stage_ms, "timed_region_stage_ms": timed_stage_ms,
     }
+    kp = {
+        "what": "device-resident filter throughput: batches already in HBM, tgsf_submit_device, per-read records copied "
+                "back every step; NOT the end-to-end metric",
+        "value": bases_all / dt / 1e9, "unit": "Gbases/s", "steps": K, "warmup": W, "ms_per_step": dt / max(len(my_steps), 1) * 1e3,
+        "scaling": "strong (fixed job of %d batches dealt over %d ranks)" % (K, world) if world > 1 else "single GPU",
+        "workload": ("C3 shape: synthetic HiFi reads N(%.0f,/6) bp, %s" % (mean_len, flags)) if hifi else
+                    ("C2: synthetic ONT reads, lognormal mean %.0f bp, %s, adapters ONT rapid + reverse complement" % (mean_len, flags)),
+        "reads_per_step": args.reads, "gbases_per_step": bases / steps_mine / 1e9, "batches_in_flight_per_gpu": NS,
+        "oracle_check": oracle_note,
+    }
+    for c in ctxs:
+        c.close()
+    return kp, roofline
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3, help="timed end-to-end runs of the command line")
+    ap.add_argument("--warmup", type=int, default=1, help="untimed end-to-end runs before them")
+    ap.add_argument("--e2e-reads", type=int, default=400_000, help="reads in the end-to-end FASTQ file (C2 shape, ~90 KB of text each)")
+    ap.add_argument("--no-e2e", action="store_true", help="kernel path only (profiling runs); the headline is then the kernel path")
+    ap.add_argument("--no-kernel-path", action="store_true")
+    ap.add_argument("--kernel-steps", type=int, default=24)
+    ap.add_argument("--kernel-warmup", type=int, default=3)
+    ap.add_argument("--job-steps", type=int, default=31, help="N > 1: batches of the fixed C4 job (31 x 131072 = 4.06 M reads)")
+    ap.add_argument("--reads", type=int, default=131072, help="reads per kernel-path step")
+    ap.add_argument("--mean-len", type=float, default=None)
+    ap.add_argument("--min-repeat", type=int, default=0, help="-p of config C5, for information")
+    ap.add_argument("--kmer", type=int, default=11)
+    ap.add_argument("--workload", choices=["ont", "hifi"], default="ont")
+    ap.add_argument("--max-len", type=int, default=2_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-oracle-check", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the tally all-reduce (nccl = RCCL)")
+    ap.add_argument("--share-gpu", action="store_true", help="validation on a 1-GPU box: every rank uses device 0")
+    ap.add_argument("--streams", type=int, default=3, help="kernel path: batches in flight per GPU")
+    args = ap.parse_args()
+    # stdout carries exactly one line, the result: whatever libraries print there meanwhile goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.share_gpu:
+        local_rank = 0
+
+    import torch
+    import torch.distributed as dist
+    host_group = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # host-side group (barriers, timing) first: it does not touch the GPU
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        host_group = dist.group.WORLD
+
+    # ---- end-to-end leg first (rank 0; subprocesses only, this process has not touched the GPU yet) ----
+    e2e = None
+    if not args.no_e2e:
+        if rank == 0:
+            e2e = e2e_leg(args, 1 if args.share_gpu else world)
+        if world > 1:
+            dist.barrier(group=host_group)
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    xdev = device if args.backend == "nccl" else None
+
+    kp = roofline = None
+    if not args.no_kernel_path:
+        if world > 1 and args.backend == "nccl":
+            from tgsfilter_amd import dist as tdist
+            tdist.set_group(dist.new_group(backend="nccl", device_id=device))
+        kp, roofline = kernel_leg(args, torch, dist, world, rank, local_rank, device, xdev, host_group)
+
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(torch, batches[0], flags,
-                                               b">ad\n" + wl_adapters[0] + b"\n", args.cpu_sample_reads)
+        if e2e:
+            s = e2e["sinks"]["tmpfs_file"]
+            value, ms, steps, warmup = s["gbases_per_s"], s["wall_s_mean"] * 1e3, s["runs"], args.warmup
+            metric = "filtered Gbases/sec (end-to-end, excl. gzip I/O)"
+            workload = ("C2 (BASELINE.json configs[1]) END-TO-END: %d synthetic ONT reads (lognormal mean 45 kb, %.2f Gbases, %.1f GB of "
+                        "FASTQ text on tmpfs) -> tgsfilter_amd/bin/tgsfilter %s -t %d -> FASTQ file on tmpfs (%.1f GB) + report; "
+                        "a step = one whole run of the command line; the 4M-read job is %.0f such files"
+                        % (e2e["reads"], e2e["bases"] / 1e9, e2e["fastq_bytes"] / 1e9, e2e["flags"], e2e["threads"],
+                           s.get("output_bytes", 0) / 1e9, 4_000_000 / e2e["reads"]))
+        else:
+            value, ms, steps, warmup = kp["value"], kp["ms_per_step"], kp["steps"], kp["warmup"]
+            metric = "device-resident filter throughput (Gbases/sec, inputs in HBM; NOT end-to-end)"
+            workload = kp["workload"] + "; %d reads (%.2f Gbases) per step, inputs resident in HBM" % (kp["reads_per_step"], kp["gbases_per_step"])
+        out = {
+            "metric": metric, "value": value, "unit": "Gbases/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": workload,
+                       "parallelism": "reads sharded over %d GPU(s) (one feeder set per GPU), one merge of the tallies" % world},
+        }
+        if e2e:
+            out["e2e"] = e2e
+            s = e2e["sinks"]["tmpfs_file"]
+            if "reference_gbases_per_s" in s:
+                out["cpu_baseline"] = {
+                    "value": s["reference_gbases_per_s"], "unit": "Gbases/s", "cores": e2e["threads"], "kind": "reference",
+                    "sample": "the whole end-to-end file (%d reads, %.2f Gbases, %.1f GB FASTQ on tmpfs), same flags, same sink "
+                              "(tmpfs file), oracle/_ref/tgsfilter_ref -t %d, wall %.2f s; output multiset and INFO counters "
+                              "identical to ours (asserted)" % (e2e["reads"], e2e["bases"] / 1e9, e2e["fastq_bytes"] / 1e9,
+                                                               e2e["threads"], s["reference_wall_s"])}
+                out["e2e_speedup_vs_reference"] = {k: v.get("speedup_vs_reference") for k, v in e2e["sinks"].items()}
+        if kp:
+            out["kernel_path"] = kp
+            out["roofline"] = roofline
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1:
+        dist.barrier(group=host_group)
         dist.destroy_process_group()
 
 

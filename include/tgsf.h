@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TGSF_ABI_VERSION 2
+#define TGSF_ABI_VERSION 3
 #define TGSF_MAX_ADAPTERS 32      /* adapters.size(): 2 or 4 in practice (src/TGSFilter.cpp:3105-3125) */
 #define TGSF_MAX_ADAPTER_LEN 128  /* two 64-row blocks; library adapters are 22..64 bp (:2970-2991) */
 #define TGSF_N_DROPINFO 17        /* DropInfo row, src/TGSFilter.cpp:1776 */
@@ -247,6 +247,11 @@ int tgsf_counters_len(tgsf_ctx* ctx, uint64_t* n_words, int32_t* bc_len, uint32_
 /* Copy the tallies to host memory (synchronises the context). Replaces the
  * per-thread merge of src/TGSFilter.cpp:3208-3213 / :2673-2725 / :2586-2597. */
 int tgsf_counters(tgsf_ctx* ctx, uint64_t* dst, uint64_t n_words);
+/* Same, but of the four bin tables ([n_bins][5] each, n_bins sized by max_read_len at tgsf_create -- possibly far
+ * more rows than any read of the run needed) only the rows in use are copied: rows[0] rows of the two raw tables,
+ * rows[1] rows of the two clean ones (the values of dst[TGSF_CTR_ROWS], dst[TGSF_CTR_ROWS+1]).  Words of dst
+ * beyond those rows are left as they were (zero them beforehand).  rows may be NULL. */
+int tgsf_counters_used(tgsf_ctx* ctx, uint64_t* dst, uint64_t n_words, uint64_t rows[2]);
 /* Device address of the same vector (for an in-place RCCL all-reduce). */
 int tgsf_counters_device(tgsf_ctx* ctx, void** d_ptr, uint64_t* n_words);
 /* Zero the tallies (start of a new run). */

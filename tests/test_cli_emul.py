@@ -65,6 +65,20 @@ def test_cli_parallel_line_scan(binary, golden_dir, name, block, monkeypatch):
     cli_check.run_case(binary, golden_dir, name)
 
 
+@pytest.mark.parametrize("name", ["ont_zoo", "hifi_zoo", "hifi_bam", "ont_fasta"])
+@pytest.mark.parametrize("writer", ["auto", "writev"])
+def test_cli_threaded_pipeline(binary, golden_dir, name, writer, monkeypatch):
+    """-t 8 with tiny batches: three contexts / feeders on the device, batches re-sequenced by the planner, the
+    records of every batch copied into the mapped output file by several fill threads (or gathered by the
+    single-stream writer): byte-equal output, same stderr, same report."""
+    monkeypatch.setenv("TGSF_BATCH_BYTES", "30000")
+    monkeypatch.setenv("TGSF_CTX_PER_DEVICE", "3")
+    monkeypatch.setenv("TGSF_FILL_MIN_BYTES", "1")
+    monkeypatch.setenv("TGSF_SCAN_BLOCK", "5000")
+    monkeypatch.setenv("TGSF_WRITER", writer)
+    cli_check.run_case(binary, golden_dir, name, extra_args=["-t", "8"])
+
+
 def test_cli_usage_and_errors(binary, tmp_path):
     p = subprocess.run([binary], capture_output=True)
     assert p.returncode == 1 and p.stdout.startswith(b"Usage: tgsfilter -i TGS.raw.fq.gz -x ont -o TGS.clean.fq.gz")

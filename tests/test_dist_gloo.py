@@ -25,7 +25,8 @@ lo, hi = tdist.shard_range(len(reads), rank, world)
 ctx = capi.Context(p, 0, os.environ["TGSF_EMUL_LIB"])
 seq, qual, off, ln = synth.pack(reads[lo:hi])
 res, frags = ctx.submit(seq, qual, off[:-1].copy(), ln)
-total = tdist.allreduce_counters(ctx.counters())
+tdist.check_layout(ctx.ctr_words)                    # setup-time check, not part of the job's exchange
+total = tdist.allreduce_counters(ctx.counters())     # ONE sum all-reduce
 pickle.dump(dict(lo=lo, hi=hi, res=res, frags=frags, total=total), open(os.environ["TGSF_OUT"] + ".%d" % rank, "wb"))
 dist.destroy_process_group()
 '''
@@ -72,7 +73,7 @@ from tgsfilter_amd import dist as tdist
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 try:
-    tdist.allreduce_counters(np.zeros(2000 + 100 * rank, dtype=np.uint64))   # layouts differ between the ranks
+    tdist.check_layout(2000 + 100 * rank)   # layouts differ between the ranks
     code = 1
 except ValueError as e:
     code = 0 if "differ in length" in str(e) else 2
@@ -83,7 +84,7 @@ sys.exit(code)
 
 def test_allreduce_refuses_mismatched_layouts(tmp_path):
     """Ranks that built their contexts with different max_read_len hold tally vectors of different lengths:
-    the exchange must refuse (on every rank) instead of summing words that mean different things."""
+    the setup-time layout check must refuse (on every rank) instead of summing words that mean different things."""
     script = tmp_path / "worker.py"
     script.write_text(MISMATCH_WORKER)
     env = dict(os.environ, TGSF_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29612", WORLD_SIZE="2")

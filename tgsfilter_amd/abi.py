@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_ADAPTERS = 32
 MAX_ADAPTER_LEN = 128
 N_DROPINFO = 17

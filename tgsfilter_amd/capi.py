@@ -21,7 +21,7 @@ _LIBS = {}
 SYMBOLS = [
     "tgsf_abi_version", "tgsf_prepare_device", "tgsf_create", "tgsf_destroy", "tgsf_submit", "tgsf_submit_async", "tgsf_submit_device",
     "tgsf_wait",
-    "tgsf_counters_len", "tgsf_counters", "tgsf_counters_device", "tgsf_reset_counters", "tgsf_profile",
+    "tgsf_counters_len", "tgsf_counters", "tgsf_counters_used", "tgsf_counters_device", "tgsf_reset_counters", "tgsf_profile",
     "tgsf_stage_times", "tgsf_stage_name", "tgsf_align_windows", "tgsf_last_error",
 ]
 

@@ -73,6 +73,9 @@ struct tgsf_ctx {
     hipStream_t hp;                       // optional high-priority stream for the HBM-bound stats kernels (TGSF_STATS_PRIO=1)
     hipEvent_t ev_hp[2];
     bool side_mid = false;                // TGSF_BIG_LOWPRIO=1: stats AND scan kernels on a lowest-priority side stream
+    static constexpr size_t kStageBytes = 32u << 20;
+    uint8_t* stage[2] = {nullptr, nullptr};   // pinned staging for host batches in pageable memory (text_h2d)
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
 #endif
     uint32_t h_status[4];
     // batch enqueued by tgsf_submit_async, completed by tgsf_wait
@@ -259,6 +262,10 @@ extern "C" void tgsf_destroy(tgsf_ctx* c)
         for (int i = 0; i <= TGSF_N_STAGES; i++) if (c->ev[k][i]) (void)hipEventDestroy(c->ev[k][i]);
         for (int i = 0; i < 3; i++) if (c->ev_aux[k][i]) (void)hipEventDestroy(c->ev_aux[k][i]);
     }
+    for (int i = 0; i < 2; i++) {
+        if (c->stage[i]) (void)hipHostFree(c->stage[i]);
+        if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]);
+    }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->aux) (void)hipStreamDestroy(c->aux);
@@ -351,6 +358,15 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     c->stream = nullptr; c->own_stream = false;
 #endif
     c->last_stream = c->stream;
+#if !defined(TGSF_EMUL)
+    if (p->max_batch_bases > (8u << 20)) {      // contexts for small batches (tests, the pre-pass) copy directly
+        for (int i = 0; i < 2; i++)
+            if (hipHostMalloc((void**)&c->stage[i], tgsf_ctx::kStageBytes, hipHostMallocDefault) != hipSuccess ||
+                hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming) != hipSuccess) {
+                tgsf_destroy(c); return fail(nullptr, TGSF_E_HIP, "pinned staging buffers: allocation failed");
+            }
+    }
+#endif
     DevParams& P = c->P;
     memset(&P, 0, sizeof P);
     P.min_len = p->min_len; P.max_len = p->max_len; P.min_q = p->min_q; P.max_q = p->max_q;
@@ -639,6 +655,33 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     return TGSF_OK;
 }
 
+// Host-to-device copy of a batch's bytes.  Memory the runtime knows (pinned / registered) is copied as it is.  Plain
+// pageable memory -- the command line hands over slices of its input mapping -- goes through the context's two pinned
+// staging buffers, the CPU copy of one piece overlapping the DMA of the previous one: the runtime's own pageable path
+// pins the caller's pages piece by piece instead, which is as fast but registers MMU notifiers on the caller's
+// mapping (a caller that drops parts of that mapping meanwhile then stalls the device queues).
+static int text_h2d(tgsf_ctx* c, uint8_t* dst, const uint8_t* src, uint64_t n, rt_stream st)
+{
+#if !defined(TGSF_EMUL)
+    hipPointerAttribute_t at;
+    const bool known = hipPointerGetAttributes(&at, src) == hipSuccess && at.type != hipMemoryTypeUnregistered;
+    (void)hipGetLastError();
+    if (!known && c->stage[0] && n > (1u << 20)) {
+        int he = 0, k = 0;
+        for (uint64_t o = 0; o < n; o += tgsf_ctx::kStageBytes, k ^= 1) {
+            const size_t m = (size_t)std::min<uint64_t>(tgsf_ctx::kStageBytes, n - o);
+            (void)hipEventSynchronize(c->stage_ev[k]);           // the DMA that last read this buffer
+            memcpy(c->stage[k], src + o, m);
+            he |= (int)hipMemcpyAsync(dst + o, c->stage[k], m, hipMemcpyHostToDevice, st);
+            he |= (int)hipEventRecord(c->stage_ev[k], st);
+        }
+        return he;
+    }
+#endif
+    (void)c;
+    return rt_h2d(dst, src, n, st);
+}
+
 static int check_batch(tgsf_ctx* c, const tgsf_batch_in* in)
 {
     if (!in || !in->seq || (!in->qual && !c->P.no_qual) || !in->offsets) return fail(c, TGSF_E_INVALID, "null batch pointer");
@@ -685,7 +728,15 @@ static int finish_pending(tgsf_ctx* c)
 extern "C" int tgsf_wait(tgsf_ctx* c)
 {
     if (!c) return TGSF_E_INVALID;
-    int e = rt_d2h(c->h_status, c->B.status, 16, c->stream);
+    int e = 0;
+#if !defined(TGSF_EMUL)
+    // a batch enqueued with tgsf_submit_device runs on the caller's stream (and the auxiliary one): both must be
+    // idle before the status words mean anything
+    (void)hipSetDevice(c->device);
+    if (c->last_stream != c->stream) e = (int)hipStreamSynchronize(c->last_stream);
+    if (!e) e = (int)hipStreamSynchronize(c->aux);
+#endif
+    if (!e) e = rt_d2h(c->h_status, c->B.status, 16, c->stream);
     if (!e) e = rt_sync(c->stream);
     if (e) { c->pend_out = nullptr; return fail(c, TGSF_E_HIP, "stream synchronize failed: %s", rt_errstr(e)); }
     e = check_status(c);
@@ -728,8 +779,8 @@ extern "C" int tgsf_submit_async(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_batc
     rt_stream st = c->stream;
     int he = 0;
     const bool one_buffer = in->qual == in->seq || c->P.no_qual;   // raw FASTQ text: both streams are read in place (no_qual: none)
-    he |= rt_h2d(c->d_seq, in->seq, span, st);
-    if (!one_buffer) he |= rt_h2d(c->d_qual, in->qual, span, st);
+    he |= text_h2d(c, c->d_seq, in->seq, span, st);
+    if (!one_buffer) he |= text_h2d(c, c->d_qual, in->qual, span, st);
     he |= rt_h2d(c->d_off, in->offsets, (size_t)(in->lengths ? n : n + 1) * 8, st);
     if (in->lengths) he |= rt_h2d(c->d_lenin, in->lengths, (size_t)n * 4, st);
     if (in->qual_offsets) he |= rt_h2d(c->d_qoff, in->qual_offsets, (size_t)n * 8, st);
@@ -775,6 +826,28 @@ extern "C" int tgsf_counters(tgsf_ctx* c, uint64_t* dst, uint64_t n_words)
     if (e) return e;
     int he = rt_d2h(dst, c->B.ctr, c->ctr_words * 8, c->stream);
     if (!he) he = rt_sync(c->stream);
+    return he ? fail(c, TGSF_E_HIP, "device to host copy failed") : TGSF_OK;
+}
+
+extern "C" int tgsf_counters_used(tgsf_ctx* c, uint64_t* dst, uint64_t n_words, uint64_t rows[2])
+{
+    if (!c || !dst) return TGSF_E_INVALID;
+    if (n_words < c->ctr_words) return fail(c, TGSF_E_CAPACITY, "counter buffer too small");
+    int e = tgsf_wait(c);
+    if (e) return e;
+    // fixed part: DropInfo, both DiffQual histograms, the "rows used" words, the eight end tables
+    const size_t head = tgsf_ctr_bin_table(0, c->P.bc_len, c->n_bins);
+    int he = rt_d2h(dst, c->B.ctr, head * 8, c->stream);
+    if (!he) he = rt_sync(c->stream);
+    if (he) return fail(c, TGSF_E_HIP, "device to host copy failed");
+    const uint64_t used[2] = {std::min<uint64_t>(dst[TGSF_CTR_ROWS], c->n_bins), std::min<uint64_t>(dst[TGSF_CTR_ROWS + 1], c->n_bins)};
+    for (int b = 0; b < 4 && !he; b++) {
+        const size_t at = tgsf_ctr_bin_table(b, c->P.bc_len, c->n_bins);
+        const uint64_t r = used[b >> 1];
+        if (r) he = rt_d2h(dst + at, c->B.ctr + at, (size_t)r * 5 * 8, c->stream);
+    }
+    if (!he) he = rt_sync(c->stream);
+    if (rows) { rows[0] = used[0]; rows[1] = used[1]; }
     return he ? fail(c, TGSF_E_HIP, "device to host copy failed") : TGSF_OK;
 }
 

@@ -31,25 +31,54 @@ def merge_counters(vectors):
     return tot
 
 
-def allreduce_counters(ctr: np.ndarray, device=None, group=None) -> np.ndarray:
-    """Sum the tally vector over all ranks (the four 'rows used' words are maxima).
+_GROUP = None
 
-    uint64 sums are done as int64 (two's complement: identical bits); every rank gets the result.
+
+def set_group(group):
+    """Process group of the tally exchange (default: the world group).  bench.py keeps a gloo world group for
+    host-side barriers and hands the RCCL group in here."""
+    global _GROUP
+    _GROUP = group
+
+
+def check_layout(n_words: int, group=None):
+    """Setup-time check (once, before any batch): every rank must hold the same tally layout (same bc_len and
+    max_read_len at tgsf_create), or the job's all-reduce would sum words that mean different things."""
+    import torch
+    import torch.distributed as dist
+
+    group = group if group is not None else _GROUP
+    dev = "cuda" if (group is not None and dist.get_backend(group) == "nccl") or (group is None and dist.get_backend() == "nccl") else "cpu"
+    n = torch.tensor([n_words, -n_words], dtype=torch.int64, device=dev)
+    dist.all_reduce(n, op=dist.ReduceOp.MAX, group=group)
+    if int(n[0].item()) != -int(n[1].item()):
+        raise ValueError("tally vectors differ in length across ranks (%d here, %d..%d over the job): create every "
+                         "context with the same bc_len and max_read_len" % (n_words, -int(n[1].item()), int(n[0].item())))
+
+
+def allreduce_counters(ctr: np.ndarray, rank=None, world=None, device=None, group=None) -> np.ndarray:
+    """The job's ONE collective: a SUM all-reduce of the tally vector; every rank gets the result.
+
+    The four 'rows used' words are maxima, not sums: each rank carries them in a slot of its own behind the vector
+    (zeros in the other ranks' slots), so the same SUM delivers every rank's values and the maximum is taken
+    locally.  uint64 sums are done as int64 (two's complement: identical bits).
     """
     import torch
     import torch.distributed as dist
 
-    t = torch.from_numpy(np.ascontiguousarray(ctr, dtype=np.uint64).view(np.int64).copy())
+    group = group if group is not None else _GROUP
+    rank = dist.get_rank(group) if rank is None else rank
+    world = dist.get_world_size(group) if world is None else world
+    n = len(ctr)
+    buf = np.zeros(n + 4 * world, dtype=np.uint64)
+    buf[:n] = ctr
+    buf[abi.CTR_ROWS:abi.CTR_ROWS + 4] = 0
+    buf[n + 4 * rank:n + 4 * rank + 4] = ctr[abi.CTR_ROWS:abi.CTR_ROWS + 4]
+    t = torch.from_numpy(buf.view(np.int64))
     if device is not None:
         t = t.to(device)
-    # every rank must hold the same layout (same bc_len and max_read_len at tgsf_create): check before summing
-    n = torch.tensor([t.numel(), -t.numel()], dtype=torch.int64, device=t.device)
-    dist.all_reduce(n, op=dist.ReduceOp.MAX, group=group)
-    if int(n[0].item()) != -int(n[1].item()):
-        raise ValueError("tally vectors differ in length across ranks (%d here, %d..%d over the job): create every "
-                         "context with the same bc_len and max_read_len" % (t.numel(), -int(n[1].item()), int(n[0].item())))
-    rows = t[abi.CTR_ROWS:abi.CTR_ROWS + 4].clone()
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    dist.all_reduce(rows, op=dist.ReduceOp.MAX, group=group)
-    t[abi.CTR_ROWS:abi.CTR_ROWS + 4] = rows
-    return t.cpu().numpy().view(np.uint64).copy()
+    out = t.cpu().numpy().view(np.uint64)
+    res = out[:n].copy()
+    res[abi.CTR_ROWS:abi.CTR_ROWS + 4] = out[n:].reshape(world, 4).max(axis=0)
+    return res

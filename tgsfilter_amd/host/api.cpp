@@ -1,0 +1,87 @@
+#include "api.h"
+
+#include <dlfcn.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <string>
+#include <thread>
+
+#ifndef TGSF_LIB_REL
+#define TGSF_LIB_REL "../libtgsf.so"        // relative to the executable (tgsfilter_amd/bin/tgsfilter)
+#endif
+
+namespace host {
+
+namespace {
+Api g_api;
+std::thread g_thread;
+std::string g_error;
+double g_load_s = 0, g_device_s = 0;
+bool g_started = false;
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+std::string lib_path()
+{
+    if (const char* e = getenv("TGSF_LIB")) return e;
+    char exe[4096];
+    const ssize_t n = readlink("/proc/self/exe", exe, sizeof exe - 1);
+    std::string dir = n > 0 ? std::string(exe, (size_t)n) : std::string(".");
+    const size_t slash = dir.rfind('/');
+    dir = slash == std::string::npos ? "." : dir.substr(0, slash);
+    return dir + "/" + TGSF_LIB_REL;
+}
+
+void load(std::vector<int> devices)
+{
+    const double t0 = now_s();
+    const std::string path = lib_path();
+    void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!h) { g_error = std::string("cannot load ") + path + ": " + dlerror() + " (there is no CPU fallback)"; return; }
+#define BIND(field, sym) \
+    g_api.field = reinterpret_cast<decltype(g_api.field)>(dlsym(h, sym)); \
+    if (!g_api.field) { g_error = std::string("symbol ") + sym + " missing in " + path; return; }
+    BIND(abi_version, "tgsf_abi_version")
+    BIND(prepare_device, "tgsf_prepare_device")
+    BIND(create, "tgsf_create")
+    BIND(destroy, "tgsf_destroy")
+    BIND(submit, "tgsf_submit")
+    BIND(wait, "tgsf_wait")
+    BIND(counters_len, "tgsf_counters_len")
+    BIND(counters, "tgsf_counters")
+    BIND(counters_used, "tgsf_counters_used")
+    BIND(align_windows, "tgsf_align_windows")
+    BIND(last_error, "tgsf_last_error")
+#undef BIND
+    if (g_api.abi_version() != TGSF_ABI_VERSION) { g_error = path + ": ABI version mismatch"; return; }
+    g_load_s = now_s() - t0;
+    for (int d : devices) (void)g_api.prepare_device(d);     // failures surface at tgsf_create, with its message
+    g_device_s = now_s() - t0 - g_load_s;
+}
+}  // namespace
+
+void lib_start(const std::vector<int>& devices)
+{
+    g_started = true;
+    g_thread = std::thread(load, devices);
+}
+
+const Api& lib()
+{
+    if (!g_started) lib_start({});
+    if (g_thread.joinable()) g_thread.join();
+    if (!g_error.empty()) {
+        std::cerr << "Error: " << g_error << std::endl;
+        fflush(nullptr);
+        _exit(255);
+    }
+    return g_api;
+}
+
+void lib_times(double& load_s, double& device_s) { load_s = g_load_s; device_s = g_device_s; }
+
+}  // namespace host

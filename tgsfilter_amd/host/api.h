@@ -1,0 +1,34 @@
+// api.h -- the C ABI of include/tgsf.h, bound at run time.  The command line does not link libtgsf.so:
+// loading the HIP runtime's libraries costs a few tenths of a second before main() would even start, so a
+// helper thread dlopen()s the library (and brings the device up, tgsf_prepare_device) while the main thread
+// already maps and indexes the input.  There is no other implementation behind these pointers: if the
+// library or a device is missing the program stops with an error.
+#pragma once
+#include <vector>
+
+#include "tgsf.h"
+
+namespace host {
+
+struct Api {
+    decltype(&tgsf_abi_version) abi_version;
+    decltype(&tgsf_prepare_device) prepare_device;
+    decltype(&tgsf_create) create;
+    decltype(&tgsf_destroy) destroy;
+    decltype(&tgsf_submit) submit;
+    decltype(&tgsf_wait) wait;
+    decltype(&tgsf_counters_len) counters_len;
+    decltype(&tgsf_counters) counters;
+    decltype(&tgsf_counters_used) counters_used;
+    decltype(&tgsf_align_windows) align_windows;
+    decltype(&tgsf_last_error) last_error;
+};
+
+// Starts the helper thread: dlopen + tgsf_prepare_device on each device.  Call once, early.
+void lib_start(const std::vector<int>& devices);
+// The bound entry points; blocks until the helper thread is done.  Exits with an error if loading failed.
+const Api& lib();
+// seconds the helper thread took (library load, device bring-up), for TGSF_TIMING
+void lib_times(double& load_s, double& device_s);
+
+}  // namespace host

@@ -78,45 +78,92 @@ int FastxReader::scan_threads_from_env(int dflt)
     return v > 0 ? std::min(v, 64) : dflt;
 }
 
-void FastxReader::scan_block(const char* from)
+static size_t scan_block_bytes()
 {
     static const size_t kBlock = [] {                      // TGSF_SCAN_BLOCK: test knob (block edges on small inputs)
         const char* e = getenv("TGSF_SCAN_BLOCK");
         const size_t v = e ? (size_t)strtoull(e, nullptr, 10) : 0;
-        return v ? v : (size_t)(256u << 20);
+        return v ? v : (size_t)(16u << 20);
     }();
-    block_begin_ = from;
-    block_end_ = (size_t)(end_ - from) > kBlock ? from + kBlock : end_;
-    const int T = scan_threads_;
-    std::vector<std::vector<const char*>> part((size_t)T);
-    std::vector<std::thread> th;
-    const size_t per = ((size_t)(block_end_ - block_begin_) + (size_t)T - 1) / (size_t)T;
-    for (int t = 0; t < T; t++)
-        th.emplace_back([&, t] {
-            const char* a = block_begin_ + std::min(per * (size_t)t, (size_t)(block_end_ - block_begin_));
-            const char* b = block_begin_ + std::min(per * (size_t)(t + 1), (size_t)(block_end_ - block_begin_));
-            while (a < b) {
-                const char* q = static_cast<const char*>(memchr(a, '\n', (size_t)(b - a)));
-                if (!q) break;
-                part[(size_t)t].push_back(q);
-                a = q + 1;
-            }
-        });
-    for (std::thread& x : th) x.join();
-    nl_.clear();
-    for (const auto& v : part) nl_.insert(nl_.end(), v.begin(), v.end());
-    nl_at_ = 0;
+    return kBlock;
+}
+
+LineScanner::LineScanner(const char* begin, const char* end, int threads, size_t block_bytes)
+    : begin_(begin), end_(end), block_(block_bytes)
+{
+    n_blocks_ = ((size_t)(end - begin) + block_ - 1) / block_;
+    ring_ = (size_t)threads * 3;
+    slot_.resize(ring_);
+    ready_.assign(ring_, 0);
+    for (int t = 0; t < threads; t++) th_.emplace_back([this] { work(); });
+}
+
+LineScanner::~LineScanner()
+{
+    { std::lock_guard<std::mutex> l(m_); stop_ = true; }
+    cv_.notify_all();
+    for (std::thread& t : th_) t.join();
+}
+
+void LineScanner::work()
+{
+    std::vector<const char*> found;
+    for (;;) {
+        size_t b;
+        {
+            std::unique_lock<std::mutex> l(m_);
+            cv_.wait(l, [&] { return stop_ || next_claim_ >= n_blocks_ || next_claim_ < low_ + ring_; });
+            if (stop_ || next_claim_ >= n_blocks_) return;
+            b = next_claim_++;
+        }
+        found.clear();
+        const char* a = begin_ + b * block_;
+        const char* e = block_end(b);
+        while (a < e) {
+            const char* q = static_cast<const char*>(memchr(a, '\n', (size_t)(e - a)));
+            if (!q) break;
+            found.push_back(q);
+            a = q + 1;
+        }
+        {
+            std::lock_guard<std::mutex> l(m_);
+            slot_[b % ring_].swap(found);
+            ready_[b % ring_] = b + 1;
+        }
+        cv_.notify_all();
+    }
+}
+
+const std::vector<const char*>& LineScanner::lines(size_t b)
+{
+    std::unique_lock<std::mutex> l(m_);
+    if (b > low_) { low_ = b; cv_.notify_all(); }
+    cv_.wait(l, [&] { return ready_[b % ring_] == b + 1; });
+    return slot_[b % ring_];
+}
+
+FastxReader::FastxReader(const char* data, size_t size, bool fastq, int scan_threads, std::string* message)
+    : p_(data), end_(data + size), scan_threads_(scan_threads_from_env(scan_threads)), fastq_(fastq), message_(message)
+{
+    if (scan_threads_ > 1 && size > 0) scan_.reset(new LineScanner(data, data + size, scan_threads_, scan_block_bytes()));
+}
+
+void FastxReader::say(const std::string& text, std::string_view name)
+{
+    if (message_) { *message_ = text; message_->append(name); }
+    else std::cerr << text << name << std::endl;
 }
 
 const char* FastxReader::next_newline(const char* from)
 {
-    if (scan_threads_ <= 1) return static_cast<const char*>(memchr(from, '\n', (size_t)(end_ - from)));
+    if (!scan_) return static_cast<const char*>(memchr(from, '\n', (size_t)(end_ - from)));
     for (;;) {
         if (from >= end_) return nullptr;
-        if (!block_begin_ || from < block_begin_ || from >= block_end_) scan_block(from);
-        while (nl_at_ < nl_.size() && nl_[nl_at_] < from) nl_at_++;
-        if (nl_at_ < nl_.size()) return nl_[nl_at_];
-        from = block_end_;                 // none left in this block: the line runs on into the next one
+        const size_t b = scan_->block_of(from);
+        if (b != block_) { nl_ = &scan_->lines(b); block_ = b; nl_at_ = 0; }
+        while (nl_at_ < nl_->size() && (*nl_)[nl_at_] < from) nl_at_++;
+        if (nl_at_ < nl_->size()) return (*nl_)[nl_at_];
+        from = scan_->block_end(b);        // none left in this block: the line runs on into the next one
     }
 }
 
@@ -146,14 +193,11 @@ bool FastxReader::next_fastq(Record& r)
         }
     }
     if (done_) return false;                                          // :700-702
-    if (name.empty()) { std::cerr << "Error: input format wrong!" << std::endl; return false; }
+    if (name.empty()) { say("Error: input format wrong!", {}); return false; }
     name.remove_prefix(1);                                            // :709
     std::string_view qual = line();
-    if (qual.empty()) { std::cerr << "Error: quality are empty:" << name << std::endl; return false; }
-    if (qual.size() != seq.size()) {
-        std::cerr << "warning: sequence and quality have different length:" << name << std::endl;
-        return false;
-    }
+    if (qual.empty()) { say("Error: quality are empty:", name); return false; }
+    if (qual.size() != seq.size()) { say("warning: sequence and quality have different length:", name); return false; }
     r.name = name; r.seq = seq; r.qual = qual;
     return true;
 }
@@ -166,12 +210,88 @@ bool FastxReader::next_fasta(Record& r)
         if (!name.empty() && name[0] == '>') break;
     }
     if (done_) return false;
-    if (name.empty()) { std::cerr << "Error: input format wrong!" << std::endl; return false; }
+    if (name.empty()) { say("Error: input format wrong!", {}); return false; }
     name.remove_prefix(1);
     std::string_view seq = line();
-    if (seq.empty()) { std::cerr << "Error: sequence are empty:" << name << std::endl; return false; }
+    if (seq.empty()) { say("Error: sequence are empty:", name); return false; }
     r.name = name; r.seq = seq; r.qual = {};
     return true;
+}
+
+// ---------------------------------------------------------------------------
+RecordIndex::RecordIndex(const char* data, size_t size, bool fastq, int threads)
+{
+    chunks_.resize(1u << 17);                    // x 32768 records: room for 4e9
+    th_ = std::thread([=] { produce(data, size, fastq, threads); });
+}
+
+RecordIndex::~RecordIndex()
+{
+    if (th_.joinable()) th_.join();
+}
+
+void RecordIndex::produce(const char* data, size_t size, bool fastq, int threads)
+{
+    std::string msg;
+    {
+        FastxReader rd(data, size, fastq, threads, &msg);
+        Record r;
+        size_t n = 0, published = 0;
+        uint32_t longest = 0;
+        while (rd.next(r)) {
+            if (n / kChunk >= chunks_.size()) break;
+            if (n % kChunk == 0) chunks_[n / kChunk].reset(new Rec[kChunk]);
+            Rec& x = chunks_[n / kChunk][n % kChunk];
+            x.name = r.name.data(); x.name_len = (uint32_t)r.name.size();
+            x.seq = r.seq.data(); x.len = (uint32_t)r.seq.size();
+            x.qual = fastq ? r.qual.data() : r.seq.data();
+            if (x.len > longest) longest = x.len;
+            n++;
+            if (n - published >= 256) {           // publish in small groups: one wake-up per group
+                longest_.store(longest);
+                { std::lock_guard<std::mutex> l(m_); count_.store(n, std::memory_order_release); }
+                cv_.notify_all();
+                published = n;
+            }
+        }
+        longest_.store(longest);
+        std::lock_guard<std::mutex> l(m_);
+        count_.store(n, std::memory_order_release);
+        message_ = msg;
+        done_ = true;
+    }
+    cv_.notify_all();
+}
+
+bool RecordIndex::get(size_t i, Rec& r)
+{
+    if (i >= count_.load(std::memory_order_acquire)) {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [&] { return done_ || i < count_.load(std::memory_order_acquire); });
+        if (i >= count_.load(std::memory_order_acquire)) return false;
+    }
+    r = chunks_[i / kChunk][i % kChunk];
+    return true;
+}
+
+bool RecordIndex::complete()
+{
+    std::lock_guard<std::mutex> l(m_);
+    return done_;
+}
+
+size_t RecordIndex::wait_complete()
+{
+    std::unique_lock<std::mutex> l(m_);
+    cv_.wait(l, [&] { return done_; });
+    return count_.load();
+}
+
+bool RecordIndex::Cursor::next(Rec& r)
+{
+    if (ix_.get(i_, r)) { i_++; return true; }
+    if (!ix_.end_message().empty()) std::cerr << ix_.end_message() << std::endl;
+    return false;
 }
 
 }  // namespace host

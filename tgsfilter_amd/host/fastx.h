@@ -5,9 +5,15 @@
 // Input is a flat byte range: plain files are mmap'ed, .gz files are inflated into memory (zlib),
 // SAM/BAM files are decoded into FASTQ text in memory (bam.h).
 #pragma once
+#include <atomic>
+#include <condition_variable>
 #include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <string_view>
+#include <thread>
 #include <vector>
 
 namespace host {
@@ -20,6 +26,7 @@ public:
     bool open(const std::string& path, bool sam_or_bam = false);
     const char* data() const { return data_; }
     size_t size() const { return size_; }
+    bool mapped() const { return map_ != nullptr; }   // a read-only file mapping (not decoded text in memory)
 private:
     bool open_plain(const std::string& path);   // mmap, no message
     const char* data_ = nullptr;
@@ -31,30 +38,92 @@ private:
 
 struct Record { std::string_view name, seq, qual; };
 
+// Line ends of a byte range, located AHEAD of the record assembler by a few threads: the range is cut into
+// blocks, the threads claim blocks in order and stay at most `ring` blocks ahead of the consumer (finding the
+// newlines is all the work of indexing long reads; at 4 lines per record the assembly itself is nothing).
+class LineScanner {
+public:
+    LineScanner(const char* begin, const char* end, int threads, size_t block_bytes);
+    ~LineScanner();
+    size_t block_of(const char* p) const { return (size_t)(p - begin_) / block_; }
+    const char* block_end(size_t b) const { return (size_t)(end_ - begin_) > (b + 1) * block_ ? begin_ + (b + 1) * block_ : end_; }
+    // newlines of block b, ascending (blocks until scanned); blocks below b are given back to the scanners
+    const std::vector<const char*>& lines(size_t b);
+private:
+    void work();
+    const char* begin_;
+    const char* end_;
+    size_t block_, n_blocks_, ring_;
+    std::vector<std::vector<const char*>> slot_;  // slot_[b % ring_]
+    std::vector<size_t> ready_;                   // ready_[b % ring_] == b + 1 once block b is scanned
+    size_t next_claim_ = 0, low_ = 0;             // first block not yet claimed / first block still held by the consumer
+    bool stop_ = false;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::vector<std::thread> th_;
+};
+
 class FastxReader {
 public:
-    // scan_threads > 1: line ends are located ahead of the parser, one 256-MB block of the text at a time, by
-    // that many threads (finding the newlines is all the work of indexing long reads); the records are then
-    // assembled from the lines exactly as without it.
-    FastxReader(const char* data, size_t size, bool fastq, int scan_threads = 1)
-        : p_(data), end_(data + size), scan_threads_(scan_threads_from_env(scan_threads)), fastq_(fastq) {}
+    // scan_threads > 1: line ends come from a LineScanner; the records are assembled from the lines exactly as
+    // without it.  `message`: where the reference's message about a malformed record goes instead of stderr
+    // (RecordIndex prints it when a pass over the records reaches that point).
+    FastxReader(const char* data, size_t size, bool fastq, int scan_threads = 1, std::string* message = nullptr);
     static int scan_threads_from_env(int dflt);   // TGSF_SCAN_THREADS overrides (test knob)
     bool next(Record& r);        // false: end of input (or first malformed record, after the reference's message)
 private:
     std::string_view line();     // "" at end of input (then done_ is set, like getLine :676-680)
     const char* next_newline(const char* from);   // first '\n' in [from, end_), or nullptr
-    void scan_block(const char* from);
     bool next_fastq(Record& r);
     bool next_fasta(Record& r);
+    void say(const std::string& text, std::string_view name);
     const char* p_;
     const char* end_;
     int scan_threads_ = 1;
     bool fastq_;
     bool done_ = false;
-    std::vector<const char*> nl_;                 // newlines of the current block, ascending
-    size_t nl_at_ = 0;
-    const char* block_begin_ = nullptr;
-    const char* block_end_ = nullptr;
+    std::string* message_ = nullptr;
+    std::unique_ptr<LineScanner> scan_;
+    const std::vector<const char*>* nl_ = nullptr;   // newlines of the current block
+    size_t nl_at_ = 0, block_ = (size_t)-1;
+};
+
+// The records of an input, indexed ONCE, in the background, for every pass over them (the reference reads its
+// input twice: GetFilterParameterTask::read_fastx :949-982, then TGSFilterTask::read_fastx :1845-1870).  32 bytes
+// per record stay in memory; the text itself is only referenced.
+struct Rec {
+    const char* name; const char* seq; const char* qual;    // qual == seq for FASTA
+    uint32_t name_len, len;
+};
+class RecordIndex {
+public:
+    RecordIndex(const char* data, size_t size, bool fastq, int threads);
+    ~RecordIndex();
+    bool get(size_t i, Rec& r);          // blocks until record i is indexed; false: the input has fewer records
+    bool complete();                     // the whole input is indexed (non-blocking)
+    size_t wait_complete();              // blocks; number of records
+    uint32_t longest() const { return longest_.load(); }    // longest read so far
+    const std::string& end_message() const { return message_; }   // valid once a get() returned false
+    // one pass over the records; prints the reference's message when it ends at a malformed record
+    class Cursor {
+    public:
+        explicit Cursor(RecordIndex& ix) : ix_(ix) {}
+        bool next(Rec& r);
+    private:
+        RecordIndex& ix_;
+        size_t i_ = 0;
+    };
+private:
+    static constexpr size_t kChunk = 1u << 15;
+    void produce(const char* data, size_t size, bool fastq, int threads);
+    std::vector<std::unique_ptr<Rec[]>> chunks_;   // table preallocated: readers never see it move
+    std::atomic<size_t> count_{0};
+    std::atomic<uint32_t> longest_{0};
+    bool done_ = false;
+    std::string message_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::thread th_;
 };
 
 }  // namespace host

@@ -1,11 +1,15 @@
 // main.cpp -- `tgsfilter` for MI355X: the reference's command line, stderr lines and report around
-// the batch pipeline  reader -> [batch queue] -> GPU feeder (tgsf_submit) -> [batch queue] -> writer.
+// the batch pipeline  indexer -> batcher -> [queue] -> GPU feeders (tgsf_submit) -> [queue] -> ordered planner -> fill threads.
 //
 // Replaces main (src/TGSFilter.cpp:2945-3332) and TGSFilterTask (:1755-2162): the reference moves one
 // read at a time as three std::string copies through lock-free queues to N worker threads; here reads
 // are only INDEXED on the host (the mmap'ed FASTQ text itself is the batch buffer: sequence and quality
 // lines are read in place by the kernels), filtered on the GPU through the C ABI, and the kept
 // fragments are formatted straight from the input text in input order (= the reference's -t 1 order).
+#include <fcntl.h>
+#include <malloc.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <sys/uio.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -19,6 +23,7 @@
 #include <cstring>
 #include <deque>
 #include <fstream>
+#include <functional>
 #include <iostream>
 #include <map>
 #include <memory>
@@ -27,11 +32,11 @@
 #include <unordered_map>
 #include <unordered_set>
 
+#include "api.h"
 #include "fastx.h"
 #include "options.h"
 #include "prepass.h"
 #include "report.h"
-#include "tgsf.h"
 
 using namespace host;
 
@@ -44,12 +49,45 @@ struct Batch {
     uint64_t span = 0;                       // bytes of the slice
     std::vector<uint64_t> off, qoff;         // sequence / quality line of each read, relative to base
     std::vector<uint32_t> len;
-    std::vector<std::string_view> names;     // views into the input
+    std::vector<Rec> recs;                   // header / sequence / quality lines, in the input
     std::vector<tgsf_read_result> res;
     std::vector<tgsf_fragment> frags;
     uint32_t n_frags = 0;
     uint64_t bases = 0;
     uint64_t id = 0;                         // position in the input: the writer puts batches back in order
+    struct Emit { uint32_t read, frag; int pass_num; uint64_t at; };   // a record to write, `at` bytes into the batch's output
+    std::vector<Emit> em;
+    char* dst = nullptr;                     // where the batch's output starts in the mapped file
+    uint64_t out_bytes = 0;
+    std::atomic<int> left{0};                // fill jobs still running
+    void reset() {
+        base = nullptr; span = 0; off.clear(); qoff.clear(); len.clear(); recs.clear(); n_frags = 0; bases = 0; id = 0;
+        em.clear(); dst = nullptr; out_bytes = 0; left = 0;
+    }
+};
+
+// Batches are recycled, never freed while the pipeline runs: their vectors are MBs each, which malloc takes from and
+// gives back to the kernel with mmap/munmap -- and those need the address-space lock for writing, which the page
+// faults of the fill threads hold for reading all the time (measured: 170 ms per freed batch, 12 s over a run).
+class BatchStore {
+public:
+    std::shared_ptr<Batch> get() {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            if (!free_.empty()) { std::shared_ptr<Batch> b = std::move(free_.back()); free_.pop_back(); return b; }
+        }
+        std::shared_ptr<Batch> b(new Batch);
+        b->off.reserve(4096); b->qoff.reserve(4096); b->len.reserve(4096); b->recs.reserve(4096);
+        return b;
+    }
+    void put(std::shared_ptr<Batch> b) {
+        b->reset();
+        std::lock_guard<std::mutex> l(m_);
+        free_.push_back(std::move(b));
+    }
+private:
+    std::mutex m_;
+    std::vector<std::shared_ptr<Batch>> free_;
 };
 
 // a kept fragment, addressed in the input text (used when a downsampling pass follows the filter pass)
@@ -96,6 +134,20 @@ void append_name(std::string& out, std::string_view raw, int number)
     out.append(raw.substr(0, i));
     out += add;
     out.append(raw.substr(i));
+}
+
+double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Fatal errors can come from any thread while others are inside HIP calls or blocked on queues: no static
+// destructors, no runtime teardown -- flush what was said and leave with the reference's exit status (-1).
+[[noreturn]] void die(const std::string& msg)
+{
+    std::cerr << "Error: " << msg << std::endl;
+    fflush(nullptr);
+    _exit(255);
 }
 
 class Output {                                // plain or per-record gzip members (:2020-2053, :786-812)
@@ -172,8 +224,8 @@ public:
         for (int t = 1; t < T; t++) th.emplace_back(work, t);
         work(0);
         for (std::thread& x : th) x.join();
-        if (bad) { std::cerr << "Error: compression failed" << std::endl; exit(-1); }
-        for (const auto& o : outv) if (!o.empty() && fwrite(o.data(), 1, o.size(), f_) != o.size()) { std::cerr << "Error: write failed" << std::endl; exit(-1); }
+        if (bad) die("compression failed");
+        for (const auto& o : outv) if (!o.empty() && fwrite(o.data(), 1, o.size(), f_) != o.size()) die("write failed");
         gzbuf_.clear();
         ends_.clear();
     }
@@ -182,7 +234,7 @@ public:
         size_t i = 0;
         while (i < iov_.size()) {
             ssize_t w = writev(fd_, &iov_[i], (int)std::min<size_t>(iov_.size() - i, 1000));
-            if (w < 0) { std::cerr << "Error: write failed" << std::endl; exit(-1); }
+            if (w < 0) die("write failed");
             size_t left = (size_t)w;
             while (i < iov_.size() && left >= iov_[i].iov_len) { left -= iov_[i].iov_len; i++; }
             if (left) { iov_[i].iov_base = (char*)iov_[i].iov_base + left; iov_[i].iov_len -= left; }
@@ -206,26 +258,136 @@ private:
     std::vector<iovec> iov_;
 };
 
-double now_s()
-{
-    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
+// Plain output into a regular file, from several threads.  Measured on the MI355X host (tools/hostio_probe.cpp,
+// tools/sink_probe*.cpp): one write() stream into a tmpfs file is a single-thread copy under the inode lock, ~6 GB/s,
+// and several streams into one file serialise on that lock.  What the kernel does faster: fallocate() instantiates
+// pages at ~16 GB/s (one thread), and threads storing into a shared mapping of EXISTING pages scale (> 20 GB/s with
+// 16) -- but only while no fallocate() runs on the file: page faults beside it drag both down to ~7 GB/s together.
+// So the two never overlap here: the planner reserves the output in few, large strides (sized from the share of the
+// input that survived so far), waiting for the fill jobs in flight to drain before each; the fill threads copy the
+// records of the planned batches into the mapping, each its own run of records.  Used when the output is a regular
+// file that takes fallocate; everything else (pipes, /dev/null, gzip) goes through Output above.
+class MappedSink {
+public:
+    bool open(const std::string& path, uint64_t virt_bytes) {
+        fd_ = ::open(path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
+        if (fd_ < 0) return false;
+        struct stat st;
+        bool ok = fstat(fd_, &st) == 0 && S_ISREG(st.st_mode) && fallocate(fd_, 0, 0, 4096) == 0 && ftruncate(fd_, 0) == 0;   // not every file system has fallocate
+        if (ok) {
+            cap_ = (virt_bytes + 4095) & ~uint64_t(4095);
+            map_ = (char*)mmap(nullptr, cap_, PROT_READ | PROT_WRITE, MAP_SHARED, fd_, 0);      // beyond the end of the file for now
+            ok = map_ != MAP_FAILED;
+        }
+        if (!ok) { ::close(fd_); fd_ = -1; return false; }
+        return true;
+    }
+    uint64_t reserved() const { return reserved_; }
+    uint64_t planned() const { return size_; }
+    uint64_t capacity() const { return cap_; }
+    // instantiate the pages up to `end` (no fill job may be running)
+    void reserve_to(uint64_t end) {
+        if (end <= reserved_) return;
+        const double t0 = now_s();
+        if (fallocate(fd_, 0, (off_t)reserved_, (off_t)(end - reserved_)) != 0) die(std::string("cannot extend the output file: ") + strerror(errno));
+        t_falloc += now_s() - t0;
+        reserved_ = end;
+    }
+    // the next n bytes of the file (inside what was reserved)
+    char* place(uint64_t n) { char* p = map_ + size_; size_ += n; return p; }
+    // the pages wholly inside [p, p+n) are done with: drop their mappings now, from the calling (fill) thread, instead of
+    // all of them at exit from one
+    static void release(const char* p, size_t n) {
+        const uintptr_t lo = ((uintptr_t)p + 4095) & ~uintptr_t(4095), hi = ((uintptr_t)p + n) & ~uintptr_t(4095);
+        if (hi > lo) madvise((void*)lo, hi - lo, MADV_DONTNEED);
+    }
+    void close() {
+        if (fd_ < 0) return;
+        if (reserved_ != size_ && ftruncate(fd_, (off_t)size_) != 0) die("cannot set the size of the output file");
+        ::close(fd_);
+        fd_ = -1;
+    }
+    bool is_open() const { return fd_ >= 0; }
+    double t_falloc = 0;
+private:
+    int fd_ = -1;
+    char* map_ = nullptr;
+    uint64_t size_ = 0, reserved_ = 0, cap_ = 0;
+};
 
-[[noreturn]] void die(const std::string& msg)
-{
-    std::cerr << "Error: " << msg << std::endl;
-    exit(-1);
-}
+// worker threads for the fill jobs
+class Pool {
+public:
+    explicit Pool(int n) { for (int i = 0; i < n; i++) th_.emplace_back([this] { run(); }); }
+    double busy_s() { std::lock_guard<std::mutex> l(m_); return busy_; }
+    void add(std::function<void()> f) {
+        { std::lock_guard<std::mutex> l(m_); q_.push_back(std::move(f)); open_++; }
+        cv_.notify_one();
+    }
+    void drain() {                              // until every job added so far has run
+        std::unique_lock<std::mutex> l(m_);
+        idle_.wait(l, [&] { return open_ == 0; });
+    }
+    void finish() {                             // runs what is queued, then stops the threads
+        { std::lock_guard<std::mutex> l(m_); stop_ = true; }
+        cv_.notify_all();
+        for (std::thread& t : th_) t.join();
+        th_.clear();
+    }
+private:
+    void run() {
+        for (;;) {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [&] { return stop_ || !q_.empty(); });
+                if (q_.empty()) return;
+                f = std::move(q_.front());
+                q_.pop_front();
+            }
+            const double t0 = now_s();
+            f();
+            const double dt = now_s() - t0;
+            f = nullptr;                            // what the job held goes now, outside the lock
+            const double dd = now_s() - t0 - dt;
+            std::lock_guard<std::mutex> l(m_);
+            busy_ += dt;
+            destroy_ += dd;
+            if (dt > longest_) longest_ = dt;
+            jobs_++;
+            if (first_ == 0) first_ = t0;
+            last_ = std::max(last_, t0 + dt + dd);
+            if (--open_ == 0) idle_.notify_all();
+        }
+    }
+    double busy_ = 0;
+public:
+    double destroy_ = 0, longest_ = 0, first_ = 0, last_ = 0;
+    size_t jobs_ = 0;
+private:
+    size_t open_ = 0;
+    std::condition_variable idle_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<std::function<void()>> q_;
+    std::vector<std::thread> th_;
+    bool stop_ = false;
+};
 
 }  // namespace
 
 int main(int argc, char** argv)
 {
+    double t_epoch0;
+    { struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts); t_epoch0 = (double)ts.tv_sec + ts.tv_nsec * 1e-9; }
     Options o;
     if (parse_args(argc, argv, o)) return 1;
+    // big blocks stay in the heap instead of being mapped and unmapped one by one (see BatchStore)
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, -1);
     const bool timing = getenv("TGSF_TIMING") != nullptr;      // stage wall times on stderr (not part of the surface)
     const double t_start = now_s();
-    double t_prepass = 0, t_create = 0, t_pipe = 0, t_parse = 0, t_gpu = 0, t_write = 0, t_widle = 0, t_first = 0;
+    double t_drain = 0, t_prepass = 0, t_pipe = 0, t_parse = 0, t_gpu = 0, t_write = 0, t_widle = 0, t_first = 0;
 
     // file types and report name, :2993-3033
     o.in_type = file_type(o.in_file);
@@ -248,16 +410,19 @@ int main(int argc, char** argv)
     // rows of SURVEY 8(f) that are not built yet fail loudly instead of silently doing something else
     const bool fasta_in = o.in_type == 0;                              // records without qualities: count-only tallies, no Q gate
 
-    // HIP start-up and kernel loading run beside the input open and the pre-pass
+    // loading the HIP library, device bring-up and kernel loading run beside the input open, the indexing and
+    // the pre-pass (api.h)
     if (o.devices.empty()) o.devices.push_back(o.device);
-    std::thread warm([&] { for (int d : o.devices) (void)tgsf_prepare_device(d); });
-    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } warm_join{warm};
+    lib_start(o.devices);
 
     InputBytes in;
     if (!in.open(o.in_file, o.in_type == 2)) return 1;            // SAM/BAM: decoded to FASTQ text (read_bam, :1872-1917)
+    // the records are indexed once, in the background, for the pre-pass and for the filter pass
+    const int scan_threads = std::max(1, std::min(o.n_thread, 32));
+    RecordIndex records(in.data(), in.size(), !fasta_in, scan_threads);
 
     // ---- pre-pass, :3058-3126 ----
-    PrepassResult pp = run_prepass(o, in);
+    PrepassResult pp = run_prepass(o, records);
     t_prepass = now_s() - t_start;
     std::vector<std::string> adapters;
     if (o.filter) {
@@ -286,7 +451,7 @@ int main(int argc, char** argv)
             std::cerr << "INFO: 3' adapter: " << a3 << std::endl;
             std::cerr << "INFO: mean depth of 5' adapter: " << d5 << std::endl;
             std::cerr << "INFO: mean depth of 3' adapter: " << d3 << std::endl;
-            if (o.only_adapters) return 0;
+            if (o.only_adapters) { fflush(nullptr); _exit(0); }
             if (!a5.empty()) { add(a5); add(rev_comp(a5)); }
             if (!a3.empty()) { add(a3); add(rev_comp(a3)); }
             if (a5.empty() && a3.empty()) {                            // :3115-3125
@@ -301,10 +466,37 @@ int main(int argc, char** argv)
         }
     }
 
-    // ---- context ----
+    // ---- contexts ----
     // batches are slices of the input text: sized in text bytes (about 2 bytes per base + headers)
-    const uint64_t batch_text = std::min<uint64_t>(512ull << 20, std::max<uint64_t>(in.size() / 4 + 4096, 1 << 16));
+    uint64_t batch_text = std::min<uint64_t>(256ull << 20, std::max<uint64_t>(in.size() / 8 + 4096, 1 << 16));
+    if (const char* e = getenv("TGSF_BATCH_BYTES")) { const long long v = atoll(e); if (v > 0) batch_text = (uint64_t)v; }   // tuning / test knob
     const uint32_t batch_reads = 1u << 16;
+    const bool fastq_out = o.out_type == 1;
+    const bool run_filter_pass = o.filter || o.only_qc;                // :3061; with -F the input goes straight to downsampling
+    Output out;
+    MappedSink sink;
+    {
+        const char* w = getenv("TGSF_WRITER");                         // "writev": always the single-stream writer
+        const bool may_map = !o.only_qc && !o.out_gz && !o.downsample && run_filter_pass && !o.out_file.empty() &&
+                             !(w && !strcmp(w, "writev"));
+        if (may_map) sink.open(o.out_file, (uint64_t)in.size() + in.size() / 4 + (16u << 20));
+        if (!o.only_qc && !sink.is_open() && !out.open(o)) return 1;
+    }
+    // While the library loads and the device comes up nothing else needs this thread's core: pages of the output file
+    // are instantiated meanwhile, up to a quarter of the input's size (what a run keeps is not known yet; a surplus is
+    // cut off at the end).  Stops as soon as the planner has its first batch.
+    std::atomic<bool> spec_stop{false};
+    std::thread spec;
+    if (sink.is_open() && in.size() > (256u << 20) && !getenv("TGSF_NO_EARLY_RESERVE"))
+        spec = std::thread([&] {
+            const uint64_t limit = (uint64_t)in.size() / 4;
+            while (!spec_stop.load() && sink.reserved() < limit) sink.reserve_to(std::min<uint64_t>(limit, sink.reserved() + (128u << 20)));
+        });
+    auto end_spec = [&] { if (spec.joinable()) { spec_stop = true; spec.join(); } };
+    const Api& L = lib();                                              // joins the loader thread
+    double t_load = 0, t_dev = 0;
+    lib_times(t_load, t_dev);
+    const double t_libwait = now_s() - t_start - t_prepass;
     tgsf_params p;
     memset(&p, 0, sizeof p);
     p.struct_size = sizeof p;
@@ -318,55 +510,51 @@ int main(int argc, char** argv)
     p.n_adapters = (int)adapters.size();
     for (size_t a = 0; a < adapters.size(); a++) { p.adapters[a] = adapters[a].data(); p.adapter_len[a] = (int)adapters[a].size(); }
     p.max_batch_reads = batch_reads;
-    p.max_read_len = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(in.size() / 2, 1024), 1u << 26);
+    // rows of the per-100-bp tables: from the longest read when the index is complete by now (it usually is: it runs
+    // at tens of GB/s beside the device bring-up), else from what the file could hold
+    if (records.complete()) p.max_read_len = std::max<uint32_t>(records.longest(), 1024);
+    else p.max_read_len = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(in.size() / 2, 1024), 1u << 26);
     // capacity is in buffer bytes: a text slice must fit, and so must one record of the longest read on its own
     // (header + two lines of max_read_len)
     p.max_batch_bases = std::max<uint64_t>(batch_text, 2ull * p.max_read_len + (1u << 16)) + (1 << 20);
-    // one context (and one feeder thread) per device of --devices; batches are dealt to whichever feeder is
-    // free, the writer re-sequences them, the tallies are merged at the end (host side)
-    if (warm.joinable()) warm.join();
-    std::vector<tgsf_ctx*> ctxs(o.devices.size(), nullptr);
-    const double t_c0 = now_s();
-    for (size_t d = 0; d < ctxs.size(); d++)
-        if (tgsf_create(&p, o.devices[d], &ctxs[d]) != TGSF_OK) die(tgsf_last_error(nullptr));
-    tgsf_ctx* ctx = ctxs[0];
-    t_create = now_s() - t_c0;
+    // Per device of --devices: a few contexts, each with its own feeder thread.  A feeder's tgsf_submit is
+    // synchronous (H2D from the pageable input mapping, kernels, D2H): one of them moves ~26 GB/s over the link, two
+    // or three together saturate it (~55 GB/s) and keep the kernels of one batch under the copy of another.  Batches
+    // are dealt to whichever feeder is free, the planner re-sequences them, the tallies are merged at the end
+    // (host side).
+    int per_dev = in.size() > (64u << 20) ? 3 : 1;
+    if (const char* e = getenv("TGSF_CTX_PER_DEVICE")) { const int v = atoi(e); if (v >= 1 && v <= 8) per_dev = v; }
+    std::vector<int> ctx_dev;
+    for (int d : o.devices) for (int k = 0; k < per_dev; k++) ctx_dev.push_back(d);
+    std::vector<tgsf_ctx*> ctxs(ctx_dev.size(), nullptr);
     const double t_p0 = now_s();
 
     // ---- pipeline ----
-    Channel<std::unique_ptr<Batch>> to_gpu(2 + o.devices.size()), to_writer(2 + o.devices.size());
+    Channel<std::shared_ptr<Batch>> to_gpu(2 + ctxs.size()), to_writer(256);
     std::vector<int> raw_lens, clean_lens;
     uint64_t raw_bases = 0, clean_bases = 0;
-    const bool fastq_out = o.out_type == 1;
-    Output out;
-    if (!o.only_qc && !out.open(o)) return 1;
     std::vector<CleanRec> clean_recs;                                  // only filled when downsampling follows
-    const bool run_filter_pass = o.filter || o.only_qc;                // :3061; with -F the input goes straight to downsampling
     if (!run_filter_pass) {                                            // get_fastx_SeqLen, :2256-2269
-        FastxReader rd(in.data(), in.size(), !fasta_in);
-        Record r;
+        RecordIndex::Cursor rd(records);
+        Rec r;
         while (rd.next(r)) {
-            clean_recs.push_back({r.name, 1, r.seq.data(), r.qual.data(), (uint32_t)r.seq.size()});
-            clean_bases += r.seq.size();
+            clean_recs.push_back({std::string_view(r.name, r.name_len), 1, r.seq, r.qual, r.len});
+            clean_bases += r.len;
         }
     }
 
-    const int scan_threads = std::max(1, std::min(o.n_thread, 8));
-    std::thread reader([&] {                                           // read_fastx, :1845-1870 (index only)
+    BatchStore store;
+    std::thread reader([&] {                                           // read_fastx, :1845-1870 (batches of indexed records)
         if (!run_filter_pass) { for (size_t d = 0; d < ctxs.size(); d++) to_gpu.put(nullptr); return; }
-        FastxReader rd(in.data(), in.size(), !fasta_in, scan_threads);
-        Record r;
-        auto fresh = [&] {
-            std::unique_ptr<Batch> nb(new Batch);
-            nb->off.reserve(batch_reads); nb->qoff.reserve(batch_reads); nb->len.reserve(batch_reads); nb->names.reserve(batch_reads);
-            return nb;
-        };
-        std::unique_ptr<Batch> b = fresh();
+        RecordIndex::Cursor rd(records);
+        Rec r;
+        auto fresh = [&] { return store.get(); };
+        std::shared_ptr<Batch> b = fresh();
         const double t0 = now_s();
         double waited = 0;
         uint64_t next_id = 0;
         auto flush = [&] {
-            if (b->names.empty()) return;
+            if (b->recs.empty()) return;
             const double w0 = now_s();
             b->id = next_id++;
             to_gpu.put(std::move(b));
@@ -374,14 +562,14 @@ int main(int argc, char** argv)
             b = fresh();
         };
         while (rd.next(r)) {
-            const size_t L = r.seq.size();
+            const size_t L = r.len;
             if (L > p.max_read_len) die("read longer than the supported maximum");
-            const char* rec_end = (fasta_in ? r.seq.data() : r.qual.data()) + L;
-            if (!b->names.empty() && ((uint64_t)(rec_end - b->base) > batch_text || b->names.size() >= batch_reads)) flush();
-            if (b->names.empty()) b->base = r.name.data();
-            b->off.push_back((uint64_t)(r.seq.data() - b->base));
-            b->qoff.push_back(fasta_in ? b->off.back() : (uint64_t)(r.qual.data() - b->base));
-            b->len.push_back((uint32_t)L); b->names.push_back(r.name);
+            const char* rec_end = (fasta_in ? r.seq : r.qual) + L;
+            if (!b->recs.empty() && ((uint64_t)(rec_end - b->base) > batch_text || b->recs.size() >= batch_reads)) flush();
+            if (b->recs.empty()) b->base = r.name;
+            b->off.push_back((uint64_t)(r.seq - b->base));
+            b->qoff.push_back(fasta_in ? b->off.back() : (uint64_t)(r.qual - b->base));
+            b->len.push_back((uint32_t)L); b->recs.push_back(r);
             b->span = (uint64_t)(rec_end - b->base);
             if (b->span > p.max_batch_bases) die("record larger than a batch");
             b->bases += L;
@@ -393,21 +581,24 @@ int main(int argc, char** argv)
     });
 
     std::mutex gpu_time_m;
-    auto feed = [&](tgsf_ctx* fctx) {                                  // filter_sequence, :1919-2064, one batch per call
+    auto feed = [&](size_t k) {                                        // filter_sequence, :1919-2064, one batch per call
+        if (L.create(&p, ctx_dev[k], &ctxs[k]) != TGSF_OK) die(L.last_error(nullptr));
+        tgsf_ctx* fctx = ctxs[k];
         for (;;) {
-            std::unique_ptr<Batch> b = to_gpu.get();
+            std::shared_ptr<Batch> b = to_gpu.get();
             if (!b) break;
             const double g0 = now_s();
-            b->res.resize(b->names.size());
-            b->frags.resize((size_t)(b->bases / (uint64_t)std::max(p.min_len, 1)) + b->names.size() + 16);
+            if (b->res.size() < b->recs.size()) b->res.resize(b->recs.size());
+            const size_t fneed = (size_t)(b->bases / (uint64_t)std::max(p.min_len, 1)) + b->recs.size() + 16;
+            if (b->frags.size() < fneed) b->frags.resize(fneed);
             const uint8_t* text = reinterpret_cast<const uint8_t*>(b->base);
             tgsf_batch_in bi;
             memset(&bi, 0, sizeof bi);
             bi.seq = text; bi.qual = text;                             // one buffer: the FASTQ text itself
             bi.offsets = b->off.data(); bi.qual_offsets = b->qoff.data(); bi.lengths = b->len.data();
-            bi.n_reads = (uint32_t)b->names.size(); bi.n_bytes = b->span;
+            bi.n_reads = (uint32_t)b->recs.size(); bi.n_bytes = b->span;
             tgsf_batch_out bo{b->res.data(), b->frags.data(), (uint32_t)b->frags.size(), 0};
-            if (tgsf_submit(fctx, &bi, &bo) != TGSF_OK) die(tgsf_last_error(fctx));
+            if (L.submit(fctx, &bi, &bo) != TGSF_OK) die(L.last_error(fctx));
             { std::lock_guard<std::mutex> l(gpu_time_m); t_gpu += now_s() - g0; if (t_first == 0) t_first = now_s() - t_p0; }
             b->n_frags = bo.n_frags;
             to_writer.put(std::move(b));
@@ -415,16 +606,45 @@ int main(int argc, char** argv)
         to_writer.put(nullptr);
     };
     std::vector<std::thread> feeders;
-    for (tgsf_ctx* c : ctxs) feeders.emplace_back(feed, c);
+    for (size_t k = 0; k < ctxs.size(); k++) feeders.emplace_back(feed, k);
 
-    std::thread writer([&] {                                           // record formatting :2011-2053 + write_output :2095-2145
+    // record formatting :2011-2053 + write_output :2095-2145.  The planner takes the batches in input order (= the
+    // reference's -t 1 order), lays the records of a batch out in the output file and hands runs of them to the fill
+    // threads (MappedSink); or, for the other kinds of output, gathers the pieces and writes them itself (Output).
+    int fill_threads = std::max(1, std::min(o.n_thread, 16));
+    if (const char* e = getenv("TGSF_FILL_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) fill_threads = v; }   // tuning knob
+    uint64_t fill_min = 1u << 20;                                      // bytes worth a job of their own
+    if (const char* e = getenv("TGSF_FILL_MIN_BYTES")) { const long long v = atoll(e); if (v > 0) fill_min = (uint64_t)v; }   // test knob
+    Pool pool(sink.is_open() ? fill_threads : 1);
+    // Taking down the mapping of an N-GB input costs ~90 ns per 4-KB page, 0.4 s for 18 GB -- at exit, on one thread,
+    // after everything is written.  One background thread drops the pages of written batches while the pipeline runs
+    // instead (several threads doing it only get in each other's way).  Only for a file mapping whose text nothing
+    // refers to later.
+    const bool release_input = in.mapped() && !o.downsample && getenv("TGSF_KEEP_INPUT_MAPPED") == nullptr;
+    Channel<std::pair<const char*, uint64_t>> to_release(1 << 16);
+    std::thread releaser([&] {
+        for (;;) {
+            const std::pair<const char*, uint64_t> r = to_release.get();
+            if (!r.first) break;
+            for (uint64_t o2 = 0; o2 < r.second; o2 += (16u << 20)) MappedSink::release(r.first + o2, std::min<uint64_t>(16u << 20, r.second - o2));
+        }
+    });
+    using Emit = Batch::Emit;
+    // a written batch: the mappings of its pages of the output go at once (from the fill thread, not all at exit
+    // from one), the batch itself back to the store
+    auto batch_done = [&](std::shared_ptr<Batch> b) {
+        if (b->out_bytes) MappedSink::release(b->dst, b->out_bytes);
+        if (release_input) to_release.put({b->base, b->span});
+        store.put(std::move(b));
+    };
+    std::thread writer([&] {
         const std::string lead(1, fastq_out ? '@' : '>'), nl("\n"), sep("\n+\n");
         std::string name;
-        std::map<uint64_t, std::unique_ptr<Batch>> held;               // batches that arrived ahead of their turn
-        uint64_t want = 0;
+        std::map<uint64_t, std::shared_ptr<Batch>> held;               // batches that arrived ahead of their turn
+        uint64_t want = 0, in_seen = 0;
         size_t open_feeders = ctxs.size();
         for (;;) {
-            std::unique_ptr<Batch> b;
+            std::shared_ptr<Batch> b;
             auto it = held.find(want);
             if (it != held.end()) { b = std::move(it->second); held.erase(it); }
             else {
@@ -437,43 +657,119 @@ int main(int argc, char** argv)
             }
             want++;
             const double w0 = now_s();
-            for (size_t r = 0; r < b->names.size(); r++) {
+            const bool fill = sink.is_open();
+            end_spec();
+            uint64_t at = 0;
+            for (size_t r = 0; r < b->recs.size(); r++) {
                 int pass_num = 1;
                 const tgsf_read_result& rr = b->res[r];
+                const Rec& rec = b->recs[r];
+                const std::string_view rname(rec.name, rec.name_len);
                 for (uint32_t f = rr.frag_begin; f < rr.frag_begin + rr.n_frags; f++) {
                     const tgsf_fragment& fr = b->frags[f];
                     if (!(fr.flags & TGSF_FF_PASS)) continue;
                     if (o.downsample) {                                // kept in memory instead of a tmp file (:3129-3137)
-                        clean_recs.push_back({b->names[r], pass_num++, b->base + b->off[r] + fr.start,
-                                              b->base + b->qoff[r] + fr.start, (uint32_t)fr.len});
+                        clean_recs.push_back({rname, pass_num++, rec.seq + fr.start, rec.qual + fr.start, (uint32_t)fr.len});
                         clean_bases += (uint64_t)fr.len;
                         clean_lens.push_back(fr.len);
                         continue;
                     }
+                    clean_bases += (uint64_t)fr.len;
+                    clean_lens.push_back(fr.len);
+                    if (o.only_qc) { pass_num++; continue; }
+                    if (fill) {
+                        b->em.push_back({(uint32_t)r, f, pass_num, at});
+                        size_t nlen = rname.size();
+                        if (pass_num >= 2) { int v = pass_num; nlen += 1; while (v) { nlen++; v /= 10; } }
+                        at += 1 + nlen + 1 + (uint64_t)fr.len + (fastq_out ? 3 + (uint64_t)fr.len : 0) + 1;
+                        pass_num++;
+                        continue;
+                    }
                     out.text(lead);
-                    if (pass_num < 2) out.piece(b->names[r].data(), b->names[r].size());
-                    else { name.clear(); append_name(name, b->names[r], pass_num); out.text(name); }
+                    if (pass_num < 2) out.piece(rname.data(), rname.size());
+                    else { name.clear(); append_name(name, rname, pass_num); out.text(name); }
                     pass_num++;
                     out.text(nl);
-                    out.piece(b->base + b->off[r] + fr.start, (size_t)fr.len);
+                    out.piece(rec.seq + fr.start, (size_t)fr.len);
                     if (fastq_out) {
                         out.text(sep);
-                        out.piece(b->base + b->qoff[r] + fr.start, (size_t)fr.len);
+                        out.piece(rec.qual + fr.start, (size_t)fr.len);
                     }
                     out.text(nl);
                     out.end_record();
-                    clean_bases += (uint64_t)fr.len;
-                    clean_lens.push_back(fr.len);
                 }
             }
-            if (!o.only_qc) out.flush_iov();                             // the batch (and its views) goes away
+            in_seen += b->span;
+            if (fill && at) {
+                if (sink.planned() + at > sink.capacity()) die("output larger than the space mapped for it");
+                if (sink.planned() + at > sink.reserved()) {
+                    // reserve a large stride: what is left of the input times the share of it that was written so far
+                    // (plus a little); page faults and fallocate do not mix, so the fill jobs drain first
+                    const double share = in_seen ? (double)(sink.planned() + at) / (double)in_seen : 1.0;
+                    uint64_t upto = sink.planned() + at + (uint64_t)(share * 1.02 * (double)((uint64_t)in.size() - std::min<uint64_t>(in_seen, in.size())));
+                    upto = std::min<uint64_t>(std::max<uint64_t>(upto, sink.planned() + at), sink.capacity());
+                    const double d0 = now_s();
+                    pool.drain();
+                    t_drain += now_s() - d0;
+                    sink.reserve_to(upto);
+                }
+                b->dst = sink.place(at);
+                b->out_bytes = at;
+                const size_t n = b->em.size();
+                const int parts = (int)std::min<size_t>((size_t)fill_threads, std::max<size_t>(1, at / fill_min));
+                b->left = parts;
+                size_t lo = 0;
+                for (int k = 0; k < parts; k++) {                      // byte-balanced runs of records
+                    size_t hi = n;
+                    if (k + 1 < parts) {
+                        const uint64_t target = at / (uint64_t)parts * (uint64_t)(k + 1);
+                        hi = (size_t)(std::lower_bound(b->em.begin() + (long)lo, b->em.end(), target,
+                                                       [](const Emit& e, uint64_t t) { return e.at < t; }) - b->em.begin());
+                    }
+                    pool.add([b, lo, hi, fastq_out, &batch_done] {
+                        Batch& bb = *b;
+                        std::string nm;
+                        for (size_t i = lo; i < hi; i++) {
+                            const Emit& e = bb.em[i];
+                            const Rec& rec = bb.recs[e.read];
+                            const tgsf_fragment& fr = bb.frags[e.frag];
+                            char* d = bb.dst + e.at;
+                            *d++ = fastq_out ? '@' : '>';
+                            if (e.pass_num < 2) { memcpy(d, rec.name, rec.name_len); d += rec.name_len; }
+                            else { nm.clear(); append_name(nm, std::string_view(rec.name, rec.name_len), e.pass_num); memcpy(d, nm.data(), nm.size()); d += nm.size(); }
+                            *d++ = '\n';
+                            memcpy(d, rec.seq + fr.start, (size_t)fr.len); d += fr.len;
+                            if (fastq_out) {
+                                memcpy(d, "\n+\n", 3); d += 3;
+                                memcpy(d, rec.qual + fr.start, (size_t)fr.len); d += fr.len;
+                            }
+                            *d++ = '\n';
+                        }
+                        if (--bb.left == 0) batch_done(b);
+                    });
+                    lo = hi;
+                }
+            }
+            if (!o.only_qc && !fill) out.flush_iov();                   // the batch (and its views) goes away
+            if (!(fill && at)) batch_done(b);                           // written (or nothing to write)
             t_write += now_s() - w0;
         }
     });
     reader.join();
     for (std::thread& f : feeders) f.join();
     writer.join();
+    end_spec();
+    const bool mapped_out = sink.is_open();
+    const double t_f0 = now_s();
+    pool.finish();
+    to_release.put({nullptr, 0});
+    releaser.join();
+    const double t_busy = pool.busy_s();
+    const double t_fill_tail = now_s() - t_f0;
+    sink.close();
+    const double t_close = now_s() - t_f0 - t_fill_tail;
     t_pipe = now_s() - t_p0;
+    tgsf_ctx* ctx = ctxs[0];
 
     // ---- downsampling: DownSampleTask, :2164-2568 ----
     // keep the longest reads until the target is met (:2297-2344), then a QC-only pass over the kept reads
@@ -522,7 +818,7 @@ int main(int argc, char** argv)
         qp.no_qual = down_no_qual ? 1 : 0;
         qp.max_batch_bases = (1ull << 30); qp.max_batch_reads = 1u << 16;
         tgsf_ctx* qctx = nullptr;
-        if (tgsf_create(&qp, o.devices[0], &qctx) != TGSF_OK) die(tgsf_last_error(nullptr));
+        if (L.create(&qp, o.devices[0], &qctx) != TGSF_OK) die(L.last_error(nullptr));
         std::vector<uint8_t> bs, bq; std::vector<uint64_t> boff; std::vector<uint32_t> blen;
         std::vector<tgsf_read_result> bres; std::vector<tgsf_fragment> bfr(16);
         auto run = [&] {
@@ -533,7 +829,7 @@ int main(int argc, char** argv)
             bi.seq = bs.data(); bi.qual = bq.data(); bi.offsets = boff.data(); bi.lengths = blen.data();
             bi.n_reads = (uint32_t)blen.size(); bi.n_bytes = bs.size() - 64;
             tgsf_batch_out bo{bres.data(), bfr.data(), (uint32_t)bfr.size(), 0};
-            if (tgsf_submit(qctx, &bi, &bo) != TGSF_OK) die(tgsf_last_error(qctx));
+            if (L.submit(qctx, &bi, &bo) != TGSF_OK) die(L.last_error(qctx));
             bs.clear(); bq.clear(); boff.clear(); blen.clear();
         };
         const std::string lead(1, fastq_out ? '@' : '>'), nl("\n"), sep("\n+\n");
@@ -558,24 +854,29 @@ int main(int argc, char** argv)
         }
         run();
         uint64_t qnw = 0; int32_t qbc = 0; uint32_t qnb = 0;
-        tgsf_counters_len(qctx, &qnw, &qbc, &qnb);
+        L.counters_len(qctx, &qnw, &qbc, &qnb);
         down_t.resize(qnw);
-        if (tgsf_counters(qctx, down_t.data(), qnw) != TGSF_OK) die(tgsf_last_error(qctx));
-        tgsf_destroy(qctx);
+        if (L.counters(qctx, down_t.data(), qnw) != TGSF_OK) die(L.last_error(qctx));
+        L.destroy(qctx);
     }
-    if (!o.only_qc) out.close();
+    if (!o.only_qc && !mapped_out) out.close();
 
     // ---- statistics, stderr, report: :3146-3235, :3240-3279, :3285-3328 ----
     uint64_t nw = 0; int32_t bc = 0; uint32_t nbins = 0;
-    tgsf_counters_len(ctx, &nw, &bc, &nbins);
+    L.counters_len(ctx, &nw, &bc, &nbins);
     std::vector<uint64_t> t(nw, 0), part(nw);
     for (tgsf_ctx* c : ctxs) {                                         // sums; the four "rows used" words are maxima
-        if (tgsf_counters(c, part.data(), nw) != TGSF_OK) die(tgsf_last_error(c));
+        uint64_t used[2] = {0, 0};                                     // of the bin tables only the rows in use travel
+        if (L.counters_used(c, part.data(), nw, used) != TGSF_OK) die(L.last_error(c));
         uint64_t rows[4];
         for (int k = 0; k < 4; k++) rows[k] = std::max(t[TGSF_CTR_ROWS + k], part[TGSF_CTR_ROWS + k]);
-        for (uint64_t i = 0; i < nw; i++) t[i] += part[i];
+        const size_t head = tgsf_ctr_bin_table(0, bc, nbins);
+        for (size_t i = 0; i < head; i++) t[i] += part[i];
+        for (int b = 0; b < 4; b++) {
+            const size_t at = tgsf_ctr_bin_table(b, bc, nbins), n = (size_t)used[b >> 1] * 5;
+            for (size_t i = 0; i < n; i++) t[at + i] += part[at + i];
+        }
         for (int k = 0; k < 4; k++) t[TGSF_CTR_ROWS + k] = rows[k];
-        tgsf_destroy(c);
     }
     auto tables = [&](const std::vector<uint64_t>& v, bool clean) {
         SideTables s;
@@ -638,11 +939,20 @@ int main(int argc, char** argv)
     write_report(ofs, qc, raw, clean);
     ofs.close();
     std::cerr << "INFO: Quality control report was written to: " << html << "." << std::endl;
-    if (timing)
-        fprintf(stderr, "TIMING: total %.3f s | prepass %.3f | tgsf_create %.3f | pipeline %.3f (parse+pack %.3f, tgsf_submit %.3f, "
-                        "format+write %.3f, writer waiting %.3f, first batch filtered after %.3f; stages overlap) | stats+report %.3f\n",
-                now_s() - t_start, t_prepass, t_create, t_pipe, t_parse, t_gpu, t_write, t_widle, t_first, now_s() - t_p0 - t_pipe);
+    if (timing) {
+        fprintf(stderr, "POOL: %zu jobs, busy %.3f, freeing job state %.3f, longest job %.3f, first job at %.3f, last job done at %.3f (pipeline start = 0, planner done at %.3f)\n",
+                pool.jobs_, t_busy, pool.destroy_, pool.longest_, pool.first_ - t_p0, pool.last_ - t_p0, t_f0 - t_p0);
+        fprintf(stderr, "TIMING: total %.3f s | index+prepass %.3f | waiting for the library %.3f (load %.3f + device %.3f, beside the pre-pass) | "
+                        "pipeline %.3f (batching %.3f, tgsf_submit summed over %zu feeders %.3f, plan+write %.3f, planner waiting %.3f, "
+                        "first batch filtered after %.3f, fill tail %.3f, closing the output %.3f; stages overlap) | stats+report %.3f | %s (fallocate %.3f, waiting for fill jobs before it %.3f, fill threads busy %.3f summed)\n",
+                now_s() - t_start, t_prepass, t_libwait, t_load, t_dev, t_pipe, t_parse, ctxs.size(), t_gpu, t_write, t_widle, t_first,
+                t_fill_tail, t_close, now_s() - t_p0 - t_pipe, mapped_out ? "output: fallocate + mapped fill" : "output: writev", sink.t_falloc, t_drain, t_busy);
+    }
     // everything is written and closed: skip the teardown of multi-GB mappings and of the HIP runtime
+    if (timing) {
+        struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts);
+        fprintf(stderr, "CLOCK: main entered at %.6f, leaving at %.6f (epoch seconds)\n", t_epoch0, (double)ts.tv_sec + ts.tv_nsec * 1e-9);
+    }
     fflush(nullptr);
     _exit(0);
 }

@@ -8,7 +8,7 @@
 #include <unordered_map>
 #include <vector>
 
-#include "tgsf.h"
+#include "api.h"
 
 namespace host {
 
@@ -114,7 +114,7 @@ static void adapter_search(const Options& o, const std::vector<std::string>& end
     p.max_batch_reads = (uint32_t)(per_call * 22 / (22 * 2) + 64);      // n problems <= cap_reads * A * 2
     p.max_batch_bases = 1 << 20; p.max_read_len = 1 << 16;
     tgsf_ctx* ctx = nullptr;
-    if (tgsf_create(&p, o.device, &ctx) != TGSF_OK) { std::cerr << "Error: " << tgsf_last_error(nullptr) << std::endl; exit(-1); }
+    if (lib().create(&p, o.devices.empty() ? o.device : o.devices[0], &ctx) != TGSF_OK) { std::cerr << "Error: " << lib().last_error(nullptr) << std::endl; exit(-1); }
 
     // totals per adapter in the reference's own container (:1150, :1171): the winner among equal totals is
     // whatever its iteration order and std::sort make of it, reproduced here by using the same ones
@@ -133,14 +133,14 @@ static void adapter_search(const Options& o, const std::vector<std::string>& end
         const uint32_t n = (uint32_t)off.size();
         if (!n) continue;
         res.assign((size_t)n * 4, 0); eds.assign((size_t)n * 2, 0);
-        if (tgsf_align_windows(ctx, buf.data(), buf.size(), off.data(), len.data(), aid.data(), kk.data(), n, res.data(), eds.data()) != TGSF_OK) {
-            std::cerr << "Error: " << tgsf_last_error(ctx) << std::endl; exit(-1);
+        if (lib().align_windows(ctx, buf.data(), buf.size(), off.data(), len.data(), aid.data(), kk.data(), n, res.data(), eds.data()) != TGSF_OK) {
+            std::cerr << "Error: " << lib().last_error(ctx) << std::endl; exit(-1);
         }
         for (uint32_t i = 0; i < n; i++)
             if (res[(size_t)i * 4 + 1] > 0)                             // numAln > 0, :1170 (problems are read-major, as :1156-1158)
                 maps[(int)aid[i]] += res[(size_t)i * 4 + 2] - res[(size_t)i * 4 + 0];   // mlen = alignmentLength - editDistance
     }
-    tgsf_destroy(ctx);
+    lib().destroy(ctx);
     std::vector<std::pair<int, int>> vec(maps.begin(), maps.end());     // :1179-1182
     std::sort(vec.begin(), vec.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.second > b.second; });
     if (vec.empty()) return;
@@ -150,7 +150,7 @@ static void adapter_search(const Options& o, const std::vector<std::string>& end
     if (mean_dep >= 2 * min_sim) { adapter = cand; depth = mean_dep; }  // :1193
 }
 
-PrepassResult run_prepass(Options& o, const InputBytes& in)
+PrepassResult run_prepass(Options& o, RecordIndex& records)
 {
     PrepassResult R;
     int check_len = std::max(std::max(o.end_len, o.bc_len), 100);       // :897-904
@@ -161,18 +161,19 @@ PrepassResult run_prepass(Options& o, const InputBytes& in)
     const bool need3 = o.filter && (o.tail_trim < 0 || o.adapter_file.empty());
     int seq_num = 0, min_qc = 255, max_qc = 0;
     {
-        FastxReader rd(in.data(), in.size(), o.in_type != 0, std::max(1, std::min(o.n_thread, 8)));           // read_fastx / read_bam, :949-1040
-        Record r;
+        RecordIndex::Cursor rd(records);                                // read_fastx / read_bam, :949-1040
+        Rec r;
+        const bool has_qual = o.in_type != 0;
         while (rd.next(r)) {
-            const int L = (int)r.seq.size();
+            const int L = (int)r.len;
             if (L < min_len) continue;
             if (seq_num >= max_seq) break;
             seq_num++;
             // the read ends are only looked at by the base-content check and the adapter search
-            if (need5) ends5.emplace_back(r.seq.substr(0, (size_t)check_len));
-            if (need3) ends3.emplace_back(rev_comp(std::string(r.seq.substr((size_t)(L - check_len)))));
-            const std::string_view q = r.qual.substr(0, std::min((size_t)check_len, r.qual.size()));
-            for (char c : q) { if (min_qc > c) min_qc = c; if (max_qc < c) max_qc = c; }
+            if (need5) ends5.emplace_back(r.seq, (size_t)check_len);
+            if (need3) ends3.emplace_back(rev_comp(std::string(r.seq + (L - check_len), (size_t)check_len)));
+            if (has_qual)
+                for (int i = 0; i < check_len; i++) { const char c = r.qual[i]; if (min_qc > c) min_qc = c; if (max_qc < c) max_qc = c; }
         }
     }
     if (o.in_type == 1 || o.in_type == 2) {                             // Get_qType, :1042-1077

@@ -24,6 +24,6 @@ struct PrepassResult {
 
 // Runs the pre-pass; prints the reference's INFO lines; may exit(-1) like Get_qType (:1060-1065).
 // Updates o.min_q when -q was not given.
-PrepassResult run_prepass(Options& o, const InputBytes& in);
+PrepassResult run_prepass(Options& o, RecordIndex& records);
 
 }  // namespace host

@@ -209,3 +209,78 @@ def pack(reads, align: int = 16):
         seq[o:o + len(s)] = np.frombuffer(s, dtype=np.uint8)
         qual[o:o + len(q)] = np.frombuffer(q, dtype=np.uint8)
     return seq, qual, offsets, lengths
+
+
+# ---------------------------------------------------------------------------
+# C2-shaped FASTQ text, written by several processes (bench.py's end-to-end leg: GBs of text in seconds)
+# ---------------------------------------------------------------------------
+def _fastq_chunk(job):
+    """One run of reads -> its byte range of the file.  Same distributions as make_reads(kind='ont')."""
+    path, file_off, first, lens, seed = job
+    rng = np.random.default_rng(seed)
+    n = len(lens)
+    names = [b"@r%d\n" % (first + i) for i in range(n)]
+    sizes = np.array([len(nm) for nm in names], dtype=np.int64) + 2 * lens + 4
+    starts = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(sizes, out=starts[1:])
+    total = int(starts[-1])
+    buf = _ACGT[rng.integers(0, 4, total, dtype=np.uint8)]
+    B = int(lens.sum())
+    mq = rng.choice(np.array([7, 9, 12, 14, 18], dtype=np.float32), n)
+    q = rng.standard_normal(B, dtype=np.float32)
+    q *= 4.0
+    q += np.repeat(mq, lens)
+    np.rint(q, out=q)
+    np.clip(q, 1, 50, out=q)
+    q += 33
+    q8 = q.astype(np.uint8)
+    del q
+    at = 0
+    for i in range(n):
+        L = int(lens[i])
+        s = int(starts[i])
+        nm = names[i]
+        buf[s:s + len(nm)] = np.frombuffer(nm, dtype=np.uint8)
+        s0 = s + len(nm)
+        if rng.random() < 0.80:                       # rapid adapter at the 5' end, 0-30 bases in, 10 % errors
+            a = np.frombuffer(mutate(rng, ONT_RAPID, 0.10), dtype=np.uint8)
+            pre = int(rng.integers(0, 31))
+            if pre + len(a) < L:
+                buf[s0 + pre:s0 + pre + len(a)] = a
+        if rng.random() < 0.0003 and L > 2000:        # 0.03 % in the middle
+            a = np.frombuffer(mutate(rng, ONT_RAPID if rng.random() < 0.5 else ONT_RAPID_RC, 0.05), dtype=np.uint8)
+            p = int(rng.integers(300, L - 300 - len(a)))
+            buf[s0 + p:s0 + p + len(a)] = a
+        buf[s0 + L:s0 + L + 3] = (10, 43, 10)         # "\n+\n"
+        buf[s0 + L + 3:s0 + 2 * L + 3] = q8[at:at + L]
+        buf[s0 + 2 * L + 3] = 10
+        at += L
+    with open(path, "r+b") as f:
+        f.seek(file_off)
+        f.write(memoryview(buf))
+    return B
+
+
+def write_ont_fastq(path, n_reads, seed=2, mean_len=45000.0, max_len=2_000_000, procs=None, reads_per_job=256):
+    """FASTQ text of config C2's shape at `path`; returns (bases, file bytes).  Deterministic in
+    (n_reads, seed, mean_len, max_len, reads_per_job), whatever the number of processes."""
+    import multiprocessing as mp
+    import os
+    rng = np.random.default_rng(seed)
+    lens = np.minimum(ont_lengths(rng, n_reads, mean_len), max_len).astype(np.int64)
+    name_len = np.array([len(b"@r%d\n" % i) for i in range(n_reads)], dtype=np.int64)
+    sizes = name_len + 2 * lens + 4
+    jobs, off = [], 0
+    for a in range(0, n_reads, reads_per_job):
+        b = min(n_reads, a + reads_per_job)
+        jobs.append((path, off, a, lens[a:b], seed * 1_000_003 + a))
+        off += int(sizes[a:b].sum())
+    with open(path, "wb") as f:
+        f.truncate(off)
+    procs = procs or max(1, min(32, (os.cpu_count() or 2) - 1))
+    if procs == 1:
+        done = [_fastq_chunk(j) for j in jobs]
+    else:
+        with mp.get_context("fork").Pool(procs) as pool:
+            done = pool.map(_fastq_chunk, jobs, chunksize=1)
+    return int(sum(done)), off
