@@ -253,7 +253,7 @@ def oracle_slice_check(torch, batch, p_kwargs, workload, reads_rec, frags_rec, m
 
 
 def kernel_leg(args, torch, dist, world, rank, local_rank, device, xdev, host_group):
-    from tgsfilter_amd import abi, capi, synth
+    from tgsfilter_amd import abi, capi, rccl, synth
     from tgsfilter_amd import dist as tdist
     hifi = args.workload == "hifi"
     mean_len = args.mean_len or (18000.0 if hifi else 45000.0)
@@ -268,8 +268,14 @@ def kernel_leg(args, torch, dist, world, rank, local_rank, device, xdev, host_gr
     p = abi.make_params(args.workload, max_batch_bases=max_bases + 64, max_batch_reads=args.reads, max_read_len=max_len, **p_kwargs)
     NS = max(1, args.streams)
     ctxs = [capi.Context(p, local_rank) for _ in range(NS)]
+    comm = None
     if world > 1:
-        tdist.check_layout(ctxs[0].ctr_words)            # setup: same tally layout on every rank
+        tdist.check_layout(ctxs[0].ctr_words, group=host_group)     # setup: same tally layout on every rank
+        if args.backend == "nccl":
+            # RCCL communicator of the job: rank 0 draws the id, the host-side group hands it round
+            box = [rccl.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=host_group)
+            comm = rccl.comm_init_rank(box[0], rank, world)
     fcap = max_bases // 1000 + args.reads + 16
     # every context gets a stream of its own (never torch's null stream: the library's streams are non-blocking,
     # nothing orders the null stream against them)
@@ -322,10 +328,17 @@ def kernel_leg(args, torch, dist, world, rank, local_rank, device, xdev, host_gr
     sync_streams()                                   # every submit stream is idle before the tallies are read
     for c in ctxs:
         c.wait()
-    total_ctr = tdist.merge_counters([c.counters() for c in ctxs])
-    if world > 1:
-        # the job's only exchange: ONE sum all-reduce of the tally vector (RCCL over xGMI)
-        total_ctr = tdist.allreduce_counters(total_ctr, rank, world, device=xdev)
+    if world > 1 and comm is not None:
+        # the job's only exchange, through the product's own entry point: the contexts of this rank become one vector
+        # in HBM (tgsf_counters_merge), then ONE sum all-reduce of it over RCCL / xGMI (libtgsf_rccl)
+        for c in ctxs[1:]:
+            ctxs[0].merge_from(c)
+        rccl.allreduce_counters(ctxs[0], comm, rank, world, check_layout=False)
+        total_ctr = ctxs[0].counters()
+    else:
+        total_ctr = tdist.merge_counters([c.counters() for c in ctxs])
+        if world > 1:                                # validation path (gloo): the same single sum through torch.distributed
+            total_ctr = tdist.allreduce_counters(total_ctr, rank, world, device=xdev)
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
@@ -433,6 +446,8 @@ def kernel_leg(args, torch, dist, world, rank, local_rank, device, xdev, host_gr
     }
     for c in ctxs:
         c.close()
+    if comm is not None:
+        rccl.comm_destroy(comm)
     return kp, roofline
 
 
@@ -495,9 +510,6 @@ def main():
 
     kp = roofline = None
     if not args.no_kernel_path:
-        if world > 1 and args.backend == "nccl":
-            from tgsfilter_amd import dist as tdist
-            tdist.set_group(dist.new_group(backend="nccl", device_id=device))
         kp, roofline = kernel_leg(args, torch, dist, world, rank, local_rank, device, xdev, host_group)
 
     if rank == 0:

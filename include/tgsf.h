@@ -252,6 +252,10 @@ int tgsf_counters(tgsf_ctx* ctx, uint64_t* dst, uint64_t n_words);
  * rows[1] rows of the two clean ones (the values of dst[TGSF_CTR_ROWS], dst[TGSF_CTR_ROWS+1]).  Words of dst
  * beyond those rows are left as they were (zero them beforehand).  rows may be NULL. */
 int tgsf_counters_used(tgsf_ctx* ctx, uint64_t* dst, uint64_t n_words, uint64_t rows[2]);
+/* Add the tallies of `src` to those of `dst` (same device, same bc_len and max_read_len), in HBM; `src` keeps its
+ * own.  Several contexts of one process (one per batch in flight) become one vector this way -- e.g. before the
+ * job's all-reduce (include/tgsf_rccl.h).  Waits for both contexts. */
+int tgsf_counters_merge(tgsf_ctx* dst, tgsf_ctx* src);
 /* Device address of the same vector (for an in-place RCCL all-reduce). */
 int tgsf_counters_device(tgsf_ctx* ctx, void** d_ptr, uint64_t* n_words);
 /* Zero the tallies (start of a new run). */

@@ -58,3 +58,15 @@ def test_parameter_validation(lib):
     with pytest.raises(capi.TgsfError) as ei:
         capi.Context(p, 0)
     assert ei.value.code == abi.E_UNSUPPORTED
+
+
+def test_rccl_library_exports():
+    """libtgsf_rccl.so (include/tgsf_rccl.h, the optional tally all-reduce) loads and exports what its header declares."""
+    hdr = open(os.path.join(ROOT, "include", "tgsf_rccl.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|void|const char\*)\s+(tgsf_rccl_\w+)\s*\(", hdr, flags=re.M))
+    assert declared == {"tgsf_rccl_allreduce_counters", "tgsf_rccl_last_error"}
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tgsfilter_amd", "csrc")], check=True)
+    from tgsfilter_amd import rccl
+    lib = rccl.load()
+    for s in declared:
+        assert hasattr(lib, s)

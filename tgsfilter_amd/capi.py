@@ -21,7 +21,7 @@ _LIBS = {}
 SYMBOLS = [
     "tgsf_abi_version", "tgsf_prepare_device", "tgsf_create", "tgsf_destroy", "tgsf_submit", "tgsf_submit_async", "tgsf_submit_device",
     "tgsf_wait",
-    "tgsf_counters_len", "tgsf_counters", "tgsf_counters_used", "tgsf_counters_device", "tgsf_reset_counters", "tgsf_profile",
+    "tgsf_counters_len", "tgsf_counters", "tgsf_counters_used", "tgsf_counters_merge", "tgsf_counters_device", "tgsf_reset_counters", "tgsf_profile",
     "tgsf_stage_times", "tgsf_stage_name", "tgsf_align_windows", "tgsf_last_error",
 ]
 
@@ -52,6 +52,8 @@ def load(path: str | None = None):
     L.tgsf_wait.argtypes = [vp]
     L.tgsf_counters_len.argtypes = [vp, C.POINTER(u64), C.POINTER(i32), C.POINTER(u32)]
     L.tgsf_counters.argtypes = [vp, vp, u64]
+    L.tgsf_counters_used.argtypes = [vp, vp, u64, vp]
+    L.tgsf_counters_merge.argtypes = [vp, vp]
     L.tgsf_counters_device.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     L.tgsf_reset_counters.argtypes = [vp]
     L.tgsf_profile.argtypes = [vp, C.c_int]
@@ -155,6 +157,17 @@ class Context:
         out = np.zeros(self.ctr_words, dtype=np.uint64)
         self._chk(self.lib.tgsf_counters(self.h, out.ctypes.data, self.ctr_words))
         return out
+
+    def counters_used(self):
+        """Like counters(), but only the rows in use of the bin tables travel (tgsf_counters_used)."""
+        out = np.zeros(self.ctr_words, dtype=np.uint64)
+        rows = (C.c_uint64 * 2)()
+        self._chk(self.lib.tgsf_counters_used(self.h, out.ctypes.data, self.ctr_words, rows))
+        return out, (rows[0], rows[1])
+
+    def merge_from(self, other: "Context"):
+        """Add the tallies of another context of this device to this one's, in HBM (tgsf_counters_merge)."""
+        self._chk(self.lib.tgsf_counters_merge(self.h, other.h))
 
     def counters_device_ptr(self):
         p, n = C.c_void_p(), C.c_uint64()

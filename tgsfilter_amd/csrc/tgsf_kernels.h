@@ -1554,6 +1554,17 @@ TGSF_KERNEL k_gate_frags(DevParams P, DevBatch B)
 }
 
 // ---------------------------------------------------------------------------
+// k_ctr_merge: tallies of one context added to another's (sums; the four "rows used" words are maxima).
+// ---------------------------------------------------------------------------
+TGSF_KERNEL k_ctr_merge(uint64_t* dst, const uint64_t* src, uint64_t n)
+{
+    for (uint64_t i = gtid(); i < n; i += gsize()) {
+        const uint64_t a = dst[i], b = src[i];
+        dst[i] = (i >= TGSF_CTR_ROWS && i < TGSF_CTR_ROWS + 4) ? (a > b ? a : b) : a + b;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // k_finalize: the records handed back across the C ABI.
 // ---------------------------------------------------------------------------
 TGSF_KERNEL k_finalize(DevBatch B, tgsf_read_result* out_reads, tgsf_fragment* out_frags,

@@ -851,6 +851,19 @@ extern "C" int tgsf_counters_used(tgsf_ctx* c, uint64_t* dst, uint64_t n_words, 
     return he ? fail(c, TGSF_E_HIP, "device to host copy failed") : TGSF_OK;
 }
 
+extern "C" int tgsf_counters_merge(tgsf_ctx* dst, tgsf_ctx* src)
+{
+    if (!dst || !src || dst == src) return TGSF_E_INVALID;
+    if (dst->ctr_words != src->ctr_words || dst->P.bc_len != src->P.bc_len || dst->device != src->device)
+        return fail(dst, TGSF_E_INVALID, "tgsf_counters_merge: the contexts differ in tally layout or device");
+    int e = tgsf_wait(src);
+    if (e) return fail(dst, e, "%s", src->error.c_str());
+    if ((e = tgsf_wait(dst))) return e;
+    TGSF_LAUNCH(k_ctr_merge, grid_cap(blocks_for(dst->ctr_words, 256)), 256, dst->stream, dst->B.ctr, (const uint64_t*)src->B.ctr, dst->ctr_words);
+    const int he = rt_sync(dst->stream);
+    return he ? fail(dst, TGSF_E_HIP, "tgsf_counters_merge failed") : TGSF_OK;
+}
+
 extern "C" int tgsf_counters_device(tgsf_ctx* c, void** d_ptr, uint64_t* n_words)
 {
     if (!c || !d_ptr) return TGSF_E_INVALID;

@@ -1,0 +1,84 @@
+// tgsf_rccl.hip -- libtgsf_rccl.so: the tally all-reduce of a multi-GPU job (include/tgsf_rccl.h).
+// Built on the public ABI of libtgsf only (tgsf_wait, tgsf_counters_device) plus RCCL.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include <string>
+
+#include "tgsf_rccl.h"
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+extern "C" const char* tgsf_rccl_last_error(void) { return g_err.c_str(); }
+
+// buf = [ tallies (n words) | world slots of 4 words ]: this rank's "rows used" words move into its slot
+__global__ void k_pack_rows(unsigned long long* buf, const unsigned long long* ctr, unsigned long long n, int rank, int world)
+{
+    const unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x;
+    if (i < n) buf[i] = (i >= TGSF_CTR_ROWS && i < TGSF_CTR_ROWS + 4) ? 0ull : ctr[i];
+    if (i < 4ull * world) buf[n + i] = ((int)(i / 4) == rank) ? ctr[TGSF_CTR_ROWS + (i & 3)] : 0ull;
+}
+
+__global__ void k_unpack_rows(unsigned long long* ctr, const unsigned long long* buf, unsigned long long n, int world)
+{
+    const unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long v = buf[i];
+    if (i >= TGSF_CTR_ROWS && i < TGSF_CTR_ROWS + 4) {
+        v = 0;
+        for (int r = 0; r < world; r++) { const unsigned long long x = buf[n + 4ull * r + (i - TGSF_CTR_ROWS)]; v = x > v ? x : v; }
+    }
+    ctr[i] = v;
+}
+
+extern "C" int tgsf_rccl_allreduce_counters(tgsf_ctx* ctx, void* nccl_comm, int rank, int world, int check_layout, void* hip_stream)
+{
+    if (!ctx || !nccl_comm || world < 1 || rank < 0 || rank >= world) return fail(TGSF_E_INVALID, "bad argument");
+    int e = tgsf_wait(ctx);                              // every batch of this rank is in the tallies
+    if (e) return fail(e, "%s", tgsf_last_error(ctx));
+    void* d_ctr = nullptr;
+    uint64_t n = 0;
+    if ((e = tgsf_counters_device(ctx, &d_ctr, &n))) return fail(e, "%s", tgsf_last_error(ctx));
+    ncclComm_t comm = (ncclComm_t)nccl_comm;
+    hipStream_t st = (hipStream_t)hip_stream;
+    hipStream_t own = nullptr;
+    if (!st) { if (hipStreamCreateWithFlags(&own, hipStreamNonBlocking) != hipSuccess) return fail(TGSF_E_HIP, "stream"); st = own; }
+    unsigned long long* buf = nullptr;
+    const size_t words = (size_t)n + 4u * (size_t)world + 2;
+    if (hipMalloc((void**)&buf, words * 8) != hipSuccess) { if (own) (void)hipStreamDestroy(own); return fail(TGSF_E_HIP, "device allocation failed"); }
+    int rc = TGSF_OK;
+    if (check_layout) {                                  // max(n) == -max(-n) on every rank, or nobody sums anything
+        long long h[2] = {(long long)n, -(long long)n};
+        long long* d2 = (long long*)(buf + n + 4u * (size_t)world);
+        (void)hipMemcpyAsync(d2, h, 16, hipMemcpyHostToDevice, st);
+        ncclResult_t r = ncclAllReduce(d2, d2, 2, ncclInt64, ncclMax, comm, st);
+        (void)hipMemcpyAsync(h, d2, 16, hipMemcpyDeviceToHost, st);
+        if (r != ncclSuccess || hipStreamSynchronize(st) != hipSuccess) rc = fail(TGSF_E_HIP, "layout check: %s", ncclGetErrorString(r));
+        else if (h[0] != -h[1]) rc = fail(TGSF_E_INVALID, "tally vectors differ in length across ranks (%llu words here, %lld..%lld over the job): create every context with the same bc_len and max_read_len",
+                                          (unsigned long long)n, -h[1], h[0]);
+    }
+    if (rc == TGSF_OK) {
+        const unsigned T = 256, G = (unsigned)((n + 4u * (size_t)world + T - 1) / T);
+        hipLaunchKernelGGL(k_pack_rows, dim3(G), dim3(T), 0, st, buf, (const unsigned long long*)d_ctr, (unsigned long long)n, rank, world);
+        ncclResult_t r = ncclAllReduce(buf, buf, (size_t)n + 4u * (size_t)world, ncclUint64, ncclSum, comm, st);   // the job's one collective
+        hipLaunchKernelGGL(k_unpack_rows, dim3(G), dim3(T), 0, st, (unsigned long long*)d_ctr, (const unsigned long long*)buf, (unsigned long long)n, world);
+        if (r != ncclSuccess) rc = fail(TGSF_E_HIP, "ncclAllReduce: %s", ncclGetErrorString(r));
+        else if (hipStreamSynchronize(st) != hipSuccess) rc = fail(TGSF_E_HIP, "stream synchronize failed");
+    }
+    (void)hipFree(buf);
+    if (own) (void)hipStreamDestroy(own);
+    return rc;
+}
