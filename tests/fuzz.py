@@ -10,7 +10,10 @@ from tgsfilter_amd import abi, capi, synth
 LIB_ADAPTERS = [synth.ONT_RAPID, synth.ONT_RAPID_RC, synth.PACBIO_BLUNT, synth.PACBIO_BLUNT_RC,
                 b"AATGTACTTCGTTCAGTTACGTATTGCT", b"AGCAATACGTAACTGAACGAAGTACATT",
                 b"GGCGTCTGCTTGGGTGTTTAACCTTTTTGTCAGAGAGGTTCCAAGTCAGAGAGGTTCCT",
-                b"CTTGCGGGCGGCGGACTCTCCTCTGAAGATAGAGCGACAGGCAAG"]
+                b"CTTGCGGGCGGCGGACTCTCCTCTGAAGATAGAGCGACAGGCAAG",
+                # beyond the library: 3- and 4-word adapters (-a accepts any length; the reference's edlib is multi-block)
+                bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[np.random.default_rng(150).integers(0, 4, 150)]),
+                bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[np.random.default_rng(241).integers(0, 4, 241)])]
 
 
 def random_case(seed: int, n_reads: int):
@@ -33,8 +36,8 @@ def random_case(seed: int, n_reads: int):
         head_trim=int(rng.choice([0, 0, 5, 40])),
         tail_trim=int(rng.choice([0, 0, 7, 33])),
         end_len=end_len,
-        end_match_len=int(rng.choice([4, 8, 15])),
-        mid_match_len=int(rng.choice([35, 20, 25])),
+        end_match_len=int(rng.choice([4, 8, 15, 1])),           # 1: edlib's k >= Q corner (-m 1 / -M 1)
+        mid_match_len=int(rng.choice([35, 20, 25, 35, 1])),
         extra_len=int(rng.choice([50, 0, 10])),
         end_sim=float(rng.choice([0.75, 0.8, 0.9])),
         mid_sim=float(rng.choice([0.9, 0.95, 0.8])),

@@ -75,7 +75,34 @@ CASES = {
                    [synth.ONT_RAPID], "-x ont -l 1000 -5 4 -3 0 -r 15 -p 2", "fa"),
 }
 
+HUGE_A = bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[np.random.default_rng(1501).integers(0, 4, 150)])   # 3 blocks
+HUGE_B = bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[np.random.default_rng(2301).integers(0, 4, 230)])   # 4 blocks
+CASES.update({
+    # parameter domain beyond the defaults: edlib's k >= Q corner (-m 1 / -M 1; read ends made of
+    # N only, where no adapter character matches and edlib reports the location -1), adapters of 3 and 4 blocks
+    "ont_m1": (dict(seed=30, n=96, kind="ont", mean_len=3500, zoo=True, pmid=0.1),
+               [synth.ONT_RAPID], "-x ont -l 500 -q 9 -5 0 -3 0 -m 1 -M 1", "fq", "n_ends"),
+    "huge_adapter": (dict(seed=31, n=72, kind="ont", mean_len=3500, zoo=True, adapter=HUGE_A, pmid=0.15, err=0.06),
+                     [HUGE_A, HUGE_B], "-x ont -l 800 -q 9 -5 0 -3 2"),
+    # Phred+64 qualities through the whole command line (Get_qType :1042-1077 decides from the first reads)
+    "ont_phred64": (dict(seed=32, n=90, kind="ont", mean_len=3000, zoo=True, pmid=0.05),
+                    [synth.ONT_RAPID], "-x ont -l 1000 -q 10 -5 0 -3 0", "fq", "phred64"),
+    "hifi_phred64_auto": (dict(seed=33, n=900, kind="hifi", mean_len=1400, p5=0.5, p3=0.4), None, "-x hifi -l 1000 -b 8", "fq", "phred64"),
+})
+
 IN_EXT = {"fq": "in.fq", "bam": "in.bam", "sam": "in.sam", "fa": "in.fa"}
+
+
+def tweak(reads, how):
+    out = []
+    for i, (name, sq, q) in enumerate(reads):
+        if how == "phred64":
+            q = bytes(min(max(c, 33 + 16) + 31, 126) for c in q)     # every quality >= 16: min char 80 > 78 decides Phred64 (:1050)
+        elif how == "n_ends" and i % 5 == 2 and len(sq) > 900:
+            sq = b"N" * 260 + sq[260:-260] + b"N" * 260
+        out.append((name, sq, q))
+    return out
+
 
 
 def soft_mask(reads, seed):
@@ -116,8 +143,10 @@ def html_slices(html: str):
     return {"table_rows": table, "data": m.group(1) if m else None}
 
 
-def run_case(name, kwargs, adapters, flags, fmt="fq"):
+def run_case(name, kwargs, adapters, flags, fmt="fq", how=None):
     reads = synth.make_reads(**kwargs)
+    if how:
+        reads = tweak(reads, how)
     with tempfile.TemporaryDirectory() as td:
         fin = os.path.join(td, IN_EXT[fmt])
         fout = os.path.join(td, "out.fa" if fmt == "fa" else "out.fq")

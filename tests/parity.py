@@ -236,14 +236,14 @@ def async_two_contexts(lib_path):
 
 def align_windows_random(lib_path, n, seed=9, golden_dir=None):
     """tgsf_align_windows against edlib itself where oracle/_ref/libedlib_ref.so exists (compiled from the
-    reference's include/edlib.cpp), else against the oracle's DP restatement: random adapters of 20..128 bp,
+    reference's include/edlib.cpp), else against the oracle's DP restatement: random adapters of 20..256 bp,
     windows of 5..400 bp with planted mutated copies, homopolymers and Ns, assorted k."""
     import ctypes as C
     ref_so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libedlib_ref.so")
     rng = np.random.default_rng(seed)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
     adapters = [synth.ONT_RAPID, synth.PACBIO_BLUNT, b"AATGTACTTCGTTCAGTTACGTATTGCT", b"GCAATACGTAACTGAACGAAGT"]
-    adapters += [bytes(acgt[rng.integers(0, 4, int(L))]) for L in (20, 33, 64, 65, 90, 127, 128)]
+    adapters += [bytes(acgt[rng.integers(0, 4, int(L))]) for L in (20, 33, 64, 65, 90, 127, 128, 129, 150, 192, 193, 230, 256)]
     p = abi.make_params("ont", adapters=adapters, max_batch_bases=1 << 22, max_batch_reads=4096, max_read_len=4096)
     ctx = capi.Context(p, 0, lib_path)
     buf, off, ln, aid, ks, trip = bytearray(), [], [], [], [], []
@@ -301,3 +301,31 @@ def align_windows_random(lib_path, n, seed=9, golden_dir=None):
         if got != exp:
             bad.append((i, q, t, k, got, exp))
     assert not bad, "%d of %d alignments differ, first: %s" % (len(bad), n, bad[0])
+
+
+def studded_reads(n_copies=90, gap=400, seed=21):
+    """A read studded with exact adapter copies (more disjoint drop regions than the region kernel's in-register list
+    holds) among ordinary ones: the reference completes such a run (src/TGSFilter.cpp:1376-1424 sort + merge)."""
+    rng = np.random.default_rng(seed)
+    reads = synth.make_reads(seed, 6, "ont", mean_len=3000, zoo=True, pmid=0.2)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for copies, ad in ((n_copies, synth.ONT_RAPID), (n_copies + 7, synth.ONT_RAPID_RC)):
+        L = 600 + copies * gap
+        seq = bytearray(acgt[rng.integers(0, 4, L)].tobytes())
+        for c in range(copies):
+            at = 400 + c * gap
+            seq[at:at + len(ad)] = ad
+        qual = bytes((np.clip(np.rint(rng.normal(18, 3, L)), 2, 40) + 33).astype(np.uint8))
+        reads.append((b"studded%d" % copies, bytes(seq), qual))
+    return reads
+
+
+def many_regions(lib_path):
+    reads = studded_reads()
+    p = sized(abi.make_params("ont", adapters=[synth.ONT_RAPID, synth.ONT_RAPID_RC], min_q=8.0, min_len=100), reads)
+    ctx = capi.Context(p, 0, lib_path)
+    try:
+        res, frags, ctr = compare_batch(ctx, p, reads)
+        assert int(res["n_frags"].max()) > 64            # more kept fragments than the in-register region list holds
+    finally:
+        ctx.close()

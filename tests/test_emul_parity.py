@@ -26,7 +26,7 @@ def test_emul_edlib_vectors(emul, golden_dir):
     parity.edlib_vectors(emul, golden_dir)
 
 
-@pytest.mark.parametrize("name", ["ont_zoo", "ont_trim", "ont_discard", "hifi_zoo", "long_adapter", "qc_only"])
+@pytest.mark.parametrize("name", ["ont_zoo", "ont_trim", "ont_discard", "hifi_zoo", "long_adapter", "qc_only", "ont_m1", "huge_adapter", "ont_phred64"])
 def test_emul_golden(emul, golden_dir, name):
     parity.golden_case(emul, golden_dir, name)
 
@@ -110,3 +110,7 @@ def test_emul_submit_async(emul):
 
 def test_emul_align_windows_random(emul):
     parity.align_windows_random(emul, 1500)
+
+
+def test_emul_more_than_64_drop_regions(emul):
+    parity.many_regions(emul)

@@ -184,3 +184,7 @@ def test_gpu_submit_async():
 def test_gpu_align_windows_random():
     parity.align_windows_random(None, 4000)
     parity.align_windows_random(None, 4000, seed=10)
+
+
+def test_gpu_more_than_64_drop_regions():
+    parity.many_regions(None)

@@ -27,7 +27,8 @@
 namespace tgsf {
 
 constexpr int kMaxAdapters = 32;
-constexpr int kMaxQ = 128;         // two 64-row words
+constexpr int kMaxQ = 256;         // four 64-row words
+constexpr int kPeqW = 4;           // words per symbol in the standard-layout Peq tables
 constexpr int kBin = 100;          // CalcAvgQuality bin width
 constexpr int kTileBins = 64;      // one bin per lane
 constexpr int kTileBases = kBin * kTileBins;   // 6400 bases per stats tile
@@ -68,7 +69,7 @@ TGSF_HD uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) {
 // Bit-vector edit distance, standard layout: row r of the adapter is bit r%64 of
 // word r/64.  Rows >= Q of the last word are don't-care (information only moves
 // towards higher bits).  Used by every off-the-hot-loop search (end windows,
-// start locations) and by adapters of 65..128 bp in the middle scan.
+// start locations) and by adapters of 65..256 bp in the middle scan.
 // ---------------------------------------------------------------------------
 template <int NW>
 struct Bv {

@@ -688,12 +688,17 @@ TGSF_KERNEL k_gate_reads(DevParams P, DevBatch B)
 // One block; each thread owns 16 consecutive elements per sweep.
 // ---------------------------------------------------------------------------
 constexpr int kScanPer = 16;
+// Exclusive prefix sums of a[0..n) in place, a[n] = total.  One block (n is the reads of a batch, 1e5: the cost is
+// latency, not work): per pass every thread sums kScanPer entries, 32 threads scan a run of those sums each, one
+// thread the 32 run totals -- three barriers per pass (a Hillis-Steele scan of the 1024 sums took twenty).
 TGSF_KERNEL k_scan_u32(uint32_t* a, const uint32_t* n_ptr, uint32_t n_fixed)
 {
     TGSF_SHARED uint32_t part[1024];
+    TGSF_SHARED uint32_t run_tot[32];
     TGSF_SHARED uint32_t carry_s;
     const uint32_t n = n_ptr ? *n_ptr : n_fixed;
     const uint32_t T = blockDim.x;
+    const uint32_t runs = T < 32u ? T : 32u, per_run = (T + runs - 1) / runs;
     if (threadIdx.x == 0) carry_s = 0;
     TGSF_BLOCK_SYNC();
     for (uint32_t base = 0; base < n; base += T * kScanPer) {
@@ -704,19 +709,22 @@ TGSF_KERNEL k_scan_u32(uint32_t* a, const uint32_t* n_ptr, uint32_t n_fixed)
         for (int k = 0; k < kScanPer; k++) { v[k] = (i0 + k < n) ? a[i0 + k] : 0u; s += v[k]; }
         part[threadIdx.x] = s;
         TGSF_BLOCK_SYNC();
-        // Hillis-Steele over the per-thread sums
-        for (uint32_t o = 1; o < T; o <<= 1) {
-            uint32_t add = (threadIdx.x >= o) ? part[threadIdx.x - o] : 0u;
-            TGSF_BLOCK_SYNC();
-            part[threadIdx.x] += add;
-            TGSF_BLOCK_SYNC();
+        if (threadIdx.x < runs) {                          // exclusive scan of this run of per-thread sums
+            uint32_t acc = 0;
+            const uint32_t lo = threadIdx.x * per_run, hi = lo + per_run < T ? lo + per_run : T;
+            for (uint32_t i = lo; i < hi; i++) { const uint32_t x = part[i]; part[i] = acc; acc += x; }
+            run_tot[threadIdx.x] = acc;
         }
-        uint32_t excl = carry_s + part[threadIdx.x] - s;
-        const uint32_t total = part[T - 1];
         TGSF_BLOCK_SYNC();
+        if (threadIdx.x == 0) {
+            uint32_t acc = carry_s;
+            for (uint32_t i = 0; i < runs; i++) { const uint32_t x = run_tot[i]; run_tot[i] = acc; acc += x; }
+            carry_s = acc;
+        }
+        TGSF_BLOCK_SYNC();
+        uint32_t excl = run_tot[threadIdx.x / per_run] + part[threadIdx.x];
 #pragma unroll
         for (int k = 0; k < kScanPer; k++) { if (i0 + k < n) a[i0 + k] = excl; excl += v[k]; }
-        if (threadIdx.x == 0) carry_s += total;
         TGSF_BLOCK_SYNC();
     }
     if (threadIdx.x == 0) a[n] = carry_s;
@@ -859,7 +867,7 @@ TGSF_D int path_len_bv(const uint64_t* pf /*[256][2]*/, int Q, const uint8_t* t,
     bv_init(s, Q);
     for (int j = 1; j <= T; j++) {
         uint64_t ph[NW];
-        bv_step_global<NW>(s, pf + (size_t)t[j - 1] * 2, ph, Q);
+        bv_step_global<NW>(s, pf + (size_t)t[j - 1] * kPeqW, ph, Q);
 #pragma unroll
         for (int w = 0; w < NW; w++) { sc.at(j, w, 2 * NW) = s.p[w]; sc.at(j, NW + w, 2 * NW) = ph[w]; }
     }
@@ -881,14 +889,14 @@ template <int NW>
 TGSF_D int start_of(const DevParams& P, int a, const uint8_t* t, int end, int best)
 {
     const int Q = P.Q[a];
-    const uint64_t* pr = P.peq_rev + (size_t)a * 512;
+    const uint64_t* pr = P.peq_rev + (size_t)a * 256 * kPeqW;
     Bv<NW> b;
     bv_init(b, Q);
     int maxl = end + 1;
     if (maxl > Q + best) maxl = Q + best;
     int best_l = 1;
     for (int l = 1; l <= maxl; l++) {
-        bv_step<NW>(b, pr + (size_t)t[end - (l - 1)] * 2, 1, Q);
+        bv_step<NW>(b, pr + (size_t)t[end - (l - 1)] * kPeqW, 1, Q);
         if (b.score == best) best_l = l;
     }
     return end - best_l + 1;
@@ -909,22 +917,22 @@ TGSF_D int first_mlen(const DevParams& P, int a, const uint8_t* t, int start0, i
         if (lo >= need) return lo;          // passes whatever the path
         if (hi < need) return -1;           // fails whatever the path
     }
-    return path_len_bv<NW>(P.peq_fwd + (size_t)a * 512, Q, t + start0, T, sc) - best;
+    return path_len_bv<NW>(P.peq_fwd + (size_t)a * 256 * kPeqW, Q, t + start0, T, sc) - best;
 }
 
 template <int NW>
 TGSF_D WinAln align_window(const DevParams& P, int a, const uint8_t* t, int T, int kk, int need, LaneScratch sc, bool exact)
 {
     const int Q = P.Q[a];
-    const uint64_t* pf = P.peq_fwd + (size_t)a * 512;
+    const uint64_t* pf = P.peq_fwd + (size_t)a * 256 * kPeqW;
     WinAln r;
     r.best = -1; r.n = 0; r.first_end = r.last_end = -1; r.start0 = 0; r.mlen = 0;
-    // peq tables are [256][2]; with NW == 1 only word 0 of each symbol is used
+    // peq tables are [256][kPeqW]; only the first NW words of each symbol are used
     Bv<NW> s;
     bv_init(s, Q);
     int cur = kk + 1;
     for (int j = 0; j < T; j++) {
-        bv_step<NW>(s, pf + (size_t)t[j] * 2, 0, Q);
+        bv_step<NW>(s, pf + (size_t)t[j] * kPeqW, 0, Q);
         if (s.score < cur) { cur = s.score; r.first_end = j; r.n = 0; }
         if (s.score == cur && cur <= kk) { r.last_end = j; r.n++; }
     }
@@ -940,12 +948,12 @@ template <int NW>
 TGSF_D int min_start_all(const DevParams& P, int a, const uint8_t* t, int T, int best)
 {
     const int Q = P.Q[a];
-    const uint64_t* pf = P.peq_fwd + (size_t)a * 512;
+    const uint64_t* pf = P.peq_fwd + (size_t)a * 256 * kPeqW;
     Bv<NW> s;
     bv_init(s, Q);
     int mn = T;
     for (int j = 0; j < T; j++) {
-        bv_step<NW>(s, pf + (size_t)t[j] * 2, 0, Q);
+        bv_step<NW>(s, pf + (size_t)t[j] * kPeqW, 0, Q);
         if (s.score == best) {
             int st = start_of<NW>(P, a, t, j, best);
             mn = st < mn ? st : mn;
@@ -964,12 +972,45 @@ TGSF_D LaneScratch lane_scratch(const DevBatch& B, size_t first_wave)
     return sc;
 }
 
+// Word count by adapter length = ceil(Q / 64): 1 (all library adapters), 2, and 3 or 4 (<= 256 bp; only kernels
+// instantiated with MAXNW = 4 carry that path -- they are launched when an adapter of the run needs it, so the
+// common configurations keep their register budget).
+template <int MAXNW>
+TGSF_D WinAln align_window_any(const DevParams& P, int a, const uint8_t* t, int T, int k, int need, const LaneScratch& sc, bool exact) {
+    const int Q = P.Q[a];
+    if (Q <= 64) return align_window<1>(P, a, t, T, k, need, sc, exact);
+    if constexpr (MAXNW > 2) { if (Q > 192) return align_window<4>(P, a, t, T, k, need, sc, exact); if (Q > 128) return align_window<3>(P, a, t, T, k, need, sc, exact); }
+    return align_window<2>(P, a, t, T, k, need, sc, exact);
+}
+template <int MAXNW>
+TGSF_D int min_start_all_any(const DevParams& P, int a, const uint8_t* t, int T, int best) {
+    const int Q = P.Q[a];
+    if (Q <= 64) return min_start_all<1>(P, a, t, T, best);
+    if constexpr (MAXNW > 2) { if (Q > 192) return min_start_all<4>(P, a, t, T, best); if (Q > 128) return min_start_all<3>(P, a, t, T, best); }
+    return min_start_all<2>(P, a, t, T, best);
+}
+template <int MAXNW>
+TGSF_D int start_of_any(const DevParams& P, int a, const uint8_t* t, int end, int best) {
+    const int Q = P.Q[a];
+    if (Q <= 64) return start_of<1>(P, a, t, end, best);
+    if constexpr (MAXNW > 2) { if (Q > 192) return start_of<4>(P, a, t, end, best); if (Q > 128) return start_of<3>(P, a, t, end, best); }
+    return start_of<2>(P, a, t, end, best);
+}
+template <int MAXNW>
+TGSF_D int first_mlen_any(const DevParams& P, int a, const uint8_t* t, int s0, int e0, int best, int need, const LaneScratch& sc, bool exact) {
+    const int Q = P.Q[a];
+    if (Q <= 64) return first_mlen<1>(P, a, t, s0, e0, best, need, sc, exact);
+    if constexpr (MAXNW > 2) { if (Q > 192) return first_mlen<4>(P, a, t, s0, e0, best, need, sc, exact); if (Q > 128) return first_mlen<3>(P, a, t, s0, e0, best, need, sc, exact); }
+    return first_mlen<2>(P, a, t, s0, e0, best, need, sc, exact);
+}
+
 // ---------------------------------------------------------------------------
 // k_end_windows: the 5' and 3' searches of GetEditDistance (src/TGSFilter.cpp:1266-1321).
 // One lane per (read, adapter, end).  Every reported location pushes [0, end+1)
 // (5') or [L-W5+start, L) (3'); only their union matters downstream, i.e. the
 // last end / the smallest start.
 // ---------------------------------------------------------------------------
+template <int MAXNW>
 TGSF_KERNEL k_end_windows(DevParams P, DevBatch B)
 {
     const int A = P.n_adapters;
@@ -981,7 +1022,7 @@ TGSF_KERNEL k_end_windows(DevParams P, DevBatch B)
     const int e = (int)(idx & 1u);
     const uint32_t Lr = B.len[r];
     if (!Lr || (B.flags[r] & TGSF_RF_LOWQ)) return;
-    const int L = (int)Lr, Q = P.Q[a];
+    const int L = (int)Lr;
     int W5 = P.w5[a];
     if (W5 > L) W5 = L;                                   // :1268-1270
     if (W5 < 5) return;                                   // :1274
@@ -989,8 +1030,7 @@ TGSF_KERNEL k_end_windows(DevParams P, DevBatch B)
     const uint8_t* t = B.seq + B.off[r] + (e ? (L - W5) : 0);
     const LaneScratch sc = lane_scratch(B, 0);
     const int need = P.need_end[a];                        // mlen >= EndMatchLen && float(mlen)/Q >= EndSim (:1283-1288)
-    WinAln w = (Q <= 64) ? align_window<1>(P, a, t, W5, P.k_end[a], need, sc, false)
-                         : align_window<2>(P, a, t, W5, P.k_end[a], need, sc, false);
+    WinAln w = align_window_any<MAXNW>(P, a, t, W5, P.k_end[a], need, sc, false);
     if (w.best < 0) return;
     if (w.mlen < need) return;
     if (e == 0) {
@@ -998,7 +1038,7 @@ TGSF_KERNEL k_end_windows(DevParams P, DevBatch B)
         atomicOr(&B.flags[r], (uint32_t)TGSF_RF_AD5P);
     } else {
         int mn = w.start0;
-        if (w.n > 1) mn = (Q <= 64) ? min_start_all<1>(P, a, t, W5, w.best) : min_start_all<2>(P, a, t, W5, w.best);
+        if (w.n > 1) mn = min_start_all_any<MAXNW>(P, a, t, W5, w.best);
         B.clip3[(size_t)r * A + a] = L - W5 + mn;         // union of [L-W5+start_i, L)
         atomicOr(&B.flags[r], (uint32_t)TGSF_RF_AD3P);
     }
@@ -1182,12 +1222,13 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
     }
 }
 
-// adapters of 65..128 bp: two-word standard layout, one adapter per pass
-TGSF_KERNEL k_mid_scan2(DevParams P, DevBatch B, int a)
+// adapters of 65..256 bp: NW-word standard layout (NW = ceil(Q / 64) = 2, 3 or 4), one adapter per pass
+template <int NW>
+TGSF_KERNEL k_mid_scanw(DevParams P, DevBatch B, int a)
 {
-    TGSF_SHARED uint64_t eqt[256][2];
-    for (uint32_t i = TGSF_COOP_BEGIN; i < 512u; i += TGSF_COOP_STRIDE)
-        eqt[i >> 1][i & 1] = P.peq_fwd[(size_t)a * 512 + i];
+    TGSF_SHARED uint64_t eqt[256][NW];
+    for (uint32_t i = TGSF_COOP_BEGIN; i < 256u * NW; i += TGSF_COOP_STRIDE)
+        eqt[i / NW][i % NW] = P.peq_fwd[(size_t)a * 256 * kPeqW + (size_t)(i / NW) * kPeqW + (i % NW)];
     TGSF_BLOCK_SYNC();
     const uint32_t total = B.seg_cnt[B.n];
     const uint32_t g = gtid();
@@ -1206,14 +1247,14 @@ TGSF_KERNEL k_mid_scan2(DevParams P, DevBatch B, int a)
     const int c0 = blk * S > amid ? (int)(blk * S - amid) : 0;
     int c1 = (int)((blk + 1) * S - amid);
     if (c1 > ML) c1 = ML;
-    Bv<2> s;
+    Bv<NW> s;
     bv_init(s, Q);
     int lim = P.k_mid[a];
     int c = c0 - (Q + P.k_mid[a]);
     if (c < 0) c = 0;
-    for (; c < c0; c++) bv_step<2>(s, eqt[mid[c]], 0, Q);
+    for (; c < c0; c++) bv_step<NW>(s, eqt[mid[c]], 0, Q);
     for (; c < c1; c++) {
-        bv_step<2>(s, eqt[mid[c]], 0, Q);
+        bv_step<NW>(s, eqt[mid[c]], 0, Q);
         if (s.score <= lim) { lim = s.score; push_candidate(B, r, c, s.score, a); }
     }
 }
@@ -1224,6 +1265,7 @@ TGSF_KERNEL k_mid_scan2(DevParams P, DevBatch B, int a)
 // attain it are its endLocations (include/edlib.cpp:660-672).  The path of the
 // FIRST location gives mlen, which gates ALL locations (src/TGSFilter.cpp:1245-1260).
 // ---------------------------------------------------------------------------
+template <int MAXNW>
 TGSF_KERNEL k_mid_resolve(DevParams P, DevBatch B)
 {
     const int A = P.n_adapters;
@@ -1241,20 +1283,19 @@ TGSF_KERNEL k_mid_resolve(DevParams P, DevBatch B)
         if (sc < best || (sc == best && pos < e0)) { best = sc; e0 = pos; }
     }
     if (best == (1 << 30)) return;
-    const int L = (int)B.len[r], E = P.end_len, Q = P.Q[a];
+    const int L = (int)B.len[r], E = P.end_len;
     const uint8_t* win = B.seq + B.off[r] + E;
     const LaneScratch sc = lane_scratch(B, B.scratch_mid_wave0);
     const int need = P.need_mid[a];                                      // :1246, :1250-1252
-    const int s0 = (Q <= 64) ? start_of<1>(P, a, win, e0, best) : start_of<2>(P, a, win, e0, best);
-    const int mlen = (Q <= 64) ? first_mlen<1>(P, a, win, s0, e0, best, need, sc, false)
-                               : first_mlen<2>(P, a, win, s0, e0, best, need, sc, false);
+    const int s0 = start_of_any<MAXNW>(P, a, win, e0, best);
+    const int mlen = first_mlen_any<MAXNW>(P, a, win, s0, e0, best, need, sc, false);
     if (mlen < need) return;
     atomicOr(&B.flags[r], (uint32_t)TGSF_RF_ADMID);
     for (int32_t i = head; i >= 0; i = B.pool[i].next) {
         const int aux = B.pool[i].aux;
         if ((aux >> 8) != a || (aux & 0xFF) != best) continue;
         const int pos = B.pool[i].pos;
-        const int st = (pos == e0) ? s0 : ((Q <= 64) ? start_of<1>(P, a, win, pos, best) : start_of<2>(P, a, win, pos, best));
+        const int st = (pos == e0) ? s0 : start_of_any<MAXNW>(P, a, win, pos, best);
         int ts = st + E - P.extra_len, te = pos + E + 1 + P.extra_len;   // :1248-1256
         if (ts < 0) ts = 0;
         if (te > L) te = L;
@@ -1334,23 +1375,24 @@ TGSF_KERNEL k_regions(DevParams P, DevBatch B)
         } else if (!P.filter) {
             if (!P.only_qc) keep(0, L);                                   // :1963-1965, :1976
         } else {
+            // the raw drop regions of this read, in any order: fixed trims, end hits, resolved middle hits
+            int n5 = 0, n3 = 0, nm = 0;
+            auto each_raw = [&](auto&& f, bool count) {
+                if (P.head_trim > 0) f(0, P.head_trim >= L ? L : P.head_trim);                  // :1334-1340
+                if (P.tail_trim > 0) { if (P.tail_trim >= L) f(0, L); else f(L - P.tail_trim, L); }   // :1342-1348
+                for (int a = 0; a < A; a++) {
+                    const int c5 = B.clip5[(size_t)r * A + a], c3 = B.clip3[(size_t)r * A + a];
+                    if (c5 > 0) { if (count) n5++; f(0, c5); }
+                    if (c3 >= 0) { if (count) n3++; f(c3, L); }
+                }
+                for (int32_t i = B.mid_head[r]; i >= 0; i = B.pool[i].next) {
+                    const int stt = B.pool[i].state;
+                    if ((stt & 3) == 1) { if (count) nm++; f(B.pool[i].pos, stt >> 2); }
+                }
+            };
             RegList R;
             R.n = 0; R.overflow = false;
-            if (P.head_trim > 0) reg_insert(R, 0, P.head_trim >= L ? L : P.head_trim);          // :1334-1340
-            if (P.tail_trim > 0) {                                                               // :1342-1348
-                if (P.tail_trim >= L) reg_insert(R, 0, L); else reg_insert(R, L - P.tail_trim, L);
-            }
-            int n5 = 0, n3 = 0, nm = 0;
-            for (int a = 0; a < A; a++) {
-                int c5 = B.clip5[(size_t)r * A + a], c3 = B.clip3[(size_t)r * A + a];
-                if (c5 > 0) { n5++; reg_insert(R, 0, c5); }
-                if (c3 >= 0) { n3++; reg_insert(R, c3, L); }
-            }
-            for (int32_t i = B.mid_head[r]; i >= 0; i = B.pool[i].next) {
-                const int stt = B.pool[i].state;
-                if ((stt & 3) == 1) { nm++; reg_insert(R, B.pool[i].pos, stt >> 2); }
-            }
-            if (R.overflow) set_status(B, DS_TOO_MANY_REGIONS, r);
+            each_raw([&](int s0, int e0) { reg_insert(R, s0, e0); }, true);
             if (EMIT) {                                                                          // :1354-1370
                 const int cls = (nm > 0 && n5 > 0 && n3 > 0) ? 2 : (nm > 0 && n5 > 0) ? 3 : (nm > 0 && n3 > 0) ? 4
                         : (n5 > 0 && n3 > 0) ? 5 : (nm > 0) ? 6 : (n5 > 0) ? 7 : (n3 > 0) ? 8 : 9;
@@ -1362,16 +1404,36 @@ TGSF_KERNEL k_regions(DevParams P, DevBatch B)
             } else if (R.n >= 1) {                                                               // :1396-1424
                 int cur = 0;
                 uint32_t tr = 0;
-                for (int i = 0; i < R.n; i++) {
-                    const int dl = R.e[i] - R.s[i];
+                auto on_region = [&](int rs, int re) {       // merged drop regions, ascending
+                    const int dl = re - rs;
                     d[10] += (uint64_t)dl; tr += (uint32_t)dl;
                     if (dl == L) d[11]++;
-                    if (R.s[i] > cur) {
-                        const int kl = R.s[i] - cur;
+                    if (rs > cur) {
+                        const int kl = rs - cur;
                         if (kl >= P.min_len && kl <= P.max_len) keep(cur, kl);
                         else { d[11]++; d[12] += (uint64_t)kl; }
                     }
-                    cur = R.e[i];
+                    cur = re;
+                };
+                if (!R.overflow) {
+                    for (int i = 0; i < R.n; i++) on_region(R.s[i], R.e[i]);
+                } else {
+                    // More disjoint regions than the list holds (a read studded with adapter copies): the same union,
+                    // region by region, without storing it -- the next region starts at the smallest raw start beyond
+                    // the previous one's end and grows while a raw region touches it (quadratic in the raw regions,
+                    // which only such a read pays).
+                    int last_e = -1;
+                    for (;;) {
+                        int ms = 0x7FFFFFFF, me = 0;
+                        each_raw([&](int s0, int e0) { if (s0 > last_e && (s0 < ms || (s0 == ms && e0 > me))) { ms = s0; me = e0; } }, false);
+                        if (ms == 0x7FFFFFFF) break;
+                        for (bool grew = true; grew;) {
+                            grew = false;
+                            each_raw([&](int s0, int e0) { if (s0 >= ms && s0 <= me && e0 > me) { me = e0; grew = true; } }, false);
+                        }
+                        on_region(ms, me);
+                        last_e = me;
+                    }
                 }
                 if (cur < L) {
                     const int kl = L - cur;
@@ -1599,6 +1661,7 @@ TGSF_KERNEL k_finalize(DevBatch B, tgsf_read_result* out_reads, tgsf_fragment* o
 // ---------------------------------------------------------------------------
 // k_align_windows: stand-alone edlib-compatible alignments (tgsf_align_windows).
 // ---------------------------------------------------------------------------
+template <int MAXNW>
 TGSF_KERNEL k_align_windows(DevParams P, DevBatch B, const uint8_t* seq, const uint64_t* win_off, const uint32_t* win_len,
                             const uint8_t* adapter_id, const int32_t* kk, uint32_t n, int32_t* res, int32_t* ends)
 {
@@ -1610,8 +1673,7 @@ TGSF_KERNEL k_align_windows(DevParams P, DevBatch B, const uint8_t* seq, const u
     if (k > Q) k = Q;                                    // edlib.cpp:565-567
     const LaneScratch sc = lane_scratch(B, 0);
     const uint8_t* t = seq + win_off[i];
-    WinAln w = (Q <= 64) ? align_window<1>(P, a, t, (int)win_len[i], k, 0, sc, true)
-                         : align_window<2>(P, a, t, (int)win_len[i], k, 0, sc, true);
+    WinAln w = align_window_any<MAXNW>(P, a, t, (int)win_len[i], k, 0, sc, true);
     res[i * 4 + 0] = w.best;
     res[i * 4 + 1] = w.best < 0 ? 0 : w.n;
     res[i * 4 + 2] = w.best < 0 ? 0 : w.mlen + w.best;

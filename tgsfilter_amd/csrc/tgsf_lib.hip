@@ -148,7 +148,8 @@ static int build_tables(tgsf_ctx* c)
     DevParams& P = c->P;
     const int A = p.n_adapters;
     std::vector<uint8_t> ad((size_t)kMaxAdapters * kMaxQ, 0);
-    std::vector<uint64_t> fwd((size_t)kMaxAdapters * 512, 0), rev((size_t)kMaxAdapters * 512, 0),
+    const size_t per_ad = (size_t)256 * kPeqW;              // standard-layout Peq: [symbol][word]
+    std::vector<uint64_t> fwd((size_t)kMaxAdapters * per_ad, 0), rev((size_t)kMaxAdapters * per_ad, 0),
         top((size_t)kMaxAdapters * 256, 0);
     P.max_nw = 1;
     P.min_Q = 1 << 30;
@@ -156,12 +157,17 @@ static int build_tables(tgsf_ctx* c)
         const std::string& s = c->adapters[a];
         const int Q = (int)s.size();
         P.Q[a] = Q;
-        if (Q > 64) P.max_nw = 2;
+        if (Q > 64 && P.max_nw < 2) P.max_nw = 2;
+        if (Q > 128) P.max_nw = 4;
         if (Q < P.min_Q) P.min_Q = Q;
         int km = Q - p.mid_match_len + 1;                 // src/TGSFilter.cpp:1233
         int ke = Q - p.end_match_len + 1;                 // :1271
-        P.k_mid[a] = km > Q ? Q : km;                     // include/edlib.cpp:565-567 (negative: see k_end_windows)
-        P.k_end[a] = ke > Q ? Q : ke;
+        // edlib clamps k to Q (include/edlib.cpp:565-567); here it is clamped to Q - 1.  A best value of exactly Q
+        // (reachable only with -m 1 / -M 1) means no character of the adapter matches anywhere in the window: edlib
+        // then reports every column (and the location -1, :232-244, :670) with a path of Q insertions, i.e. mlen = 0,
+        // which no gate passes (:1246, :1283) -- the same outcome as reporting nothing.  Values below Q are unaffected.
+        P.k_mid[a] = km > Q - 1 ? Q - 1 : km;             // (negative: see k_end_windows)
+        P.k_end[a] = ke > Q - 1 ? Q - 1 : ke;
         P.w5[a] = p.end_len + (int)((float)Q / p.end_sim);   // :1267 int(qLen / endSim), float division
         // the similarity gates are monotone in mlen: evaluate the reference's float predicates here, once
         P.need_end[a] = P.need_mid[a] = Q + 1;                // Q+1: cannot pass (mlen <= Q)
@@ -172,14 +178,14 @@ static int build_tables(tgsf_ctx* c)
         memcpy(&ad[(size_t)a * kMaxQ], s.data(), (size_t)Q);
         for (int r = 0; r < Q; r++) {
             uint8_t cf = (uint8_t)s[r], cr = (uint8_t)s[Q - 1 - r];
-            fwd[(size_t)a * 512 + (size_t)cf * 2 + (r >> 6)] |= 1ull << (r & 63);
-            rev[(size_t)a * 512 + (size_t)cr * 2 + (r >> 6)] |= 1ull << (r & 63);
+            fwd[(size_t)a * per_ad + (size_t)cf * kPeqW + (r >> 6)] |= 1ull << (r & 63);
+            rev[(size_t)a * per_ad + (size_t)cr * kPeqW + (r >> 6)] |= 1ull << (r & 63);
         }
         if (Q <= 64) {
             const int sh = 64 - Q;
             const uint64_t pad = sh ? ((1ull << sh) - 1ull) : 0ull;    // wildcard rows below the adapter
             for (int sym = 0; sym < 256; sym++)
-                top[(size_t)a * 256 + sym] = (fwd[(size_t)a * 512 + (size_t)sym * 2] << sh) | pad;
+                top[(size_t)a * 256 + sym] = (fwd[(size_t)a * per_ad + (size_t)sym * kPeqW] << sh) | pad;
         }
     }
     if (A == 0) P.min_Q = 1 << 30;
@@ -292,9 +298,8 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     if (p->filter && p->n_adapters > 0) {
         if (!(p->end_sim > 0.f) || !(p->mid_sim > 0.f)) return fail(nullptr, TGSF_E_INVALID, "similarities must be > 0");
         if (p->end_len < 0 || p->extra_len < 0) return fail(nullptr, TGSF_E_INVALID, "end_len / extra_len must be >= 0");
-        // k >= Q ("-m 1"/"-M 1") makes edlib report the location -1 (edlib.cpp:232-244); not reproduced
-        if (p->end_match_len < 2 || p->mid_match_len < 2)
-            return fail(nullptr, TGSF_E_UNSUPPORTED, "match lengths < 2 (edlib k >= adapter length) are outside the supported domain");
+        if (p->end_match_len < 1 || p->mid_match_len < 1)
+            return fail(nullptr, TGSF_E_INVALID, "match lengths must be >= 1");
     }
     for (int a = 0; a < p->n_adapters; a++) {
         if (!p->adapters[a] || p->adapter_len[a] < 1 || p->adapter_len[a] > TGSF_MAX_ADAPTER_LEN)
@@ -541,7 +546,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     rt_memset(B.pool_n, 0, 4, st);
     rt_memset(B.plan, 0, 32, st);
     TGSF_LAUNCH(k_prepare, gsmall, T, st, P, B, c->max_read_len);
-    TGSF_LAUNCH_COOP(k_tile_scan, 1, 1024, st, B);
+    TGSF_LAUNCH_COOP(k_tile_scan, 1, 64, st, B);       // a few hundred buckets: one wave
     TGSF_LAUNCH(k_tile_scatter<false>, gsmall, T, st, B);
     const unsigned gwork = grid_cap(std::min(blocks_for(in->n_bytes / kTileBases + n + 1, T), 4096u));
     TGSF_LAUNCH(k_build_work<false>, gwork, T, st, B);
@@ -576,7 +581,8 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
 #endif
     if (P.filter && A > 0) {
         const uint64_t nw = (uint64_t)n * A * 2;
-        TGSF_LAUNCH(k_end_windows, blocks_for(nw, 64), 64, ax, P, B);
+        if (P.max_nw > 2) TGSF_LAUNCH(k_end_windows<4>, blocks_for(nw, 64), 64, ax, P, B);
+        else TGSF_LAUNCH(k_end_windows<2>, blocks_for(nw, 64), 64, ax, P, B);
     }
 #if !defined(TGSF_EMUL)
     if (c->profile) (void)hipEventRecord(evx[2], ax);
@@ -597,7 +603,9 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
 #endif
         int a = 0;
         while (a < A) {
-            if (P.Q[a] > 64) { TGSF_LAUNCH(k_mid_scan2, gseg, T, ms, P, B, a); a++; continue; }
+            if (P.Q[a] > 192) { TGSF_LAUNCH(k_mid_scanw<4>, gseg, T, ms, P, B, a); a++; continue; }
+            if (P.Q[a] > 128) { TGSF_LAUNCH(k_mid_scanw<3>, gseg, T, ms, P, B, a); a++; continue; }
+            if (P.Q[a] > 64) { TGSF_LAUNCH(k_mid_scanw<2>, gseg, T, ms, P, B, a); a++; continue; }
             int na = 0;
             while (a + na < A && na < 4 && P.Q[a + na] <= 64) na++;
             switch (na) {
@@ -613,7 +621,10 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
 #endif
     }
     STAGE_MARK();
-    if (P.filter && A > 0) TGSF_LAUNCH(k_mid_resolve, blocks_for((uint64_t)n * A, 64), 64, st, P, B);
+    if (P.filter && A > 0) {
+        if (P.max_nw > 2) TGSF_LAUNCH(k_mid_resolve<4>, blocks_for((uint64_t)n * A, 64), 64, st, P, B);
+        else TGSF_LAUNCH(k_mid_resolve<2>, blocks_for((uint64_t)n * A, 64), 64, st, P, B);
+    }
     STAGE_MARK();
 #if !defined(TGSF_EMUL)
     (void)hipStreamWaitEvent(st, c->ev_join, 0);      // regions need the end-window results
@@ -631,7 +642,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     TGSF_LAUNCH(k_clean_plan, gsmall, T, st, P, B);
     TGSF_LAUNCH(k_fold_raw<true>, gfold, T, st, P, B);
     TGSF_LAUNCH(k_frag_prepare, gfr, T, st, P, B);
-    TGSF_LAUNCH_COOP(k_tile_scan, 1, 1024, st, B);
+    TGSF_LAUNCH_COOP(k_tile_scan, 1, 64, st, B);       // a few hundred buckets: one wave
     TGSF_LAUNCH(k_tile_scatter<true>, gfr, T, st, B);
     TGSF_LAUNCH(k_build_work<true>, gwork, T, st, B);
 #if !defined(TGSF_EMUL)
@@ -946,8 +957,12 @@ extern "C" int tgsf_align_windows(tgsf_ctx* c, const uint8_t* seq, uint64_t n_by
         e |= rt_h2d(d_k, k, (size_t)n * 4, st);
     }
     if (!e) {
-        TGSF_LAUNCH(k_align_windows, blocks_for(n, 64), 64, st, c->P, c->B, (const uint8_t*)d_seq, (const uint64_t*)d_off,
-                    (const uint32_t*)d_len, (const uint8_t*)d_aid, (const int32_t*)d_k, n, d_res, d_ends);
+        if (c->P.max_nw > 2)
+            TGSF_LAUNCH(k_align_windows<4>, blocks_for(n, 64), 64, st, c->P, c->B, (const uint8_t*)d_seq, (const uint64_t*)d_off,
+                        (const uint32_t*)d_len, (const uint8_t*)d_aid, (const int32_t*)d_k, n, d_res, d_ends);
+        else
+            TGSF_LAUNCH(k_align_windows<2>, blocks_for(n, 64), 64, st, c->P, c->B, (const uint8_t*)d_seq, (const uint64_t*)d_off,
+                        (const uint32_t*)d_len, (const uint8_t*)d_aid, (const int32_t*)d_k, n, d_res, d_ends);
         e |= rt_d2h(res, d_res, (size_t)n * 16, st);
         e |= rt_d2h(ends, d_ends, (size_t)n * 8, st);
         e |= rt_sync(st);
