@@ -162,7 +162,7 @@ def e2e_leg(args, n_gpus):
 # ---------------------------------------------------------------------------------------------------------
 # kernel path: batches resident in HBM
 # ---------------------------------------------------------------------------------------------------------
-def gen_batch(torch, device, n_reads, seed, mean_len, max_len, workload="ont"):
+def gen_batch(torch, device, n_reads, seed, mean_len, max_len, workload="ont", hifi_rates=(0.0027, 0.0026, 0.00002)):
     """Synthetic C2 (ont) / C3 (hifi) batch built directly in HBM (generation is outside every timed region)."""
     from tgsfilter_amd import synth
     rng = np.random.default_rng(seed)
@@ -198,9 +198,10 @@ def gen_batch(torch, device, n_reads, seed, mean_len, max_len, workload="ont"):
         if hifi:
             # blunt adapter 5' in 0.27 %, 3' in 0.26 %, middle in 0.002 % of reads, 3 % errors (README ratios)
             u = rng.random()
-            if u < 0.0027 + 0.0026 + 0.00002 and L > 2000:
+            r5, r3, rm = hifi_rates
+            if u < r5 + r3 + rm and L > 2000:
                 a = synth.mutate(rng, synth.PACBIO_BLUNT, 0.03)
-                p = 0 if u < 0.0027 else (L - len(a) if u < 0.0053 else int(rng.integers(300, L - 300 - len(a))))
+                p = 0 if u < r5 else (L - len(a) if u < r5 + r3 else int(rng.integers(300, L - 300 - len(a))))
                 idx.append(np.arange(len(a), dtype=np.int64) + offsets[i] + p)
                 val.append(np.frombuffer(a, dtype=np.uint8))
             continue
@@ -222,13 +223,16 @@ def gen_batch(torch, device, n_reads, seed, mean_len, max_len, workload="ont"):
                 n=n_reads, n_bytes=total, bases=int(lens.sum()), h_lens=lens, h_offsets=offsets)
 
 
-def oracle_slice_check(torch, batch, p_kwargs, workload, reads_rec, frags_rec, m=256, seed=11):
+def oracle_slice_check(torch, batch, p_kwargs, workload, reads_rec, frags_rec, m=256, seed=11, must_include=None):
     """A random slice of the batch through the oracle (the checker, never the thing measured): the per-read records
     and the fragments the HIP path produced for those reads must be identical."""
     from oracle import orc
     from tgsfilter_amd import abi
     rng = np.random.default_rng(seed)
-    pick = np.sort(rng.choice(batch["n"], size=min(m, batch["n"]), replace=False))
+    pick = rng.choice(batch["n"], size=min(m, batch["n"]), replace=False)
+    if must_include is not None:
+        pick = np.concatenate([pick, np.asarray(must_include, dtype=pick.dtype)])
+    pick = np.unique(pick)
     lens = batch["h_lens"][pick]
     offs = np.zeros(len(pick) + 1, dtype=np.int64)
     np.cumsum((lens + 15) // 16 * 16, out=offs[1:])

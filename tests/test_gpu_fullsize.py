@@ -103,18 +103,11 @@ def test_full_size_conservation_and_oracle_slice(batch):
     # input bases = low-Q reads + trimmed + too-short/too-long fragments + low-Q fragments + kept
     assert lens.sum() == drop[1] + drop[10] + drop[12] + drop[14] + kept
     assert int(ctr[abi.CTR_RAW_DIFFQ:abi.CTR_RAW_DIFFQ + 256].sum()) == lens.sum()
-    # oracle on the first 150 reads: per-read records must agree
-    m = 150
-    end = int(batch["h_offsets"][m])
-    seq = batch["seq"][:end].cpu().numpy()
-    qual = batch["qual"][:end].cpu().numpy()
-    p = abi.make_params("ont", adapters=[synth.ONT_RAPID, synth.ONT_RAPID_RC], min_len=1000, min_q=10.0,
-                        head_trim=0, tail_trim=0, max_read_len=int(lens.max()))
-    er, ef, _ = orc.filter_batch(p, seq, qual, batch["h_offsets"][:m].astype(np.uint64), batch["h_lens"][:m].astype(np.uint32))
-    for name in ("sum_q", "flags", "n_frags", "trimmed"):
-        assert np.array_equal(reads[name][:m], er[name]), name
-    nf = int(er["n_frags"].sum())
-    assert np.array_equal(frags[["start", "len", "flags", "sum_q"]][:nf], ef[["start", "len", "flags", "sum_q"]])
+    # oracle on 500 random reads of the batch: per-read records and fragments must agree
+    import bench
+    kw = dict(adapters=[synth.ONT_RAPID, synth.ONT_RAPID_RC], min_len=1000, min_q=10.0, head_trim=0, tail_trim=0)
+    n_chk, _ = bench.oracle_slice_check(batch["torch"], batch, kw, "ont", reads, frags, m=500, seed=5)
+    assert n_chk == 500
 
 
 def test_full_size_concurrent_contexts(batch):
@@ -151,3 +144,100 @@ def test_full_size_concurrent_contexts(batch):
         exp[rows] = ref_ctr[rows]
         assert np.array_equal(ctr, exp)
         c.close()
+
+
+def test_wait_and_counters_cover_a_caller_stream(batch):
+    """tgsf_wait / tgsf_counters after tgsf_submit_device on a CALLER's side stream, with nothing else synchronised:
+    the contract says they block until everything submitted on the context has finished (include/tgsf.h)."""
+    torch, dev = batch["torch"], batch["dev"]
+    ref_reads, ref_frags, ref_ctr = run(batch)
+    n = batch["n"]
+    p = abi.make_params("ont", adapters=[synth.ONT_RAPID, synth.ONT_RAPID_RC], min_len=1000, min_q=10.0,
+                        head_trim=0, tail_trim=0, max_batch_bases=batch["bases"] + 64, max_batch_reads=n,
+                        max_read_len=int(batch["h_lens"].max()))
+    fcap = batch["bases"] // 1000 + n + 16
+    ctx = capi.Context(p, 0)
+    side = torch.cuda.Stream(device=dev)
+    d_reads = torch.empty(n * 32, dtype=torch.uint8, device=dev)
+    d_frags = torch.zeros(fcap * 24, dtype=torch.uint8, device=dev)
+    d_nf = torch.zeros(4, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.submit_device(batch["seq"].data_ptr(), batch["qual"].data_ptr(), batch["offsets"].data_ptr(), batch["lengths"].data_ptr(), n,
+                      batch["n_bytes"], d_reads.data_ptr(), d_frags.data_ptr(), fcap, d_nf.data_ptr(), side.cuda_stream)
+    ctr = ctx.counters()                    # no stream or device synchronisation by the caller
+    assert np.array_equal(ctr, ref_ctr)
+    ctx.wait()
+    assert np.array_equal(d_reads.cpu().numpy().view(abi.READ_RESULT_DTYPE), ref_reads)
+    ctx.close()
+
+
+# ---- config C3's shape: HiFi reads, all of them survive the gate (the clean tables are tallied "by difference"),
+# ---- blunt adapter at both ends and -- far more often than in real data, so that splits are exercised -- in the middle
+N_HIFI = 262144        # 4.7 Gbases
+
+
+@pytest.fixture(scope="module")
+def hifi_batch():
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    b = bench.gen_batch(torch, dev, N_HIFI, 9, 18000.0, 2_000_000, "hifi", hifi_rates=(0.01, 0.01, 0.004))
+    b["torch"], b["dev"] = torch, dev
+    return b
+
+
+HIFI_KW = dict(adapters=[synth.PACBIO_BLUNT, synth.PACBIO_BLUNT_RC], min_len=1000, min_q=20.0, head_trim=0, tail_trim=0,
+               mid_match_len=35, extra_len=50)
+
+
+def run_hifi(batch, env=None):
+    torch, dev = batch["torch"], batch["dev"]
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        n = batch["n"]
+        p = abi.make_params("hifi", max_batch_bases=batch["bases"] + 64, max_batch_reads=n,
+                            max_read_len=int(batch["h_lens"].max()), **HIFI_KW)
+        ctx = capi.Context(p, 0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    fcap = batch["bases"] // 1000 + n + 16
+    d_reads = torch.empty(n * 32, dtype=torch.uint8, device=dev)
+    d_frags = torch.zeros(fcap * 24, dtype=torch.uint8, device=dev)
+    d_nf = torch.zeros(4, dtype=torch.int32, device=dev)
+    ctx.submit_device(batch["seq"].data_ptr(), batch["qual"].data_ptr(), batch["offsets"].data_ptr(), batch["lengths"].data_ptr(), n,
+                      batch["n_bytes"], d_reads.data_ptr(), d_frags.data_ptr(), fcap, d_nf.data_ptr(),
+                      torch.cuda.current_stream().cuda_stream)
+    ctx.wait()
+    nf = int(d_nf[0].item())
+    reads = d_reads.cpu().numpy().view(abi.READ_RESULT_DTYPE)
+    frags = d_frags.cpu().numpy().view(abi.FRAGMENT_DTYPE)[:nf].copy()
+    ctr = ctx.counters()
+    ctx.close()
+    return reads, frags, ctr
+
+
+def test_hifi_full_size_invariances_and_oracle_slice(hifi_batch):
+    ref = run_hifi(hifi_batch)
+    reads, frags, ctr = ref
+    # default strategy for this shape is "difference": the direct tally must give the same tables; so must other segmentings
+    assert same(ref, run_hifi(hifi_batch, {"TGSF_CLEAN_TABLES": "direct"}))
+    assert same(ref, run_hifi(hifi_batch, {"TGSF_CLEAN_TABLES": "difference"}))
+    assert same(ref, run_hifi(hifi_batch, {"TGSF_SEG_COLS": "512"}))
+    n, lens = hifi_batch["n"], hifi_batch["h_lens"].astype(np.int64)
+    drop = ctr[abi.CTR_DROPINFO:abi.CTR_DROPINFO + 17].astype(np.int64)
+    assert drop[0] + drop[2:10].sum() == n
+    kept = frags["len"][(frags["flags"] & abi.FF_PASS) != 0].astype(np.int64).sum()
+    assert lens.sum() == drop[1] + drop[10] + drop[12] + drop[14] + kept
+    split = np.nonzero(reads["n_frags"] >= 2)[0]
+    assert split.size > 200                                   # reads cut at a middle adapter
+    assert drop[2] + drop[3] + drop[4] + drop[6] > 500        # classes with a middle hit
+    import bench
+    rng = np.random.default_rng(12)
+    must = rng.choice(split, size=150, replace=False)
+    n_chk, _ = bench.oracle_slice_check(hifi_batch["torch"], hifi_batch, HIFI_KW, "hifi", reads, frags, m=350, seed=6, must_include=must)
+    assert n_chk >= 350
