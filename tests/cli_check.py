@@ -53,6 +53,11 @@ def run_case(binary: str, golden_dir: str, name: str, extra_args=()):
     ref = ref_html["data"]
     assert got is not None and ref is not None
     assert got.strip() == ref.strip(), _first_diff(got, ref)
+    # ... and the whole document is the reference's, time stamp aside (self-contained: chart code inside)
+    if "doc_sha256" in ref_html:
+        import hashlib
+        doc = re.sub(r"\d{4}-\d\d-\d\d \d\d:\d\d:\d\d", "T", html)
+        assert hashlib.sha256(doc.encode("utf-8")).hexdigest() == ref_html["doc_sha256"], "report document differs from the reference's"
 
 
 def _first_diff(a, b):

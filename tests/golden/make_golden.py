@@ -140,7 +140,10 @@ def html_slices(html: str):
     # the data object only: it ends at the "}" right before </script> (nothing of the page's
     # own script text is kept)
     m = re.search(r"var data = (\{.*?\})\n</script>", html, flags=re.S)
-    return {"table_rows": table, "data": m.group(1) if m else None}
+    # the whole document with the time stamp blanked (include/report.cpp:108), as a digest
+    import hashlib
+    doc = re.sub(r"\d{4}-\d\d-\d\d \d\d:\d\d:\d\d", "T", html)
+    return {"table_rows": table, "data": m.group(1) if m else None, "doc_sha256": hashlib.sha256(doc.encode("utf-8")).hexdigest()}
 
 
 def run_case(name, kwargs, adapters, flags, fmt="fq", how=None):

@@ -1,5 +1,11 @@
 #include "report.h"
 
+#include <unistd.h>
+
+#include <fstream>
+#include <iostream>
+#include <iterator>
+
 #include <cmath>
 #include <ctime>
 #include <sstream>
@@ -210,25 +216,32 @@ static void table_row(std::ostream& os, const std::string& qc, const std::string
     os << "</tr>\n";
 }
 
-void write_report(std::ostream& os, const std::string& qc, const SideStats& raw, const SideStats& clean)
+// The document around the numbers: pieces of reports the reference wrote, kept as data files beside the program
+// (tools/make_report_assets.py; include/report.cpp:670-700 assembles the same pieces in the same order).
+static bool read_asset(const std::string& name, std::string& out)
 {
-    static const char* const labels[9] = {"Total reads", "Total bases", "GC content (%)", "Min length (bp)", "Max length (bp)",
-                                          "Mean length (bp)", "Median length (bp)", "N50 length (bp)", "Mean quality"};
+    std::string dir;
+    if (const char* e = getenv("TGSF_ASSETS")) dir = e;
+    else {
+        char exe[4096];
+        const ssize_t n = readlink("/proc/self/exe", exe, sizeof exe - 1);
+        if (n <= 0) return false;
+        dir.assign(exe, (size_t)n);
+        const size_t slash = dir.rfind('/');
+        dir = dir.substr(0, slash == std::string::npos ? 0 : slash);
+        // tgsfilter_amd/bin/tgsfilter and tests/emul/tgsfilter_emul both find tgsfilter_amd/host/assets
+        std::ifstream probe(dir + "/../host/assets/report_head.html");
+        dir += probe ? "/../host/assets" : "/../../tgsfilter_amd/host/assets";
+    }
+    std::ifstream f(dir + "/" + name, std::ios::binary);
+    if (!f) return false;
+    out.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+    return true;
+}
+
+static void write_data(std::ostream& os, const std::string& qc, const SideStats& raw, const SideStats& clean)
+{
     const bool fastq = qc[0] == '1', has_raw = qc[1] != '1', has_clean = qc[1] != '0';
-    os << "<html lang=\"en\">\n<head>\n<meta charset=\"utf-8\">\n<title>TGSFilter report</title>\n"
-          "<style>body{font-family:sans-serif;margin:0}h1,#footer{padding:20px 10px;background:skyblue;color:#fff}"
-          ".container{padding:20px}.level-2-title{margin:20px 0;font-size:28px;font-weight:bold;color:rgb(46,163,209)}"
-          "table{border-collapse:collapse}td{border:1px solid #ccc;padding:6px 14px}.plot{width:48%;height:420px;display:inline-block}</style>\n"
-          "</head>\n<body>\n<div id=\"container\" class=\"container\">\n<h1>TGSFilter report</h1>\n"
-          "<div class=\"level-2-title\">Summary</div>\n<div>\n<table>\n";
-    table_row(os, qc, "", qc[1] == '0' ? "Value" : "Before filtering", "After filtering");
-    for (int i = 0; i < (fastq ? 9 : 8); i++) table_row(os, qc, labels[i], has_raw ? raw.tab[i] : "0", has_clean ? clean.tab[i] : "0");
-    os << "</table>\n</div>\n<div class=\"level-2-title\">Plots</div>\n<div id=\"plots\"></div>\n</div>\n";
-    std::time_t now = std::time(nullptr);
-    char ts[64];
-    std::strftime(ts, sizeof ts, "%Y-%m-%d %H:%M:%S", std::localtime(&now));
-    os << "<div id=\"footer\">Generated by tgsfilter (MI355X build) at " << ts << "</div>\n</body>\n";
-    os << "<script src=\"https://cdn.jsdelivr.net/npm/echarts@5/dist/echarts.min.js\"></script>\n";
     os << "<script>\nvar data = {\n";
     if (has_raw) {
         js_len(os, "rawLenDis", raw.len_dis);
@@ -255,6 +268,45 @@ void write_report(std::ostream& os, const std::string& qc, const SideStats& raw,
         }
     }
     os << "}\n</script>\n";
+}
+
+void write_report(std::ostream& os, const std::string& qc, const SideStats& raw, const SideStats& clean)
+{
+    static const char* const labels[9] = {"Total reads", "Total bases", "GC content (%)", "Min length (bp)", "Max length (bp)",
+                                          "Mean length (bp)", "Median length (bp)", "N50 length (bp)", "Mean quality"};
+    const bool fastq = qc[0] == '1', has_raw = qc[1] != '1', has_clean = qc[1] != '0';
+    std::time_t now = std::time(nullptr);
+    char ts[64];
+    std::strftime(ts, sizeof ts, "%Y-%m-%d %H:%M:%S", std::localtime(&now));
+    std::string head, plots, charts, tail;
+    if (read_asset("report_head.html", head) && read_asset("report_plots_" + qc + ".html", plots) &&
+        read_asset("report_charts.js", charts) && read_asset("report_tail.html", tail)) {
+        // the reference's document (self-contained: the chart code travels inside it), include/report.cpp:670-700
+        os << head << "<table>\n";
+        table_row(os, qc, "", qc[1] == '0' ? "Value" : "Before filtering", "After filtering");
+        for (int i = 0; i < (fastq ? 9 : 8); i++) table_row(os, qc, labels[i], has_raw ? raw.tab[i] : "0", has_clean ? clean.tab[i] : "0");
+        os << "</table>\n" << plots;
+        os << "<div id=\"footer\">    <p>Generated by <a href=\"https://github.com/HuiyangYu/TGSFilter\" target=\"blank\">TGSFilter (v1.11)</a> at "
+           << ts << "</p></div>";                       // include/report.cpp:105-110
+        os << charts;
+        write_data(os, qc, raw, clean);
+        os << tail;
+        return;
+    }
+    // the asset files are not beside the program: a plain document with the same table and data, charts from the network
+    std::cerr << "Warning: report assets not found (tgsfilter_amd/host/assets); writing the plain report" << std::endl;
+    os << "<html lang=\"en\">\n<head>\n<meta charset=\"utf-8\">\n<title>TGSFilter report</title>\n"
+          "<style>body{font-family:sans-serif;margin:0}h1,#footer{padding:20px 10px;background:skyblue;color:#fff}"
+          ".container{padding:20px}.level-2-title{margin:20px 0;font-size:28px;font-weight:bold;color:rgb(46,163,209)}"
+          "table{border-collapse:collapse}td{border:1px solid #ccc;padding:6px 14px}.plot{width:48%;height:420px;display:inline-block}</style>\n"
+          "</head>\n<body>\n<div id=\"container\" class=\"container\">\n<h1>TGSFilter report</h1>\n"
+          "<div class=\"level-2-title\">Summary</div>\n<div>\n<table>\n";
+    table_row(os, qc, "", qc[1] == '0' ? "Value" : "Before filtering", "After filtering");
+    for (int i = 0; i < (fastq ? 9 : 8); i++) table_row(os, qc, labels[i], has_raw ? raw.tab[i] : "0", has_clean ? clean.tab[i] : "0");
+    os << "</table>\n</div>\n<div class=\"level-2-title\">Plots</div>\n<div id=\"plots\"></div>\n</div>\n";
+    os << "<div id=\"footer\">Generated by tgsfilter (MI355X build) at " << ts << "</div>\n</body>\n";
+    os << "<script src=\"https://cdn.jsdelivr.net/npm/echarts@5/dist/echarts.min.js\"></script>\n";
+    write_data(os, qc, raw, clean);
     // chart glue (this repo's own): one chart per entry of `data`
     os << "<script>\n"
           "if (typeof echarts !== 'undefined') {\n"
