@@ -79,6 +79,20 @@ def test_cli_threaded_pipeline(binary, golden_dir, name, writer, monkeypatch):
     cli_check.run_case(binary, golden_dir, name, extra_args=["-t", "8"])
 
 
+@pytest.mark.parametrize("name,compress", [("ont_zoo", "gzip"), ("ont_zoo", "bgzf"), ("hifi_auto", "gzip"), ("ont_fasta", "bgzf"),
+                                           ("hifi_fasta_auto", "gzip"), ("hifi_bam", None), ("hifi_bam_auto", None), ("ont_sam", None),
+                                           ("ont_repeat", "bgzf"), ("huge_adapter", "gzip")])
+@pytest.mark.parametrize("chunk", ["20000", "3000000"])
+def test_cli_streamed_input(binary, golden_dir, name, compress, chunk, monkeypatch):
+    """Compressed / BAM / SAM input decoded piece by piece in bounded memory (textsource.h), forced here on small
+    files with tiny chunks (records larger than a chunk, lines cut by chunk and gzip-member ends): same output, same
+    stderr, same report as the whole-file way and as the reference."""
+    monkeypatch.setenv("TGSF_STREAM_MIN_BYTES", "1")
+    monkeypatch.setenv("TGSF_CHUNK_BYTES", chunk)
+    monkeypatch.setenv("TGSF_FILL_MIN_BYTES", "1")
+    cli_check.run_case(binary, golden_dir, name, extra_args=["-t", "4"], compress=compress)
+
+
 def test_cli_usage_and_errors(binary, tmp_path):
     p = subprocess.run([binary], capture_output=True)
     assert p.returncode == 1 and p.stdout.startswith(b"Usage: tgsfilter -i TGS.raw.fq.gz -x ont -o TGS.clean.fq.gz")

@@ -7,10 +7,18 @@
 // the SAM text -> 4-bit code table are restated from the SAM specification.
 #pragma once
 #include <cstddef>
+#include <memory>
 #include <string>
 #include <vector>
 
+#include "textsource.h"
+
 namespace host {
+
+// The same decoders as streams (textsource.h): bounded memory whatever the size of the file.
+std::unique_ptr<ByteStream> make_gz_bytes(const char* data, size_t size);                 // any series of gzip members
+std::unique_ptr<TextSource> make_bam_text(std::unique_ptr<ByteStream> bytes);             // decompressed BAM -> FASTQ text
+std::unique_ptr<TextSource> make_sam_text(std::unique_ptr<ByteStream> bytes);             // SAM text -> FASTQ text
 
 // true if `data` starts like BGZF/gzip or like BAM/SAM is irrelevant here: the caller decides by file name
 // (file_type() == 2, src/TGSFilter.cpp:833); the content decides BAM vs SAM, as hts_open does.

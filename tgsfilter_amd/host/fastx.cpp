@@ -54,6 +54,12 @@ bool InputBytes::open(const std::string& path, bool sam_or_bam)
     return true;
 }
 
+bool InputBytes::open_raw(const std::string& path)
+{
+    if (!open_plain(path)) { std::cerr << "Failed to open file: " << path << std::endl; return false; }
+    return true;
+}
+
 bool InputBytes::open_plain(const std::string& path)
 {
     const int fd = ::open(path.c_str(), O_RDONLY);
@@ -169,8 +175,9 @@ const char* FastxReader::next_newline(const char* from)
 
 std::string_view FastxReader::line()
 {
-    if (p_ >= end_) { done_ = true; return {}; }
+    if (p_ >= end_) { done_ = true; hit_end_ = true; return {}; }
     const char* nl = next_newline(p_);
+    if (!nl) hit_end_ = true;
     const char* e = nl ? nl : end_;          // a last line without '\n' is still a line here (the reference reads out of bounds)
     size_t n = (size_t)(e - p_);
     if (n > 0 && e[-1] == '\r') n--;         // :666-668
@@ -180,6 +187,22 @@ std::string_view FastxReader::line()
 }
 
 bool FastxReader::next(Record& r) { return fastq_ ? next_fastq(r) : next_fasta(r); }
+
+bool FastxReader::next_partial(Record& r, bool final, bool& incomplete)
+{
+    const char* save = p_;
+    const bool save_done = done_;
+    hit_end_ = false;
+    std::string msg;
+    std::string* sink = message_;
+    message_ = &msg;
+    const bool ok = next(r);
+    message_ = sink;
+    if (!final && hit_end_) { p_ = save; done_ = save_done; incomplete = true; return false; }
+    incomplete = false;
+    if (!ok && !msg.empty()) { if (message_) *message_ = msg; else std::cerr << msg << std::endl; }
+    return ok;
+}
 
 bool FastxReader::next_fastq(Record& r)
 {

@@ -24,6 +24,8 @@ public:
     // prints "Failed to open file: <path>" on failure (:564).  sam_or_bam: the file is SAM/BAM (by name, as the
     // reference decides) and is decoded to FASTQ text in memory (bam.h).
     bool open(const std::string& path, bool sam_or_bam = false);
+    // the bytes of the file as they are (no decoding): for textsource.h, which decodes them piece by piece
+    bool open_raw(const std::string& path);
     const char* data() const { return data_; }
     size_t size() const { return size_; }
     bool mapped() const { return map_ != nullptr; }   // a read-only file mapping (not decoded text in memory)
@@ -71,6 +73,11 @@ public:
     FastxReader(const char* data, size_t size, bool fastq, int scan_threads = 1, std::string* message = nullptr);
     static int scan_threads_from_env(int dflt);   // TGSF_SCAN_THREADS overrides (test knob)
     bool next(Record& r);        // false: end of input (or first malformed record, after the reference's message)
+    // The same over a buffer that may end in the middle of a record (a chunk of a stream, textsource.h): when the
+    // attempt ran into the end of the buffer and more text follows (!final) nothing is consumed, nothing is said,
+    // `incomplete` is set and the caller retries from pos() with more text.
+    bool next_partial(Record& r, bool final, bool& incomplete);
+    const char* pos() const { return p_; }
 private:
     std::string_view line();     // "" at end of input (then done_ is set, like getLine :676-680)
     const char* next_newline(const char* from);   // first '\n' in [from, end_), or nullptr
@@ -82,6 +89,7 @@ private:
     int scan_threads_ = 1;
     bool fastq_;
     bool done_ = false;
+    bool hit_end_ = false;       // a line of the current attempt ended at the end of the buffer, not at a newline
     std::string* message_ = nullptr;
     std::unique_ptr<LineScanner> scan_;
     const std::vector<const char*>* nl_ = nullptr;   // newlines of the current block

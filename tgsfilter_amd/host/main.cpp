@@ -37,6 +37,7 @@
 #include "options.h"
 #include "prepass.h"
 #include "report.h"
+#include "textsource.h"
 
 using namespace host;
 
@@ -57,12 +58,13 @@ struct Batch {
     uint64_t id = 0;                         // position in the input: the writer puts batches back in order
     struct Emit { uint32_t read, frag; int pass_num; uint64_t at; };   // a record to write, `at` bytes into the batch's output
     std::vector<Emit> em;
+    std::shared_ptr<Chunk> hold;             // streamed input: the chunk of text this batch's records live in
     char* dst = nullptr;                     // where the batch's output starts in the mapped file
     uint64_t out_bytes = 0;
     std::atomic<int> left{0};                // fill jobs still running
     void reset() {
         base = nullptr; span = 0; off.clear(); qoff.clear(); len.clear(); recs.clear(); n_frags = 0; bases = 0; id = 0;
-        em.clear(); dst = nullptr; out_bytes = 0; left = 0;
+        em.clear(); hold.reset(); dst = nullptr; out_bytes = 0; left = 0;
     }
 };
 
@@ -415,14 +417,55 @@ int main(int argc, char** argv)
     if (o.devices.empty()) o.devices.push_back(o.device);
     lib_start(o.devices);
 
+    // Compressed / BAM / SAM input beyond a size is STREAMED: decoded piece by piece in bounded memory, once for the
+    // pre-pass (which stops after its sample of reads) and once for the filter pass, as the reference reads it twice
+    // (:949-1040, :1845-1917).  Smaller ones are decoded whole (below), plain files are mapped.  A downsampling run keeps
+    // its kept fragments addressed in the input text, so it takes the whole-file way.
+    const bool coded = o.in_type == 2 || (o.in_file.size() > 3 && o.in_file.compare(o.in_file.size() - 3, 3, ".gz") == 0);
+    uint64_t stream_min = 256ull << 20;
+    if (const char* e = getenv("TGSF_STREAM_MIN_BYTES")) stream_min = strtoull(e, nullptr, 10);      // test knob
     InputBytes in;
-    if (!in.open(o.in_file, o.in_type == 2)) return 1;            // SAM/BAM: decoded to FASTQ text (read_bam, :1872-1917)
-    // the records are indexed once, in the background, for the pre-pass and for the filter pass
+    bool streaming = false;
+    if (coded && !o.downsample) {
+        if (!in.open_raw(o.in_file)) return 1;
+        streaming = in.size() >= stream_min;
+    }
+    if (!streaming && !in.open(o.in_file, o.in_type == 2)) return 1;   // SAM/BAM: decoded to FASTQ text (read_bam, :1872-1917)
+    const size_t chunk_bytes = [] { const char* e = getenv("TGSF_CHUNK_BYTES"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)(64u << 20); }();
+    auto open_stream = [&]() {
+        std::string err;
+        std::unique_ptr<TextSource> src = open_text(in.data(), in.size(), o.in_type == 2, err);
+        if (!src) { std::cerr << "Error: " << err << " (" << o.in_file << ")" << std::endl; fflush(nullptr); _exit(255); }
+        return std::unique_ptr<ChunkReader>(new ChunkReader(std::move(src), !fasta_in, chunk_bytes, 24));   // <= 24 x 64 MB of text alive
+    };
+    // mapped / decoded input: the records are indexed once, in the background, for the pre-pass and for the filter pass
     const int scan_threads = std::max(1, std::min(o.n_thread, 32));
-    RecordIndex records(in.data(), in.size(), !fasta_in, scan_threads);
+    std::unique_ptr<RecordIndex> records_p;
+    if (!streaming) records_p.reset(new RecordIndex(in.data(), in.size(), !fasta_in, scan_threads));
 
     // ---- pre-pass, :3058-3126 ----
-    PrepassResult pp = run_prepass(o, records);
+    PrepassResult pp;
+    if (streaming) {
+        std::unique_ptr<ChunkReader> cr = open_stream();
+        std::shared_ptr<Chunk> ch;
+        size_t at = 0;
+        bool over = false;
+        pp = run_prepass(o, [&](Rec& r) {
+            while (!over && (!ch || at >= ch->recs.size())) {
+                if (ch && !ch->message.empty()) std::cerr << ch->message << std::endl;
+                if (ch && ch->last) { over = true; break; }
+                ch = cr->next(o.in_file);
+                at = 0;
+                if (!ch) over = true;
+            }
+            if (over) return false;
+            r = ch->recs[at++];
+            return true;
+        });
+    } else {
+        RecordIndex::Cursor cur(*records_p);
+        pp = run_prepass(o, [&](Rec& r) { return cur.next(r); });
+    }
     t_prepass = now_s() - t_start;
     std::vector<std::string> adapters;
     if (o.filter) {
@@ -468,7 +511,8 @@ int main(int argc, char** argv)
 
     // ---- contexts ----
     // batches are slices of the input text: sized in text bytes (about 2 bytes per base + headers)
-    uint64_t batch_text = std::min<uint64_t>(256ull << 20, std::max<uint64_t>(in.size() / 8 + 4096, 1 << 16));
+    uint64_t batch_text = streaming ? std::min<uint64_t>(256ull << 20, chunk_bytes)
+                                    : std::min<uint64_t>(256ull << 20, std::max<uint64_t>(in.size() / 8 + 4096, 1 << 16));
     if (const char* e = getenv("TGSF_BATCH_BYTES")) { const long long v = atoll(e); if (v > 0) batch_text = (uint64_t)v; }   // tuning / test knob
     const uint32_t batch_reads = 1u << 16;
     const bool fastq_out = o.out_type == 1;
@@ -479,7 +523,9 @@ int main(int argc, char** argv)
         const char* w = getenv("TGSF_WRITER");                         // "writev": always the single-stream writer
         const bool may_map = !o.only_qc && !o.out_gz && !o.downsample && run_filter_pass && !o.out_file.empty() &&
                              !(w && !strcmp(w, "writev"));
-        if (may_map) sink.open(o.out_file, (uint64_t)in.size() + in.size() / 4 + (16u << 20));
+        // address space for the output mapping: what the input could turn into (a streamed input's text size is unknown)
+        if (may_map) sink.open(o.out_file, streaming ? std::max<uint64_t>(64ull << 30, 64ull * in.size())
+                                                     : (uint64_t)in.size() + in.size() / 4 + (16u << 20));
         if (!o.only_qc && !sink.is_open() && !out.open(o)) return 1;
     }
     // While the library loads and the device comes up nothing else needs this thread's core: pages of the output file
@@ -487,7 +533,7 @@ int main(int argc, char** argv)
     // cut off at the end).  Stops as soon as the planner has its first batch.
     std::atomic<bool> spec_stop{false};
     std::thread spec;
-    if (sink.is_open() && in.size() > (256u << 20) && !getenv("TGSF_NO_EARLY_RESERVE"))
+    if (sink.is_open() && !streaming && in.size() > (256u << 20) && !getenv("TGSF_NO_EARLY_RESERVE"))
         spec = std::thread([&] {
             const uint64_t limit = (uint64_t)in.size() / 4;
             while (!spec_stop.load() && sink.reserved() < limit) sink.reserve_to(std::min<uint64_t>(limit, sink.reserved() + (128u << 20)));
@@ -512,7 +558,8 @@ int main(int argc, char** argv)
     p.max_batch_reads = batch_reads;
     // rows of the per-100-bp tables: from the longest read when the index is complete by now (it usually is: it runs
     // at tens of GB/s beside the device bring-up), else from what the file could hold
-    if (records.complete()) p.max_read_len = std::max<uint32_t>(records.longest(), 1024);
+    if (streaming) p.max_read_len = 1u << 26;
+    else if (records_p->complete()) p.max_read_len = std::max<uint32_t>(records_p->longest(), 1024);
     else p.max_read_len = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(in.size() / 2, 1024), 1u << 26);
     // capacity is in buffer bytes: a text slice must fit, and so must one record of the longest read on its own
     // (header + two lines of max_read_len)
@@ -522,7 +569,7 @@ int main(int argc, char** argv)
     // or three together saturate it (~55 GB/s) and keep the kernels of one batch under the copy of another.  Batches
     // are dealt to whichever feeder is free, the planner re-sequences them, the tallies are merged at the end
     // (host side).
-    int per_dev = in.size() > (64u << 20) ? 3 : 1;
+    int per_dev = (streaming || in.size() > (64u << 20)) ? 3 : 1;
     if (const char* e = getenv("TGSF_CTX_PER_DEVICE")) { const int v = atoi(e); if (v >= 1 && v <= 8) per_dev = v; }
     std::vector<int> ctx_dev;
     for (int d : o.devices) for (int k = 0; k < per_dev; k++) ctx_dev.push_back(d);
@@ -535,7 +582,7 @@ int main(int argc, char** argv)
     uint64_t raw_bases = 0, clean_bases = 0;
     std::vector<CleanRec> clean_recs;                                  // only filled when downsampling follows
     if (!run_filter_pass) {                                            // get_fastx_SeqLen, :2256-2269
-        RecordIndex::Cursor rd(records);
+        RecordIndex::Cursor rd(*records_p);
         Rec r;
         while (rd.next(r)) {
             clean_recs.push_back({std::string_view(r.name, r.name_len), 1, r.seq, r.qual, r.len});
@@ -544,9 +591,17 @@ int main(int argc, char** argv)
     }
 
     BatchStore store;
+    std::atomic<uint64_t> stream_text{0};                             // streamed input: text handed out so far ...
+    std::atomic<double> stream_share{0.0};                            // ... out of this share of the file's bytes
     std::thread reader([&] {                                           // read_fastx, :1845-1870 (batches of indexed records)
         if (!run_filter_pass) { for (size_t d = 0; d < ctxs.size(); d++) to_gpu.put(nullptr); return; }
-        RecordIndex::Cursor rd(records);
+        std::unique_ptr<RecordIndex::Cursor> rd;
+        if (!streaming) rd.reset(new RecordIndex::Cursor(*records_p));
+        std::unique_ptr<ChunkReader> cr;
+        if (streaming) cr = open_stream();
+        std::shared_ptr<Chunk> ch;                                     // streamed input: the chunk being dealt into batches
+        size_t ch_at = 0;
+        bool over = false;
         Rec r;
         auto fresh = [&] { return store.get(); };
         std::shared_ptr<Batch> b = fresh();
@@ -561,12 +616,28 @@ int main(int argc, char** argv)
             waited += now_s() - w0;
             b = fresh();
         };
-        while (rd.next(r)) {
+        auto next_record = [&]() {
+            if (!streaming) return rd->next(r);
+            while (!over && (!ch || ch_at >= ch->recs.size())) {
+                flush();                                               // a batch never spans two chunks
+                if (ch && !ch->message.empty()) std::cerr << ch->message << std::endl;
+                if (ch && ch->last) { over = true; break; }
+                ch = cr->next(o.in_file);
+                ch_at = 0;
+                if (!ch) { over = true; break; }
+                stream_text.store(cr->text_bytes());
+                stream_share.store(cr->consumed());
+            }
+            if (over) return false;
+            r = ch->recs[ch_at++];
+            return true;
+        };
+        while (next_record()) {
             const size_t L = r.len;
             if (L > p.max_read_len) die("read longer than the supported maximum");
             const char* rec_end = (fasta_in ? r.seq : r.qual) + L;
             if (!b->recs.empty() && ((uint64_t)(rec_end - b->base) > batch_text || b->recs.size() >= batch_reads)) flush();
-            if (b->recs.empty()) b->base = r.name;
+            if (b->recs.empty()) { b->base = r.name; b->hold = ch; }
             b->off.push_back((uint64_t)(r.seq - b->base));
             b->qoff.push_back(fasta_in ? b->off.back() : (uint64_t)(r.qual - b->base));
             b->len.push_back((uint32_t)L); b->recs.push_back(r);
@@ -620,7 +691,7 @@ int main(int argc, char** argv)
     // after everything is written.  One background thread drops the pages of written batches while the pipeline runs
     // instead (several threads doing it only get in each other's way).  Only for a file mapping whose text nothing
     // refers to later.
-    const bool release_input = in.mapped() && !o.downsample && getenv("TGSF_KEEP_INPUT_MAPPED") == nullptr;
+    const bool release_input = !streaming && in.mapped() && !o.downsample && getenv("TGSF_KEEP_INPUT_MAPPED") == nullptr;
     Channel<std::pair<const char*, uint64_t>> to_release(1 << 16);
     std::thread releaser([&] {
         for (;;) {
@@ -706,7 +777,11 @@ int main(int argc, char** argv)
                     // reserve a large stride: what is left of the input times the share of it that was written so far
                     // (plus a little); page faults and fallocate do not mix, so the fill jobs drain first
                     const double share = in_seen ? (double)(sink.planned() + at) / (double)in_seen : 1.0;
-                    uint64_t upto = sink.planned() + at + (uint64_t)(share * 1.02 * (double)((uint64_t)in.size() - std::min<uint64_t>(in_seen, in.size())));
+                    // (a streamed input's text size is estimated from the share of the file decoded so far)
+                    const double sh = stream_share.load();
+                    const uint64_t in_total = !streaming ? (uint64_t)in.size()
+                                            : (uint64_t)((double)stream_text.load() / (sh > 1e-6 ? sh : 1e-6));
+                    uint64_t upto = sink.planned() + at + (uint64_t)(share * 1.02 * (double)(in_total - std::min<uint64_t>(in_seen, in_total)));
                     upto = std::min<uint64_t>(std::max<uint64_t>(upto, sink.planned() + at), sink.capacity());
                     const double d0 = now_s();
                     pool.drain();

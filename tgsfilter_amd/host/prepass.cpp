@@ -150,7 +150,7 @@ static void adapter_search(const Options& o, const std::vector<std::string>& end
     if (mean_dep >= 2 * min_sim) { adapter = cand; depth = mean_dep; }  // :1193
 }
 
-PrepassResult run_prepass(Options& o, RecordIndex& records)
+PrepassResult run_prepass(Options& o, const std::function<bool(Rec&)>& next_record)
 {
     PrepassResult R;
     int check_len = std::max(std::max(o.end_len, o.bc_len), 100);       // :897-904
@@ -161,10 +161,9 @@ PrepassResult run_prepass(Options& o, RecordIndex& records)
     const bool need3 = o.filter && (o.tail_trim < 0 || o.adapter_file.empty());
     int seq_num = 0, min_qc = 255, max_qc = 0;
     {
-        RecordIndex::Cursor rd(records);                                // read_fastx / read_bam, :949-1040
-        Rec r;
+        Rec r;                                                          // read_fastx / read_bam, :949-1040
         const bool has_qual = o.in_type != 0;
-        while (rd.next(r)) {
+        while (next_record(r)) {
             const int L = (int)r.len;
             if (L < min_len) continue;
             if (seq_num >= max_seq) break;

@@ -3,6 +3,7 @@
 // P1/P2 are a few integer passes over <= 100k read ends and stay on the host; P3 is 2 x 100k x 22
 // edlib alignments and goes through tgsf_align_windows (the library's edlib-compatible entry point).
 #pragma once
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -24,6 +25,7 @@ struct PrepassResult {
 
 // Runs the pre-pass; prints the reference's INFO lines; may exit(-1) like Get_qType (:1060-1065).
 // Updates o.min_q when -q was not given.
-PrepassResult run_prepass(Options& o, RecordIndex& records);
+// next_record: one pass over the records of the input, in order (false at the end)
+PrepassResult run_prepass(Options& o, const std::function<bool(Rec&)>& next_record);
 
 }  // namespace host
