@@ -1,5 +1,6 @@
 #include "bam.h"
 
+#include <sys/mman.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -260,8 +261,17 @@ public:
     }
     ~GzBytes() override { if (z_open_) inflateEnd(&z_); }
     double consumed() const override { return n_ ? (double)at_ / (double)n_ : 1.0; }
+    // the mapping of the compressed bytes already decoded goes (they stay in the page cache for the second pass):
+    // the resident size of a run does not grow with the file
+    void drop_consumed() {
+        const size_t done = at_ - (z_open_ ? (size_t)z_.avail_in : 0);
+        const size_t upto = done > (1u << 20) ? (done - (1u << 20)) & ~size_t(4095) : 0;
+        const uintptr_t lo = ((uintptr_t)p_ + dropped_ + 4095) & ~uintptr_t(4095), hi = ((uintptr_t)p_ + upto) & ~uintptr_t(4095);
+        if (hi > lo + (8u << 20)) { madvise((void*)lo, hi - lo, MADV_DONTNEED); dropped_ = upto; }
+    }
     bool read(char* dst, size_t cap, size_t& got, bool& eof, std::string& err) override {
         got = 0;
+        drop_consumed();
         if (bgzf_) {
             // the members that fit, located from their 'BC' fields, inflated side by side
             std::vector<BgzfBlock> blocks;
@@ -323,7 +333,7 @@ public:
     }
 private:
     const unsigned char* p_;
-    size_t n_, at_ = 0;
+    size_t n_, at_ = 0, dropped_ = 0;
     bool bgzf_ = false, z_open_ = false, done_ = false;
     z_stream z_;
 };
