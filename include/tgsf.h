@@ -78,7 +78,7 @@ typedef struct tgsf_params {
     int32_t  filter;          /* Para_A24::Filter (0 with -F / --qc)                  */
     int32_t  only_qc;         /* --qc                                                 */
     int32_t  min_repeat;      /* -p  MinRepeat (0 disables the repeat gate)           */
-    int32_t  kmer;            /* -k  Kmer, 1..13 when min_repeat > 0 (GetKmerCount :1703-1753) */
+    int32_t  kmer;            /* -k  Kmer, 1..32 when min_repeat > 0 (GetKmerCount :1703-1753) */
     int32_t  qtype;           /* global qType: 33 or 64 (:80, :1042-1053)             */
     int32_t  n_adapters;      /* size of the global `adapters` set (:1324)            */
     const char* adapters[TGSF_MAX_ADAPTERS];     /* not NUL-terminated necessarily    */

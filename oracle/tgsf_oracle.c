@@ -437,10 +437,14 @@ static int kmer_repeat(const uint8_t* seq, int len, int k)
     int total = len - k + 1;
     if (total <= 0) return 0;
     uint64_t* v = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)total);
-    uint64_t mask = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1ull), km = 0;
+    /* :1748 masks with (1ULL << (2 * k)) - 1 from the SECOND k-mer on (the first is inserted as built, :1727).  At
+     * k = 32 that shift is by 64: what the reference binary does there (x86 takes the count modulo 64: 1 << 0, so
+     * the mask is 0 and every later k-mer is 0) is pinned by the goldens repeat_k32 / repeat_k32b. */
+    uint64_t mask = k >= 32 ? 0ull : ((1ull << (2 * k)) - 1ull), km = 0;
     for (int i = 0; i < len; i++) {
         uint64_t c = seq[i] == 'C' ? 1 : seq[i] == 'G' ? 2 : seq[i] == 'T' ? 3 : 0;
-        km = ((km << 2) | c) & mask;
+        km = (km << 2) | c;
+        if (i >= k) km &= mask;
         if (i >= k - 1) v[i - k + 1] = km;
     }
     qsort(v, (size_t)total, sizeof(uint64_t), u64_cmp);

@@ -46,7 +46,7 @@ def random_case(seed: int, n_reads: int):
         qtype=33,
     )
     if rng.random() < 0.2:
-        kw.update(min_repeat=int(rng.choice([50, 400])), kmer=int(rng.choice([7, 11, 12])))
+        kw.update(min_repeat=int(rng.choice([50, 400])), kmer=int(rng.choice([7, 11, 12, 14, 20, 32])))
     if rng.random() < 0.15:
         kw.update(no_qual=True)
     return kind, reads, kw

@@ -84,6 +84,12 @@ CASES.update({
                [synth.ONT_RAPID], "-x ont -l 500 -q 9 -5 0 -3 0 -m 1 -M 1", "fq", "n_ends"),
     "huge_adapter": (dict(seed=31, n=72, kind="ont", mean_len=3500, zoo=True, adapter=HUGE_A, pmid=0.15, err=0.06),
                      [HUGE_A, HUGE_B], "-x ont -l 800 -q 9 -5 0 -3 2"),
+    # the repeat gate beyond k = 13 (64-bit k-mers; at k = 32 the reference's mask (1ULL << 64) - 1 is what the
+    # machine makes of it, :1748)
+    "repeat_k15": (dict(seed=34, n=70, kind="ont", mean_len=4000, zoo=True, pmid=0.05), [synth.ONT_RAPID], "-x ont -l 1000 -q 10 -5 0 -3 0 -p 3 -k 15"),
+    "repeat_k21": (dict(seed=35, n=70, kind="ont", mean_len=4000, zoo=True, pmid=0.05), [synth.ONT_RAPID], "-x ont -l 1000 -q 10 -5 0 -3 0 -p 2 -k 21"),
+    "repeat_k32": (dict(seed=36, n=70, kind="ont", mean_len=4000, zoo=True, pmid=0.05), [synth.ONT_RAPID], "-x ont -l 1000 -q 10 -5 0 -3 0 -p 2 -k 32"),
+    "repeat_k32b": (dict(seed=36, n=70, kind="ont", mean_len=4000, zoo=True, pmid=0.05), [synth.ONT_RAPID], "-x ont -l 1000 -q 10 -5 0 -3 0 -p 3000 -k 32"),
     # Phred+64 qualities through the whole command line (Get_qType :1042-1077 decides from the first reads)
     "ont_phred64": (dict(seed=32, n=90, kind="ont", mean_len=3000, zoo=True, pmid=0.05),
                     [synth.ONT_RAPID], "-x ont -l 1000 -q 10 -5 0 -3 0", "fq", "phred64"),

@@ -158,5 +158,5 @@ GOLDEN_CASES = ["ont_zoo", "ont_trim", "ont_discard", "hifi_zoo", "long_adapter"
                 "hifi_auto", "qc_only", "ont_m1", "huge_adapter", "ont_phred64", "hifi_phred64_auto"]
 # whole-program cases that involve the host-side second pass (checked through the CLI only)
 # ... or a non-FASTQ input format (SAM / unaligned BAM decoded by the host; FASTA = records without qualities)
-GOLDEN_CLI_ONLY = ["ont_repeat", "down_gd", "down_r", "down_R", "down_F", "hifi_bam", "ont_sam", "hifi_bam_auto",
+GOLDEN_CLI_ONLY = ["ont_repeat", "repeat_k15", "repeat_k21", "repeat_k32", "repeat_k32b", "down_gd", "down_r", "down_R", "down_F", "hifi_bam", "ont_sam", "hifi_bam_auto",
                    "ont_fasta", "hifi_fasta_auto", "fasta_down"]

@@ -83,7 +83,7 @@ def test_emul_in_place_fastq_text(emul):
     ctx.close()
 
 
-@pytest.mark.parametrize("pval,k", [(300, 11), (40, 9), (2000, 12)])
+@pytest.mark.parametrize("pval,k", [(300, 11), (40, 9), (2000, 12), (40, 15), (30, 21), (4000, 32)])
 def test_emul_repeat_gate(emul, pval, k):
     reads = parity.repeat_reads()
     p = parity.sized(abi.make_params("ont", adapters=[synth.ONT_RAPID, synth.ONT_RAPID_RC], min_q=10.0,

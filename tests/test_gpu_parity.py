@@ -144,7 +144,7 @@ def test_gpu_in_place_fastq_text():
     ctx.close()
 
 
-@pytest.mark.parametrize("pval,k", [(300, 11), (40, 9), (2000, 12), (100, 13)])
+@pytest.mark.parametrize("pval,k", [(300, 11), (40, 9), (2000, 12), (100, 13), (40, 15), (30, 21), (25, 31), (4000, 32)])
 def test_gpu_repeat_gate(pval, k):
     """-p/-k: GetKmerCount on the device (LDS bitmap partitions) against the oracle."""
     reads = parity.repeat_reads(n=150)

@@ -61,6 +61,7 @@ struct DevBatch {
     uint32_t* pool_n;          // number of slots used
     uint32_t* seg_cnt;         // [n+1] middle segments per read, scanned in place to bases
     uint32_t* nfr;             // [n+1] fragments per read, scanned in place to frag_begin
+    uint32_t* scan_part;       // [n / kScanTile + 2] per-tile totals of the prefix scans
     uint32_t* trimmed;         // [n]
 
     // stats work lists (raw: items are reads; clean: items are fragments [0,fcap) and, in the

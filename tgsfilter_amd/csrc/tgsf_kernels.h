@@ -49,6 +49,7 @@ template <class T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *
 template <class T> static inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <class T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 template <class T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+template <class T> static inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
 #else
 #define TGSF_KERNEL __global__ void
 #define TGSF_INLINE_LAMBDA __attribute__((always_inline))
@@ -687,47 +688,49 @@ TGSF_KERNEL k_gate_reads(DevParams P, DevBatch B)
 // k_scan_u32: exclusive prefix sum in place over a[0..n], a[n] receives the total.
 // One block; each thread owns 16 consecutive elements per sweep.
 // ---------------------------------------------------------------------------
-constexpr int kScanPer = 16;
-// Exclusive prefix sums of a[0..n) in place, a[n] = total.  One block (n is the reads of a batch, 1e5: the cost is
-// latency, not work): per pass every thread sums kScanPer entries, 32 threads scan a run of those sums each, one
-// thread the 32 run totals -- three barriers per pass (a Hillis-Steele scan of the 1024 sums took twenty).
-TGSF_KERNEL k_scan_u32(uint32_t* a, const uint32_t* n_ptr, uint32_t n_fixed)
+// Exclusive prefix sums of a[0..n) in place, a[n] = total (n = the reads of a batch, ~1e5: the cost is latency, not
+// work).  Three small launches instead of one block walking the whole array: every block scans its own kScanTile
+// entries and leaves its total in part[]; one block scans the totals; every block adds its offset.
+constexpr int kScanTile = 4096;
+TGSF_KERNEL k_scan_tiles(uint32_t* a, uint32_t n, uint32_t* part)
 {
-    TGSF_SHARED uint32_t part[1024];
-    TGSF_SHARED uint32_t run_tot[32];
-    TGSF_SHARED uint32_t carry_s;
-    const uint32_t n = n_ptr ? *n_ptr : n_fixed;
-    const uint32_t T = blockDim.x;
-    const uint32_t runs = T < 32u ? T : 32u, per_run = (T + runs - 1) / runs;
-    if (threadIdx.x == 0) carry_s = 0;
+    TGSF_SHARED uint32_t sums[1024];
+    const uint32_t T = blockDim.x, per = (kScanTile + T - 1) / T;
+    const uint32_t base = blockIdx.x * kScanTile;
+    const uint32_t lo = base + threadIdx.x * per;
+    uint32_t hi = lo + per;
+    if (hi > base + kScanTile) hi = base + kScanTile;
+    if (hi > n) hi = n;
+    uint32_t s = 0;
+    for (uint32_t i = lo; i < hi; i++) s += a[i];
+    sums[threadIdx.x] = s;
     TGSF_BLOCK_SYNC();
-    for (uint32_t base = 0; base < n; base += T * kScanPer) {
-        uint32_t v[kScanPer];
-        uint32_t s = 0;
-        const uint32_t i0 = base + threadIdx.x * kScanPer;
-#pragma unroll
-        for (int k = 0; k < kScanPer; k++) { v[k] = (i0 + k < n) ? a[i0 + k] : 0u; s += v[k]; }
-        part[threadIdx.x] = s;
-        TGSF_BLOCK_SYNC();
-        if (threadIdx.x < runs) {                          // exclusive scan of this run of per-thread sums
-            uint32_t acc = 0;
-            const uint32_t lo = threadIdx.x * per_run, hi = lo + per_run < T ? lo + per_run : T;
-            for (uint32_t i = lo; i < hi; i++) { const uint32_t x = part[i]; part[i] = acc; acc += x; }
-            run_tot[threadIdx.x] = acc;
-        }
-        TGSF_BLOCK_SYNC();
-        if (threadIdx.x == 0) {
-            uint32_t acc = carry_s;
-            for (uint32_t i = 0; i < runs; i++) { const uint32_t x = run_tot[i]; run_tot[i] = acc; acc += x; }
-            carry_s = acc;
-        }
-        TGSF_BLOCK_SYNC();
-        uint32_t excl = run_tot[threadIdx.x / per_run] + part[threadIdx.x];
-#pragma unroll
-        for (int k = 0; k < kScanPer; k++) { if (i0 + k < n) a[i0 + k] = excl; excl += v[k]; }
-        TGSF_BLOCK_SYNC();
+    if (threadIdx.x == 0) {                                 // T <= 256 sums: a serial pass is as good as anything
+        uint32_t acc = 0;
+        for (uint32_t t = 0; t < T; t++) { const uint32_t x = sums[t]; sums[t] = acc; acc += x; }
+        part[blockIdx.x] = acc;
     }
-    if (threadIdx.x == 0) a[n] = carry_s;
+    TGSF_BLOCK_SYNC();
+    uint32_t acc = sums[threadIdx.x];
+    for (uint32_t i = lo; i < hi; i++) { const uint32_t x = a[i]; a[i] = acc; acc += x; }
+}
+TGSF_KERNEL k_scan_top(uint32_t* part, uint32_t nb, uint32_t* total_out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t acc = 0;
+    for (uint32_t b = 0; b < nb; b++) { const uint32_t x = part[b]; part[b] = acc; acc += x; }
+    *total_out = acc;
+}
+TGSF_KERNEL k_scan_add(uint32_t* a, uint32_t n, const uint32_t* part)
+{
+    const uint32_t T = blockDim.x, per = (kScanTile + T - 1) / T;
+    const uint32_t base = blockIdx.x * kScanTile, off = part[blockIdx.x];
+    if (!off) return;
+    const uint32_t lo = base + threadIdx.x * per;
+    uint32_t hi = lo + per;
+    if (hi > base + kScanTile) hi = base + kScanTile;
+    if (hi > n) hi = n;
+    for (uint32_t i = lo; i < hi; i++) a[i] += off;
 }
 
 // ---------------------------------------------------------------------------
@@ -1562,6 +1565,88 @@ TGSF_KERNEL k_repeat(DevParams P, DevBatch B)
             // distinct k-mers of this partition = set bits of the bitmap
             TGSF_BLOCK_SYNC();
             for (uint32_t w = tid; w < part_words; w += nthr) mine += popc32(bm[w]);
+        }
+        if (mine) atomicAdd(&distinct_s, mine);
+        TGSF_BLOCK_SYNC();
+        if (tid == 0) {
+            const int repeat = (total > 0 ? total : 0) - (int)distinct_s;
+            if (repeat < P.min_repeat) {                               // :1984-1988
+                B.frag_flags[f] |= TGSF_FF_REPEAT;
+                drop_n++; drop_b += (uint64_t)L;
+            }
+        }
+        TGSF_BLOCK_SYNC();
+    }
+    if (tid == 0 && drop_n) {
+        atomicAdd((ull*)&B.ctr[TGSF_CTR_DROPINFO + 15], (ull)drop_n);
+        atomicAdd((ull*)&B.ctr[TGSF_CTR_DROPINFO + 16], (ull)drop_b);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_repeat_wide: the same gate for k = 14..32, where the 4^k-bit set no longer exists as a bitmap: the distinct
+// k-mers (64-bit keys, compared in full -- exact) are counted by inserting them into an open-addressing table in
+// HBM, one table region per workgroup (L2-resident for ordinary fragments), sized to twice the fragment's k-mers
+// (power of two), cleared per fragment; a slot is claimed with one 64-bit compare-and-swap.  k = 32 follows the
+// reference's machine there (:1748, see the oracle): the first k-mer as built, every later one 0.
+// ---------------------------------------------------------------------------
+TGSF_KERNEL k_repeat_wide(DevParams P, DevBatch B, unsigned long long* tables, uint64_t slots_per_wg)
+{
+    TGSF_SHARED uint32_t distinct_s;
+    const int k = P.kmer;
+    const uint64_t kmask = k >= 32 ? 0ull : ((1ull << (2 * k)) - 1ull);
+    const ull kEmpty = ~0ull;                                           // no key below k = 32 has all bits set
+    const uint32_t nf = stored_frags(B);
+    ull* tab = tables + (size_t)blockIdx.x * slots_per_wg;
+    uint64_t drop_n = 0, drop_b = 0;
+#if defined(TGSF_EMUL)
+    const uint32_t nthr = 1, tid = 0;
+    if (threadIdx.x != 0) return;
+#else
+    const uint32_t nthr = blockDim.x, tid = threadIdx.x;
+#endif
+    for (uint32_t f = blockIdx.x; f < nf; f += gridDim.x) {
+        const int L = (int)B.frag_len[f];
+        const int total = L - k + 1;
+        const uint8_t* seq = B.seq + B.frag_off[f];
+        if (tid == 0) distinct_s = 0;
+        TGSF_BLOCK_SYNC();
+        uint32_t mine = 0;
+        if (total > 0 && k >= 32) {
+            if (tid == 0) {
+                ull first = 0;
+                for (int i = 0; i < k; i++) first = (first << 2) | base_code(seq[i]);
+                mine = (total > 1 && first != 0ull) ? 2u : 1u;
+            }
+        } else if (total > 0) {
+            uint64_t slots = 64;
+            while (slots < 2ull * (uint64_t)total) slots <<= 1;
+            if (slots > slots_per_wg) { set_status(B, DS_POOL_FULL, B.frag_read[f]); slots = slots_per_wg; }
+            for (uint64_t i = tid; i < slots; i += nthr) tab[i] = kEmpty;
+            TGSF_BLOCK_SYNC();
+            // every thread takes a contiguous run of k-mers (rolls its own window)
+            const int per = (total + (int)nthr - 1) / (int)nthr;
+            const int i0 = (int)tid * per;
+            int i1 = i0 + per;
+            if (i1 > total) i1 = total;
+            if (i0 < i1) {
+                ull km = 0;
+                for (int j = i0; j < i0 + k - 1; j++) km = (km << 2) | base_code(seq[j]);
+                for (int i = i0; i < i1; i++) {
+                    km = (km << 2) | base_code(seq[i + k - 1]);
+                    if (i > 0) km &= kmask;                         // the first k-mer of a fragment is taken as built (:1727)
+                    else if (k < 32) km &= kmask;                   // (k bases never exceed 2k bits below k = 32)
+                    uint64_t h = km * 0x9E3779B97F4A7C15ull;
+                    h ^= h >> 29;
+                    uint64_t slot = h & (slots - 1);
+                    for (;;) {
+                        const ull old = atomicCAS(&tab[slot], kEmpty, km);
+                        if (old == kEmpty) { mine++; break; }
+                        if (old == km) break;
+                        slot = (slot + 1) & (slots - 1);
+                    }
+                }
+            }
         }
         if (mine) atomicAdd(&distinct_s, mine);
         TGSF_BLOCK_SYNC();

@@ -48,6 +48,9 @@ struct tgsf_ctx {
     uint32_t cap_reads, max_read_len, n_bins;
     unsigned stats_grid = 768, mid_grid = 0;   // tuning knobs (TGSF_STATS_GRID, TGSF_MID_GRID; 0 = one lane per segment)
     uint64_t ctr_words;
+    unsigned long long* rep_tables = nullptr;      // k_repeat_wide (-k 14..31): per-workgroup k-mer tables
+    uint64_t rep_slots = 0;
+    unsigned rep_wgs = 0;
     int scratch_cols;
     // internal input / output staging for tgsf_submit
     uint8_t *d_seq, *d_qual;
@@ -291,8 +294,8 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
         return fail(nullptr, TGSF_E_INVALID, "tgsf_params.struct_size %u != %zu (ABI mismatch)", p->struct_size, sizeof(tgsf_params));
     if (p->n_adapters < 0 || p->n_adapters > TGSF_MAX_ADAPTERS)
         return fail(nullptr, TGSF_E_INVALID, "n_adapters %d outside [0,%d]", p->n_adapters, TGSF_MAX_ADAPTERS);
-    if (p->min_repeat > 0 && (p->kmer < 1 || p->kmer > 13))
-        return fail(nullptr, TGSF_E_UNSUPPORTED, "-k %d: the repeat gate supports k-mer sizes 1..13 (4^k-bit set in LDS partitions)", p->kmer);
+    if (p->min_repeat > 0 && (p->kmer < 1 || p->kmer > 32))
+        return fail(nullptr, TGSF_E_UNSUPPORTED, "-k %d: the repeat gate supports k-mer sizes 1..32 (the reference's k-mers are 64 bits)", p->kmer);
     if (p->qtype != 33 && p->qtype != 64) return fail(nullptr, TGSF_E_INVALID, "qtype must be 33 or 64");
     if (p->bc_len < 0 || p->bc_len > kMaxBcLen) return fail(nullptr, TGSF_E_INVALID, "bc_len (-e) outside [0,%d]", kMaxBcLen);
     if (p->filter && p->n_adapters > 0) {
@@ -423,6 +426,7 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     if (!e) e = dev_alloc(c, &B.pool_n, 4);
     if (!e) e = dev_alloc(c, &B.seg_cnt, n + 1);
     if (!e) e = dev_alloc(c, &B.nfr, n + 1);
+    if (!e) e = dev_alloc(c, &B.scan_part, n / kScanTile + 2);
     if (!e) e = dev_alloc(c, &B.trimmed, n);
     if (!e) e = dev_alloc(c, &B.tile_hist, (size_t)B.max_tiles + 2);
     if (!e) e = dev_alloc(c, &B.tile_cnt, (size_t)B.max_tiles + 2);
@@ -458,6 +462,16 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
         B.scratch_mid_wave0 = ((size_t)n * A * 2 + 63) / 64 + 1;
         const size_t waves = B.scratch_mid_wave0 + ((size_t)n * A + 63) / 64 + 1;
         if (!e) e = dev_alloc(c, &B.scratch, waves * B.scratch_wave_words);
+    }
+    if (!e && p->min_repeat > 0 && p->kmer > 13 && p->kmer < 32 && !p->only_qc) {
+        // k_repeat_wide: one table region per workgroup, twice the k-mers of the longest fragment (power of two);
+        // as many workgroups as 8 GB of them allow
+        uint64_t slots = 64;
+        while (slots < 2ull * c->max_read_len) slots <<= 1;
+        uint64_t wgs = (8ull << 30) / (slots * 8);
+        c->rep_wgs = (unsigned)std::max<uint64_t>(8, std::min<uint64_t>(wgs, 512));
+        c->rep_slots = slots;
+        e = dev_alloc(c, &c->rep_tables, (size_t)c->rep_wgs * (size_t)slots);
     }
     if (!e) e = dev_alloc(c, &B.ctr, (size_t)c->ctr_words);
     if (!e) e = dev_alloc(c, &B.status, 4);
@@ -508,6 +522,15 @@ static int harvest_profile(tgsf_ctx* c, rt_stream st)
     return TGSF_OK;
 }
 #endif
+
+// exclusive prefix sums of a[0..n) in place, a[n] = total
+static void scan_u32(const DevBatch& B, uint32_t* a, uint32_t n, rt_stream st)
+{
+    const unsigned nb = (n + kScanTile - 1) / kScanTile;
+    TGSF_LAUNCH_COOP(k_scan_tiles, nb, 256, st, a, n, B.scan_part);
+    TGSF_LAUNCH_COOP(k_scan_top, 1, 64, st, B.scan_part, (uint32_t)nb, a + n);
+    TGSF_LAUNCH_COOP(k_scan_add, nb, 256, st, a, n, (const uint32_t*)B.scan_part);
+}
 
 static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* d_reads, tgsf_fragment* d_frags,
                         uint32_t out_fcap, uint32_t* d_nfrags, rt_stream st)
@@ -591,7 +614,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     STAGE_MARK();
     STAGE_MARK();
     if (P.filter && A > 0) {
-        TGSF_LAUNCH_COOP(k_scan_u32, 1, 1024, st, B.seg_cnt, (const uint32_t*)nullptr, n);
+        scan_u32(B, B.seg_cnt, n, st);
         // upper bound of the segment count, known on the host: no device round trip
         const uint64_t max_segs = in->n_bytes / (uint64_t)P.seg_cols + 2ull * n + 1;
         const unsigned gseg = blocks_for(max_segs, T);
@@ -630,10 +653,12 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     (void)hipStreamWaitEvent(st, c->ev_join, 0);      // regions need the end-window results
 #endif
     TGSF_LAUNCH(k_regions<false>, gsmall, T, st, P, B);
-    TGSF_LAUNCH_COOP(k_scan_u32, 1, 1024, st, B.nfr, (const uint32_t*)nullptr, n);
+    scan_u32(B, B.nfr, n, st);
     TGSF_LAUNCH(k_regions<true>, gsmall, T, st, P, B);
-    if (P.min_repeat > 0 && !P.only_qc)
-        TGSF_LAUNCH(k_repeat, grid_cap(256u), 256, st, P, B);          // one workgroup per CU: 128 KB of LDS each
+    if (P.min_repeat > 0 && !P.only_qc) {
+        if (P.kmer <= 13) TGSF_LAUNCH(k_repeat, grid_cap(256u), 256, st, P, B);          // one workgroup per CU: 128 KB of LDS each
+        else TGSF_LAUNCH(k_repeat_wide, grid_cap(P.kmer >= 32 ? 256u : c->rep_wgs), 256, st, P, B, c->rep_tables, c->rep_slots);
+    }
     STAGE_MARK();
     // -- clean stats over the fragments
     rt_memset(B.tile_hist, 0, tl, st);

@@ -7,10 +7,11 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof_$tag
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_default -- python3 $R/bench.py --no-cpu-baseline > $O/kt_default.json 2> $O/kt_default.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_single -- python3 $R/bench.py --no-cpu-baseline --streams 1 > $O/kt_single.json 2> $O/kt_single.err
-B="python3 $R/bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline"
+# kernel-path runs only under the profiler (the end-to-end leg starts other programs; it is timed by bench.py itself)
+K="--no-e2e --no-cpu-baseline --no-oracle-check"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_default -- python3 $R/bench.py $K > $O/kt_default.json 2> $O/kt_default.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_single -- python3 $R/bench.py $K --streams 1 > $O/kt_single.json 2> $O/kt_single.err
+B="python3 $R/bench.py $K --kernel-steps 2 --kernel-warmup 1 --streams 1"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $B > $O/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $B > $O/pmc_write.log 2>&1
 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_tcc -- $B > $O/pmc_tcc.log 2>&1
@@ -74,7 +75,11 @@ with open(O + "/%s_pmc_valu.csv" % tag, "w") as o:
 b = json.load(open(O + "/kt_single.json"))
 def hbm(k):
     return tcc.get(k, {}).get("TCC_EA0_RDREQ_sum", 0) * 128 + write.get(k, {}).get("WRITE_SIZE", 0) * 1024
-json.dump({"reads_per_step": b["config"]["reads_per_step_per_gpu"],
+import hashlib
+h = hashlib.sha256()
+for fn in ("tgsf_core.h", "tgsf_dev.h", "tgsf_kernels.h", "tgsf_lib.hip"):      # = bench.py kernel_source_hash()
+    h.update(open(os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.getcwd()), "tgsfilter_amd", "csrc", fn), "rb").read())
+json.dump({"reads_per_step": b["kernel_path"]["reads_per_step"], "kernel_source_hash": h.hexdigest()[:16],
            "mid_scan_hbm_bytes_per_launch": hbm("tgsf::k_mid_scan1<2>"),
            "stats_raw_hbm_bytes_per_launch": hbm("tgsf::k_stats<false>"),
            "mid_scan_valu_insts_per_launch": sq.get("tgsf::k_mid_scan1<2>", {}).get("SQ_INSTS_VALU"),
