@@ -93,6 +93,21 @@ def test_cli_streamed_input(binary, golden_dir, name, compress, chunk, monkeypat
     cli_check.run_case(binary, golden_dir, name, extra_args=["-t", "4"], compress=compress)
 
 
+@pytest.mark.parametrize("stream_min", ["1", "999999999"])
+def test_cli_corrupt_gzip(binary, golden_dir, tmp_path, stream_min, monkeypatch):
+    """A damaged .gz ends the run with the reference's message (:636) and exit status, streamed or decoded whole."""
+    import gzip
+    raw = gzip.open(os.path.join(golden_dir, "ont_zoo.in.fq.gz"), "rb").read()
+    blob = bytearray(gzip.compress(raw, 4))
+    for k in range(len(blob) // 2, len(blob) // 2 + 64):
+        blob[k] ^= 0x5A
+    f = tmp_path / "bad.fq.gz"
+    f.write_bytes(bytes(blob))
+    monkeypatch.setenv("TGSF_STREAM_MIN_BYTES", stream_min)
+    p = subprocess.run([binary, "-i", str(f), "-o", str(tmp_path / "o.fq"), "-x", "ont", "-t", "2"], capture_output=True)
+    assert p.returncode == 255 and b"Error encountered while decompressing file" in p.stderr
+
+
 def test_cli_usage_and_errors(binary, tmp_path):
     p = subprocess.run([binary], capture_output=True)
     assert p.returncode == 1 and p.stdout.startswith(b"Usage: tgsfilter -i TGS.raw.fq.gz -x ont -o TGS.clean.fq.gz")

@@ -40,7 +40,7 @@ def case(seed, n):
     if rng.random() < 0.3:
         flags += ["-e", str(int(rng.choice([150, 220]) if auto_trims else rng.choice([80, 150, 220])))]
     if rng.random() < 0.3:
-        flags += ["-m", str(int(rng.choice([6, 12]))), "-M", str(int(rng.choice([25, 30])))]
+        flags += ["-m", str(int(rng.choice([6, 12, 1]))), "-M", str(int(rng.choice([25, 30, 1])))]     # 1: edlib's k >= Q corner
     if rng.random() < 0.3:
         flags += ["-T", str(int(rng.choice([0, 20])))]
     if rng.random() < 0.3:
@@ -48,7 +48,7 @@ def case(seed, n):
     if rng.random() < 0.2:
         flags += ["-D"]
     if rng.random() < 0.2:
-        flags += ["-p", str(int(rng.choice([2, 5]))), "-k", str(int(rng.choice([9, 11])))]
+        flags += ["-p", str(int(rng.choice([2, 5]))), "-k", str(int(rng.choice([9, 11, 15, 24, 32])))]
     if rng.random() < 0.2:
         flags += ["-r", str(int(rng.integers(3, n)))]
     adapters = None
@@ -57,7 +57,8 @@ def case(seed, n):
         if rng.random() < 0.35:                      # several adapters (passes of up to 4), one of them two words long
             extra = [b"AATGTACTTCGTTCAGTTACGTATTGCT", b"GCAATACGTAACTGAACGAAGT",
                      b"GGCGTCTGCTTGGGTGTTTAACCTTTTTGTCAGAGAGGTTCCAAGTCAGAGAGGTTCCTACGTTGCAATCGGATCCGATTACGGATCAAGT",
-                     b"CTTGCGGGCGGCGGACTCTCCTCTGAAGATAGAGCGACAGGCAAG"]
+                     b"CTTGCGGGCGGCGGACTCTCCTCTGAAGATAGAGCGACAGGCAAG",
+                     bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[np.random.default_rng(77).integers(0, 4, 170)])]   # three words
             for i in rng.choice(len(extra), int(rng.integers(1, 3)), replace=False):
                 adapters.append(extra[int(i)])
     return reads, flags, adapters, fasta

@@ -34,7 +34,7 @@ bool InputBytes::open(const std::string& path, bool sam_or_bam)
         std::string err;
         if (!decode_sam_or_bam(raw.data(), raw.size(), owned_, err)) {
             std::cerr << "Error: " << err << " (" << path << ")" << std::endl;
-            exit(-1);
+            fflush(nullptr); _exit(255);      // other threads are running: no static destructors, the reference's status
         }
         data_ = owned_.data(); size_ = owned_.size();
         return true;
@@ -45,7 +45,7 @@ bool InputBytes::open(const std::string& path, bool sam_or_bam)
         std::string err;
         if (!inflate_gzip(raw.data(), raw.size(), owned_, err)) {
             std::cerr << "Error: Error encountered while decompressing file: " << path << std::endl;
-            exit(-1);
+            fflush(nullptr); _exit(255);      // other threads are running: no static destructors, the reference's status
         }
         data_ = owned_.data(); size_ = owned_.size();
         return true;

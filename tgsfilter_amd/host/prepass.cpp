@@ -1,5 +1,7 @@
 #include "prepass.h"
 
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -114,7 +116,7 @@ static void adapter_search(const Options& o, const std::vector<std::string>& end
     p.max_batch_reads = (uint32_t)(per_call * 22 / (22 * 2) + 64);      // n problems <= cap_reads * A * 2
     p.max_batch_bases = 1 << 20; p.max_read_len = 1 << 16;
     tgsf_ctx* ctx = nullptr;
-    if (lib().create(&p, o.devices.empty() ? o.device : o.devices[0], &ctx) != TGSF_OK) { std::cerr << "Error: " << lib().last_error(nullptr) << std::endl; exit(-1); }
+    if (lib().create(&p, o.devices.empty() ? o.device : o.devices[0], &ctx) != TGSF_OK) { std::cerr << "Error: " << lib().last_error(nullptr) << std::endl; fflush(nullptr); _exit(255); }
 
     // totals per adapter in the reference's own container (:1150, :1171): the winner among equal totals is
     // whatever its iteration order and std::sort make of it, reproduced here by using the same ones
@@ -134,7 +136,7 @@ static void adapter_search(const Options& o, const std::vector<std::string>& end
         if (!n) continue;
         res.assign((size_t)n * 4, 0); eds.assign((size_t)n * 2, 0);
         if (lib().align_windows(ctx, buf.data(), buf.size(), off.data(), len.data(), aid.data(), kk.data(), n, res.data(), eds.data()) != TGSF_OK) {
-            std::cerr << "Error: " << lib().last_error(ctx) << std::endl; exit(-1);
+            std::cerr << "Error: " << lib().last_error(ctx) << std::endl; fflush(nullptr); _exit(255);
         }
         for (uint32_t i = 0; i < n; i++)
             if (res[(size_t)i * 4 + 1] > 0)                             // numAln > 0, :1170 (problems are read-major, as :1156-1158)
@@ -185,7 +187,7 @@ PrepassResult run_prepass(Options& o, const std::function<bool(Rec&)>& next_reco
             if (o.min_q >= maxq) {
                 std::cerr << "Warning: max base quality score was: " << maxq << std::endl;
                 std::cerr << "INFO: Please reset -q parameter." << std::endl;
-                exit(-1);
+                fflush(nullptr); _exit(255);
             }
         } else {
             if (maxq > 10 && o.read_type == "clr") o.min_q = 10;
