@@ -76,14 +76,17 @@ struct tgsf_ctx {
     hipStream_t hp;                       // optional high-priority stream for the HBM-bound stats kernels (TGSF_STATS_PRIO=1)
     hipEvent_t ev_hp[2];
     bool side_mid = false;                // TGSF_BIG_LOWPRIO=1: stats AND scan kernels on a lowest-priority side stream
+    uint32_t* h_pinned = nullptr;
     static constexpr size_t kStageBytes = 32u << 20;
     uint8_t* stage[2] = {nullptr, nullptr};   // pinned staging for host batches in pageable memory (text_h2d)
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
 #endif
-    uint32_t h_status[4];
+    uint32_t h_words_[8];      // backing store of h_status / pend_nf when no pinned page is available (emulation)
+    uint32_t* h_status;        // [4] device status words as last fetched  } one pinned allocation: the small D2H copies
+    uint32_t* pend_nf_p;       // fragment count of the pending batch       } into it are truly asynchronous
     // batch enqueued by tgsf_submit_async, completed by tgsf_wait
     tgsf_batch_out* pend_out = nullptr;
-    uint32_t pend_nf = 0;
+
 };
 
 static int fail(tgsf_ctx* c, int code, const char* fmt, ...)
@@ -271,6 +274,7 @@ extern "C" void tgsf_destroy(tgsf_ctx* c)
         for (int i = 0; i <= TGSF_N_STAGES; i++) if (c->ev[k][i]) (void)hipEventDestroy(c->ev[k][i]);
         for (int i = 0; i < 3; i++) if (c->ev_aux[k][i]) (void)hipEventDestroy(c->ev_aux[k][i]);
     }
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     for (int i = 0; i < 2; i++) {
         if (c->stage[i]) (void)hipHostFree(c->stage[i]);
         if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]);
@@ -318,7 +322,9 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     c->profile = false;
     c->prof_batches = 0;
     memset(c->stage_ms, 0, sizeof c->stage_ms);
-    memset(c->h_status, 0, sizeof c->h_status);
+    memset(c->h_words_, 0, sizeof c->h_words_);
+    c->h_status = c->h_words_;
+    c->pend_nf_p = c->h_words_ + 4;
     for (int a = 0; a < p->n_adapters; a++) {
         c->adapters.emplace_back(p->adapters[a], (size_t)p->adapter_len[a]);
         c->params.adapters[a] = c->adapters.back().data();
@@ -342,6 +348,13 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     }
     c->own_stream = true;
     c->prof_pending = 0;
+    {
+        uint32_t* pw = nullptr;
+        if (hipHostMalloc((void**)&pw, 64, hipHostMallocDefault) == hipSuccess && pw) {
+            memset(pw, 0, 64);
+            c->h_pinned = pw; c->h_status = pw; c->pend_nf_p = pw + 4;
+        }
+    }
     if ((he = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking)) != hipSuccess ||
         (he = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess ||
         (he = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) {
@@ -749,7 +762,7 @@ static int finish_pending(tgsf_ctx* c)
     tgsf_batch_out* out = c->pend_out;
     if (!out) return TGSF_OK;
     c->pend_out = nullptr;
-    const uint32_t nf = c->pend_nf;
+    const uint32_t nf = *c->pend_nf_p;
     out->n_frags = nf;
     if (nf > out->frag_capacity || (nf && !out->frags))
         return fail(c, TGSF_E_CAPACITY, "batch produced %u fragments, caller provided room for %u", nf, out->frag_capacity);
@@ -828,8 +841,8 @@ extern "C" int tgsf_submit_async(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_batc
     din.n_bytes = span;
     e = run_pipeline(c, &din, c->d_out_reads, c->d_out_frags, c->B.fcap, c->d_out_nfrags, st);
     if (e) return e;
-    c->pend_nf = 0;
-    he |= rt_d2h(&c->pend_nf, c->d_out_nfrags, 4, st);
+    *c->pend_nf_p = 0;
+    he |= rt_d2h(c->pend_nf_p, c->d_out_nfrags, 4, st);
     he |= rt_d2h(out->reads, c->d_out_reads, (size_t)n * sizeof(tgsf_read_result), st);
     if (he) return fail(c, TGSF_E_HIP, "device to host copy failed");
     c->pend_out = out;
