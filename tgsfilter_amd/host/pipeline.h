@@ -1,0 +1,375 @@
+// pipeline.h -- the moving parts of the command line's batch pipeline (main.cpp wires them together):
+//   Batch / BatchStore   a slice of the input text + the index of its records + its results, recycled
+//   Channel              small bounded queue between the stages
+//   Output               single-stream writer: records gathered with writev straight from the input text, or per-record
+//                        gzip members (the reference's writer, src/TGSFilter.cpp:2095-2145, :786-812)
+//   MappedSink + Pool    plain output into a regular file from several threads (phased fallocate + mapped fill)
+#pragma once
+#include <fcntl.h>
+#include <malloc.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <sys/uio.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <fstream>
+#include <functional>
+#include <iostream>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <unordered_map>
+#include <unordered_set>
+
+#include "fastx.h"
+#include "options.h"
+#include "tgsf.h"
+#include "textsource.h"
+
+namespace host {
+
+// A batch is a slice [base, base+span) of the input text plus an index of its records: nothing is
+// copied on the host; the library reads sequence and quality lines in place (tgsf_batch_in.qual_offsets).
+struct Batch {
+    const char* base = nullptr;              // first byte of the slice (inside the mmap'ed input)
+    uint64_t span = 0;                       // bytes of the slice
+    std::vector<uint64_t> off, qoff;         // sequence / quality line of each read, relative to base
+    std::vector<uint32_t> len;
+    std::vector<Rec> recs;                   // header / sequence / quality lines, in the input
+    std::vector<tgsf_read_result> res;
+    std::vector<tgsf_fragment> frags;
+    uint32_t n_frags = 0;
+    uint64_t bases = 0;
+    uint64_t id = 0;                         // position in the input: the writer puts batches back in order
+    struct Emit { uint32_t read, frag; int pass_num; uint64_t at; };   // a record to write, `at` bytes into the batch's output
+    std::vector<Emit> em;
+    std::shared_ptr<Chunk> hold;             // streamed input: the chunk of text this batch's records live in
+    char* dst = nullptr;                     // where the batch's output starts in the mapped file
+    uint64_t out_bytes = 0;
+    std::atomic<int> left{0};                // fill jobs still running
+    void reset() {
+        base = nullptr; span = 0; off.clear(); qoff.clear(); len.clear(); recs.clear(); n_frags = 0; bases = 0; id = 0;
+        em.clear(); hold.reset(); dst = nullptr; out_bytes = 0; left = 0;
+    }
+};
+
+// Batches are recycled, never freed while the pipeline runs: their vectors are MBs each, which malloc takes from and
+// gives back to the kernel with mmap/munmap -- and those need the address-space lock for writing, which the page
+// faults of the fill threads hold for reading all the time (measured: 170 ms per freed batch, 12 s over a run).
+class BatchStore {
+public:
+    std::shared_ptr<Batch> get() {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            if (!free_.empty()) { std::shared_ptr<Batch> b = std::move(free_.back()); free_.pop_back(); return b; }
+        }
+        std::shared_ptr<Batch> b(new Batch);
+        b->off.reserve(4096); b->qoff.reserve(4096); b->len.reserve(4096); b->recs.reserve(4096);
+        return b;
+    }
+    void put(std::shared_ptr<Batch> b) {
+        b->reset();
+        std::lock_guard<std::mutex> l(m_);
+        free_.push_back(std::move(b));
+    }
+private:
+    std::mutex m_;
+    std::vector<std::shared_ptr<Batch>> free_;
+};
+
+// a kept fragment, addressed in the input text (used when a downsampling pass follows the filter pass)
+struct CleanRec {
+    std::string_view name;
+    int pass_num;
+    const char* seq;
+    const char* qual;
+    uint32_t len;
+};
+
+template <class T>
+class Channel {                               // small bounded queue; nullptr closes it
+public:
+    explicit Channel(size_t cap) : cap_(cap) {}
+    void put(T v) {
+        std::unique_lock<std::mutex> l(m_);
+        not_full_.wait(l, [&] { return q_.size() < cap_; });
+        q_.push_back(std::move(v));
+        not_empty_.notify_one();
+    }
+    T get() {
+        std::unique_lock<std::mutex> l(m_);
+        not_empty_.wait(l, [&] { return !q_.empty(); });
+        T v = std::move(q_.front());
+        q_.pop_front();
+        not_full_.notify_one();
+        return v;
+    }
+private:
+    std::mutex m_;
+    std::condition_variable not_full_, not_empty_;
+    std::deque<T> q_;
+    size_t cap_;
+};
+
+// newSeqName, src/TGSFilter.cpp:1680-1701: ":<n>" goes before the first whitespace of the header
+inline void append_name(std::string& out, std::string_view raw, int number)
+{
+    if (number < 2) { out.append(raw); return; }
+    const std::string add = ":" + std::to_string(number);
+    size_t i = 0;
+    while (i < raw.size() && !std::isspace((unsigned char)raw[i])) i++;
+    out.append(raw.substr(0, i));
+    out += add;
+    out.append(raw.substr(i));
+}
+
+inline double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Fatal errors can come from any thread while others are inside HIP calls or blocked on queues: no static
+// destructors, no runtime teardown -- flush what was said and leave with the reference's exit status (-1).
+[[noreturn]] inline void die(const std::string& msg)
+{
+    std::cerr << "Error: " << msg << std::endl;
+    fflush(nullptr);
+    _exit(255);
+}
+
+class Output {                                // plain or per-record gzip members (:2020-2053, :786-812)
+public:
+    bool open(const Options& o) {
+        gz_ = o.out_gz;
+        if (o.out_file.empty()) f_ = stdout;
+        else f_ = fopen(o.out_file.c_str(), "wb");
+        if (!f_) { std::cerr << "Error: Failed to open file: " << o.out_file << std::endl; return false; }
+        if (gz_) {
+            setvbuf(f_, nullptr, _IOFBF, 8 << 20);
+            level_ = o.comp_level;
+            gz_threads_ = std::max(1, std::min(o.n_thread, 32));
+        } else {
+            fflush(f_);
+            fd_ = fileno(f_);
+        }
+        return true;
+    }
+    // Plain output: the pieces of a record (header, sequence, separator, qualities) are gathered with
+    // writev straight from the input text -- no intermediate record string.
+    void piece(const char* p, size_t n) {
+        if (!n) return;
+        if (gz_) { gzbuf_.append(p, n); return; }
+        iov_.push_back({const_cast<char*>(p), n});
+        if (iov_.size() >= 1000) flush_iov();
+    }
+    // small generated text (":<n>" suffixes, separators that are not in the input)
+    void text(const std::string& t) {
+        if (gz_) { gzbuf_ += t; return; }
+        if (pool_.size() + t.size() > pool_.capacity()) flush_iov();
+        const size_t o0 = pool_.size();
+        pool_ += t;
+        iov_.push_back({&pool_[o0], t.size()});
+    }
+    void end_record() {
+        if (!gz_) return;
+        ends_.push_back(gzbuf_.size());
+        if (gzbuf_.size() >= (256u << 20)) flush_gz();
+    }
+    // One gzip member per record, as the reference writes them (:786-812, compressed by its worker threads):
+    // the records gathered since the last flush are split into byte-balanced runs, each run is compressed
+    // member by member on its own thread, and the runs are written in order.
+    void flush_gz() {
+        if (ends_.empty()) return;
+        const size_t nrec = ends_.size();
+        const int T = (int)std::min<size_t>((size_t)gz_threads_, nrec);
+        std::vector<std::vector<char>> outv((size_t)T);
+        std::vector<size_t> cut((size_t)T + 1, nrec);
+        cut[0] = 0;
+        for (int t = 1; t < T; t++) {
+            const size_t target = gzbuf_.size() / (size_t)T * (size_t)t;
+            cut[(size_t)t] = (size_t)(std::lower_bound(ends_.begin(), ends_.end(), target) - ends_.begin());
+        }
+        std::atomic<bool> bad{false};
+        auto work = [&](int t) {
+            z_stream z;
+            memset(&z, 0, sizeof z);
+            if (deflateInit2(&z, level_, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad = true; return; }
+            std::vector<char>& o = outv[(size_t)t];
+            for (size_t r = cut[(size_t)t]; r < cut[(size_t)t + 1]; r++) {
+                const size_t b = r ? ends_[r - 1] : 0, n = ends_[r] - b;
+                deflateReset(&z);
+                const size_t at = o.size(), room = deflateBound(&z, (uLong)n) + 64;
+                o.resize(at + room);
+                z.next_in = (Bytef*)(gzbuf_.data() + b); z.avail_in = (uInt)n;
+                z.next_out = (Bytef*)(o.data() + at); z.avail_out = (uInt)room;
+                if (deflate(&z, Z_FINISH) != Z_STREAM_END) bad = true;
+                o.resize(at + room - z.avail_out);
+            }
+            deflateEnd(&z);
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; t++) th.emplace_back(work, t);
+        work(0);
+        for (std::thread& x : th) x.join();
+        if (bad) die("compression failed");
+        for (const auto& o : outv) if (!o.empty() && fwrite(o.data(), 1, o.size(), f_) != o.size()) die("write failed");
+        gzbuf_.clear();
+        ends_.clear();
+    }
+    void flush_iov() {
+        if (gz_) { flush_gz(); return; }
+        size_t i = 0;
+        while (i < iov_.size()) {
+            ssize_t w = writev(fd_, &iov_[i], (int)std::min<size_t>(iov_.size() - i, 1000));
+            if (w < 0) die("write failed");
+            size_t left = (size_t)w;
+            while (i < iov_.size() && left >= iov_[i].iov_len) { left -= iov_[i].iov_len; i++; }
+            if (left) { iov_[i].iov_base = (char*)iov_[i].iov_base + left; iov_[i].iov_len -= left; }
+        }
+        iov_.clear();
+        pool_.clear();
+    }
+    void close() {
+        flush_iov();
+        if (f_ && f_ != stdout) fclose(f_); else if (f_) fflush(f_);
+        f_ = nullptr;
+    }
+    Output() { pool_.reserve(1 << 16); }
+private:
+    FILE* f_ = nullptr;
+    int fd_ = -1;
+    bool gz_ = false;
+    int level_ = 6, gz_threads_ = 1;
+    std::string gzbuf_, pool_;              // gz: the records since the last flush, back to back
+    std::vector<size_t> ends_;              // ... and where each of them ends
+    std::vector<iovec> iov_;
+};
+
+// Plain output into a regular file, from several threads.  Measured on the MI355X host (tools/hostio_probe.cpp,
+// tools/sink_probe*.cpp): one write() stream into a tmpfs file is a single-thread copy under the inode lock, ~6 GB/s,
+// and several streams into one file serialise on that lock.  What the kernel does faster: fallocate() instantiates
+// pages at ~16 GB/s (one thread), and threads storing into a shared mapping of EXISTING pages scale (> 20 GB/s with
+// 16) -- but only while no fallocate() runs on the file: page faults beside it drag both down to ~7 GB/s together.
+// So the two never overlap here: the planner reserves the output in few, large strides (sized from the share of the
+// input that survived so far), waiting for the fill jobs in flight to drain before each; the fill threads copy the
+// records of the planned batches into the mapping, each its own run of records.  Used when the output is a regular
+// file that takes fallocate; everything else (pipes, /dev/null, gzip) goes through Output above.
+class MappedSink {
+public:
+    bool open(const std::string& path, uint64_t virt_bytes) {
+        fd_ = ::open(path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
+        if (fd_ < 0) return false;
+        struct stat st;
+        bool ok = fstat(fd_, &st) == 0 && S_ISREG(st.st_mode) && fallocate(fd_, 0, 0, 4096) == 0 && ftruncate(fd_, 0) == 0;   // not every file system has fallocate
+        if (ok) {
+            cap_ = (virt_bytes + 4095) & ~uint64_t(4095);
+            map_ = (char*)mmap(nullptr, cap_, PROT_READ | PROT_WRITE, MAP_SHARED, fd_, 0);      // beyond the end of the file for now
+            ok = map_ != MAP_FAILED;
+        }
+        if (!ok) { ::close(fd_); fd_ = -1; return false; }
+        return true;
+    }
+    uint64_t reserved() const { return reserved_; }
+    uint64_t planned() const { return size_; }
+    uint64_t capacity() const { return cap_; }
+    // instantiate the pages up to `end` (no fill job may be running)
+    void reserve_to(uint64_t end) {
+        if (end <= reserved_) return;
+        const double t0 = now_s();
+        if (fallocate(fd_, 0, (off_t)reserved_, (off_t)(end - reserved_)) != 0) die(std::string("cannot extend the output file: ") + strerror(errno));
+        t_falloc += now_s() - t0;
+        reserved_ = end;
+    }
+    // the next n bytes of the file (inside what was reserved)
+    char* place(uint64_t n) { char* p = map_ + size_; size_ += n; return p; }
+    // the pages wholly inside [p, p+n) are done with: drop their mappings now, from the calling (fill) thread, instead of
+    // all of them at exit from one
+    static void release(const char* p, size_t n) {
+        const uintptr_t lo = ((uintptr_t)p + 4095) & ~uintptr_t(4095), hi = ((uintptr_t)p + n) & ~uintptr_t(4095);
+        if (hi > lo) madvise((void*)lo, hi - lo, MADV_DONTNEED);
+    }
+    void close() {
+        if (fd_ < 0) return;
+        if (reserved_ != size_ && ftruncate(fd_, (off_t)size_) != 0) die("cannot set the size of the output file");
+        ::close(fd_);
+        fd_ = -1;
+    }
+    bool is_open() const { return fd_ >= 0; }
+    double t_falloc = 0;
+private:
+    int fd_ = -1;
+    char* map_ = nullptr;
+    uint64_t size_ = 0, reserved_ = 0, cap_ = 0;
+};
+
+// worker threads for the fill jobs
+class Pool {
+public:
+    explicit Pool(int n) { for (int i = 0; i < n; i++) th_.emplace_back([this] { run(); }); }
+    double busy_s() { std::lock_guard<std::mutex> l(m_); return busy_; }
+    void add(std::function<void()> f) {
+        { std::lock_guard<std::mutex> l(m_); q_.push_back(std::move(f)); open_++; }
+        cv_.notify_one();
+    }
+    void drain() {                              // until every job added so far has run
+        std::unique_lock<std::mutex> l(m_);
+        idle_.wait(l, [&] { return open_ == 0; });
+    }
+    void finish() {                             // runs what is queued, then stops the threads
+        { std::lock_guard<std::mutex> l(m_); stop_ = true; }
+        cv_.notify_all();
+        for (std::thread& t : th_) t.join();
+        th_.clear();
+    }
+private:
+    void run() {
+        for (;;) {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [&] { return stop_ || !q_.empty(); });
+                if (q_.empty()) return;
+                f = std::move(q_.front());
+                q_.pop_front();
+            }
+            const double t0 = now_s();
+            f();
+            const double dt = now_s() - t0;
+            f = nullptr;                            // what the job held goes now, outside the lock
+            const double dd = now_s() - t0 - dt;
+            std::lock_guard<std::mutex> l(m_);
+            busy_ += dt;
+            destroy_ += dd;
+            if (dt > longest_) longest_ = dt;
+            jobs_++;
+            if (first_ == 0) first_ = t0;
+            last_ = std::max(last_, t0 + dt + dd);
+            if (--open_ == 0) idle_.notify_all();
+        }
+    }
+    double busy_ = 0;
+public:
+    double destroy_ = 0, longest_ = 0, first_ = 0, last_ = 0;
+    size_t jobs_ = 0;
+private:
+    size_t open_ = 0;
+    std::condition_variable idle_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<std::function<void()>> q_;
+    std::vector<std::thread> th_;
+    bool stop_ = false;
+};
+
+
+}  // namespace host
