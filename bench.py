@@ -38,7 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-CLI = os.path.join(ROOT, "tgsfilter_amd", "bin", "tgsfilter")
+CLI = os.environ.get("TGSF_BENCH_CLI") or os.path.join(ROOT, "tgsfilter_amd", "bin", "tgsfilter")   # override: tests only
 REF = os.path.join(ROOT, "oracle", "_ref", "tgsfilter_ref")
 FQ_MULTISET = os.path.join(ROOT, "tools", "fq_multiset")
 
