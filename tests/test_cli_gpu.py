@@ -34,6 +34,7 @@ def test_cli_gpu_threaded_pipeline(golden_dir, name, writer, monkeypatch):
     monkeypatch.setenv("TGSF_FILL_MIN_BYTES", "1")
     monkeypatch.setenv("TGSF_SCAN_BLOCK", "5000")
     monkeypatch.setenv("TGSF_WRITER", writer)
+    monkeypatch.setenv("TGSF_STRIDE_BYTES", "70000")              # the output file grows stride by stride
     cli_check.run_case(binary, golden_dir, name, extra_args=["-t", "8"])
 
 

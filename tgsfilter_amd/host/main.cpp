@@ -323,6 +323,11 @@ int main(int argc, char** argv)
     uint64_t fill_min = 1u << 20;                                      // bytes worth a job of their own
     if (const char* e = getenv("TGSF_FILL_MIN_BYTES")) { const long long v = atoll(e); if (v > 0) fill_min = (uint64_t)v; }   // test knob
     Pool pool(sink.is_open() ? fill_threads : 1);
+    int populate_threads = std::max(1, std::min(o.n_thread, 32));      // short bursts between two fallocates: the more the shorter
+    if (const char* e = getenv("TGSF_POPULATE_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) populate_threads = v; }   // tuning knob
+    Pool populate(sink.is_open() ? populate_threads : 0);              // maps the pages of a reserved stride (between two fallocates)
+    uint64_t stride_bytes = 2ull << 30;
+    if (const char* e = getenv("TGSF_STRIDE_BYTES")) { const long long v = atoll(e); if (v > 0) stride_bytes = (uint64_t)v; }   // tuning / test knob
     // Taking down the mapping of an N-GB input costs ~90 ns per 4-KB page, 0.4 s for 18 GB -- at exit, on one thread,
     // after everything is written.  One background thread drops the pages of written batches while the pipeline runs
     // instead (several threads doing it only get in each other's way).  Only for a file mapping whose text nothing
@@ -349,6 +354,7 @@ int main(int argc, char** argv)
         std::string name;
         std::map<uint64_t, std::shared_ptr<Batch>> held;               // batches that arrived ahead of their turn
         uint64_t want = 0, in_seen = 0;
+        uint64_t ready_end = 0;                                        // bytes of the output file instantiated AND mapped
         size_t open_feeders = ctxs.size();
         for (;;) {
             std::shared_ptr<Batch> b;
@@ -409,20 +415,33 @@ int main(int argc, char** argv)
             in_seen += b->span;
             if (fill && at) {
                 if (sink.planned() + at > sink.capacity()) die("output larger than the space mapped for it");
-                if (sink.planned() + at > sink.reserved()) {
-                    // reserve a large stride: what is left of the input times the share of it that was written so far
-                    // (plus a little); page faults and fallocate do not mix, so the fill jobs drain first
+                if (sink.planned() + at > ready_end) {
+                    // Make more of the file ready, stride by stride: (1) fallocate instantiates the stride's pages --
+                    // fill jobs of earlier strides keep running meanwhile, they only store into pages that are already
+                    // mapped; (2) the pool's populate threads map the stride's pages (page faults and fallocate do not
+                    // mix, so this runs between two fallocates, in parallel, and is waited for).  How far: what is left
+                    // of the input times the share of it that was written so far (plus a little).
                     const double share = in_seen ? (double)(sink.planned() + at) / (double)in_seen : 1.0;
                     // (a streamed input's text size is estimated from the share of the file decoded so far)
                     const double sh = stream_share.load();
                     const uint64_t in_total = !streaming ? (uint64_t)in.size()
                                             : (uint64_t)((double)stream_text.load() / (sh > 1e-6 ? sh : 1e-6));
-                    uint64_t upto = sink.planned() + at + (uint64_t)(share * 1.02 * (double)(in_total - std::min<uint64_t>(in_seen, in_total)));
-                    upto = std::min<uint64_t>(std::max<uint64_t>(upto, sink.planned() + at), sink.capacity());
-                    const double d0 = now_s();
-                    pool.drain();
-                    t_drain += now_s() - d0;
-                    sink.reserve_to(upto);
+                    uint64_t goal = sink.planned() + at + (uint64_t)(share * 1.02 * (double)(in_total - std::min<uint64_t>(in_seen, in_total)));
+                    goal = std::min<uint64_t>(std::max<uint64_t>(goal, sink.planned() + at), sink.capacity());
+                    while (ready_end < sink.planned() + at) {
+                        uint64_t upto = std::min<uint64_t>(goal, std::max<uint64_t>(ready_end + stride_bytes, sink.planned() + at));
+                        if (upto < sink.reserved()) upto = sink.reserved();      // what the early reserve already holds
+                        sink.reserve_to(upto);
+                        const double d0 = now_s();
+                        const uint64_t lo = ready_end & ~uint64_t(4095), piece = 32u << 20;
+                        for (uint64_t o2 = lo; o2 < upto; o2 += piece) {
+                            const uint64_t n2 = std::min<uint64_t>(piece, upto - o2);
+                            populate.add([&sink, o2, n2] { sink.populate(o2, n2); });
+                        }
+                        populate.drain();
+                        t_drain += now_s() - d0;
+                        ready_end = upto;
+                    }
                 }
                 b->dst = sink.place(at);
                 b->out_bytes = at;
@@ -473,6 +492,7 @@ int main(int argc, char** argv)
     const bool mapped_out = sink.is_open();
     const double t_f0 = now_s();
     pool.finish();
+    populate.finish();
     to_release.put({nullptr, 0});
     releaser.join();
     const double t_busy = pool.busy_s();
@@ -655,7 +675,7 @@ int main(int argc, char** argv)
                 pool.jobs_, t_busy, pool.destroy_, pool.longest_, pool.first_ - t_p0, pool.last_ - t_p0, t_f0 - t_p0);
         fprintf(stderr, "TIMING: total %.3f s | index+prepass %.3f | waiting for the library %.3f (load %.3f + device %.3f, beside the pre-pass) | "
                         "pipeline %.3f (batching %.3f, tgsf_submit summed over %zu feeders %.3f, plan+write %.3f, planner waiting %.3f, "
-                        "first batch filtered after %.3f, fill tail %.3f, closing the output %.3f; stages overlap) | stats+report %.3f | %s (fallocate %.3f, waiting for fill jobs before it %.3f, fill threads busy %.3f summed)\n",
+                        "first batch filtered after %.3f, fill tail %.3f, closing the output %.3f; stages overlap) | stats+report %.3f | %s (fallocate %.3f, mapping the reserved pages %.3f, fill threads busy %.3f summed)\n",
                 now_s() - t_start, t_prepass, t_libwait, t_load, t_dev, t_pipe, t_parse, ctxs.size(), t_gpu, t_write, t_widle, t_first,
                 t_fill_tail, t_close, now_s() - t_p0 - t_pipe, mapped_out ? "output: fallocate + mapped fill" : "output: writev", sink.t_falloc, t_drain, t_busy);
     }

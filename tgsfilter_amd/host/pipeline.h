@@ -256,14 +256,14 @@ private:
 };
 
 // Plain output into a regular file, from several threads.  Measured on the MI355X host (tools/hostio_probe.cpp,
-// tools/sink_probe*.cpp): one write() stream into a tmpfs file is a single-thread copy under the inode lock, ~6 GB/s,
-// and several streams into one file serialise on that lock.  What the kernel does faster: fallocate() instantiates
-// pages at ~16 GB/s (one thread), and threads storing into a shared mapping of EXISTING pages scale (> 20 GB/s with
-// 16) -- but only while no fallocate() runs on the file: page faults beside it drag both down to ~7 GB/s together.
-// So the two never overlap here: the planner reserves the output in few, large strides (sized from the share of the
-// input that survived so far), waiting for the fill jobs in flight to drain before each; the fill threads copy the
-// records of the planned batches into the mapping, each its own run of records.  Used when the output is a regular
-// file that takes fallocate; everything else (pipes, /dev/null, gzip) goes through Output above.
+// tools/sink_probe*.cpp, tests/manual/e2e_knobs.py): one write() stream into a tmpfs file is a single-thread copy under
+// the inode lock, ~6 GB/s, and several streams into one file serialise on that lock.  What the kernel does faster:
+// fallocate() instantiates pages at 14-19 GB/s (one thread), and threads storing into a shared mapping of EXISTING,
+// ALREADY MAPPED pages run at memory speed.  Page FAULTS on the file while fallocate() runs on it drag both down (~7 GB/s
+// together), so the work is arranged in strides (main.cpp, the planner): fallocate a stride of the file; then map its
+// pages (MADV_POPULATE_WRITE, 32 threads, 0.2 s for 21 GB in all) while no fallocate runs; from then on the fill threads'
+// copies into that stride take no fault and overlap the next stride's fallocate.  Used when the output is a regular file
+// that takes fallocate; everything else (pipes, /dev/null, gzip) goes through Output above.
 class MappedSink {
 public:
     bool open(const std::string& path, uint64_t virt_bytes) {
@@ -289,6 +289,14 @@ public:
         if (fallocate(fd_, 0, (off_t)reserved_, (off_t)(end - reserved_)) != 0) die(std::string("cannot extend the output file: ") + strerror(errno));
         t_falloc += now_s() - t0;
         reserved_ = end;
+    }
+    // map the (instantiated) pages of [at, at+n) into the address space now, so that storing into them later takes no
+    // page fault -- page faults on this file while fallocate() runs on it slow both down to a crawl
+    void populate(uint64_t at, uint64_t n) {
+        char* p = map_ + (at & ~uint64_t(4095));
+        const size_t len = (size_t)(((at + n + 4095) & ~uint64_t(4095)) - (at & ~uint64_t(4095)));
+        if (madvise(p, len, 23 /* MADV_POPULATE_WRITE, Linux 5.14 */) != 0)
+            for (size_t o = 0; o < len; o += 4096) { volatile char* q = p + o; *q = *q; }     // older kernels: one touch per page
     }
     // the next n bytes of the file (inside what was reserved)
     char* place(uint64_t n) { char* p = map_ + size_; size_ += n; return p; }

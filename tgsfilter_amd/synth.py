@@ -216,7 +216,8 @@ def pack(reads, align: int = 16):
 # ---------------------------------------------------------------------------
 def _fastq_chunk(job):
     """One run of reads -> its byte range of the file.  Same distributions as make_reads(kind='ont')."""
-    path, file_off, first, lens, seed = job
+    path, file_off, first, lens, seed = job[:5]
+    hifi = len(job) > 5 and job[5] == "hifi"
     rng = np.random.default_rng(seed)
     n = len(lens)
     names = [b"@r%d\n" % (first + i) for i in range(n)]
@@ -226,12 +227,12 @@ def _fastq_chunk(job):
     total = int(starts[-1])
     buf = _ACGT[rng.integers(0, 4, total, dtype=np.uint8)]
     B = int(lens.sum())
-    mq = rng.choice(np.array([7, 9, 12, 14, 18], dtype=np.float32), n)
+    mq = rng.choice(np.array([30], dtype=np.float32) if hifi else np.array([7, 9, 12, 14, 18], dtype=np.float32), n)
     q = rng.standard_normal(B, dtype=np.float32)
-    q *= 4.0
+    q *= 6.0 if hifi else 4.0
     q += np.repeat(mq, lens)
     np.rint(q, out=q)
-    np.clip(q, 1, 50, out=q)
+    np.clip(q, 2 if hifi else 1, 60 if hifi else 50, out=q)
     q += 33
     q8 = q.astype(np.uint8)
     del q
@@ -242,12 +243,18 @@ def _fastq_chunk(job):
         nm = names[i]
         buf[s:s + len(nm)] = np.frombuffer(nm, dtype=np.uint8)
         s0 = s + len(nm)
-        if rng.random() < 0.80:                       # rapid adapter at the 5' end, 0-30 bases in, 10 % errors
+        if hifi:                                      # blunt adapter: 5' 0.27 %, 3' 0.26 %, middle 0.002 % of reads, 3 % errors
+            u = rng.random()
+            if u < 0.0027 + 0.0026 + 0.00002 and L > 2000:
+                a = np.frombuffer(mutate(rng, PACBIO_BLUNT, 0.03), dtype=np.uint8)
+                p = 0 if u < 0.0027 else (L - len(a) if u < 0.0053 else int(rng.integers(300, L - 300 - len(a))))
+                buf[s0 + p:s0 + p + len(a)] = a
+        elif rng.random() < 0.80:                     # rapid adapter at the 5' end, 0-30 bases in, 10 % errors
             a = np.frombuffer(mutate(rng, ONT_RAPID, 0.10), dtype=np.uint8)
             pre = int(rng.integers(0, 31))
             if pre + len(a) < L:
                 buf[s0 + pre:s0 + pre + len(a)] = a
-        if rng.random() < 0.0003 and L > 2000:        # 0.03 % in the middle
+        if not hifi and rng.random() < 0.0003 and L > 2000:        # 0.03 % in the middle
             a = np.frombuffer(mutate(rng, ONT_RAPID if rng.random() < 0.5 else ONT_RAPID_RC, 0.05), dtype=np.uint8)
             p = int(rng.integers(300, L - 300 - len(a)))
             buf[s0 + p:s0 + p + len(a)] = a
@@ -261,19 +268,23 @@ def _fastq_chunk(job):
     return B
 
 
-def write_ont_fastq(path, n_reads, seed=2, mean_len=45000.0, max_len=2_000_000, procs=None, reads_per_job=256):
-    """FASTQ text of config C2's shape at `path`; returns (bases, file bytes).  Deterministic in
-    (n_reads, seed, mean_len, max_len, reads_per_job), whatever the number of processes."""
+def write_ont_fastq(path, n_reads, seed=2, mean_len=45000.0, max_len=2_000_000, procs=None, reads_per_job=256, kind="ont"):
+    """FASTQ text of config C2's shape (kind="hifi": C1/C3's, mean_len 18000) at `path`; returns
+    (bases, file bytes).  Deterministic in (n_reads, seed, mean_len, max_len, reads_per_job), whatever the number of
+    processes."""
     import multiprocessing as mp
     import os
     rng = np.random.default_rng(seed)
-    lens = np.minimum(ont_lengths(rng, n_reads, mean_len), max_len).astype(np.int64)
+    if kind == "hifi":
+        lens = np.minimum(hifi_lengths(rng, n_reads, mean_len, sd=mean_len / 6.0), max_len).astype(np.int64)
+    else:
+        lens = np.minimum(ont_lengths(rng, n_reads, mean_len), max_len).astype(np.int64)
     name_len = np.array([len(b"@r%d\n" % i) for i in range(n_reads)], dtype=np.int64)
     sizes = name_len + 2 * lens + 4
     jobs, off = [], 0
     for a in range(0, n_reads, reads_per_job):
         b = min(n_reads, a + reads_per_job)
-        jobs.append((path, off, a, lens[a:b], seed * 1_000_003 + a))
+        jobs.append((path, off, a, lens[a:b], seed * 1_000_003 + a, kind))
         off += int(sizes[a:b].sum())
     with open(path, "wb") as f:
         f.truncate(off)
