@@ -468,13 +468,14 @@ int main(int argc, char** argv)
                             if (e.pass_num < 2) { memcpy(d, rec.name, rec.name_len); d += rec.name_len; }
                             else { nm.clear(); append_name(nm, std::string_view(rec.name, rec.name_len), e.pass_num); memcpy(d, nm.data(), nm.size()); d += nm.size(); }
                             *d++ = '\n';
-                            memcpy(d, rec.seq + fr.start, (size_t)fr.len); d += fr.len;
+                            stream_copy(d, rec.seq + fr.start, (size_t)fr.len); d += fr.len;
                             if (fastq_out) {
                                 memcpy(d, "\n+\n", 3); d += 3;
-                                memcpy(d, rec.qual + fr.start, (size_t)fr.len); d += fr.len;
+                                stream_copy(d, rec.qual + fr.start, (size_t)fr.len); d += fr.len;
                             }
                             *d++ = '\n';
                         }
+                        stream_fence();
                         if (--bb.left == 0) batch_done(b);
                     });
                     lo = hi;

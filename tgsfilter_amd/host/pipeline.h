@@ -320,6 +320,36 @@ private:
     uint64_t size_ = 0, reserved_ = 0, cap_ = 0;
 };
 
+// Copy for the fill jobs: the bulk of a sequence / quality line goes out with non-temporal stores.  The destination pages
+// were zeroed by fallocate a moment ago and are not read again by this program: ordinary stores would first fetch every
+// line they overwrite and push the input text out of the caches, next to a fallocate that is itself memory-bound.
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("avx2"))) inline void stream_copy_avx2(char* d, const char* s, size_t n)
+{
+    const size_t head = (size_t)(-(uintptr_t)d & 31u) < n ? (size_t)(-(uintptr_t)d & 31u) : n;      // up to a 32-byte boundary
+    memcpy(d, s, head);
+    d += head; s += head; n -= head;
+    size_t i = 0;
+    for (; i + 128 <= n; i += 128) {
+        const __m256i a = _mm256_loadu_si256((const __m256i*)(s + i)), b = _mm256_loadu_si256((const __m256i*)(s + i + 32));
+        const __m256i c = _mm256_loadu_si256((const __m256i*)(s + i + 64)), e = _mm256_loadu_si256((const __m256i*)(s + i + 96));
+        _mm256_stream_si256((__m256i*)(d + i), a); _mm256_stream_si256((__m256i*)(d + i + 32), b);
+        _mm256_stream_si256((__m256i*)(d + i + 64), c); _mm256_stream_si256((__m256i*)(d + i + 96), e);
+    }
+    memcpy(d + i, s + i, n - i);
+}
+inline void stream_copy(char* d, const char* s, size_t n)
+{
+    static const bool avx2 = __builtin_cpu_supports("avx2") && getenv("TGSF_PLAIN_COPY") == nullptr;
+    if (avx2 && n >= 4096) stream_copy_avx2(d, s, n); else memcpy(d, s, n);
+}
+inline void stream_fence() { _mm_sfence(); }
+#else
+inline void stream_copy(char* d, const char* s, size_t n) { memcpy(d, s, n); }
+inline void stream_fence() {}
+#endif
+
 // worker threads for the fill jobs
 class Pool {
 public:
