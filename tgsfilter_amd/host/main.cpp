@@ -172,7 +172,8 @@ int main(int argc, char** argv)
     if (sink.is_open() && !streaming && in.size() > (256u << 20) && !getenv("TGSF_NO_EARLY_RESERVE"))
         spec = std::thread([&] {
             const uint64_t limit = (uint64_t)in.size() / 4;
-            while (!spec_stop.load() && sink.reserved() < limit) sink.reserve_to(std::min<uint64_t>(limit, sink.reserved() + (128u << 20)));
+            while (!spec_stop.load() && sink.reserved() < limit)
+                if (!sink.reserve_to(std::min<uint64_t>(limit, sink.reserved() + (128u << 20)), false)) break;   // e.g. a nearly full file system: not this thread's call
         });
     auto end_spec = [&] { if (spec.joinable()) { spec_stop = true; spec.join(); } };
     const Api& L = lib();                                              // joins the loader thread
@@ -431,7 +432,10 @@ int main(int argc, char** argv)
                     while (ready_end < sink.planned() + at) {
                         uint64_t upto = std::min<uint64_t>(goal, std::max<uint64_t>(ready_end + stride_bytes, sink.planned() + at));
                         if (upto < sink.reserved()) upto = sink.reserved();      // what the early reserve already holds
-                        sink.reserve_to(upto);
+                        if (!sink.reserve_to(upto, false)) {                     // no room for the estimate: exactly what this batch needs
+                            upto = std::max<uint64_t>(sink.planned() + at, sink.reserved());
+                            sink.reserve_to(upto);
+                        }
                         const double d0 = now_s();
                         const uint64_t lo = ready_end & ~uint64_t(4095), piece = 32u << 20;
                         for (uint64_t o2 = lo; o2 < upto; o2 += piece) {

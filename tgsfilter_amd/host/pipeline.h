@@ -282,13 +282,18 @@ public:
     uint64_t reserved() const { return reserved_; }
     uint64_t planned() const { return size_; }
     uint64_t capacity() const { return cap_; }
-    // instantiate the pages up to `end` (no fill job may be running)
-    void reserve_to(uint64_t end) {
-        if (end <= reserved_) return;
+    // instantiate the pages up to `end`.  must: a failure ends the run (the records need the space); otherwise (the
+    // speculative early reserve) it just reports false
+    bool reserve_to(uint64_t end, bool must = true) {
+        if (end <= reserved_) return true;
         const double t0 = now_s();
-        if (fallocate(fd_, 0, (off_t)reserved_, (off_t)(end - reserved_)) != 0) die(std::string("cannot extend the output file: ") + strerror(errno));
+        if (fallocate(fd_, 0, (off_t)reserved_, (off_t)(end - reserved_)) != 0) {
+            if (must) die(std::string("cannot extend the output file: ") + strerror(errno));
+            return false;
+        }
         t_falloc += now_s() - t0;
         reserved_ = end;
+        return true;
     }
     // map the (instantiated) pages of [at, at+n) into the address space now, so that storing into them later takes no
     // page fault -- page faults on this file while fallocate() runs on it slow both down to a crawl
