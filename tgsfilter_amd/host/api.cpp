@@ -59,7 +59,16 @@ void load(std::vector<int> devices)
 #undef BIND
     if (g_api.abi_version() != TGSF_ABI_VERSION) { g_error = path + ": ABI version mismatch"; return; }
     g_load_s = now_s() - t0;
-    for (int d : devices) (void)g_api.prepare_device(d);     // failures surface at tgsf_create, with its message
+    // every device on a thread of its own (a device takes 0.1-0.3 s to come up); failures surface at tgsf_create, with
+    // its message
+    std::vector<std::thread> up;
+    for (size_t i = 1; i < devices.size(); i++) {
+        bool seen = false;
+        for (size_t j = 0; j < i; j++) seen = seen || devices[j] == devices[i];
+        if (!seen) up.emplace_back([d = devices[i]] { (void)g_api.prepare_device(d); });
+    }
+    if (!devices.empty()) (void)g_api.prepare_device(devices[0]);
+    for (std::thread& t : up) t.join();
     g_device_s = now_s() - t0 - g_load_s;
 }
 }  // namespace
