@@ -47,3 +47,36 @@ def test_cli_gpu_streamed_input(golden_dir, name, compress, monkeypatch):
     monkeypatch.setenv("TGSF_CHUNK_BYTES", "20000")
     monkeypatch.setenv("TGSF_FILL_MIN_BYTES", "1")
     cli_check.run_case(binary, golden_dir, name, extra_args=["-t", "4"], compress=compress)
+
+
+REF = os.path.join(ROOT, "oracle", "_ref", "tgsfilter_ref")
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/tgsfilter_ref not built (make -C oracle ref)")
+@pytest.mark.parametrize("n_reads,flags", [(800, ["-p", "100", "-k", "11", "-g", "30m", "-d", "2"]), (400, ["-p", "60", "-k", "15"])])
+def test_cli_gpu_config5_shape_against_the_reference(tmp_path, n_reads, flags):
+    """Config C5's shape at a size the reference finishes in seconds: ultra-long ONT reads (lognormal, mean 150 kb, up to
+    2 Mb; 0.06-0.12 Gbases -- the reference's repeat gate runs at 6 Mbases/s per thread), repeat gate and downsampling, the real command line against the reference
+    binary (-t 1: its downsampling ties depend on write order) -- byte-equal output, same counters."""
+    import subprocess
+    import tempfile
+    from tgsfilter_amd import synth
+    binary = os.path.join(ROOT, "tgsfilter_amd", "bin", "tgsfilter")
+    shm = "/dev/shm" if os.access("/dev/shm", os.W_OK) else None
+    with tempfile.TemporaryDirectory(dir=shm) as td:
+        fq = os.path.join(td, "c5.fq")
+        bases, _ = synth.write_ont_fastq(fq, n_reads, seed=5, mean_len=150000.0, max_len=2_000_000, reads_per_job=64)
+        assert bases > 4e7
+        fa = os.path.join(td, "rapid.fa")
+        open(fa, "wb").write(b">rapid\n" + synth.ONT_RAPID + b"\n")
+        common = ["-i", fq, "-x", "ont", "-l", "1000", "-q", "10", "-5", "0", "-3", "0", "-a", fa] + flags
+        outs = {}
+        for tag, exe, t in (("ref", REF, "1"), ("ours", binary, "16")):
+            out = os.path.join(td, tag + ".fq")
+            p = subprocess.run([exe, "-o", out, "-t", t] + common, capture_output=True)
+            assert p.returncode == 0, p.stderr.decode()[-2000:]
+            info = [l for l in p.stderr.decode().splitlines() if l.startswith("INFO: ") and "written to" not in l and "input adapter" not in l]
+            outs[tag] = (open(out, "rb").read(), info)
+        assert outs["ours"][1] == outs["ref"][1]
+        assert outs["ours"][0] == outs["ref"][0]
+        assert len(outs["ref"][0]) > 1e6
