@@ -46,6 +46,7 @@ struct tgsf_ctx {
     // capacities
     uint64_t cap_bases;
     uint32_t cap_reads, max_read_len, n_bins;
+    unsigned endtab_grid = 512;             // k_end_tables: LDS-atomic bound, 40 KB of LDS per block: two blocks per CU (128: 0.36 ms, 512: 0.19 ms)
     unsigned stats_grid = 768, mid_grid = 0;   // tuning knobs (TGSF_STATS_GRID, TGSF_MID_GRID; 0 = one lane per segment)
     uint64_t ctr_words;
     unsigned long long* rep_tables = nullptr;      // k_repeat_wide (-k 14..31): per-workgroup k-mer tables
@@ -405,6 +406,7 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     c->ctr_words = tgsf_ctr_len(p->bc_len, c->n_bins);
     P.seg_cols = kSegCols;
     if (const char* e = getenv("TGSF_STATS_GRID")) { int v = atoi(e); if (v >= 1 && v <= 65536) c->stats_grid = (unsigned)v; }
+    if (const char* e = getenv("TGSF_ENDTAB_GRID")) { int v = atoi(e); if (v >= 1 && v <= 4096) c->endtab_grid = (unsigned)v; }
     if (const char* e = getenv("TGSF_MID_GRID")) { int v = atoi(e); if (v >= 1) c->mid_grid = (unsigned)v; }
     if (const char* e = getenv("TGSF_SEG_COLS")) { int v = atoi(e); if (v >= 256 && v <= 65536) P.seg_cols = v & ~15; }   // tuning knob
 
@@ -611,7 +613,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     rt_stream ax = st;
     (void)ax;
 #endif
-    if (P.bc_len > 0) TGSF_LAUNCH(k_end_tables<false>, grid_cap(128u), 64 * kEndWaves, ax, P, B);
+    if (P.bc_len > 0) TGSF_LAUNCH(k_end_tables<false>, grid_cap(c->endtab_grid), 64 * kEndWaves, ax, P, B);
 #if !defined(TGSF_EMUL)
     if (c->profile) (void)hipEventRecord(evx[1], ax);
 #endif
@@ -692,7 +694,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
 #endif
     STAGE_MARK();
     TGSF_LAUNCH(k_gate_frags, gfr, T, st, P, B);
-    if (P.bc_len > 0) TGSF_LAUNCH(k_end_tables<true>, grid_cap(128u), 64 * kEndWaves, st, P, B);
+    if (P.bc_len > 0) TGSF_LAUNCH(k_end_tables<true>, grid_cap(c->endtab_grid), 64 * kEndWaves, st, P, B);
     STAGE_MARK();
     TGSF_LAUNCH(k_finalize, gsmall, T, st, B, d_reads, d_frags, out_fcap, d_nfrags);
     STAGE_MARK();
