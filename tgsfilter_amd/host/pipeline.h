@@ -5,6 +5,7 @@
 //                        gzip members (the reference's writer, src/TGSFilter.cpp:2095-2145, :786-812)
 //   MappedSink + Pool    plain output into a regular file from several threads (phased fallocate + mapped fill)
 #pragma once
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <malloc.h>
 #include <sys/mman.h>
@@ -147,6 +148,36 @@ inline double now_s()
     _exit(255);
 }
 
+// libdeflate, the compressor the reference writes its .gz records with (libdeflate_gzip_compress, src/TGSFilter.cpp:
+// 786-812), bound at run time when the system has it (no header needed: four entry points of its stable C API);
+// without it the members come from zlib -- slower, the same decompressed bytes.
+class Deflater {
+public:
+    static const Deflater& get() { static const Deflater d; return d; }
+    bool ok() const { return alloc_ && compress_ && bound_ && free__; }
+    void* alloc(int level) const { return alloc_(level); }
+    size_t bound(void* c, size_t n) const { return bound_(c, n); }
+    size_t compress(void* c, const void* in, size_t n, void* out, size_t room) const { return compress_(c, in, n, out, room); }
+    void free_(void* c) const { free__(c); }
+private:
+    Deflater() {
+        if (getenv("TGSF_ZLIB_OUTPUT")) return;                 // test knob: the zlib path
+        for (const char* name : {"libdeflate.so.0", "libdeflate.so"}) {
+            void* h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (!h) continue;
+            alloc_ = reinterpret_cast<void* (*)(int)>(dlsym(h, "libdeflate_alloc_compressor"));
+            compress_ = reinterpret_cast<size_t (*)(void*, const void*, size_t, void*, size_t)>(dlsym(h, "libdeflate_gzip_compress"));
+            bound_ = reinterpret_cast<size_t (*)(void*, size_t)>(dlsym(h, "libdeflate_gzip_compress_bound"));
+            free__ = reinterpret_cast<void (*)(void*)>(dlsym(h, "libdeflate_free_compressor"));
+            if (ok()) return;
+        }
+    }
+    void* (*alloc_)(int) = nullptr;
+    size_t (*compress_)(void*, const void*, size_t, void*, size_t) = nullptr;
+    size_t (*bound_)(void*, size_t) = nullptr;
+    void (*free__)(void*) = nullptr;
+};
+
 class Output {                                // plain or per-record gzip members (:2020-2053, :786-812)
 public:
     bool open(const Options& o) {
@@ -200,11 +231,26 @@ public:
             cut[(size_t)t] = (size_t)(std::lower_bound(ends_.begin(), ends_.end(), target) - ends_.begin());
         }
         std::atomic<bool> bad{false};
+        const Deflater& ld = Deflater::get();
         auto work = [&](int t) {
+            std::vector<char>& o = outv[(size_t)t];
+            if (ld.ok()) {                                      // the reference's compressor, one member per record (:786-812)
+                void* cz = ld.alloc(level_);
+                if (!cz) { bad = true; return; }
+                for (size_t r = cut[(size_t)t]; r < cut[(size_t)t + 1]; r++) {
+                    const size_t b = r ? ends_[r - 1] : 0, n = ends_[r] - b;
+                    const size_t at = o.size(), room = ld.bound(cz, n);
+                    o.resize(at + room);
+                    const size_t got = ld.compress(cz, gzbuf_.data() + b, n, o.data() + at, room);
+                    if (!got) bad = true;
+                    o.resize(at + got);
+                }
+                ld.free_(cz);
+                return;
+            }
             z_stream z;
             memset(&z, 0, sizeof z);
             if (deflateInit2(&z, level_, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad = true; return; }
-            std::vector<char>& o = outv[(size_t)t];
             for (size_t r = cut[(size_t)t]; r < cut[(size_t)t + 1]; r++) {
                 const size_t b = r ? ends_[r - 1] : 0, n = ends_[r] - b;
                 deflateReset(&z);
