@@ -9,7 +9,7 @@ from tgsfilter_amd import synth  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 with tempfile.TemporaryDirectory(dir="/dev/shm") as td:
     fq = os.path.join(td, "in.fq")
-    bases = e.gen(fq, n, 45000.0)
+    bases, _ = synth.write_ont_fastq(fq, n, seed=2)
     fa = os.path.join(td, "ad.fa"); open(fa, "wb").write(b">rapid\n" + synth.ONT_RAPID + b"\n")
     flags = ["-x", "ont", "-l", "1000", "-q", "10", "-5", "0", "-3", "0", "-a", fa]
     cores = max(1, min((os.cpu_count() or 2) - 1, 32))
