@@ -286,6 +286,7 @@ int main(int argc, char** argv)
         flush();
         for (size_t d = 0; d < ctxs.size(); d++) to_gpu.put(nullptr);       // one end marker per feeder
         t_parse = now_s() - t0 - waited;
+        std::sort(raw_lens.begin(), raw_lens.end());                   // for the statistics (:3151), beside the rest of the pipeline
     });
 
     std::mutex gpu_time_m;
@@ -489,6 +490,7 @@ int main(int argc, char** argv)
             if (!(fill && at)) batch_done(b);                           // written (or nothing to write)
             t_write += now_s() - w0;
         }
+        if (!o.downsample) std::sort(clean_lens.begin(), clean_lens.end());   // for the statistics (:3182), beside the last fill jobs
     });
     reader.join();
     for (std::thread& f : feeders) f.join();
