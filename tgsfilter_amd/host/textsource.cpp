@@ -79,26 +79,27 @@ std::unique_ptr<TextSource> open_text(const char* data, size_t size, bool sam_or
 }
 
 ChunkReader::ChunkReader(std::unique_ptr<TextSource> src, bool fastq, size_t chunk_bytes, int max_live)
-    : src_(std::move(src)), fastq_(fastq), chunk_bytes_(chunk_bytes), max_live_(max_live) {}
+    : src_(std::move(src)), fastq_(fastq), chunk_bytes_(chunk_bytes), gate_(new Gate), max_live_(max_live) {}
 
 std::shared_ptr<Chunk> ChunkReader::next(const std::string& path)
 {
     if (ended_) return nullptr;
     {
-        std::unique_lock<std::mutex> l(m_);
-        cv_.wait(l, [&] { return live_ < max_live_; });
-        live_++;
+        std::unique_lock<std::mutex> l(gate_->m);
+        gate_->cv.wait(l, [&] { return gate_->live < max_live_; });
+        gate_->live++;
     }
-    std::shared_ptr<Chunk> c(new Chunk, [this](Chunk* x) {
+    std::shared_ptr<Gate> gate = gate_;
+    std::shared_ptr<Chunk> c(new Chunk, [gate](Chunk* x) {
         delete x;
-        { std::lock_guard<std::mutex> l(m_); live_--; }
-        cv_.notify_one();
+        { std::lock_guard<std::mutex> l(gate->m); gate->live--; }
+        gate->cv.notify_one();
     });
     size_t cap = std::max(chunk_bytes_, carry_.size() * 2 + 4096);
     for (;;) {                                      // until the buffer holds at least one whole record (or the input ends)
         c->buf.reset(new char[cap]);
         c->cap = cap;
-        memcpy(c->buf.get(), carry_.data(), carry_.size());
+        if (!carry_.empty()) memcpy(c->buf.get(), carry_.data(), carry_.size());
         size_t have = carry_.size();
         while (!eof_ && have < cap) {
             size_t got = 0;

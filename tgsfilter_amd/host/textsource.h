@@ -62,9 +62,11 @@ private:
     size_t chunk_bytes_;
     std::vector<char> carry_;                     // bytes after the last whole record of the previous chunk
     uint64_t text_bytes_ = 0;
-    int live_ = 0, max_live_;
-    std::mutex m_;
-    std::condition_variable cv_;
+    // how many chunks are alive: shared with the chunks themselves, which may outlive the reader (a batch holds its
+    // chunk until it is written)
+    struct Gate { std::mutex m; std::condition_variable cv; int live = 0; };
+    std::shared_ptr<Gate> gate_;
+    int max_live_;
 };
 
 }  // namespace host
