@@ -150,7 +150,21 @@ int main(int argc, char** argv)
     uint64_t batch_text = streaming ? std::min<uint64_t>(256ull << 20, chunk_bytes)
                                     : std::min<uint64_t>(256ull << 20, std::max<uint64_t>(in.size() / 8 + 4096, 1 << 16));
     if (const char* e = getenv("TGSF_BATCH_BYTES")) { const long long v = atoll(e); if (v > 0) batch_text = (uint64_t)v; }   // tuning / test knob
-    const uint32_t batch_reads = 1u << 16;
+    // reads per batch: the library keeps traceback scratch for every (read, adapter, end) of a batch -- columns x words of
+    // the longest alignment each; with the library adapters that is ~12 KB per read, with 256-bp adapters and loose
+    // match lengths ~350 KB: keep it under 4 GB per context
+    uint32_t batch_reads = 1u << 16;
+    {
+        uint64_t per_read = 0;
+        for (const std::string& a : adapters) {
+            const int Q = (int)a.size();
+            const int kmax = std::max(0, std::min(Q - 1, std::max(Q - o.end_match_len + 1, Q - o.mid_match_len + 1)));
+            const uint64_t cols = (uint64_t)(Q + kmax + 2), nw = (uint64_t)((Q + 63) / 64);
+            per_read = std::max(per_read, cols * 2 * nw * 8);
+        }
+        per_read *= 3 * std::max<size_t>(adapters.size(), 1);          // two end windows + one middle alignment per adapter
+        if (per_read) batch_reads = (uint32_t)std::min<uint64_t>(batch_reads, std::max<uint64_t>(256, (4ull << 30) / per_read));
+    }
     const bool fastq_out = o.out_type == 1;
     const bool run_filter_pass = o.filter || o.only_qc;                // :3061; with -F the input goes straight to downsampling
     Output out;
