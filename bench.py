@@ -502,6 +502,8 @@ def main():
     e2e = None
     if not args.no_e2e:
         if rank == 0:
+            if world > 1:
+                args.no_cpu_baseline = True          # the reference is timed at N = 1 only (the contract: cpu_baseline on rank 0 at N=1)
             e2e = e2e_leg(args, 1 if args.share_gpu else world)
         if world > 1:
             dist.barrier(group=host_group)
