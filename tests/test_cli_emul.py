@@ -94,6 +94,19 @@ def test_cli_streamed_input(binary, golden_dir, name, compress, chunk, monkeypat
     cli_check.run_case(binary, golden_dir, name, extra_args=["-t", "4"], compress=compress)
 
 
+@pytest.mark.parametrize("cap,zlib_only", [("3000", None), ("200000", None), (None, "1")])
+def test_cli_gzip_member_paths(binary, golden_dir, cap, zlib_only, monkeypatch):
+    """gzip members are decoded whole by libdeflate while they fit its buffer limit, by zlib's streaming inflater
+    otherwise (forced here: every member too large / only the first one / libdeflate not used at all) -- same text."""
+    monkeypatch.setenv("TGSF_STREAM_MIN_BYTES", "1")
+    monkeypatch.setenv("TGSF_CHUNK_BYTES", "50000")
+    if cap:
+        monkeypatch.setenv("TGSF_GZ_MEMBER_CAP", cap)
+    if zlib_only:
+        monkeypatch.setenv("TGSF_ZLIB_INPUT", zlib_only)
+    cli_check.run_case(binary, golden_dir, "ont_zoo", extra_args=["-t", "4"], compress="gzip")
+
+
 @pytest.mark.parametrize("stream_min", ["1", "999999999"])
 def test_cli_corrupt_gzip(binary, golden_dir, tmp_path, stream_min, monkeypatch):
     """A damaged .gz ends the run with the reference's message (:636) and exit status, streamed or decoded whole."""

@@ -1,5 +1,6 @@
 #include "bam.h"
 
+#include <dlfcn.h>
 #include <sys/mman.h>
 #include <zlib.h>
 
@@ -252,6 +253,35 @@ bool bgzf_peek(const unsigned char* p, size_t n, size_t at, BgzfBlock& b)
     return true;
 }
 
+// libdeflate's whole-member gzip decompressor, bound at run time when the system has the library (as Output's compressor
+// in pipeline.h): about three times zlib's speed, but it wants a member's output in one buffer -- so it serves files made
+// of members of moderate size (concatenated per-run files, bgzip-less multi-member archives); a member that does not fit
+// the buffer limit goes through zlib's streaming inflater as before.
+class Inflater {
+public:
+    static const Inflater& get() { static const Inflater d; return d; }
+    bool ok() const { return alloc_ && run_ && free__; }
+    void* alloc() const { return alloc_(); }
+    // 0 = done, 3 = the output buffer is too small, anything else = not decodable this way
+    int run(void* d, const void* in, size_t n, void* out, size_t room, size_t* used, size_t* got) const { return run_(d, in, n, out, room, used, got); }
+    void free_(void* d) const { free__(d); }
+private:
+    Inflater() {
+        if (getenv("TGSF_ZLIB_INPUT")) return;                  // test knob: zlib only
+        for (const char* name : {"libdeflate.so.0", "libdeflate.so"}) {
+            void* h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (!h) continue;
+            alloc_ = reinterpret_cast<void* (*)()>(dlsym(h, "libdeflate_alloc_decompressor"));
+            run_ = reinterpret_cast<int (*)(void*, const void*, size_t, void*, size_t, size_t*, size_t*)>(dlsym(h, "libdeflate_gzip_decompress_ex"));
+            free__ = reinterpret_cast<void (*)(void*)>(dlsym(h, "libdeflate_free_decompressor"));
+            if (ok()) return;
+        }
+    }
+    void* (*alloc_)() = nullptr;
+    int (*run_)(void*, const void*, size_t, void*, size_t, size_t*, size_t*) = nullptr;
+    void (*free__)(void*) = nullptr;
+};
+
 class GzBytes : public ByteStream {
 public:
     GzBytes(const char* data, size_t size) : p_(reinterpret_cast<const unsigned char*>(data)), n_(size) {
@@ -259,7 +289,7 @@ public:
         BgzfBlock b;
         bgzf_ = size > 0 && bgzf_peek(p_, n_, 0, b);
     }
-    ~GzBytes() override { if (z_open_) inflateEnd(&z_); }
+    ~GzBytes() override { if (z_open_) inflateEnd(&z_); if (ld_) Inflater::get().free_(ld_); }
     double consumed() const override { return n_ ? (double)at_ / (double)n_ : 1.0; }
     // the mapping of the compressed bytes already decoded goes (they stay in the page cache for the second pass):
     // the resident size of a run does not grow with the file
@@ -305,7 +335,33 @@ public:
                 return true;
             }
         }
-        // any other gzip: one inflater, member after member (:632-639)
+        // any other gzip, member after member (:632-639): whole members through libdeflate while they fit ...
+        static const size_t member_cap = [] { const char* e = getenv("TGSF_GZ_MEMBER_CAP"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)(512u << 20); }();
+        const Inflater& fast = Inflater::get();
+        while (fast.ok() && !in_member_ && got < cap) {
+            if (mem_at_ < mem_.size()) {                             // what is left of the member decoded last
+                const size_t k = std::min(cap - got, mem_.size() - mem_at_);
+                memcpy(dst + got, mem_.data() + mem_at_, k);
+                got += k; mem_at_ += k;
+                continue;
+            }
+            if (at_ >= n_) { done_ = true; break; }
+            if (!ld_) ld_ = fast.alloc();
+            if (!ld_) break;
+            size_t room = std::max<size_t>(mem_.capacity(), std::min<size_t>(member_cap, 64u << 20));
+            int rc = 3;
+            size_t used = 0, out = 0;
+            while (rc == 3 && room <= member_cap) {
+                mem_.resize(room);
+                rc = fast.run(ld_, p_ + at_, n_ - at_, mem_.data(), room, &used, &out);
+                if (rc == 3) room *= 2;
+            }
+            if (rc != 0) { mem_.clear(); mem_at_ = 0; in_member_ = true; break; }     // too large (or damaged): zlib takes this member
+            mem_.resize(out); mem_at_ = 0;
+            at_ += used;
+        }
+        if (done_ || (fast.ok() && !in_member_)) { eof = done_ && mem_at_ >= mem_.size(); return true; }
+        // ... and zlib's streaming inflater for the rest
         if (!z_open_) {
             if (inflateInit2(&z_, 15 + 16) != Z_OK) { err = "zlib init failed"; return false; }
             z_open_ = true;
@@ -325,9 +381,14 @@ public:
             if (rc == Z_STREAM_END) {
                 if (z_.avail_in == 0 && at_ >= n_) { done_ = true; break; }
                 inflateReset(&z_);                              // next gzip member
+                if (fast.ok()) {                                // ... which may fit the fast way again
+                    at_ -= z_.avail_in; z_.avail_in = 0;
+                    in_member_ = false;
+                    break;
+                }
             } else if (rc != Z_OK) { err = "error while decompressing"; return false; }
         }
-        if (z_.avail_in == 0 && at_ >= n_ && got < cap) done_ = true;
+        if (in_member_ && z_.avail_in == 0 && at_ >= n_ && got < cap) done_ = true;
         eof = done_;
         return true;
     }
@@ -335,6 +396,10 @@ private:
     const unsigned char* p_;
     size_t n_, at_ = 0, dropped_ = 0;
     bool bgzf_ = false, z_open_ = false, done_ = false;
+    bool in_member_ = false;                  // zlib is in the middle of a member (one too large for the fast way)
+    void* ld_ = nullptr;
+    std::vector<char> mem_;                   // the member decoded last by libdeflate, handed out from mem_at_
+    size_t mem_at_ = 0;
     z_stream z_;
 };
 
