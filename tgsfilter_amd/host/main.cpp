@@ -72,7 +72,7 @@ int main(int argc, char** argv)
         std::string err;
         std::unique_ptr<TextSource> src = open_text(in.data(), in.size(), o.in_type == 2, err);
         if (!src) { std::cerr << "Error: " << err << " (" << o.in_file << ")" << std::endl; fflush(nullptr); _exit(255); }
-        return std::unique_ptr<ChunkReader>(new ChunkReader(std::move(src), !fasta_in, chunk_bytes, 24));   // <= 24 x 64 MB of text alive
+        return std::unique_ptr<ChunkReader>(new ChunkReader(std::move(src), !fasta_in, chunk_bytes, 20));   // <= 20 x 64 MB of text alive
     };
     // mapped / decoded input: the records are indexed once, in the background, for the pre-pass and for the filter pass
     const int scan_threads = std::max(1, std::min(o.n_thread, 32));
@@ -342,7 +342,8 @@ int main(int argc, char** argv)
     int populate_threads = std::max(1, std::min(o.n_thread, 32));      // short bursts between two fallocates: the more the shorter
     if (const char* e = getenv("TGSF_POPULATE_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) populate_threads = v; }   // tuning knob
     Pool populate(sink.is_open() ? populate_threads : 0);              // maps the pages of a reserved stride (between two fallocates)
-    uint64_t stride_bytes = 2ull << 30;
+    // (a streamed input is decoder-bound: small strides keep the mapped part of the output -- it counts as resident -- small)
+    uint64_t stride_bytes = streaming ? (128ull << 20) : (2ull << 30);
     if (const char* e = getenv("TGSF_STRIDE_BYTES")) { const long long v = atoll(e); if (v > 0) stride_bytes = (uint64_t)v; }   // tuning / test knob
     // Taking down the mapping of an N-GB input costs ~90 ns per 4-KB page, 0.4 s for 18 GB -- at exit, on one thread,
     // after everything is written.  One background thread drops the pages of written batches while the pipeline runs
