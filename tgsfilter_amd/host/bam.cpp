@@ -73,6 +73,8 @@ bool bgzf_index(const unsigned char* p, size_t n, std::vector<BgzfBlock>& blocks
     return true;
 }
 
+bool inflate_serial(const char* data, size_t size, std::vector<char>& out, std::string& err);   // through GzBytes, below
+
 bool inflate_members(const char* data, size_t size, std::vector<char>& out, std::string& err)
 {
     std::vector<BgzfBlock> blocks;
@@ -95,28 +97,7 @@ bool inflate_members(const char* data, size_t size, std::vector<char>& out, std:
         if (bad) { err = "error while decompressing"; return false; }
         return true;
     }
-    z_stream z;
-    memset(&z, 0, sizeof z);
-    if (inflateInit2(&z, 15 + 16) != Z_OK) { err = "zlib init failed"; return false; }
-    z.next_in = (Bytef*)data;
-    size_t left = size;
-    std::vector<char> chunk(4 << 20);
-    for (;;) {
-        if (z.avail_in == 0) {
-            if (left == 0) break;
-            const size_t take = left > (1u << 30) ? (1u << 30) : left;
-            z.avail_in = (uInt)take; left -= take;
-        }
-        z.next_out = (Bytef*)chunk.data(); z.avail_out = (uInt)chunk.size();
-        const int rc = inflate(&z, Z_NO_FLUSH);
-        out.insert(out.end(), chunk.data(), chunk.data() + (chunk.size() - z.avail_out));
-        if (rc == Z_STREAM_END) {
-            if (z.avail_in == 0 && left == 0) break;
-            inflateReset(&z);                                   // next gzip member
-        } else if (rc != Z_OK) { inflateEnd(&z); err = "error while decompressing"; return false; }
-    }
-    inflateEnd(&z);
-    return true;
+    return inflate_serial(data, size, out, err);
 }
 
 void emit(std::vector<char>& text, const char* name, size_t nlen, const std::string& seq, const std::string& qual)
@@ -402,6 +383,21 @@ private:
     size_t mem_at_ = 0;
     z_stream z_;
 };
+
+// any series of gzip members into one vector (inputs small enough to be decoded whole): the same decoder as the stream
+bool inflate_serial(const char* data, size_t size, std::vector<char>& out, std::string& err)
+{
+    GzBytes g(data, size);
+    bool eof = false;
+    while (!eof) {
+        const size_t old = out.size(), piece = 64u << 20;
+        out.resize(old + piece);
+        size_t got = 0;
+        if (!g.read(out.data() + old, piece, got, eof, err)) return false;
+        out.resize(old + got);
+    }
+    return true;
+}
 
 // decompressed bytes with a window that keeps what a decoder has not consumed yet
 class Window {
