@@ -122,6 +122,27 @@ def test_cli_corrupt_gzip(binary, golden_dir, tmp_path, stream_min, monkeypatch)
     assert p.returncode == 255 and b"Error encountered while decompressing file" in p.stderr
 
 
+@pytest.mark.parametrize("name", ["ont_zoo", "hifi_bam", "down_r"])
+def test_cli_single_process_exit(binary, golden_dir, name, monkeypatch):
+    """TGSF_SYNC_EXIT=1: no child process, mappings dropped piece by piece during the run, everything on the clock --
+    same results as the default (work in a child, address space taken down in the background after the status is out)."""
+    monkeypatch.setenv("TGSF_SYNC_EXIT", "1")
+    monkeypatch.setenv("TGSF_BATCH_BYTES", "30000")
+    monkeypatch.setenv("TGSF_FILL_MIN_BYTES", "1")
+    cli_check.run_case(binary, golden_dir, name, extra_args=["-t", "4"])
+
+
+def test_cli_exit_status_comes_through_the_parent(binary, tmp_path):
+    """Fatal paths of the working child (here: an output file that cannot be opened, after threads exist) reach the caller
+    as the reference's exit status, and the caller's pipes close when the work is done."""
+    f = tmp_path / "a.fq"
+    f.write_bytes(b"@r\n" + b"ACGT" * 400 + b"\n+\n" + b"I" * 1600 + b"\n")
+    p = subprocess.run([binary, "-i", str(f), "-x", "ont", "-o", str(tmp_path / "no_such_dir" / "o.fq")], capture_output=True, timeout=120)
+    assert p.returncode == 1 and b"Failed to open file" in p.stderr
+    p = subprocess.run([binary, "-i", str(f), "-x", "ont", "-o", str(tmp_path / "o.fq")], capture_output=True, timeout=120)
+    assert p.returncode == 0 and (tmp_path / "o.fq").read_bytes().startswith(b"@r\n")
+
+
 def test_cli_usage_and_errors(binary, tmp_path):
     p = subprocess.run([binary], capture_output=True)
     assert p.returncode == 1 and p.stdout.startswith(b"Usage: tgsfilter -i TGS.raw.fq.gz -x ont -o TGS.clean.fq.gz")

@@ -11,7 +11,52 @@
 #include "prepass.h"
 #include "report.h"
 
+#include <signal.h>
+#include <sys/prctl.h>
+#include <sys/wait.h>
+
 using namespace host;
+
+// How the program ends.  A run maps tens of GB (the input text, the output file) and holds GPU contexts: taking all
+// that down is ~1.3 s of kernel work per 57 GB of mappings, AFTER every output byte is written and every file is
+// closed.  Done synchronously it is the last 0.2-1 s of the command; done piecemeal during the run (MADV_DONTNEED) it
+// disturbs the run itself (TLB shootdowns: fallocate of the output 1.27 -> 1.6 s).  So, like linkers that map whole
+// outputs (mold), the program works in a child process: when the child has written and closed everything it hands its exit
+// status to the waiting parent, which returns to the caller at once, and the child's address space is taken down in the
+// background.  TGSF_SYNC_EXIT=1: one process, everything on the clock.
+static int g_done_fd = -1;
+
+[[noreturn]] static void leave(int code)
+{
+    fflush(nullptr);
+    if (g_done_fd >= 0) {
+        if (write(g_done_fd, &code, sizeof code) != (ssize_t)sizeof code) { /* the parent is gone: nothing to tell */ }
+        close(0); close(1); close(2);                 // the caller's pipes see end-of-file now, not when the teardown is over
+    }
+    _exit(code);
+}
+
+static void work_in_a_child()
+{
+    if (getenv("TGSF_SYNC_EXIT")) return;
+    int fds[2];
+    if (pipe(fds) != 0) return;
+    const pid_t pid = fork();                          // before any thread or GPU state exists
+    if (pid < 0) { close(fds[0]); close(fds[1]); return; }
+    if (pid > 0) {
+        close(fds[1]);
+        int code = 0;
+        ssize_t n;
+        do { n = read(fds[0], &code, sizeof code); } while (n < 0 && errno == EINTR);
+        if (n == (ssize_t)sizeof code) _exit(code);    // everything is written and closed
+        int st = 0;                                    // the child ended without saying so (a fatal path): its status is ours
+        while (waitpid(pid, &st, 0) < 0 && errno == EINTR) {}
+        _exit(WIFEXITED(st) ? WEXITSTATUS(st) : 128 + WTERMSIG(st));
+    }
+    close(fds[0]);
+    g_done_fd = fds[1];
+    prctl(PR_SET_PDEATHSIG, SIGTERM);                  // no orphan if the parent is killed
+}
 
 
 int main(int argc, char** argv)
@@ -20,6 +65,7 @@ int main(int argc, char** argv)
     { struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts); t_epoch0 = (double)ts.tv_sec + ts.tv_nsec * 1e-9; }
     Options o;
     if (parse_args(argc, argv, o)) return 1;
+    work_in_a_child();
     // big blocks stay in the heap instead of being mapped and unmapped one by one (see BatchStore)
     mallopt(M_MMAP_THRESHOLD, 1 << 30);
     mallopt(M_TRIM_THRESHOLD, -1);
@@ -63,10 +109,10 @@ int main(int argc, char** argv)
     InputBytes in;
     bool streaming = false;
     if (coded && !o.downsample) {
-        if (!in.open_raw(o.in_file)) return 1;
+        if (!in.open_raw(o.in_file)) leave(1);
         streaming = in.size() >= stream_min;
     }
-    if (!streaming && !in.open(o.in_file, o.in_type == 2)) return 1;   // SAM/BAM: decoded to FASTQ text (read_bam, :1872-1917)
+    if (!streaming && !in.open(o.in_file, o.in_type == 2)) leave(1);   // SAM/BAM: decoded to FASTQ text (read_bam, :1872-1917)
     const size_t chunk_bytes = [] { const char* e = getenv("TGSF_CHUNK_BYTES"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)(64u << 20); }();
     auto open_stream = [&]() {
         std::string err;
@@ -130,7 +176,7 @@ int main(int argc, char** argv)
             std::cerr << "INFO: 3' adapter: " << a3 << std::endl;
             std::cerr << "INFO: mean depth of 5' adapter: " << d5 << std::endl;
             std::cerr << "INFO: mean depth of 3' adapter: " << d3 << std::endl;
-            if (o.only_adapters) { fflush(nullptr); _exit(0); }
+            if (o.only_adapters) leave(0);
             if (!a5.empty()) { add(a5); add(rev_comp(a5)); }
             if (!a3.empty()) { add(a3); add(rev_comp(a3)); }
             if (a5.empty() && a3.empty()) {                            // :3115-3125
@@ -176,7 +222,7 @@ int main(int argc, char** argv)
         // address space for the output mapping: what the input could turn into (a streamed input's text size is unknown)
         if (may_map) sink.open(o.out_file, streaming ? std::max<uint64_t>(64ull << 30, 64ull * in.size())
                                                      : (uint64_t)in.size() + in.size() / 4 + (16u << 20));
-        if (!o.only_qc && !sink.is_open() && !out.open(o)) return 1;
+        if (!o.only_qc && !sink.is_open() && !out.open(o)) leave(1);
     }
     // While the library loads and the device comes up nothing else needs this thread's core: pages of the output file
     // are instantiated meanwhile, up to a quarter of the input's size (what a run keeps is not known yet; a surplus is
@@ -349,7 +395,11 @@ int main(int argc, char** argv)
     // after everything is written.  One background thread drops the pages of written batches while the pipeline runs
     // instead (several threads doing it only get in each other's way).  Only for a file mapping whose text nothing
     // refers to later.
-    const bool release_input = !streaming && in.mapped() && !o.downsample && getenv("TGSF_KEEP_INPUT_MAPPED") == nullptr;
+    // dropped piece by piece only where the teardown is on the clock (TGSF_SYNC_EXIT) or the resident size matters (a
+    // streamed input: the mapped part of the output counts as resident)
+    const bool sync_exit = getenv("TGSF_SYNC_EXIT") != nullptr;
+    const bool release_input = sync_exit && !streaming && in.mapped() && !o.downsample;
+    const bool release_output = sync_exit || streaming;
     Channel<std::pair<const char*, uint64_t>> to_release(1 << 16);
     std::thread releaser([&] {
         for (;;) {
@@ -359,10 +409,11 @@ int main(int argc, char** argv)
         }
     });
     using Emit = Batch::Emit;
-    // a written batch: the mappings of its pages of the output go at once (from the fill thread, not all at exit
-    // from one), the batch itself back to the store
+    // a written batch: the mappings of its pages of the output and of the input go to the releaser thread (dropping
+    // them from the 16 fill threads at once cost 7-15 thread-seconds of a run and slowed everything beside them), the
+    // batch itself back to the store
     auto batch_done = [&](std::shared_ptr<Batch> b) {
-        if (b->out_bytes) MappedSink::release(b->dst, b->out_bytes);
+        if (b->out_bytes && release_output) to_release.put({b->dst, b->out_bytes});
         if (release_input) to_release.put({b->base, b->span});
         store.put(std::move(b));
     };
@@ -706,6 +757,5 @@ int main(int argc, char** argv)
         struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts);
         fprintf(stderr, "CLOCK: main entered at %.6f, leaving at %.6f (epoch seconds)\n", t_epoch0, (double)ts.tv_sec + ts.tv_nsec * 1e-9);
     }
-    fflush(nullptr);
-    _exit(0);
+    leave(0);
 }
