@@ -391,12 +391,12 @@ int main(int argc, char** argv)
     // (a streamed input is decoder-bound: small strides keep the mapped part of the output -- it counts as resident -- small)
     uint64_t stride_bytes = streaming ? (128ull << 20) : (2ull << 30);
     if (const char* e = getenv("TGSF_STRIDE_BYTES")) { const long long v = atoll(e); if (v > 0) stride_bytes = (uint64_t)v; }   // tuning / test knob
-    // Taking down the mapping of an N-GB input costs ~90 ns per 4-KB page, 0.4 s for 18 GB -- at exit, on one thread,
-    // after everything is written.  One background thread drops the pages of written batches while the pipeline runs
-    // instead (several threads doing it only get in each other's way).  Only for a file mapping whose text nothing
-    // refers to later.
-    // dropped piece by piece only where the teardown is on the clock (TGSF_SYNC_EXIT) or the resident size matters (a
-    // streamed input: the mapped part of the output counts as resident)
+    // Mappings of written batches (input text, output file).  By default nothing is dropped during the run: the program
+    // works in a child process and its address space is taken down in the background after the caller has its status
+    // (see work_in_a_child).  They are dropped piece by piece -- by ONE background thread: several only get in each
+    // other's way -- where the teardown is on the clock (TGSF_SYNC_EXIT: 90 ns per page of the input, ~200 ns per dirty
+    // page of the output otherwise wait at exit) or where the resident size matters (a streamed input: the mapped part
+    // of the output counts as resident).
     const bool sync_exit = getenv("TGSF_SYNC_EXIT") != nullptr;
     const bool release_input = sync_exit && !streaming && in.mapped() && !o.downsample;
     const bool release_output = sync_exit || streaming;
@@ -409,9 +409,8 @@ int main(int argc, char** argv)
         }
     });
     using Emit = Batch::Emit;
-    // a written batch: the mappings of its pages of the output and of the input go to the releaser thread (dropping
-    // them from the 16 fill threads at once cost 7-15 thread-seconds of a run and slowed everything beside them), the
-    // batch itself back to the store
+    // a written batch: its mappings go to the releaser thread where they are dropped at all (from the 16 fill threads at
+    // once that cost 7-15 thread-seconds of a run and slowed everything beside them), the batch itself back to the store
     auto batch_done = [&](std::shared_ptr<Batch> b) {
         if (b->out_bytes && release_output) to_release.put({b->dst, b->out_bytes});
         if (release_input) to_release.put({b->base, b->span});
