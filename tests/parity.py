@@ -124,6 +124,65 @@ def repeat_reads(seed=51, n=60):
     return reads
 
 
+
+def _kmer_repeat_np(seq: bytes, k: int) -> int:
+    """GetKmerCount (src/TGSFilter.cpp:1703-1753) for k < 32 in numpy: #k-mers - #distinct k-mers."""
+    a = np.frombuffer(seq, dtype=np.uint8)
+    total = a.size - k + 1
+    if total <= 0:
+        return 0
+    code = np.zeros(256, dtype=np.uint64)
+    code[ord("C")], code[ord("G")], code[ord("T")] = 1, 2, 3
+    c = code[a]
+    km = np.zeros(total, dtype=np.uint64)
+    for j in range(k):
+        km = (km << np.uint64(2)) | c[j:j + total]
+    return int(total - np.unique(km).size)
+
+
+REPEAT_TINY = [100, 101, 111, 112, 113, 127, 128, 129, 130, 143, 144, 145]
+REPEAT_SHORT = [500, 1000, 1023, 1024, 1025, 4097, 16384, 20000]
+_W = 6 * 1024 * 16      # bases of k_repeat's window (one 16-base chunk is shared between consecutive windows)
+REPEAT_LONG = [_W - 40, _W - 17, _W - 16, _W - 15, _W - 1, _W, _W + 1, _W + 15, _W + 16, _W + 17,
+               2 * _W - 33, 2 * _W - 16, 2 * _W - 15, 2 * _W + 3, 3 * _W - 20, 250000]
+
+
+def repeat_threshold_case(lib_path, k, lens, max_runs=64):
+    """The gate at each read's own count: with -p c the read whose repeat count is c passes, with -p c+1 it is
+    dropped -- a miscount by one k-mer in either direction shows.  Lengths sit on the kernel's seams (16-base
+    chunks, the window of k_repeat, two and three windows); stray N / lower-case bytes; one low-complexity read;
+    the reads start at any alignment (runs alternate between the packed layout and the FASTQ text in place)."""
+    rng = np.random.default_rng(100 + k)
+    reads, counts = [], []
+    for i, L in enumerate(lens):
+        body = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, L)].copy()
+        if i == 1:
+            unit = body[:int(rng.integers(3, 40))]
+            body = np.tile(unit, L // unit.size + 1)[:L].copy()
+        for pos in rng.integers(0, L, max(1, L // 400)):
+            body[int(pos)] = int(np.frombuffer(b"Nacgt", dtype=np.uint8)[rng.integers(0, 5)])
+        q = bytes((rng.integers(12, 30, L) + 33).astype(np.uint8))
+        reads.append((b"r%d_%s" % (L, b"x" * int(rng.integers(0, 16))), body.tobytes(), q))
+        counts.append(_kmer_repeat_np(body.tobytes(), k))
+    counts = np.array(counts)
+    thresholds = sorted({int(c) + d for c in counts for d in (0, 1) if int(c) + d > 0})
+    if len(thresholds) > max_runs:
+        thresholds = [thresholds[i] for i in sorted(rng.choice(len(thresholds), max_runs, replace=False))]
+    for run, T in enumerate(thresholds):
+        p = abi.make_params("ont", adapters=[], min_q=5.0, min_len=100, min_repeat=T, kmer=k)
+        p.max_batch_reads = len(reads)
+        p.max_batch_bases = 2 * sum(len(r[1]) for r in reads) + 64 * len(reads) + 4096
+        p.max_read_len = max(len(r[1]) for r in reads)
+        ctx = capi.Context(p, 0, lib_path)
+        if run & 1:
+            compare_batch_in_place(ctx, p, reads)
+        else:
+            res, frags, ctr = compare_batch(ctx, p, reads, align=1 if run & 2 else 16)
+            dropped = (frags["flags"] & abi.FF_REPEAT) != 0
+            assert np.array_equal(dropped, counts < T), (T, counts, dropped)
+        ctx.close()
+
+
 def clean_table_strategy(lib_path, mode, golden_dir):
     """Both ways of tallying the clean bin tables (TGSF_CLEAN_TABLES=direct|difference, see k_clean_plan)
     must give the oracle's tallies: trimmed / split / dropped / low-quality / repeat-dropped reads, -F,

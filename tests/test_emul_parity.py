@@ -94,6 +94,13 @@ def test_emul_repeat_gate(emul, pval, k):
     ctx.close()
 
 
+@pytest.mark.parametrize("k,lens", [(11, "TINY"), (11, "SHORT"), (11, "LONG"), (9, "LONG"), (10, "SHORT"), (12, "SHORT"), (13, "TINY"),
+                                    (13, "LONG"), (5, "SHORT"), (3, "TINY"), (1, "SHORT")])
+def test_emul_repeat_gate_exact_counts(emul, k, lens):
+    """Reads built to have repeat == T and == T-1 exactly, on the chunk and window seams of k_repeat."""
+    parity.repeat_threshold_case(emul, k, getattr(parity, "REPEAT_" + lens), max_runs=16)
+
+
 @pytest.mark.parametrize("mode", ["direct", "difference"])
 def test_emul_clean_table_strategy(emul, golden_dir, mode):
     parity.clean_table_strategy(emul, mode, golden_dir)

@@ -156,6 +156,13 @@ def test_gpu_repeat_gate(pval, k):
     ctx.close()
 
 
+@pytest.mark.parametrize("k", [1, 2, 3, 5, 8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("lens", ["TINY", "SHORT", "LONG"])
+def test_gpu_repeat_gate_exact_counts(k, lens):
+    """Reads built to have repeat == T and == T-1 exactly, on the chunk and window seams of k_repeat."""
+    parity.repeat_threshold_case(None, k, getattr(parity, "REPEAT_" + lens), max_runs=20)
+
+
 @pytest.mark.parametrize("mode", ["direct", "difference"])
 def test_gpu_clean_table_strategy(golden_dir, mode):
     parity.clean_table_strategy(None, mode, golden_dir)

@@ -65,6 +65,27 @@ TGSF_HD uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) {
 #endif
 }
 
+// bits [sh, sh+32) of the 64-bit value hi:lo, sh in 0..31
+TGSF_HD uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+#else
+    uint64_t v = ((uint64_t)hi << 32) | lo;
+    return (uint32_t)(v >> (sh & 31u));
+#endif
+}
+// byte i of the result = byte sel.byte[i] of the 8-byte value hi:lo (selectors 0..7 only)
+TGSF_HD uint32_t perm_bytes(uint32_t hi, uint32_t lo, uint32_t sel) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+    uint64_t v = ((uint64_t)hi << 32) | lo;
+    uint32_t r = 0;
+    for (int i = 0; i < 4; i++) r |= (uint32_t)((v >> (8 * ((sel >> (8 * i)) & 7u))) & 0xFF) << (8 * i);
+    return r;
+#endif
+}
+
 // ---------------------------------------------------------------------------
 // Bit-vector edit distance, standard layout: row r of the adapter is bit r%64 of
 // word r/64.  Rows >= Q of the last word are don't-care (information only moves

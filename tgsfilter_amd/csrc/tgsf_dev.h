@@ -63,6 +63,7 @@ struct DevBatch {
     uint32_t* nfr;             // [n+1] fragments per read, scanned in place to frag_begin
     uint32_t* scan_part;       // [n / kScanTile + 2] per-tile totals of the prefix scans
     uint32_t* trimmed;         // [n]
+    uint32_t* rep_next;        // [1] k_repeat: next fragment to hand out
 
     // stats work lists (raw: items are reads; clean: items are fragments [0,fcap) and, in the
     // "difference" strategy, whole reads to take back out, numbered fcap + read)

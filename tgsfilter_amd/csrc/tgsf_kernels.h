@@ -1458,16 +1458,28 @@ TGSF_KERNEL k_regions(DevParams P, DevBatch B)
 }
 
 // ---------------------------------------------------------------------------
-// k_repeat: the repeat gate, GetKmerCount (src/TGSFilter.cpp:1703-1753, :1982-1989).
+// k_repeat: the repeat gate, GetKmerCount (src/TGSFilter.cpp:1703-1753, :1982-1989), for k <= 13.
 // repeat = (#k-mers) - (#distinct k-mers) of a fragment; fragments below -p are dropped before any
-// clean statistics.  k-mers are 2-bit codes (A0 C1 G2 T3, every other byte 0).  One workgroup per
-// fragment; the fragment is converted once per pass window into 2-bit codes held in LDS (16 per word), the
-// 4^k-bit "seen" set lives in LDS as a bitmap of at most 2^20 bits (128 KB), so k = 11 takes 4 passes,
-// each pass owning the k-mers whose top bits equal the pass number; the LDS atomic ORs are fire-and-forget
-// and "distinct" is the popcount of the bitmap after each pass.
+// clean statistics.  k-mers are 2-bit codes (A0 C1 G2 T3, every other byte 0), first base in the top bits.
+//
+// One 1024-lane workgroup per fragment (one per CU: the 4^k-bit "seen" set is a 2^20-bit LDS bitmap, 128 KB;
+// k = 11, 12, 13 take 4, 16, 64 passes, pass p owning the k-mers whose first k-10 bases spell p).
+//   * The text is read as aligned 16-byte chunks, one per lane, and turned into one word of sixteen 2-bit codes
+//     (four bytes at a time), first base of the chunk in the top bits; positions are counted from the chunk the
+//     fragment starts in, so the load needs no shifting and a k-mer is a bit-field of two consecutive words.
+//   * The next fragment's first window is fetched into registers before this one's passes and converted after
+//     them: its HBM latency hides behind the passes.
+//   * A lane owns the 16 k-mer starts of a word.  With one pass it marks all sixteen; with several it forms the
+//     mask of the starts whose leading bases match the pass (three logic ops per base of the prefix, for the
+//     whole word) and walks its set bits -- no pass touches a k-mer it does not own.
+//   * Marks are no-return LDS ORs (measured on gfx950: random ds_or costs what a random ds_write_b32 does, 9-12
+//     cycles per wave instruction on the CU); "distinct" is the popcount of the bitmap, taken while it is
+//     cleared for the next pass.
+//   * Fragments are dealt to the workgroups by a counter (B.rep_next, zeroed by the host before the launch).
 // ---------------------------------------------------------------------------
-constexpr uint32_t kRepBits = 1u << 20;
-constexpr int kRepWin = 96 * 1024;                  // bases of a fragment held in LDS as 2-bit codes (24 KB)
+constexpr int kRepThreads = 1024;
+constexpr int kRepSlots = 6;                          // chunks a lane holds in registers for the prefetch
+constexpr int kRepWords = kRepSlots * kRepThreads;    // words (16 bases each) of a window: 96 K bases, 24 KB
 // 2-bit code of a base as GetKmerCount assigns it: exactly 'A' 'C' 'G' 'T' -> 0 1 2 3, any other byte 0
 // (:1709-1724).  Branch-free: (c>>1)&3 is A0 C1 T2 G3, x^(x>>1) swaps the last two; validity from a bit
 // mask over c - 'A'.
@@ -1477,96 +1489,145 @@ TGSF_D uint32_t base_code(uint32_t c) {
     const uint32_t x = (c >> 1) & 3u;
     return (x ^ (x >> 1)) & (0u - valid);
 }
-TGSF_KERNEL k_repeat(DevParams P, DevBatch B)
+// the same for four text bytes at once: 8 bits, the first byte's code in bits 7..6
+TGSF_D uint32_t base_codes4(uint32_t d) {
+    const uint32_t x = (d >> 1) & 0x03030303u;
+    uint32_t y = x ^ ((x >> 1) & 0x01010101u);                                // A0 C1 G2 T3; any other byte: something in 0..3
+    const uint32_t diff = d ^ perm_bytes(0u, 0x54474341u, y);                 // a zero byte where the text byte is exactly A C G T
+    const uint32_t nz = ((((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff) >> 7) & 0x01010101u;
+    y &= ~(nz | (nz << 1));
+    return ((y << 6) | (y >> 4) | (y >> 14) | (y >> 24)) & 0xFFu;
+}
+TGSF_D uint32_t base_codes16(const uint4& r) {
+    return (base_codes4(r.x) << 24) | (base_codes4(r.y) << 16) | (base_codes4(r.z) << 8) | base_codes4(r.w);
+}
+// bit 2s set where the 2-bit group s of w equals c
+TGSF_D uint32_t rep_eq_mask(uint32_t w, uint32_t c) {
+    const uint32_t x = w ^ (c * 0x55555555u);
+    return ~(x | (x >> 1)) & 0x55555555u;
+}
+TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat(DevParams P, DevBatch B)
 {
-    TGSF_SHARED uint32_t bm[kRepBits / 32];           // 128 KB: one partition of the 4^k-bit "seen" set
-    TGSF_SHARED uint32_t codes[kRepWin / 16 + 4];     // 24 KB: 16 bases per word, base i at bits 2*(i&15)
-    TGSF_SHARED uint32_t distinct_s;
+    constexpr int W = kRepWords;
+    TGSF_SHARED uint4 bm4[8192];                      // 128 KB: one partition of the 4^k-bit "seen" set
+    TGSF_SHARED uint32_t codes[W + 4];                // a window of the fragment as 2-bit codes
+    TGSF_SHARED uint32_t distinct_s, next_s;
+    uint32_t* bm = reinterpret_cast<uint32_t*>(bm4);
     const int k = P.kmer;
     const uint32_t space_log2 = 2u * (uint32_t)k;                      // k <= 13 -> <= 26 bits
     const uint32_t part_log2 = space_log2 < 20u ? space_log2 : 20u;
-    const uint32_t passes = 1u << (space_log2 - part_log2);
-    const uint32_t part_words = ((1u << part_log2) + 31u) / 32u;
-    const uint32_t kmask = (1u << space_log2) - 1u;
+    const int PB = (int)(space_log2 - part_log2) / 2;                  // leading bases that select the pass
+    const uint32_t passes = 1u << (2 * PB);
+    const uint32_t part_q = (((1u << part_log2) + 31u) / 32u + 3u) / 4u;   // uint4s of a partition
     const uint32_t nf = stored_frags(B);
     uint64_t drop_n = 0, drop_b = 0;
 #if defined(TGSF_EMUL)
-    const uint32_t nthr = 1, tid = 0;                                  // emulation: one lane does the whole fragment
+    const int NT = 1, tid = 0;                                         // emulation: one lane does the whole fragment
     if (threadIdx.x != 0) return;
 #else
-    const uint32_t nthr = blockDim.x, tid = threadIdx.x;
+    const int NT = kRepThreads, tid = (int)threadIdx.x;
 #endif
-    for (uint32_t f = blockIdx.x; f < nf; f += gridDim.x) {
-        const int L = (int)B.frag_len[f];
+    uint4 zero4;
+    zero4.x = zero4.y = zero4.z = zero4.w = 0;
+    for (uint32_t w = (uint32_t)tid; w < 8192u; w += (uint32_t)NT) bm4[w] = zero4;
+
+    // the fragment as aligned 16-byte chunks: chunk 0 holds its first base at byte a
+    auto chunks_of = [&](uint32_t f, const uint4*& base, int& a, int& L) TGSF_INLINE_LAMBDA {
+        const uint8_t* s = B.seq + B.frag_off[f];
+        a = (int)((uintptr_t)s & 15u);
+        base = reinterpret_cast<const uint4*>(s - a);
+        L = (int)B.frag_len[f];
+    };
+    // codes[0 .. ) <- chunks [wb, wb + W) of the fragment (as many as it has)
+    auto load_window = [&](const uint4* base, int words, int wb) TGSF_INLINE_LAMBDA {
+        for (int g = tid; g < W && wb + g < words; g += NT) codes[g] = base_codes16(base[wb + g]);
+    };
+#if !defined(TGSF_EMUL)
+    uint4 raw[kRepSlots];
+    auto prefetch = [&](uint32_t f) TGSF_INLINE_LAMBDA {
+        if (f >= nf) return;
+        const uint4* base; int a, L;
+        chunks_of(f, base, a, L);
+        const int words = (a + L + 15) / 16;
+#pragma unroll
+        for (int sl = 0; sl < kRepSlots; sl++) { const int g = tid + sl * NT; if (g < words) raw[sl] = base[g]; }
+    };
+    prefetch(blockIdx.x);
+#endif
+    uint32_t f = blockIdx.x;
+    while (f < nf) {
+        const uint4* base; int a, L;
+        chunks_of(f, base, a, L);
         const int total = L - k + 1;                                   // number of k-mers
-        const uint8_t* seq = B.seq + B.frag_off[f];
-        if (tid == 0) distinct_s = 0;
+        const int words = (a + L + 15) / 16;                           // chunks holding the fragment
+        const int kwords = total > 0 ? (a + total + 15) / 16 : 0;      // chunks in which a k-mer starts
+        const bool one_window = words <= W;
+        if (tid == 0) { distinct_s = 0; next_s = gridDim.x + atomicAdd(B.rep_next, 1u); }
+        TGSF_BLOCK_SYNC();                                             // the previous fragment's readers of codes[] are done
+#if defined(TGSF_EMUL)
+        load_window(base, words, 0);
+#else
+#pragma unroll
+        for (int sl = 0; sl < kRepSlots; sl++) { const int g = tid + sl * NT; if (g < words) codes[g] = base_codes16(raw[sl]); }
+#endif
+        TGSF_BLOCK_SYNC();
+        const uint32_t fnext = next_s;
+#if !defined(TGSF_EMUL)
+        prefetch(fnext);
+#endif
         uint32_t mine = 0;
-        for (uint32_t pass = 0; pass < passes; pass++) {
-            TGSF_BLOCK_SYNC();
-            for (uint32_t w = tid; w < part_words; w += nthr) bm[w] = 0;
-            // windows of kRepWin bases (consecutive windows overlap by k-1 bases so every k-mer is seen once)
-            for (int w0 = 0; w0 < (total > 0 ? total : 0); w0 += kRepWin - (k - 1)) {
-                int wn = L - w0;                                       // bases in this window
-                if (wn > kRepWin) wn = kRepWin;
-                const int nk = wn - k + 1;                             // k-mers starting in this window
-                TGSF_BLOCK_SYNC();
-                // bases -> 2-bit codes, 16 per word
-                for (int g = (int)tid; g * 16 < wn; g += (int)nthr) {
-                    const int b0 = w0 + g * 16;
-                    const int nb = L - b0 < 16 ? L - b0 : 16;
-                    // 16 bases as five aligned dwords + funnel shifts (any alignment; bytes past the fragment
-                    // are read but masked out below)
-                    const uintptr_t a = (uintptr_t)(seq + b0);
-                    const uint32_t* w32 = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
-                    const uint32_t bs = (uint32_t)(a & 3u);
-                    uint32_t wv[5];
-#pragma unroll
-                    for (int q = 0; q < 5; q++) wv[q] = (q < 4 || bs) ? w32[q] : 0u;
-                    uint32_t word = 0;
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const uint32_t d = alignbyte(wv[q + 1], wv[q], bs);
-#pragma unroll
-                        for (int r = 0; r < 4; r++) word |= base_code((d >> (8 * r)) & 0xFFu) << (2 * (4 * q + r));
-                    }
-                    if (nb < 16) word &= (1u << (2 * nb)) - 1u;
-                    codes[g] = word;
+        for (uint32_t pass = 0; pass < passes && kwords > 0; pass++) {
+            // windows of W chunks; a k-mer starting in chunk g reads chunk g+1 too, so consecutive windows share one chunk
+            for (int wb = 0;; wb += W - 1) {
+                if (!one_window && !(pass == 0 && wb == 0)) {
+                    TGSF_BLOCK_SYNC();
+                    load_window(base, words, wb);
+                    TGSF_BLOCK_SYNC();
                 }
-                TGSF_BLOCK_SYNC();
-                const int per = (nk + (int)nthr - 1) / (int)nthr;
-                const int i0 = (int)tid * per;
-                int i1 = i0 + per;
-                if (i1 > nk) i1 = nk;
-                if (i0 < i1) {
-                    auto code_at = [&](int i) { return (codes[i >> 4] >> (2 * (i & 15))) & 3u; };
-                    uint32_t km = 0;
-                    for (int j = i0; j < i0 + k - 1; j++) km = (km << 2) | code_at(j);
-                    auto feed = [&](uint32_t c) {                              // extend the k-mer by one code, mark it if this pass owns it
-                        km = ((km << 2) | c) & kmask;
-                        if ((km >> part_log2) == pass) {
-                            const uint32_t idx = km & ((1u << part_log2) - 1u);
-                            atomicOr(&bm[idx >> 5], 1u << (idx & 31u));         // result unused: a fire-and-forget ds_or
+                const bool last = wb + W >= words;
+                const int gend = last ? kwords - wb : W - 1;           // k-mers start in chunks [wb, wb + gend)
+                for (int g = tid; g < gend; g += NT) {
+                    const uint32_t hi = codes[g], lo = codes[g + 1];
+                    const int first = a - 16 * (wb + g);               // starts before the fragment's first base (chunk 0 only)
+                    const int v = a + total - 16 * (wb + g);           // starts up to the last k-mer
+                    if (PB == 0 && first <= 0 && v >= 16) {
+#pragma unroll
+                        for (int j = 0; j < 16; j++) {
+                            const uint32_t t = j ? alignbit(hi, lo, 32u - 2u * (uint32_t)j) : hi;   // the k-mer from bit 31 down
+                            const uint32_t idx = t >> (32u - part_log2);
+                            atomicOr(&bm[idx >> 5], 1u << (idx & 31u));     // result unused: a fire-and-forget ds_or
                         }
-                    };
-                    // codes at positions [i0+k-1, i1+k-1): one LDS word feeds 16 k-mers
-                    int pos = i0 + k - 1;
-                    const int pend = i1 + k - 1;
-                    while (pos < pend && (pos & 15)) { feed(code_at(pos)); pos++; }
-                    while (pos + 16 <= pend) {
-                        uint32_t w = codes[pos >> 4];
-#pragma unroll
-                        for (int q = 0; q < 16; q++) { feed(w & 3u); w >>= 2; }
-                        pos += 16;
+                    } else {
+                        uint32_t m = 0x55555555u;                      // bit 30-2j: a k-mer of this pass starts at base j of the chunk
+                        if (PB >= 1) m = rep_eq_mask(hi, (pass >> (2 * (PB - 1))) & 3u);
+                        if (PB >= 2) m &= alignbit(rep_eq_mask(hi, (pass >> (2 * (PB - 2))) & 3u), rep_eq_mask(lo, (pass >> (2 * (PB - 2))) & 3u), 30u);
+                        if (PB >= 3) m &= alignbit(rep_eq_mask(hi, pass & 3u), rep_eq_mask(lo, pass & 3u), 28u);
+                        if (first > 0) m &= 0xFFFFFFFFu >> (2 * first);
+                        if (v < 16) m &= ~(0xFFFFFFFFu >> (2 * v));
+                        const uint64_t win = ((uint64_t)hi << 32) | lo;
+                        const int c0 = 30 + 2 * PB;
+                        while (m) {
+                            const int b = __builtin_ctz(m);
+                            m &= m - 1u;
+                            const uint32_t t = (uint32_t)((win << (c0 - b)) >> 32);   // the k-mer less its leading PB bases, from bit 31 down
+                            const uint32_t idx = t >> (32u - part_log2);
+                            atomicOr(&bm[idx >> 5], 1u << (idx & 31u));
+                        }
                     }
-                    while (pos < pend) { feed(code_at(pos)); pos++; }
                 }
+                if (last) break;
             }
-            // distinct k-mers of this partition = set bits of the bitmap
+            // distinct k-mers of this partition = set bits of the bitmap; leave it clear
             TGSF_BLOCK_SYNC();
-            for (uint32_t w = tid; w < part_words; w += nthr) mine += popc32(bm[w]);
+            for (uint32_t w = (uint32_t)tid; w < part_q; w += (uint32_t)NT) {
+                const uint4 q = bm4[w];
+                mine += popc32(q.x) + popc32(q.y) + popc32(q.z) + popc32(q.w);
+                bm4[w] = zero4;
+            }
+            TGSF_BLOCK_SYNC();
         }
-        if (mine) atomicAdd(&distinct_s, mine);
+        mine = (uint32_t)wave_sum((uint64_t)mine);
+        if (wave_leader() && mine) atomicAdd(&distinct_s, mine);
         TGSF_BLOCK_SYNC();
         if (tid == 0) {
             const int repeat = (total > 0 ? total : 0) - (int)distinct_s;
@@ -1575,7 +1636,7 @@ TGSF_KERNEL k_repeat(DevParams P, DevBatch B)
                 drop_n++; drop_b += (uint64_t)L;
             }
         }
-        TGSF_BLOCK_SYNC();
+        f = fnext;
     }
     if (tid == 0 && drop_n) {
         atomicAdd((ull*)&B.ctr[TGSF_CTR_DROPINFO + 15], (ull)drop_n);

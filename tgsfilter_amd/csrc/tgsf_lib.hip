@@ -443,6 +443,7 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     if (!e) e = dev_alloc(c, &B.nfr, n + 1);
     if (!e) e = dev_alloc(c, &B.scan_part, n / kScanTile + 2);
     if (!e) e = dev_alloc(c, &B.trimmed, n);
+    if (!e) e = dev_alloc(c, &B.rep_next, 4);
     if (!e) e = dev_alloc(c, &B.tile_hist, (size_t)B.max_tiles + 2);
     if (!e) e = dev_alloc(c, &B.tile_cnt, (size_t)B.max_tiles + 2);
     if (!e) e = dev_alloc(c, &B.tile_base, (size_t)B.max_tiles + 2);
@@ -671,7 +672,10 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     scan_u32(B, B.nfr, n, st);
     TGSF_LAUNCH(k_regions<true>, gsmall, T, st, P, B);
     if (P.min_repeat > 0 && !P.only_qc) {
-        if (P.kmer <= 13) TGSF_LAUNCH(k_repeat, grid_cap(256u), 256, st, P, B);          // one workgroup per CU: 128 KB of LDS each
+        if (P.kmer <= 13) {
+            rt_memset(B.rep_next, 0, sizeof(uint32_t), st);
+            TGSF_LAUNCH(k_repeat, grid_cap(256u), kRepThreads, st, P, B);                // one workgroup per CU: 152 KB of LDS each
+        }
         else TGSF_LAUNCH(k_repeat_wide, grid_cap(P.kmer >= 32 ? 256u : c->rep_wgs), 256, st, P, B, c->rep_tables, c->rep_slots);
     }
     STAGE_MARK();
