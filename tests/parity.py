@@ -143,19 +143,21 @@ def _kmer_repeat_np(seq: bytes, k: int) -> int:
 REPEAT_TINY = [100, 101, 111, 112, 113, 127, 128, 129, 130, 143, 144, 145]
 REPEAT_SHORT = [500, 1000, 1023, 1024, 1025, 4097, 16384, 20000]
 _W = 6 * 1024 * 16      # bases of k_repeat's window (one 16-base chunk is shared between consecutive windows)
+REPEAT_SKEW = [400000, 150000, 30000]
 REPEAT_LONG = [_W - 40, _W - 17, _W - 16, _W - 15, _W - 1, _W, _W + 1, _W + 15, _W + 16, _W + 17,
                2 * _W - 33, 2 * _W - 16, 2 * _W - 15, 2 * _W + 3, 3 * _W - 20, 250000]
 
 
-def repeat_threshold_case(lib_path, k, lens, max_runs=64):
+def repeat_threshold_case(lib_path, k, lens, max_runs=64, alphabet=b"ACGT"):
     """The gate at each read's own count: with -p c the read whose repeat count is c passes, with -p c+1 it is
     dropped -- a miscount by one k-mer in either direction shows.  Lengths sit on the kernel's seams (16-base
     chunks, the window of k_repeat, two and three windows); stray N / lower-case bytes; one low-complexity read;
+    a two-letter alphabet crowds the k-mers into a few passes (k_repeat_keys then starts over with more of them);
     the reads start at any alignment (runs alternate between the packed layout and the FASTQ text in place)."""
     rng = np.random.default_rng(100 + k)
     reads, counts = [], []
     for i, L in enumerate(lens):
-        body = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, L)].copy()
+        body = np.frombuffer(alphabet, dtype=np.uint8)[rng.integers(0, len(alphabet), L)].copy()
         if i == 1:
             unit = body[:int(rng.integers(3, 40))]
             body = np.tile(unit, L // unit.size + 1)[:L].copy()

@@ -101,6 +101,18 @@ def test_emul_repeat_gate_exact_counts(emul, k, lens):
     parity.repeat_threshold_case(emul, k, getattr(parity, "REPEAT_" + lens), max_runs=16)
 
 
+@pytest.mark.parametrize("k,lens", [(14, "SHORT"), (16, "LONG"), (16, "TINY"), (17, "SHORT"), (20, "LONG"), (31, "SHORT"), (31, "TINY")])
+def test_emul_repeat_gate_exact_counts_keys(emul, k, lens):
+    """The same through k_repeat_keys (32-bit keys to k = 16, 64-bit above)."""
+    parity.repeat_threshold_case(emul, k, getattr(parity, "REPEAT_" + lens), max_runs=10)
+
+
+@pytest.mark.parametrize("k", [14, 20])
+def test_emul_repeat_gate_skewed_composition(emul, k):
+    """Long reads over two letters: a pass's table fills up and the fragment starts over with more passes."""
+    parity.repeat_threshold_case(emul, k, parity.REPEAT_SKEW, max_runs=4, alphabet=b"AC")
+
+
 @pytest.mark.parametrize("mode", ["direct", "difference"])
 def test_emul_clean_table_strategy(emul, golden_dir, mode):
     parity.clean_table_strategy(emul, mode, golden_dir)

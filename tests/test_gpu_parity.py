@@ -156,11 +156,18 @@ def test_gpu_repeat_gate(pval, k):
     ctx.close()
 
 
-@pytest.mark.parametrize("k", [1, 2, 3, 5, 8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("k", [1, 2, 3, 5, 8, 9, 10, 11, 12, 13, 14, 16, 17, 20, 27, 31])
 @pytest.mark.parametrize("lens", ["TINY", "SHORT", "LONG"])
 def test_gpu_repeat_gate_exact_counts(k, lens):
     """Reads built to have repeat == T and == T-1 exactly, on the chunk and window seams of k_repeat."""
     parity.repeat_threshold_case(None, k, getattr(parity, "REPEAT_" + lens), max_runs=20)
+
+
+@pytest.mark.parametrize("k", [13, 14, 20, 31])
+@pytest.mark.parametrize("alphabet", [b"AC", b"AT", b"A"])
+def test_gpu_repeat_gate_skewed_composition(k, alphabet):
+    """Long reads over one or two letters: a pass's table fills up and the fragment starts over with more passes."""
+    parity.repeat_threshold_case(None, k, parity.REPEAT_SKEW, max_runs=6, alphabet=alphabet)
 
 
 @pytest.mark.parametrize("mode", ["direct", "difference"])

@@ -20,6 +20,7 @@
 // Reference lines are cited at each kernel.  The file compiles for the device
 // (hipcc) and, with -DTGSF_EMUL, as plain C++ for tests/emul (serial emulation).
 #pragma once
+#include <type_traits>
 #include "tgsf_dev.h"
 #include "../../include/tgsf.h"
 static_assert(TGSF_CTR_END_TABLES == 533, "tally layout");
@@ -1645,71 +1646,199 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat(DevParams P, DevBatch B)
 }
 
 // ---------------------------------------------------------------------------
-// k_repeat_wide: the same gate for k = 14..32, where the 4^k-bit set no longer exists as a bitmap: the distinct
-// k-mers (64-bit keys, compared in full -- exact) are counted by inserting them into an open-addressing table in
-// HBM, one table region per workgroup (L2-resident for ordinary fragments), sized to twice the fragment's k-mers
-// (power of two), cleared per fragment; a slot is claimed with one 64-bit compare-and-swap.  k = 32 follows the
-// reference's machine there (:1748, see the oracle): the first k-mer as built, every later one 0.
+// k_repeat_keys: the same gate where the 4^k-bit set is too large to sweep as LDS bitmaps (k = 13..31; 32-bit keys up to
+// k = 16, 64-bit above).  Exact, in two phases per pass, all in LDS:
+//   1. every k-mer the pass owns marks bit h(k-mer) of a 2^19-bit map A (ds_or returning the old word) and, if that bit
+//      was already set, the same bit of a second map B.  A hash value marked once stands for exactly one k-mer
+//      occurrence, so popcount(A & ~B) of them are distinct k-mers, whatever the hash does.
+//   2. the occurrences whose hash value is in B -- a few percent of a random fragment, nearly all of a repetitive one --
+//      are the only ones that can hide duplicates: the fragment is scanned again and those keys (compared in full) go into
+//      an open-addressing table that takes A's place; new insertions are counted.
+//   distinct = popcount(A & ~B) + insertions.  A pass owns the k-mers that start with its PB leading bases (the match
+//   mask of k_repeat); PB is the smallest for which a pass's share of the k-mers is at most kRepShare, and one more
+//   whenever a probe sequence of the table grows long (skewed composition, or a long fragment of many distinct repeats):
+//   the fragment then starts over.  Windows, chunk layout, prefetch and work counter as in k_repeat.
+//   k = 32 follows the reference's machine there (:1748, see the oracle): the first k-mer as built, every later one 0.
 // ---------------------------------------------------------------------------
-TGSF_KERNEL k_repeat_wide(DevParams P, DevBatch B, unsigned long long* tables, uint64_t slots_per_wg)
+constexpr uint32_t kRepShare = 49152;                 // k-mers of a pass for which the table behind the maps stays sparse
+template <bool KEY64>
+TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
 {
-    TGSF_SHARED uint32_t distinct_s;
+    constexpr int W = kRepWords;
+    constexpr int OV = KEY64 ? 2 : 1;                                  // chunks shared by consecutive windows (a key spans up to 3 / 2)
+    constexpr uint32_t TLOG = KEY64 ? 13u : 14u;                       // slots of the table (64 KB), log2
+    typedef typename std::conditional<KEY64, ull, uint32_t>::type key_t;
+    TGSF_SHARED uint4 A4[4096];                       // 64 KB: map A, then the table of full keys
+    TGSF_SHARED uint4 B4[4096];                       // 64 KB: map B
+    TGSF_SHARED uint32_t codes[W + 8];
+    TGSF_SHARED uint32_t distinct_s, next_s, over_s;
+    uint32_t* Am = reinterpret_cast<uint32_t*>(A4);
+    uint32_t* Bm = reinterpret_cast<uint32_t*>(B4);
+    key_t* tab = reinterpret_cast<key_t*>(A4);
+    const key_t kEmpty = ~(key_t)0;                                    // no key has all its bits set (k - PB < 16 / < 32, below)
     const int k = P.kmer;
-    const uint64_t kmask = k >= 32 ? 0ull : ((1ull << (2 * k)) - 1ull);
-    const ull kEmpty = ~0ull;                                           // no key below k = 32 has all bits set
     const uint32_t nf = stored_frags(B);
-    ull* tab = tables + (size_t)blockIdx.x * slots_per_wg;
     uint64_t drop_n = 0, drop_b = 0;
 #if defined(TGSF_EMUL)
-    const uint32_t nthr = 1, tid = 0;
+    const int NT = 1, tid = 0;
     if (threadIdx.x != 0) return;
 #else
-    const uint32_t nthr = blockDim.x, tid = threadIdx.x;
+    const int NT = kRepThreads, tid = (int)threadIdx.x;
 #endif
-    for (uint32_t f = blockIdx.x; f < nf; f += gridDim.x) {
-        const int L = (int)B.frag_len[f];
+    uint4 zero4, ones4;
+    zero4.x = zero4.y = zero4.z = zero4.w = 0;
+    ones4.x = ones4.y = ones4.z = ones4.w = ~0u;
+    for (uint32_t w = (uint32_t)tid; w < 4096u; w += (uint32_t)NT) { A4[w] = zero4; B4[w] = zero4; }
+
+    auto chunks_of = [&](uint32_t f, const uint4*& base, int& a, int& L) TGSF_INLINE_LAMBDA {
+        const uint8_t* s = B.seq + B.frag_off[f];
+        a = (int)((uintptr_t)s & 15u);
+        base = reinterpret_cast<const uint4*>(s - a);
+        L = (int)B.frag_len[f];
+    };
+    // codes[0 .. ) <- chunks [wb, wb + W) of the fragment, zeros behind its last chunk
+    auto load_window = [&](const uint4* base, int words, int wb) TGSF_INLINE_LAMBDA {
+        for (int g = tid; g < W + 4 && wb + g < words + 4; g += NT) codes[g] = wb + g < words ? base_codes16(base[wb + g]) : 0u;
+    };
+#if !defined(TGSF_EMUL)
+    uint4 raw[kRepSlots];
+    auto prefetch = [&](uint32_t f) TGSF_INLINE_LAMBDA {
+        if (f >= nf) return;
+        const uint4* base; int a, L;
+        chunks_of(f, base, a, L);
+        const int words = (a + L + 15) / 16;
+#pragma unroll
+        for (int sl = 0; sl < kRepSlots; sl++) { const int g = tid + sl * NT; if (g < words) raw[sl] = base[g]; }
+    };
+    prefetch(blockIdx.x);
+#endif
+    uint32_t f = blockIdx.x;
+    while (f < nf) {
+        const uint4* base; int a, L;
+        chunks_of(f, base, a, L);
         const int total = L - k + 1;
-        const uint8_t* seq = B.seq + B.frag_off[f];
-        if (tid == 0) distinct_s = 0;
+        const int words = (a + L + 15) / 16;
+        const int kwords = total > 0 ? (a + total + 15) / 16 : 0;
+        const bool one_window = words <= W;
+        if (tid == 0) { distinct_s = 0; over_s = 0; next_s = gridDim.x + atomicAdd(B.rep_next, 1u); }
         TGSF_BLOCK_SYNC();
+#if defined(TGSF_EMUL)
+        load_window(base, words, 0);
+#else
+#pragma unroll
+        for (int sl = 0; sl < kRepSlots; sl++) { const int g = tid + sl * NT; if (g < words) codes[g] = base_codes16(raw[sl]); }
+        if (tid < 8) codes[(words < W ? words : W) + tid] = 0;
+#endif
+        TGSF_BLOCK_SYNC();
+        const uint32_t fnext = next_s;
+#if !defined(TGSF_EMUL)
+        prefetch(fnext);
+#endif
         uint32_t mine = 0;
         if (total > 0 && k >= 32) {
             if (tid == 0) {
                 ull first = 0;
+                const uint8_t* seq = B.seq + B.frag_off[f];
                 for (int i = 0; i < k; i++) first = (first << 2) | base_code(seq[i]);
                 mine = (total > 1 && first != 0ull) ? 2u : 1u;
             }
         } else if (total > 0) {
-            uint64_t slots = 64;
-            while (slots < 2ull * (uint64_t)total) slots <<= 1;
-            if (slots > slots_per_wg) { set_status(B, DS_POOL_FULL, B.frag_read[f]); slots = slots_per_wg; }
-            for (uint64_t i = tid; i < slots; i += nthr) tab[i] = kEmpty;
-            TGSF_BLOCK_SYNC();
-            // every thread takes a contiguous run of k-mers (rolls its own window)
-            const int per = (total + (int)nthr - 1) / (int)nthr;
-            const int i0 = (int)tid * per;
-            int i1 = i0 + per;
-            if (i1 > total) i1 = total;
-            if (i0 < i1) {
-                ull km = 0;
-                for (int j = i0; j < i0 + k - 1; j++) km = (km << 2) | base_code(seq[j]);
-                for (int i = i0; i < i1; i++) {
-                    km = (km << 2) | base_code(seq[i + k - 1]);
-                    if (i > 0) km &= kmask;                         // the first k-mer of a fragment is taken as built (:1727)
-                    else if (k < 32) km &= kmask;                   // (k bases never exceed 2k bits below k = 32)
-                    uint64_t h = km * 0x9E3779B97F4A7C15ull;
-                    h ^= h >> 29;
-                    uint64_t slot = h & (slots - 1);
-                    for (;;) {
-                        const ull old = atomicCAS(&tab[slot], kEmpty, km);
-                        if (old == kEmpty) { mine++; break; }
-                        if (old == km) break;
-                        slot = (slot + 1) & (slots - 1);
+            int PB = (!KEY64 && k == 16) ? 1 : 0;                      // (a 32-bit key of sixteen T's is the empty mark)
+            for (;;) {
+                while (PB < k - 1 && ((uint32_t)total >> (2 * PB)) > kRepShare) PB++;
+                const int kb = 2 * (k - PB);                           // bits of a key: the k-mer less the pass's leading bases
+                const uint32_t passes = 1u << (2 * PB);
+                mine = 0;
+                for (uint32_t pass = 0; pass < passes; pass++) {
+                    for (int phase = 0; phase < 2; phase++) {
+                        for (int wb = 0;; wb += W - OV) {
+                            if (!one_window) {
+                                TGSF_BLOCK_SYNC();
+                                load_window(base, words, wb);
+                            }
+                            TGSF_BLOCK_SYNC();
+                            const bool last = wb + W >= words;
+                            const int gend = last ? kwords - wb : W - OV;
+                            for (int g = tid; g < gend; g += NT) {
+                                const uint32_t w0 = codes[g], w1 = codes[g + 1], w2 = codes[g + 2], w3 = codes[g + 3];
+                                const int first = a - 16 * (wb + g);
+                                const int v = a + total - 16 * (wb + g);
+                                uint32_t m = 0x55555555u;              // bit 30-2j: a k-mer of this pass starts at base j of the chunk
+                                for (int q = 0; q < PB; q++) {
+                                    const uint32_t c = (pass >> (2 * (PB - 1 - q))) & 3u;
+                                    const uint32_t e0 = rep_eq_mask(w0, c);
+                                    m &= q ? alignbit(e0, rep_eq_mask(w1, c), 32u - 2u * (uint32_t)q) : e0;
+                                }
+                                if (first > 0) m &= 0xFFFFFFFFu >> (2 * first);
+                                if (v < 16) m &= ~(0xFFFFFFFFu >> (2 * v));
+                                while (m) {
+                                    const int b = __builtin_ctz(m);
+                                    m &= m - 1u;
+                                    const int sh = 30 - b + 2 * PB;    // bit offset of the key in the chunk sequence w0 w1 w2 w3
+                                    const bool up = sh >= 32;
+                                    const uint32_t X = up ? w1 : w0, Y = up ? w2 : w1, Z = up ? w3 : w2;
+                                    const uint32_t sb = (uint32_t)sh & 31u;
+                                    const uint32_t x0 = sb ? alignbit(X, Y, 32u - sb) : X;
+                                    key_t key;
+                                    uint32_t h, lo32, hi32 = 0;
+                                    if (KEY64) {
+                                        const uint32_t x1 = sb ? alignbit(Y, Z, 32u - sb) : Y;
+                                        const ull k64 = (((ull)x0 << 32) | x1) >> (64 - kb);
+                                        key = (key_t)k64;
+                                        lo32 = (uint32_t)k64; hi32 = (uint32_t)(k64 >> 32);
+                                        h = (lo32 ^ (hi32 * 0x85EBCA6Bu)) * 0x9E3779B1u;
+                                    } else {
+                                        lo32 = x0 >> (32 - kb);
+                                        key = (key_t)lo32;
+                                        h = lo32 * 0x9E3779B1u;
+                                    }
+                                    const uint32_t hb = h >> 13;       // 19 bits
+                                    const uint32_t bit = 1u << (hb & 31u);
+                                    if (phase == 0) {
+                                        const uint32_t old = atomicOr(&Am[hb >> 5], bit);
+                                        if (old & bit) atomicOr(&Bm[hb >> 5], bit);
+                                    } else if (Bm[hb >> 5] & bit) {
+                                        uint32_t slot = (((lo32 * 0xC2B2AE35u) ^ (hi32 * 0x27D4EB2Fu) ^ (lo32 >> 15)) * 0x165667B1u) >> (32u - TLOG);
+                                        for (int probes = 0;; probes++) {
+                                            const key_t old = atomicCAS(&tab[slot], kEmpty, key);
+                                            if (old == kEmpty) { mine++; break; }
+                                            if (old == key) break;
+                                            if (probes >= 64) { over_s = 1; break; }
+                                            slot = (slot + 1u) & ((1u << TLOG) - 1u);
+                                        }
+                                    }
+                                }
+                            }
+                            if (last) break;
+                        }
+                        TGSF_BLOCK_SYNC();
+                        if (phase == 0) {
+                            // hash values marked once: one occurrence, one distinct k-mer each; A becomes the (empty) table
+                            for (uint32_t w = (uint32_t)tid; w < 4096u; w += (uint32_t)NT) {
+                                const uint4 x = A4[w], y = B4[w];
+                                mine += popc32(x.x & ~y.x) + popc32(x.y & ~y.y) + popc32(x.z & ~y.z) + popc32(x.w & ~y.w);
+                                A4[w] = ones4;
+                            }
+                        } else {
+                            for (uint32_t w = (uint32_t)tid; w < 4096u; w += (uint32_t)NT) { A4[w] = zero4; B4[w] = zero4; }
+                        }
+                        TGSF_BLOCK_SYNC();
                     }
+                    if (over_s) break;
                 }
+                if (!over_s) break;
+                TGSF_BLOCK_SYNC();
+                if (tid == 0) over_s = 0;
+                if (PB >= k - 1) { set_status(B, DS_POOL_FULL, B.frag_read[f]); mine = 0; TGSF_BLOCK_SYNC(); break; }   // (cannot happen: 4 keys)
+                PB++;
+#if defined(TGSF_EMUL) && defined(TGSF_REP_TRACE)
+                fprintf(stderr, "k_repeat_keys: fragment %u (%d k-mers) starts over with %d leading bases\n", f, total, PB);
+#endif
+                TGSF_BLOCK_SYNC();
             }
         }
-        if (mine) atomicAdd(&distinct_s, mine);
+        mine = (uint32_t)wave_sum((uint64_t)mine);
+        if (wave_leader() && mine) atomicAdd(&distinct_s, mine);
         TGSF_BLOCK_SYNC();
         if (tid == 0) {
             const int repeat = (total > 0 ? total : 0) - (int)distinct_s;
@@ -1718,7 +1847,7 @@ TGSF_KERNEL k_repeat_wide(DevParams P, DevBatch B, unsigned long long* tables, u
                 drop_n++; drop_b += (uint64_t)L;
             }
         }
-        TGSF_BLOCK_SYNC();
+        f = fnext;
     }
     if (tid == 0 && drop_n) {
         atomicAdd((ull*)&B.ctr[TGSF_CTR_DROPINFO + 15], (ull)drop_n);

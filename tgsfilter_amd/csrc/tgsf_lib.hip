@@ -49,9 +49,6 @@ struct tgsf_ctx {
     unsigned endtab_grid = 512;             // k_end_tables: LDS-atomic bound, 40 KB of LDS per block: two blocks per CU (128: 0.36 ms, 512: 0.19 ms)
     unsigned stats_grid = 768, mid_grid = 0;   // tuning knobs (TGSF_STATS_GRID, TGSF_MID_GRID; 0 = one lane per segment)
     uint64_t ctr_words;
-    unsigned long long* rep_tables = nullptr;      // k_repeat_wide (-k 14..31): per-workgroup k-mer tables
-    uint64_t rep_slots = 0;
-    unsigned rep_wgs = 0;
     int scratch_cols;
     // internal input / output staging for tgsf_submit
     uint8_t *d_seq, *d_qual;
@@ -479,16 +476,6 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
         const size_t waves = B.scratch_mid_wave0 + ((size_t)n * A + 63) / 64 + 1;
         if (!e) e = dev_alloc(c, &B.scratch, waves * B.scratch_wave_words);
     }
-    if (!e && p->min_repeat > 0 && p->kmer > 13 && p->kmer < 32 && !p->only_qc) {
-        // k_repeat_wide: one table region per workgroup, twice the k-mers of the longest fragment (power of two);
-        // as many workgroups as 8 GB of them allow
-        uint64_t slots = 64;
-        while (slots < 2ull * c->max_read_len) slots <<= 1;
-        uint64_t wgs = (8ull << 30) / (slots * 8);
-        c->rep_wgs = (unsigned)std::max<uint64_t>(8, std::min<uint64_t>(wgs, 512));
-        c->rep_slots = slots;
-        e = dev_alloc(c, &c->rep_tables, (size_t)c->rep_wgs * (size_t)slots);
-    }
     if (!e) e = dev_alloc(c, &B.ctr, (size_t)c->ctr_words);
     if (!e) e = dev_alloc(c, &B.status, 4);
     if (!e) e = dev_alloc(c, &c->d_out_reads, n);
@@ -672,11 +659,11 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     scan_u32(B, B.nfr, n, st);
     TGSF_LAUNCH(k_regions<true>, gsmall, T, st, P, B);
     if (P.min_repeat > 0 && !P.only_qc) {
-        if (P.kmer <= 13) {
-            rt_memset(B.rep_next, 0, sizeof(uint32_t), st);
-            TGSF_LAUNCH(k_repeat, grid_cap(256u), kRepThreads, st, P, B);                // one workgroup per CU: 152 KB of LDS each
-        }
-        else TGSF_LAUNCH(k_repeat_wide, grid_cap(P.kmer >= 32 ? 256u : c->rep_wgs), 256, st, P, B, c->rep_tables, c->rep_slots);
+        // one 1024-lane workgroup per CU (152 KB of LDS each); fragments are handed out through B.rep_next
+        rt_memset(B.rep_next, 0, sizeof(uint32_t), st);
+        if (P.kmer <= 12) TGSF_LAUNCH(k_repeat, grid_cap(256u), kRepThreads, st, P, B);
+        else if (P.kmer <= 16) TGSF_LAUNCH(k_repeat_keys<false>, grid_cap(256u), kRepThreads, st, P, B);
+        else TGSF_LAUNCH(k_repeat_keys<true>, grid_cap(256u), kRepThreads, st, P, B);
     }
     STAGE_MARK();
     // -- clean stats over the fragments

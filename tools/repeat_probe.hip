@@ -539,6 +539,190 @@ __global__ void __launch_bounds__(1024) k_rep5(const uint8_t* seqs, const uint64
     }
 }
 
+// ---- fifth family (any k up to 31): two phases per pass.  Phase 1 marks a 2^19-bit map A with a hash of every owned k-mer
+// and, when the returned word shows the bit already set, the same bit of a second map B: a hash value marked once stands for
+// exactly one k-mer occurrence.  distinct = popcount(A & ~B) + the distinct keys among the occurrences whose hash is in B,
+// which phase 2 counts exactly by inserting only those (a few percent of a random fragment) into a small table of full keys.
+template <bool KEY64, bool FAST>
+__global__ void __launch_bounds__(1024) k_rep6(const uint8_t* seqs, const uint64_t* foff, const uint32_t* flen, uint32_t nf, int k, uint32_t* distinct, uint32_t* work_ctr, uint32_t share_max)
+{
+    constexpr int NT = 1024, SLOTS = 6, W = SLOTS * NT;
+    constexpr int OV = KEY64 ? 2 : 1;
+    constexpr uint32_t TLOG = KEY64 ? 13u : 14u;                        // table slots (64 KB), log2
+    typedef typename std::conditional<KEY64, unsigned long long, uint32_t>::type key_t;
+    __shared__ uint4 A4[4096];
+    __shared__ uint4 B4[4096];
+    __shared__ uint32_t codes[W + 8];
+    __shared__ uint32_t distinct_s, next_s, over_s;
+    uint32_t* A = reinterpret_cast<uint32_t*>(A4);
+    uint32_t* Bm = reinterpret_cast<uint32_t*>(B4);
+    key_t* tab = reinterpret_cast<key_t*>(A4);
+    const key_t EMPTY = ~(key_t)0;
+    const int tid = (int)threadIdx.x;
+    const uint4 ones4 = make_uint4(~0u, ~0u, ~0u, ~0u), zero4 = make_uint4(0, 0, 0, 0);
+    for (uint32_t w = tid; w < 4096; w += NT) { A4[w] = zero4; B4[w] = zero4; }
+
+    uint4 raw[SLOTS];
+    auto chunks_of = [&](uint32_t f, const uint4*& base, int& a, int& L) {
+        const uint8_t* s = seqs + foff[f];
+        a = (int)((uintptr_t)s & 15u);
+        base = reinterpret_cast<const uint4*>(s - a);
+        L = (int)flen[f];
+    };
+    auto prefetch = [&](uint32_t f) {
+        if (f >= nf) return;
+        const uint4* base; int a, L;
+        chunks_of(f, base, a, L);
+        const int words = (a + L + 15) / 16;
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; sl++) { const int g = tid + sl * NT; if (g < words) raw[sl] = base[g]; }
+    };
+    uint32_t f = blockIdx.x;
+    prefetch(f);
+    while (f < nf) {
+        const uint4* base; int a, L;
+        chunks_of(f, base, a, L);
+        const int total = L - k + 1;
+        const int words = (a + L + 15) / 16;
+        const int kwords = total > 0 ? (a + total + 15) / 16 : 0;
+        const bool one_window = words <= W;
+        if (tid == 0) { distinct_s = 0; over_s = 0; next_s = gridDim.x + atomicAdd(work_ctr, 1u); }
+        __syncthreads();
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; sl++) { const int g = tid + sl * NT; if (g < words) codes[g] = codes16(raw[sl]); }
+        if (tid < 8) codes[(words < W ? words : W) + tid] = 0;
+        __syncthreads();
+        const uint32_t fnext = next_s;
+        prefetch(fnext);
+        int PB = (!KEY64 && k == 16) ? 1 : 0;
+        uint32_t mine = 0;
+        bool in_lds = true;                                             // codes[] holds window 0 of this fragment
+        for (;;) {
+            while (PB < k - 1 && ((uint32_t)(total > 0 ? total : 0) >> (2 * PB)) > share_max) PB++;
+            const int kb = 2 * (k - PB);
+            const uint32_t passes = 1u << (2 * PB);
+            mine = 0;
+            for (uint32_t pass = 0; pass < passes && kwords > 0; pass++) {
+                for (int phase = 0; phase < 2; phase++) {
+                    for (int wb = 0;; wb += W - OV) {
+                        if (!(one_window && in_lds)) {
+                            __syncthreads();
+                            for (int g = tid; g < W + 4 && wb + g < words + 4; g += NT) codes[g] = wb + g < words ? codes16(base[wb + g]) : 0u;
+                            in_lds = one_window;
+                        }
+                        __syncthreads();
+                        const bool last = wb + W >= words;
+                        const int gend = last ? kwords - wb : W - OV;
+                        for (int g = tid; g < gend; g += NT) {
+                            const uint32_t w0 = codes[g], w1 = codes[g + 1], w2 = codes[g + 2], w3 = codes[g + 3];
+                            const int first = a - 16 * (wb + g);
+                            const int v = a + total - 16 * (wb + g);
+                            uint32_t m = 0x55555555u;
+                            if (FAST && PB == 0 && first <= 0 && v >= 16) {
+                                // all sixteen starts of the chunk, constant shifts; the rare table insertions are left to the walk below
+                                uint32_t hbv[16];
+                                uint32_t oldv[16];
+#pragma unroll
+                                for (int j = 0; j < 16; j++) {
+                                    const uint32_t x0 = j ? __builtin_amdgcn_alignbit(w0, w1, 32 - 2 * j) : w0;
+                                    uint32_t h;
+                                    if (KEY64) {
+                                        const uint32_t x1 = j ? __builtin_amdgcn_alignbit(w1, w2, 32 - 2 * j) : w1;
+                                        const unsigned long long k64 = (((unsigned long long)x0 << 32) | x1) >> (64 - kb);
+                                        h = ((uint32_t)k64 ^ ((uint32_t)(k64 >> 32) * 0x85EBCA6Bu)) * 0x9E3779B1u;
+                                    } else {
+                                        h = (x0 >> (32 - kb)) * 0x9E3779B1u;
+                                    }
+                                    hbv[j] = h >> 13;
+                                    if (phase == 0) oldv[j] = atomicOr(&A[hbv[j] >> 5], 1u << (hbv[j] & 31u));
+                                    else oldv[j] = Bm[hbv[j] >> 5];
+                                }
+                                m = 0;
+#pragma unroll
+                                for (int j = 0; j < 16; j++) {
+                                    const uint32_t bit = 1u << (hbv[j] & 31u);
+                                    if (phase == 0) { if (oldv[j] & bit) atomicOr(&Bm[hbv[j] >> 5], bit); }
+                                    else if (oldv[j] & bit) m |= 1u << (30 - 2 * j);
+                                }
+                            } else {
+                            for (int q = 0; q < PB; q++) {
+                                const uint32_t c = (pass >> (2 * (PB - 1 - q))) & 3u;
+                                const uint32_t e0 = eq_mask(w0, c);
+                                m &= q ? __builtin_amdgcn_alignbit(e0, eq_mask(w1, c), 32 - 2 * q) : e0;
+                            }
+                            if (first > 0) m &= 0xFFFFFFFFu >> (2 * first);
+                            if (v < 16) m &= ~(0xFFFFFFFFu >> (2 * v));
+                            }
+                            while (m) {
+                                const int b = __builtin_ctz(m);
+                                m &= m - 1;
+                                const int sh = 30 - b + 2 * PB;
+                                const bool up = sh >= 32;
+                                const uint32_t X = up ? w1 : w0, Y = up ? w2 : w1, Z = up ? w3 : w2;
+                                const uint32_t sb = (uint32_t)sh & 31u;
+                                const uint32_t x0 = sb ? __builtin_amdgcn_alignbit(X, Y, 32 - sb) : X;
+                                key_t key;
+                                uint32_t h, lo32, hi32 = 0;
+                                if (KEY64) {
+                                    const uint32_t x1 = sb ? __builtin_amdgcn_alignbit(Y, Z, 32 - sb) : Y;
+                                    const unsigned long long k64 = (((unsigned long long)x0 << 32) | x1) >> (64 - kb);
+                                    key = (key_t)k64;
+                                    lo32 = (uint32_t)k64; hi32 = (uint32_t)(k64 >> 32);
+                                    h = (lo32 ^ (hi32 * 0x85EBCA6Bu)) * 0x9E3779B1u;
+                                } else {
+                                    lo32 = x0 >> (32 - kb);
+                                    key = (key_t)lo32;
+                                    h = lo32 * 0x9E3779B1u;
+                                }
+                                const uint32_t hb = h >> 13;                     // 19 bits
+                                const uint32_t bit = 1u << (hb & 31u);
+                                if (phase == 0) {
+                                    const uint32_t old = atomicOr(&A[hb >> 5], bit);
+                                    if (old & bit) atomicOr(&Bm[hb >> 5], bit);
+                                } else if (Bm[hb >> 5] & bit) {
+                                    uint32_t slot = ((lo32 * 0xC2B2AE35u) ^ (hi32 * 0x27D4EB2Fu) ^ (lo32 >> 15)) * 0x165667B1u >> (32 - TLOG);
+                                    for (int probes = 0;; probes++) {
+                                        const key_t old = atomicCAS(&tab[slot], EMPTY, key);
+                                        if (old == EMPTY) { mine++; break; }
+                                        if (old == key) break;
+                                        if (probes >= 64) { over_s = 1; break; }
+                                        slot = (slot + 1) & ((1u << TLOG) - 1u);
+                                    }
+                                }
+                            }
+                        }
+                        if (last) break;
+                    }
+                    __syncthreads();
+                    if (phase == 0) {
+                        // hash values marked once: one occurrence, one distinct k-mer each; A becomes the (empty) table
+                        for (uint32_t w = tid; w < 4096; w += NT) {
+                            const uint4 x = A4[w], y = B4[w];
+                            mine += __popc(x.x & ~y.x) + __popc(x.y & ~y.y) + __popc(x.z & ~y.z) + __popc(x.w & ~y.w);
+                            A4[w] = ones4;
+                        }
+                    } else {
+                        for (uint32_t w = tid; w < 4096; w += NT) { A4[w] = zero4; B4[w] = zero4; }
+                    }
+                    __syncthreads();
+                }
+                if (over_s) break;
+            }
+            __syncthreads();
+            if (!over_s) break;
+            __syncthreads();
+            if (tid == 0) over_s = 0;
+            PB++;
+            __syncthreads();
+        }
+        mine = wave_sum(mine);
+        if ((tid & 63) == 0 && mine) atomicAdd(&distinct_s, mine);
+        __syncthreads();
+        if (tid == 0) distinct[f] = distinct_s;
+        f = fnext;
+    }
+}
+
 struct Data {
     uint8_t* seq; uint64_t* off; uint32_t* len; uint32_t nf; uint64_t bases;
 };
@@ -678,6 +862,35 @@ static int run5(const char* name, const Data& D, int k, int grid, const std::vec
     return 0;
 }
 
+template <bool KEY64, bool FAST = true>
+static int run6(const char* name, const Data& D, int k, int grid, const std::vector<uint32_t>* ref, uint32_t share_max)
+{
+    uint32_t* d_out; uint32_t* d_ctr;
+    CK(hipMalloc(&d_out, D.nf * 4));
+    CK(hipMalloc(&d_ctr, 4));
+    CK(hipMemset(d_out, 0xFF, D.nf * 4));
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    CK(hipMemset(d_ctr, 0, 4));
+    hipLaunchKernelGGL((k_rep6<KEY64, FAST>), dim3(grid), dim3(1024), 0, 0, D.seq, D.off, D.len, D.nf, k, d_out, d_ctr, share_max);
+    CK(hipDeviceSynchronize());
+    CK(hipMemset(d_ctr, 0, 4));
+    CK(hipEventRecord(a));
+    hipLaunchKernelGGL((k_rep6<KEY64, FAST>), dim3(grid), dim3(1024), 0, 0, D.seq, D.off, D.len, D.nf, k, d_out, d_ctr, share_max);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, a, b));
+    std::vector<uint32_t> h(D.nf);
+    CK(hipMemcpy(h.data(), d_out, D.nf * 4, hipMemcpyDeviceToHost));
+    size_t bad = 0;
+    if (ref) for (uint32_t i = 0; i < D.nf; i++) if (h[i] != (*ref)[i]) { if (bad < 6) printf("   f %u got %u want %u\n", i, h[i], (*ref)[i]); bad++; }
+    printf("%-22s share<=%-6u %s k %2d threads 1024 grid %4d  %8.3f ms  %7.1f Gbases/s  -> %.2f ms per 2.93-Gbases batch  %s\n", name, share_max, KEY64 ? "64-bit keys" : "32-bit keys", k, grid, ms,
+           D.bases / (ms * 1e6), ms * 2.93e9 / D.bases, !ref ? "(not checked)" : bad ? "MISMATCH" : "same counts");
+    CK(hipFree(d_out)); CK(hipFree(d_ctr));
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     const uint32_t nf = argc > 1 ? (uint32_t)atoi(argv[1]) : 65536u;
@@ -725,16 +938,16 @@ int main(int argc, char** argv)
     printf("%u fragments, %.3f Gbases\n", nf, bases * 1e-9);
     std::vector<uint32_t> ref;
     const bool check = nf <= 8192;
-    for (int k : {11, 12, 13, 15, 16, 17, 21, 31}) {
+    for (int k : {13, 16, 21}) {
         std::vector<uint32_t> hc;
         if (check) host_counts(seq, off, len, k, hc);
-        if (k <= 13) {
-            run<0, 20>("bitmap 128K ds_or", D, k, 256, 256, ref, true);
-            if (check) { size_t bad = 0; for (uint32_t i = 0; i < nf; i++) bad += ref[i] != hc[i]; printf("   host counts vs old kernel: %zu differ\n", bad); }
-            run3<6>("aligned, prefetched", D, k, 256, ref);
+        if (k <= 13) run3<6>("aligned, prefetched", D, k, 256, check ? hc : (run<0, 20>("bitmap 128K ds_or", D, k, 1024, 256, ref, true), ref));
+        for (uint32_t share : {49152u, 65536u}) {
+            if (k <= 16) run6<false, false>("two-phase", D, k, 256, check ? &hc : nullptr, share);
+            if (k <= 16) run6<false, true>("two-phase, fast path", D, k, 256, check ? &hc : nullptr, share);
+            run6<true, false>("two-phase", D, k, 256, check ? &hc : nullptr, share);
+            run6<true, true>("two-phase, fast path", D, k, 256, check ? &hc : nullptr, share);
         }
-        if (k <= 16) run5<false>("LDS hash set", D, k, 256, check ? &hc : nullptr);
-        run5<true>("LDS hash set", D, k, 256, check ? &hc : nullptr);
     }
     return 0;
 }
