@@ -156,8 +156,8 @@ def test_gpu_repeat_gate(pval, k):
     ctx.close()
 
 
-@pytest.mark.parametrize("k", [1, 2, 3, 5, 8, 9, 10, 11, 12, 13, 14, 16, 17, 20, 27, 31])
-@pytest.mark.parametrize("lens", ["TINY", "SHORT", "LONG"])
+@pytest.mark.parametrize("k,lens", [(k, l) for k in (1, 2, 3, 5, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 20, 27, 31) for l in ("TINY", "SHORT")]
+                         + [(k, "LONG") for k in (3, 10, 11, 12, 13, 15, 16, 31)])
 def test_gpu_repeat_gate_exact_counts(k, lens):
     """Reads built to have repeat == T and == T-1 exactly, on the chunk and window seams of k_repeat."""
     parity.repeat_threshold_case(None, k, getattr(parity, "REPEAT_" + lens), max_runs=20)

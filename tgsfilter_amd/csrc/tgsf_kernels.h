@@ -1647,7 +1647,7 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat(DevParams P, DevBatch B)
 
 // ---------------------------------------------------------------------------
 // k_repeat_keys: the same gate where the 4^k-bit set is too large to sweep as LDS bitmaps (k = 13..31; 32-bit keys up to
-// k = 16, 64-bit above).  Exact, in two phases per pass, all in LDS:
+// k = 15, 64-bit above).  Exact, in two phases per pass, all in LDS:
 //   1. every k-mer the pass owns marks bit h(k-mer) of a 2^19-bit map A (ds_or returning the old word) and, if that bit
 //      was already set, the same bit of a second map B.  A hash value marked once stands for exactly one k-mer
 //      occurrence, so popcount(A & ~B) of them are distinct k-mers, whatever the hash does.
@@ -1660,7 +1660,7 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat(DevParams P, DevBatch B)
 //   the fragment then starts over.  Windows, chunk layout, prefetch and work counter as in k_repeat.
 //   k = 32 follows the reference's machine there (:1748, see the oracle): the first k-mer as built, every later one 0.
 // ---------------------------------------------------------------------------
-constexpr uint32_t kRepShare = 49152;                 // k-mers of a pass for which the table behind the maps stays sparse
+constexpr uint32_t kRepShare = 65536;                 // k-mers of a pass for which the table behind the maps stays sparse
 template <bool KEY64>
 TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
 {
@@ -1675,7 +1675,7 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
     uint32_t* Am = reinterpret_cast<uint32_t*>(A4);
     uint32_t* Bm = reinterpret_cast<uint32_t*>(B4);
     key_t* tab = reinterpret_cast<key_t*>(A4);
-    const key_t kEmpty = ~(key_t)0;                                    // no key has all its bits set (k - PB < 16 / < 32, below)
+    const key_t kEmpty = ~(key_t)0;                                    // no key has all its bits set (k < 16 / < 32)
     const int k = P.kmer;
     const uint32_t nf = stored_frags(B);
     uint64_t drop_n = 0, drop_b = 0;
@@ -1743,14 +1743,18 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
                 mine = (total > 1 && first != 0ull) ? 2u : 1u;
             }
         } else if (total > 0) {
-            int PB = (!KEY64 && k == 16) ? 1 : 0;                      // (a 32-bit key of sixteen T's is the empty mark)
+            int PB = 0;
             for (;;) {
                 while (PB < k - 1 && ((uint32_t)total >> (2 * PB)) > kRepShare) PB++;
                 const int kb = 2 * (k - PB);                           // bits of a key: the k-mer less the pass's leading bases
                 const uint32_t passes = 1u << (2 * PB);
                 mine = 0;
                 for (uint32_t pass = 0; pass < passes; pass++) {
-                    for (int phase = 0; phase < 2; phase++) {
+                    // one scan of the fragment: PHASE 0 marks A and B, PHASE 1 inserts the keys whose hash value is in B.
+                    // (Two instances: a test of the phase between the LDS operations of a chunk makes the compiler wait
+                    // for each of them in turn.)
+                    auto scan = [&](auto phase_tag) TGSF_INLINE_LAMBDA {
+                        constexpr int PHASE = decltype(phase_tag)::value;
                         for (int wb = 0;; wb += W - OV) {
                             if (!one_window) {
                                 TGSF_BLOCK_SYNC();
@@ -1763,14 +1767,42 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
                                 const uint32_t w0 = codes[g], w1 = codes[g + 1], w2 = codes[g + 2], w3 = codes[g + 3];
                                 const int first = a - 16 * (wb + g);
                                 const int v = a + total - 16 * (wb + g);
-                                uint32_t m = 0x55555555u;              // bit 30-2j: a k-mer of this pass starts at base j of the chunk
-                                for (int q = 0; q < PB; q++) {
-                                    const uint32_t c = (pass >> (2 * (PB - 1 - q))) & 3u;
-                                    const uint32_t e0 = rep_eq_mask(w0, c);
-                                    m &= q ? alignbit(e0, rep_eq_mask(w1, c), 32u - 2u * (uint32_t)q) : e0;
+                                uint32_t m = 0x55555555u;              // bit 30-2j: base j of the chunk starts a k-mer to handle below
+                                if (PB == 0 && first <= 0 && v >= 16) {
+                                    // a whole chunk of a single-pass fragment: sixteen keys at constant shifts, their LDS
+                                    // operations issued back to back; what is left for the loop below is rare
+                                    uint32_t hbv[16], oldv[16];
+#pragma unroll
+                                    for (int j = 0; j < 16; j++) {
+                                        const uint32_t x0 = j ? alignbit(w0, w1, 32u - 2u * (uint32_t)j) : w0;
+                                        uint32_t h;
+                                        if (KEY64) {
+                                            const uint32_t x1 = j ? alignbit(w1, w2, 32u - 2u * (uint32_t)j) : w1;
+                                            const ull k64 = (((ull)x0 << 32) | x1) >> (64 - kb);
+                                            h = ((uint32_t)k64 ^ ((uint32_t)(k64 >> 32) * 0x85EBCA6Bu)) * 0x9E3779B1u;
+                                        } else {
+                                            h = (x0 >> (32 - kb)) * 0x9E3779B1u;
+                                        }
+                                        hbv[j] = h >> 13;
+                                        if (PHASE == 0) oldv[j] = atomicOr(&Am[hbv[j] >> 5], 1u << (hbv[j] & 31u));
+                                        else oldv[j] = Bm[hbv[j] >> 5];
+                                    }
+                                    m = 0;
+#pragma unroll
+                                    for (int j = 0; j < 16; j++) {
+                                        const uint32_t hit = oldv[j] & (1u << (hbv[j] & 31u));
+                                        if (PHASE == 0) atomicOr(&Bm[hbv[j] >> 5], hit);          // (ORs zero where the bit was new)
+                                        else if (hit) m |= 1u << (30 - 2 * j);
+                                    }
+                                } else {
+                                    for (int q = 0; q < PB; q++) {
+                                        const uint32_t c = (pass >> (2 * (PB - 1 - q))) & 3u;
+                                        const uint32_t e0 = rep_eq_mask(w0, c);
+                                        m &= q ? alignbit(e0, rep_eq_mask(w1, c), 32u - 2u * (uint32_t)q) : e0;
+                                    }
+                                    if (first > 0) m &= 0xFFFFFFFFu >> (2 * first);
+                                    if (v < 16) m &= ~(0xFFFFFFFFu >> (2 * v));
                                 }
-                                if (first > 0) m &= 0xFFFFFFFFu >> (2 * first);
-                                if (v < 16) m &= ~(0xFFFFFFFFu >> (2 * v));
                                 while (m) {
                                     const int b = __builtin_ctz(m);
                                     m &= m - 1u;
@@ -1794,7 +1826,7 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
                                     }
                                     const uint32_t hb = h >> 13;       // 19 bits
                                     const uint32_t bit = 1u << (hb & 31u);
-                                    if (phase == 0) {
+                                    if (PHASE == 0) {
                                         const uint32_t old = atomicOr(&Am[hb >> 5], bit);
                                         if (old & bit) atomicOr(&Bm[hb >> 5], bit);
                                     } else if (Bm[hb >> 5] & bit) {
@@ -1811,6 +1843,10 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
                             }
                             if (last) break;
                         }
+                    };
+                    for (int phase = 0; phase < 2; phase++) {
+                        if (phase == 0) scan(std::integral_constant<int, 0>());
+                        else scan(std::integral_constant<int, 1>());
                         TGSF_BLOCK_SYNC();
                         if (phase == 0) {
                             // hash values marked once: one occurrence, one distinct k-mer each; A becomes the (empty) table

@@ -662,7 +662,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
         // one 1024-lane workgroup per CU (152 KB of LDS each); fragments are handed out through B.rep_next
         rt_memset(B.rep_next, 0, sizeof(uint32_t), st);
         if (P.kmer <= 12) TGSF_LAUNCH(k_repeat, grid_cap(256u), kRepThreads, st, P, B);
-        else if (P.kmer <= 16) TGSF_LAUNCH(k_repeat_keys<false>, grid_cap(256u), kRepThreads, st, P, B);
+        else if (P.kmer <= 15) TGSF_LAUNCH(k_repeat_keys<false>, grid_cap(256u), kRepThreads, st, P, B);
         else TGSF_LAUNCH(k_repeat_keys<true>, grid_cap(256u), kRepThreads, st, P, B);
     }
     STAGE_MARK();

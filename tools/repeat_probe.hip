@@ -603,7 +603,8 @@ __global__ void __launch_bounds__(1024) k_rep6(const uint8_t* seqs, const uint64
             const uint32_t passes = 1u << (2 * PB);
             mine = 0;
             for (uint32_t pass = 0; pass < passes && kwords > 0; pass++) {
-                for (int phase = 0; phase < 2; phase++) {
+                auto scan = [&](auto phase_tag) {
+                    constexpr int phase = decltype(phase_tag)::value;
                     for (int wb = 0;; wb += W - OV) {
                         if (!(one_window && in_lds)) {
                             __syncthreads();
@@ -641,7 +642,7 @@ __global__ void __launch_bounds__(1024) k_rep6(const uint8_t* seqs, const uint64
 #pragma unroll
                                 for (int j = 0; j < 16; j++) {
                                     const uint32_t bit = 1u << (hbv[j] & 31u);
-                                    if (phase == 0) { if (oldv[j] & bit) atomicOr(&Bm[hbv[j] >> 5], bit); }
+                                    if (phase == 0) atomicOr(&Bm[hbv[j] >> 5], oldv[j] & bit);
                                     else if (oldv[j] & bit) m |= 1u << (30 - 2 * j);
                                 }
                             } else {
@@ -694,6 +695,9 @@ __global__ void __launch_bounds__(1024) k_rep6(const uint8_t* seqs, const uint64
                         if (last) break;
                     }
                     __syncthreads();
+                };
+                for (int phase = 0; phase < 2; phase++) {
+                    if (phase == 0) scan(std::integral_constant<int, 0>()); else scan(std::integral_constant<int, 1>());
                     if (phase == 0) {
                         // hash values marked once: one occurrence, one distinct k-mer each; A becomes the (empty) table
                         for (uint32_t w = tid; w < 4096; w += NT) {
@@ -715,6 +719,418 @@ __global__ void __launch_bounds__(1024) k_rep6(const uint8_t* seqs, const uint64
             PB++;
             __syncthreads();
         }
+        mine = wave_sum(mine);
+        if ((tid & 63) == 0 && mine) atomicAdd(&distinct_s, mine);
+        __syncthreads();
+        if (tid == 0) distinct[f] = distinct_s;
+        f = fnext;
+    }
+}
+
+// ---- sixth family: as the fifth, but phase 2 first collects the keys whose hash value is in B into a list (HBM scratch of the
+// workgroup, L2-resident) and then inserts the list in as many sub-passes as its length asks for, each owning a range of a second
+// hash: the fragment is scanned twice whatever its length (up to share_max k-mers per pass), never once per sub-pass.
+template <bool KEY64>
+__global__ void __launch_bounds__(1024) k_rep7(const uint8_t* seqs, const uint64_t* foff, const uint32_t* flen, uint32_t nf, int k, uint32_t* distinct, uint32_t* work_ctr,
+                                                uint32_t share_max, void* lists, uint32_t list_cap, int stop)
+{
+    constexpr int NT = 1024, SLOTS = 6, W = SLOTS * NT;
+    constexpr int OV = KEY64 ? 2 : 1;
+    constexpr uint32_t TLOG = KEY64 ? 13u : 14u;
+    constexpr uint32_t CAP = (1u << TLOG) * 3u / 8u;                   // keys per sub-pass
+    typedef typename std::conditional<KEY64, unsigned long long, uint32_t>::type key_t;
+    __shared__ uint4 A4[4096];
+    __shared__ uint4 B4[4096];
+    __shared__ uint32_t codes[W + 8];
+    __shared__ uint32_t distinct_s, next_s, over_s, list_n;
+    uint32_t* A = reinterpret_cast<uint32_t*>(A4);
+    uint32_t* Bm = reinterpret_cast<uint32_t*>(B4);
+    key_t* tab = reinterpret_cast<key_t*>(A4);
+    key_t* list = reinterpret_cast<key_t*>(lists) + (size_t)blockIdx.x * list_cap;
+    const key_t EMPTY = ~(key_t)0;
+    const int tid = (int)threadIdx.x;
+    const uint4 ones4 = make_uint4(~0u, ~0u, ~0u, ~0u), zero4 = make_uint4(0, 0, 0, 0);
+    for (uint32_t w = tid; w < 4096; w += NT) { A4[w] = zero4; B4[w] = zero4; }
+
+    uint4 raw[SLOTS];
+    auto chunks_of = [&](uint32_t f, const uint4*& base, int& a, int& L) {
+        const uint8_t* s = seqs + foff[f];
+        a = (int)((uintptr_t)s & 15u);
+        base = reinterpret_cast<const uint4*>(s - a);
+        L = (int)flen[f];
+    };
+    auto prefetch = [&](uint32_t f) {
+        if (f >= nf) return;
+        const uint4* base; int a, L;
+        chunks_of(f, base, a, L);
+        const int words = (a + L + 15) / 16;
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; sl++) { const int g = tid + sl * NT; if (g < words) raw[sl] = base[g]; }
+    };
+    auto hash1 = [&](key_t key) -> uint32_t {
+        if (KEY64) return ((uint32_t)key ^ ((uint32_t)((unsigned long long)key >> 32) * 0x85EBCA6Bu)) * 0x9E3779B1u;
+        return (uint32_t)key * 0x9E3779B1u;
+    };
+    auto hash2 = [&](key_t key) -> uint32_t {
+        const uint32_t lo = (uint32_t)key, hi = KEY64 ? (uint32_t)((unsigned long long)key >> 32) : 0u;
+        return ((lo * 0xC2B2AE35u) ^ (hi * 0x27D4EB2Fu) ^ (lo >> 15)) * 0x165667B1u;
+    };
+    uint32_t f = blockIdx.x;
+    prefetch(f);
+    while (f < nf) {
+        const uint4* base; int a, L;
+        chunks_of(f, base, a, L);
+        const int total = L - k + 1;
+        const int words = (a + L + 15) / 16;
+        const int kwords = total > 0 ? (a + total + 15) / 16 : 0;
+        const bool one_window = words <= W;
+        if (tid == 0) { distinct_s = 0; over_s = 0; list_n = 0; next_s = gridDim.x + atomicAdd(work_ctr, 1u); }
+        __syncthreads();
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; sl++) { const int g = tid + sl * NT; if (g < words) codes[g] = codes16(raw[sl]); }
+        if (tid < 8) codes[(words < W ? words : W) + tid] = 0;
+        __syncthreads();
+        const uint32_t fnext = next_s;
+        prefetch(fnext);
+        int PB = (!KEY64 && k == 16) ? 1 : 0;
+        while (PB < k - 1 && ((uint32_t)(total > 0 ? total : 0) >> (2 * PB)) > share_max) PB++;
+        const int kb = 2 * (k - PB);
+        const uint32_t passes = 1u << (2 * PB);
+        uint32_t mine = 0;
+        for (uint32_t pass = 0; pass < passes && kwords > 0 && stop != 1; pass++) {
+            for (int phase = 0; phase < (stop == 2 || stop == 3 ? 1 : 2); phase++) {
+                for (int wb = 0;; wb += W - OV) {
+                    if (!one_window) {
+                        __syncthreads();
+                        for (int g = tid; g < W + 4 && wb + g < words + 4; g += NT) codes[g] = wb + g < words ? codes16(base[wb + g]) : 0u;
+                    }
+                    __syncthreads();
+                    const bool last = wb + W >= words;
+                    const int gend = last ? kwords - wb : W - OV;
+                    for (int g = tid; g < gend; g += NT) {
+                        const uint32_t w0 = codes[g], w1 = codes[g + 1], w2 = codes[g + 2], w3 = codes[g + 3];
+                        const int first = a - 16 * (wb + g);
+                        const int v = a + total - 16 * (wb + g);
+                        uint32_t m = 0x55555555u;                   // starts to handle one by one below
+                        if (PB == 0 && first <= 0 && v >= 16) {
+                            uint32_t hbv[16], oldv[16];
+#pragma unroll
+                            for (int j = 0; j < 16; j++) {
+                                const uint32_t x0 = j ? __builtin_amdgcn_alignbit(w0, w1, 32 - 2 * j) : w0;
+                                key_t key;
+                                if (KEY64) {
+                                    const uint32_t x1 = j ? __builtin_amdgcn_alignbit(w1, w2, 32 - 2 * j) : w1;
+                                    key = (key_t)((((unsigned long long)x0 << 32) | x1) >> (64 - kb));
+                                } else key = (key_t)(x0 >> (32 - kb));
+                                hbv[j] = hash1(key) >> 13;
+                                if (phase == 0) oldv[j] = atomicOr(&A[hbv[j] >> 5], 1u << (hbv[j] & 31u));
+                                else oldv[j] = Bm[hbv[j] >> 5];
+                            }
+                            m = 0;
+#pragma unroll
+                            for (int j = 0; j < 16; j++) {
+                                const uint32_t bit = 1u << (hbv[j] & 31u);
+                                if (phase == 0) { if (oldv[j] & bit) atomicOr(&Bm[hbv[j] >> 5], bit); }
+                                else if (oldv[j] & bit) m |= 1u << (30 - 2 * j);
+                            }
+                        } else {
+                            for (int q = 0; q < PB; q++) {
+                                const uint32_t c = (pass >> (2 * (PB - 1 - q))) & 3u;
+                                const uint32_t e0 = eq_mask(w0, c);
+                                m &= q ? __builtin_amdgcn_alignbit(e0, eq_mask(w1, c), 32 - 2 * q) : e0;
+                            }
+                            if (first > 0) m &= 0xFFFFFFFFu >> (2 * first);
+                            if (v < 16) m &= ~(0xFFFFFFFFu >> (2 * v));
+                        }
+                        while (m) {
+                            const int b = __builtin_ctz(m);
+                            m &= m - 1;
+                            const int sh = 30 - b + 2 * PB;
+                            const bool up = sh >= 32;
+                            const uint32_t X = up ? w1 : w0, Y = up ? w2 : w1, Z = up ? w3 : w2;
+                            const uint32_t sb = (uint32_t)sh & 31u;
+                            const uint32_t x0 = sb ? __builtin_amdgcn_alignbit(X, Y, 32 - sb) : X;
+                            key_t key;
+                            if (KEY64) {
+                                const uint32_t x1 = sb ? __builtin_amdgcn_alignbit(Y, Z, 32 - sb) : Y;
+                                key = (key_t)((((unsigned long long)x0 << 32) | x1) >> (64 - kb));
+                            } else key = (key_t)(x0 >> (32 - kb));
+                            const uint32_t hb = hash1(key) >> 13;
+                            const uint32_t bit = 1u << (hb & 31u);
+                            if (phase == 0) {
+                                const uint32_t old = atomicOr(&A[hb >> 5], bit);
+                                if (old & bit) atomicOr(&Bm[hb >> 5], bit);
+                            } else if (Bm[hb >> 5] & bit) {
+                                const uint32_t at = atomicAdd(&list_n, 1u);
+                                if (at < list_cap) list[at] = key;
+                            }
+                        }
+                    }
+                    if (last) break;
+                }
+                __syncthreads();
+                if (phase == 0 && stop != 2) {
+                    for (uint32_t w = tid; w < 4096; w += NT) {
+                        const uint4 x = A4[w], y = B4[w];
+                        mine += __popc(x.x & ~y.x) + __popc(x.y & ~y.y) + __popc(x.z & ~y.z) + __popc(x.w & ~y.w);
+                        A4[w] = ones4;
+                    }
+                    __syncthreads();
+                }
+            }
+            // phase 2b: the listed keys into the table, a range of the second hash at a time
+            const uint32_t n_list = list_n < list_cap ? list_n : list_cap;      // (list_cap >= share_max: never cut)
+            uint32_t nsub = stop == 4 ? 0u : (n_list + CAP - 1) / CAP;
+            uint32_t mine2 = 0;
+            for (;;) {
+                mine2 = 0;
+                for (uint32_t sp = 0; sp < nsub; sp++) {
+                    for (uint32_t i = tid; i < n_list; i += NT) {
+                        const key_t key = list[i];
+                        const uint32_t h2 = hash2(key);
+                        if ((((h2 & 0xFFFFu) * nsub) >> 16) != sp) continue;
+                        uint32_t slot = h2 >> (32 - TLOG);
+                        for (int probes = 0;; probes++) {
+                            const key_t old = atomicCAS(&tab[slot], EMPTY, key);
+                            if (old == EMPTY) { mine2++; break; }
+                            if (old == key) break;
+                            if (probes >= 64) { over_s = 1; break; }
+                            slot = (slot + 1) & ((1u << TLOG) - 1u);
+                        }
+                    }
+                    __syncthreads();
+                    if (over_s) break;
+                    if (sp + 1 < nsub) { for (uint32_t w = tid; w < 4096; w += NT) A4[w] = ones4; __syncthreads(); }
+                }
+                if (!over_s) break;
+                __syncthreads();
+                if (tid == 0) over_s = 0;
+                for (uint32_t w = tid; w < 4096; w += NT) A4[w] = ones4;
+                nsub *= 2;
+                __syncthreads();
+            }
+            mine += mine2;
+            if (tid == 0) list_n = 0;
+            for (uint32_t w = tid; w < 4096; w += NT) { A4[w] = zero4; B4[w] = zero4; }
+            __syncthreads();
+        }
+        mine = wave_sum(mine);
+        if ((tid & 63) == 0 && mine) atomicAdd(&distinct_s, mine);
+        __syncthreads();
+        if (tid == 0) distinct[f] = distinct_s;
+        f = fnext;
+    }
+}
+
+// ---- seventh family: the sixth with the two scans compiled separately (no test of the phase between the sixteen LDS operations of
+// a chunk, which made the compiler wait for each of them), an unconditional second mark (ORing zero where the bit was new), and
+// the listed keys kept per lane (entry i of lane t at list[i * 1024 + t]): no counter, no scan, the lane that listed a key inserts it.
+template <bool KEY64>
+__global__ void __launch_bounds__(1024) k_rep8(const uint8_t* seqs, const uint64_t* foff, const uint32_t* flen, uint32_t nf, int k, uint32_t* distinct, uint32_t* work_ctr,
+                                                uint32_t share_max, void* lists, uint32_t lane_cap, int stop)
+{
+    constexpr int NT = 1024, SLOTS = 6, W = SLOTS * NT;
+    constexpr int OV = KEY64 ? 2 : 1;
+    constexpr uint32_t TLOG = KEY64 ? 13u : 14u;
+    constexpr uint32_t CAP = (1u << TLOG) * 3u / 8u;
+    typedef typename std::conditional<KEY64, unsigned long long, uint32_t>::type key_t;
+    __shared__ uint4 A4[4096];
+    __shared__ uint4 B4[4096];
+    __shared__ uint32_t codes[W + 8];
+    __shared__ uint32_t distinct_s, next_s, over_s, list_n;
+    uint32_t* A = reinterpret_cast<uint32_t*>(A4);
+    uint32_t* Bm = reinterpret_cast<uint32_t*>(B4);
+    key_t* tab = reinterpret_cast<key_t*>(A4);
+    key_t* list = reinterpret_cast<key_t*>(lists) + (size_t)blockIdx.x * lane_cap * NT;
+    const key_t EMPTY = ~(key_t)0;
+    const int tid = (int)threadIdx.x;
+    const uint4 ones4 = make_uint4(~0u, ~0u, ~0u, ~0u), zero4 = make_uint4(0, 0, 0, 0);
+    for (uint32_t w = tid; w < 4096; w += NT) { A4[w] = zero4; B4[w] = zero4; }
+
+    uint4 raw[SLOTS];
+    auto chunks_of = [&](uint32_t f, const uint4*& base, int& a, int& L) {
+        const uint8_t* s = seqs + foff[f];
+        a = (int)((uintptr_t)s & 15u);
+        base = reinterpret_cast<const uint4*>(s - a);
+        L = (int)flen[f];
+    };
+    auto prefetch = [&](uint32_t f) {
+        if (f >= nf) return;
+        const uint4* base; int a, L;
+        chunks_of(f, base, a, L);
+        const int words = (a + L + 15) / 16;
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; sl++) { const int g = tid + sl * NT; if (g < words) raw[sl] = base[g]; }
+    };
+    auto hash1 = [&](key_t key) -> uint32_t {
+        if (KEY64) return ((uint32_t)key ^ ((uint32_t)((unsigned long long)key >> 32) * 0x85EBCA6Bu)) * 0x9E3779B1u;
+        return (uint32_t)key * 0x9E3779B1u;
+    };
+    auto hash2 = [&](key_t key) -> uint32_t {
+        const uint32_t lo = (uint32_t)key, hi = KEY64 ? (uint32_t)((unsigned long long)key >> 32) : 0u;
+        return ((lo * 0xC2B2AE35u) ^ (hi * 0x27D4EB2Fu) ^ (lo >> 15)) * 0x165667B1u;
+    };
+    uint32_t f = blockIdx.x;
+    prefetch(f);
+    while (f < nf) {
+        const uint4* base; int a, L;
+        chunks_of(f, base, a, L);
+        const int total = L - k + 1;
+        const int words = (a + L + 15) / 16;
+        const int kwords = total > 0 ? (a + total + 15) / 16 : 0;
+        const bool one_window = words <= W;
+        if (tid == 0) { distinct_s = 0; over_s = 0; list_n = 0; next_s = gridDim.x + atomicAdd(work_ctr, 1u); }
+        __syncthreads();
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; sl++) { const int g = tid + sl * NT; if (g < words) codes[g] = codes16(raw[sl]); }
+        if (tid < 8) codes[(words < W ? words : W) + tid] = 0;
+        __syncthreads();
+        const uint32_t fnext = next_s;
+        prefetch(fnext);
+        int PB = 0;
+        uint32_t mine = 0;
+        for (;;) {                                                      // (again with more passes if a lane's list fills up)
+            while (PB < k - 1 && ((uint32_t)(total > 0 ? total : 0) >> (2 * PB)) > share_max) PB++;
+            const int kb = 2 * (k - PB);
+            const uint32_t passes = 1u << (2 * PB);
+            mine = 0;
+            bool again = false;
+            for (uint32_t pass = 0; pass < passes && kwords > 0 && stop != 1; pass++) {
+                uint32_t ln = 0;                                        // keys this lane has listed
+                // one scan of the fragment: PHASE 0 marks A and B, PHASE 1 lists the keys whose hash value is in B
+                auto scan = [&](auto phase_tag) {
+                    constexpr int PHASE = decltype(phase_tag)::value;
+                    for (int wb = 0;; wb += W - OV) {
+                        if (!one_window) {
+                            __syncthreads();
+                            for (int g = tid; g < W + 4 && wb + g < words + 4; g += NT) codes[g] = wb + g < words ? codes16(base[wb + g]) : 0u;
+                        }
+                        __syncthreads();
+                        const bool last = wb + W >= words;
+                        const int gend = last ? kwords - wb : W - OV;
+                        for (int g = tid; g < gend; g += NT) {
+                            const uint32_t w0 = codes[g], w1 = codes[g + 1], w2 = codes[g + 2], w3 = codes[g + 3];
+                            const int first = a - 16 * (wb + g);
+                            const int v = a + total - 16 * (wb + g);
+                            if (PB == 0 && first <= 0 && v >= 16) {
+                                uint32_t hbv[16], oldv[16];
+                                key_t keyv[16];
+#pragma unroll
+                                for (int j = 0; j < 16; j++) {
+                                    const uint32_t x0 = j ? __builtin_amdgcn_alignbit(w0, w1, 32 - 2 * j) : w0;
+                                    if (KEY64) {
+                                        const uint32_t x1 = j ? __builtin_amdgcn_alignbit(w1, w2, 32 - 2 * j) : w1;
+                                        keyv[j] = (key_t)((((unsigned long long)x0 << 32) | x1) >> (64 - kb));
+                                    } else keyv[j] = (key_t)(x0 >> (32 - kb));
+                                    hbv[j] = hash1(keyv[j]) >> 13;
+                                    if (PHASE == 0) oldv[j] = atomicOr(&A[hbv[j] >> 5], 1u << (hbv[j] & 31u));
+                                    else oldv[j] = Bm[hbv[j] >> 5];
+                                }
+#pragma unroll
+                                for (int j = 0; j < 16; j++) {
+                                    const uint32_t hit = oldv[j] & (1u << (hbv[j] & 31u));
+                                    if (PHASE == 0) atomicOr(&Bm[hbv[j] >> 5], hit);
+                                    else if (hit) { if (ln < lane_cap) list[(size_t)ln * NT + tid] = keyv[j]; ln++; }
+                                }
+                            } else {
+                                uint32_t m = 0x55555555u;
+                                for (int q = 0; q < PB; q++) {
+                                    const uint32_t c = (pass >> (2 * (PB - 1 - q))) & 3u;
+                                    const uint32_t e0 = eq_mask(w0, c);
+                                    m &= q ? __builtin_amdgcn_alignbit(e0, eq_mask(w1, c), 32 - 2 * q) : e0;
+                                }
+                                if (first > 0) m &= 0xFFFFFFFFu >> (2 * first);
+                                if (v < 16) m &= ~(0xFFFFFFFFu >> (2 * v));
+                                while (m) {
+                                    const int b = __builtin_ctz(m);
+                                    m &= m - 1;
+                                    const int sh = 30 - b + 2 * PB;
+                                    const bool up = sh >= 32;
+                                    const uint32_t X = up ? w1 : w0, Y = up ? w2 : w1, Z = up ? w3 : w2;
+                                    const uint32_t sb = (uint32_t)sh & 31u;
+                                    const uint32_t x0 = sb ? __builtin_amdgcn_alignbit(X, Y, 32 - sb) : X;
+                                    key_t key;
+                                    if (KEY64) {
+                                        const uint32_t x1 = sb ? __builtin_amdgcn_alignbit(Y, Z, 32 - sb) : Y;
+                                        key = (key_t)((((unsigned long long)x0 << 32) | x1) >> (64 - kb));
+                                    } else key = (key_t)(x0 >> (32 - kb));
+                                    const uint32_t hb = hash1(key) >> 13;
+                                    const uint32_t bit = 1u << (hb & 31u);
+                                    if (PHASE == 0) {
+                                        const uint32_t old = atomicOr(&A[hb >> 5], bit);
+                                        if (old & bit) atomicOr(&Bm[hb >> 5], bit);
+                                    } else if (Bm[hb >> 5] & bit) {
+                                        if (ln < lane_cap) list[(size_t)ln * NT + tid] = key;
+                                        ln++;
+                                    }
+                                }
+                            }
+                        }
+                        if (last) break;
+                    }
+                    __syncthreads();
+                };
+                scan(std::integral_constant<int, 0>());
+                if (stop == 2) continue;
+                for (uint32_t w = tid; w < 4096; w += NT) {
+                    const uint4 x = A4[w], y = B4[w];
+                    mine += __popc(x.x & ~y.x) + __popc(x.y & ~y.y) + __popc(x.z & ~y.z) + __popc(x.w & ~y.w);
+                    A4[w] = ones4;
+                }
+                __syncthreads();
+                if (stop == 3) continue;
+                scan(std::integral_constant<int, 1>());
+                // the listed keys of all lanes: how many sub-passes the table needs; a lane whose list ran over asks for more passes
+                {
+                    const uint32_t t = wave_sum(ln < lane_cap ? ln : lane_cap);
+                    if ((tid & 63) == 0 && t) atomicAdd(&list_n, t);
+                    if (ln > lane_cap) over_s = 1;
+                }
+                __syncthreads();
+                if (over_s) { again = true; break; }
+                const uint32_t n_list = list_n;
+                uint32_t nsub = stop == 4 ? 0u : (n_list + CAP - 1) / CAP;
+                uint32_t mine2 = 0;
+                for (;;) {
+                    mine2 = 0;
+                    for (uint32_t sp = 0; sp < nsub; sp++) {
+                        for (uint32_t i = 0; i < ln; i++) {
+                            const key_t key = list[(size_t)i * NT + tid];
+                            const uint32_t h2 = hash2(key);
+                            if ((((h2 & 0xFFFFu) * nsub) >> 16) != sp) continue;
+                            uint32_t slot = h2 >> (32 - TLOG);
+                            for (int probes = 0;; probes++) {
+                                const key_t old = atomicCAS(&tab[slot], EMPTY, key);
+                                if (old == EMPTY) { mine2++; break; }
+                                if (old == key) break;
+                                if (probes >= 64) { over_s = 1; break; }
+                                slot = (slot + 1) & ((1u << TLOG) - 1u);
+                            }
+                        }
+                        __syncthreads();
+                        if (over_s) break;
+                        if (sp + 1 < nsub) { for (uint32_t w = tid; w < 4096; w += NT) A4[w] = ones4; __syncthreads(); }
+                    }
+                    if (!over_s) break;
+                    __syncthreads();
+                    if (tid == 0) over_s = 0;
+                    for (uint32_t w = tid; w < 4096; w += NT) A4[w] = ones4;
+                    nsub *= 2;
+                    __syncthreads();
+                }
+                mine += mine2;
+                if (tid == 0) list_n = 0;
+                for (uint32_t w = tid; w < 4096; w += NT) { A4[w] = zero4; B4[w] = zero4; }
+                __syncthreads();
+            }
+            if (!again) break;
+            __syncthreads();
+            if (tid == 0) { over_s = 0; list_n = 0; }
+            for (uint32_t w = tid; w < 4096; w += NT) { A4[w] = zero4; B4[w] = zero4; }
+            PB++;
+            __syncthreads();
+        }
+        if (stop == 2 || stop == 3) { __syncthreads(); for (uint32_t w = tid; w < 4096; w += NT) { A4[w] = zero4; B4[w] = zero4; } }
         mine = wave_sum(mine);
         if ((tid & 63) == 0 && mine) atomicAdd(&distinct_s, mine);
         __syncthreads();
@@ -891,6 +1307,66 @@ static int run6(const char* name, const Data& D, int k, int grid, const std::vec
     return 0;
 }
 
+template <bool KEY64>
+static int run7(const char* name, const Data& D, int k, int grid, const std::vector<uint32_t>* ref, uint32_t share_max, int stop = 0)
+{
+    uint32_t* d_out; uint32_t* d_ctr; void* d_lists;
+    CK(hipMalloc(&d_lists, (size_t)grid * (share_max + 64) * 8));
+    CK(hipMalloc(&d_out, D.nf * 4));
+    CK(hipMalloc(&d_ctr, 4));
+    CK(hipMemset(d_out, 0xFF, D.nf * 4));
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    CK(hipMemset(d_ctr, 0, 4));
+    hipLaunchKernelGGL((k_rep7<KEY64>), dim3(grid), dim3(1024), 0, 0, D.seq, D.off, D.len, D.nf, k, d_out, d_ctr, share_max, d_lists, share_max + 64, stop);
+    CK(hipDeviceSynchronize());
+    CK(hipMemset(d_ctr, 0, 4));
+    CK(hipEventRecord(a));
+    hipLaunchKernelGGL((k_rep7<KEY64>), dim3(grid), dim3(1024), 0, 0, D.seq, D.off, D.len, D.nf, k, d_out, d_ctr, share_max, d_lists, share_max + 64, stop);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, a, b));
+    std::vector<uint32_t> h(D.nf);
+    CK(hipMemcpy(h.data(), d_out, D.nf * 4, hipMemcpyDeviceToHost));
+    size_t bad = 0;
+    if (ref) for (uint32_t i = 0; i < D.nf; i++) if (h[i] != (*ref)[i]) { if (bad < 6) printf("   f %u got %u want %u\n", i, h[i], (*ref)[i]); bad++; }
+    printf("%-22s share<=%-6u %s k %2d threads 1024 grid %4d  %8.3f ms  %7.1f Gbases/s  -> %.2f ms per 2.93-Gbases batch  %s\n", name, share_max, KEY64 ? "64-bit keys" : "32-bit keys", k, grid, ms,
+           D.bases / (ms * 1e6), ms * 2.93e9 / D.bases, !ref ? "(not checked)" : bad ? "MISMATCH" : "same counts");
+    CK(hipFree(d_out)); CK(hipFree(d_ctr)); CK(hipFree(d_lists));
+    return 0;
+}
+
+template <bool KEY64>
+static int run8(const char* name, const Data& D, int k, int grid, const std::vector<uint32_t>* ref, uint32_t share_max, int stop = 0)
+{
+    uint32_t* d_out; uint32_t* d_ctr; void* d_lists;
+    CK(hipMalloc(&d_lists, (size_t)grid * (share_max + 65536) * 8));
+    CK(hipMalloc(&d_out, D.nf * 4));
+    CK(hipMalloc(&d_ctr, 4));
+    CK(hipMemset(d_out, 0xFF, D.nf * 4));
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    CK(hipMemset(d_ctr, 0, 4));
+    hipLaunchKernelGGL((k_rep8<KEY64>), dim3(grid), dim3(1024), 0, 0, D.seq, D.off, D.len, D.nf, k, d_out, d_ctr, share_max, d_lists, share_max / 1024 + 64, stop);
+    CK(hipDeviceSynchronize());
+    CK(hipMemset(d_ctr, 0, 4));
+    CK(hipEventRecord(a));
+    hipLaunchKernelGGL((k_rep8<KEY64>), dim3(grid), dim3(1024), 0, 0, D.seq, D.off, D.len, D.nf, k, d_out, d_ctr, share_max, d_lists, share_max / 1024 + 64, stop);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, a, b));
+    std::vector<uint32_t> h(D.nf);
+    CK(hipMemcpy(h.data(), d_out, D.nf * 4, hipMemcpyDeviceToHost));
+    size_t bad = 0;
+    if (ref) for (uint32_t i = 0; i < D.nf; i++) if (h[i] != (*ref)[i]) { if (bad < 6) printf("   f %u got %u want %u\n", i, h[i], (*ref)[i]); bad++; }
+    printf("%-22s share<=%-6u %s k %2d threads 1024 grid %4d  %8.3f ms  %7.1f Gbases/s  -> %.2f ms per 2.93-Gbases batch  %s\n", name, share_max, KEY64 ? "64-bit keys" : "32-bit keys", k, grid, ms,
+           D.bases / (ms * 1e6), ms * 2.93e9 / D.bases, !ref ? "(not checked)" : bad ? "MISMATCH" : "same counts");
+    CK(hipFree(d_out)); CK(hipFree(d_ctr)); CK(hipFree(d_lists));
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     const uint32_t nf = argc > 1 ? (uint32_t)atoi(argv[1]) : 65536u;
@@ -941,12 +1417,9 @@ int main(int argc, char** argv)
     for (int k : {13, 16, 21}) {
         std::vector<uint32_t> hc;
         if (check) host_counts(seq, off, len, k, hc);
-        if (k <= 13) run3<6>("aligned, prefetched", D, k, 256, check ? hc : (run<0, 20>("bitmap 128K ds_or", D, k, 1024, 256, ref, true), ref));
-        for (uint32_t share : {49152u, 65536u}) {
-            if (k <= 16) run6<false, false>("two-phase", D, k, 256, check ? &hc : nullptr, share);
-            if (k <= 16) run6<false, true>("two-phase, fast path", D, k, 256, check ? &hc : nullptr, share);
-            run6<true, false>("two-phase", D, k, 256, check ? &hc : nullptr, share);
-            run6<true, true>("two-phase, fast path", D, k, 256, check ? &hc : nullptr, share);
+        for (uint32_t share : {49152u, 65536u, 81920u}) {
+            if (k <= 15) run6<false, true>("two-phase, fast path", D, k, 256, check ? &hc : nullptr, share);
+            else run6<true, true>("two-phase, fast path", D, k, 256, check ? &hc : nullptr, share);
         }
     }
     return 0;
