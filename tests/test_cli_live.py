@@ -47,8 +47,8 @@ def case(seed, n):
         flags += ["-s", str(float(rng.choice([0.8, 0.85]))), "-S", str(float(rng.choice([0.85, 0.92])))]
     if rng.random() < 0.2:
         flags += ["-D"]
-    if rng.random() < 0.2:
-        flags += ["-p", str(int(rng.choice([2, 5]))), "-k", str(int(rng.choice([9, 11, 15, 24, 32])))]
+    if rng.random() < float(os.environ.get("TGSF_LIVE_GATE_P", "0.2")):       # (a campaign can ask for the repeat gate more often)
+        flags += ["-p", str(int(rng.choice([2, 5]))), "-k", str(int(rng.choice([9, 11, 12, 13, 15, 16, 24, 31, 32])))]
     if rng.random() < 0.2:
         flags += ["-r", str(int(rng.integers(3, n)))]
     adapters = None

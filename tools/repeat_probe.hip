@@ -1,5 +1,8 @@
-// repeat_probe.hip -- formulations of the repeat gate's distinct-k-mer count (k <= 13) side by side on random
-// fragments of the bench's shape; every variant's counts are checked against the first one's.
+// repeat_probe.hip -- formulations of the repeat gate's distinct-k-mer count side by side on random fragments of the
+// bench's shape (lognormal lengths, mean 45 kb): what round 1 shipped, the steps to k_repeat (k <= 12) and to
+// k_repeat_keys (k 13..31), and what was tried beside them.  Every variant's counts are checked against the round-1
+// kernel's and, in small runs (<= 8192 fragments), against a sort on the host.
+//   repeat_probe [fragments = 65536] [1 = longest first | 2 = none longer than a window]
 //   hipcc -O3 --offload-arch=gfx950 tools/repeat_probe.hip -o tools/repeat_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -1413,13 +1416,28 @@ int main(int argc, char** argv)
     CK(hipMemcpy(D.len, len.data(), nf * 4, hipMemcpyHostToDevice));
     printf("%u fragments, %.3f Gbases\n", nf, bases * 1e-9);
     std::vector<uint32_t> ref;
-    const bool check = nf <= 8192;
-    for (int k : {13, 16, 21}) {
+    const bool check = nf <= 8192;                 // small runs are checked against a sort on the host
+    for (int k : {11, 13, 21}) {
         std::vector<uint32_t> hc;
         if (check) host_counts(seq, off, len, k, hc);
-        for (uint32_t share : {49152u, 65536u, 81920u}) {
-            if (k <= 15) run6<false, true>("two-phase, fast path", D, k, 256, check ? &hc : nullptr, share);
-            else run6<true, true>("two-phase, fast path", D, k, 256, check ? &hc : nullptr, share);
+        const std::vector<uint32_t>* hp = check ? &hc : nullptr;
+        if (k <= 13) {
+            run<0, 20>("round 1: rolling k-mer", D, k, 256, 256, ref, true);
+            if (check) { size_t bad = 0; for (uint32_t i = 0; i < nf; i++) bad += ref[i] != hc[i]; printf("   host counts vs the round-1 kernel: %zu differ\n", bad); }
+            run<0, 20>("round 1: rolling k-mer", D, k, 1024, 256, ref, false);
+            run2<1>("word/lane, mask walk", D, k, 1024, 256, 0, ref);
+            run3<6>("= k_repeat", D, k, 256, ref);
+        }
+        if (k <= 15) run5<false>("LDS table of keys", D, k, 256, hp);
+        else run5<true>("LDS table of keys", D, k, 256, hp);
+        if (k <= 15) {
+            run6<false, false>("two maps + table, walk", D, k, 256, hp, 49152);
+            run6<false, true>("= k_repeat_keys", D, k, 256, hp, 65536);
+            run8<false>("two maps, lane lists", D, k, 256, hp, 131072, 0);
+        } else {
+            run6<true, false>("two maps + table, walk", D, k, 256, hp, 49152);
+            run6<true, true>("= k_repeat_keys", D, k, 256, hp, 65536);
+            run8<true>("two maps, lane lists", D, k, 256, hp, 131072, 0);
         }
     }
     return 0;
