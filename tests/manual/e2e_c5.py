@@ -14,7 +14,7 @@ bases, nbytes = synth.write_ont_fastq(fq, n, seed=5)
 print("%d ONT reads, %.2f Gbases, %.1f GB of text in %.1f s" % (n, bases / 1e9, nbytes / 1e9, time.time() - t0))
 fa = os.path.join(td, "rapid.fa")
 open(fa, "wb").write(b">rapid\n" + synth.ONT_RAPID + b"\n")
-for extra in (["-p", "100", "-k", "11"], ["-p", "100", "-k", "11", "-r", str(n // 2)], ["-p", "20", "-k", "15"], ["-p", "5", "-k", "21"]):
+for extra in (["-p", "100", "-k", "11"], ["-p", "100", "-k", "11", "-r", str(n // 2)], ["-p", "5", "-k", "13"], ["-p", "1", "-k", "16"], ["-p", "1", "-k", "16", "-g", "100m", "-d", "20"]):
     flags = ["-x", "ont", "-l", "1000", "-q", "10", "-5", "0", "-3", "0", "-a", fa, "-t", "32"] + extra
     print("flags:", " ".join(extra))
     res = {}
@@ -29,7 +29,7 @@ for extra in (["-p", "100", "-k", "11"], ["-p", "100", "-k", "11", "-r", str(n /
             best = dt if best is None else min(best, dt)
         assert p.returncode == 0, p.stderr.decode()[-1500:]
         ms = subprocess.run([os.path.join(ROOT, "tools", "fq_multiset"), out], capture_output=True).stdout.decode().split()
-        info = [l for l in p.stderr.decode().splitlines() if l.startswith("INFO: ") and "written to" not in l]
+        info = sorted(l.split(":", 2)[-1] if "input adapter" in l else l for l in p.stderr.decode().splitlines() if l.startswith("INFO: ") and "written to" not in l)
         res[tag] = (ms, info)
         print("%-9s wall %.2f s -> %.2f Gbases/s, output %s" % (tag, best, bases / best / 1e9, ms))
         for l in p.stderr.decode().splitlines():

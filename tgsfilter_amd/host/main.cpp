@@ -621,7 +621,6 @@ int main(int argc, char** argv)
         qp.no_qual = down_no_qual ? 1 : 0;
         qp.max_batch_bases = (1ull << 30); qp.max_batch_reads = 1u << 16;
         tgsf_ctx* qctx = nullptr;
-        if (L.create(&qp, o.devices[0], &qctx) != TGSF_OK) die(L.last_error(nullptr));
         std::vector<uint8_t> bs, bq; std::vector<uint64_t> boff; std::vector<uint32_t> blen;
         std::vector<tgsf_read_result> bres; std::vector<tgsf_fragment> bfr(16);
         auto run = [&] {
@@ -635,17 +634,26 @@ int main(int argc, char** argv)
             if (L.submit(qctx, &bi, &bo) != TGSF_OK) die(L.last_error(qctx));
             bs.clear(); bq.clear(); boff.clear(); blen.clear();
         };
+        // the kept records go to the device (packed, in input order) on a thread of their own while this one writes them
+        std::thread qc_pass([&] {
+            if (L.create(&qp, o.devices[0], &qctx) != TGSF_OK) die(L.last_error(nullptr));
+            for (size_t i = 0; i < clean_recs.size(); i++) {
+                if (!keep[i]) continue;
+                const CleanRec& c = clean_recs[i];
+                if (bs.size() + c.len > qp.max_batch_bases - (1u << 20) || blen.size() >= qp.max_batch_reads) run();
+                const size_t o0 = (bs.size() + 15) & ~size_t(15);
+                bs.resize(o0); bq.resize(o0);
+                bs.insert(bs.end(), c.seq, c.seq + c.len);
+                if (!down_no_qual) bq.insert(bq.end(), c.qual, c.qual + c.len); else bq.resize(bs.size());
+                boff.push_back(o0); blen.push_back(c.len);
+            }
+            run();
+        });
         const std::string lead(1, fastq_out ? '@' : '>'), nl("\n"), sep("\n+\n");
         std::string name;
         for (size_t i = 0; i < clean_recs.size(); i++) {
             if (!keep[i]) continue;
             const CleanRec& c = clean_recs[i];
-            if (bs.size() + c.len > qp.max_batch_bases - (1u << 20) || blen.size() >= qp.max_batch_reads) run();
-            const size_t o0 = (bs.size() + 15) & ~size_t(15);
-            bs.resize(o0); bq.resize(o0);
-            bs.insert(bs.end(), c.seq, c.seq + c.len);
-            if (!down_no_qual) bq.insert(bq.end(), c.qual, c.qual + c.len); else bq.resize(bs.size());
-            boff.push_back(o0); blen.push_back(c.len);
             out.text(lead);
             if (c.pass_num < 2) out.piece(c.name.data(), c.name.size());
             else { name.clear(); append_name(name, c.name, c.pass_num); out.text(name); }
@@ -655,7 +663,7 @@ int main(int argc, char** argv)
             out.text(nl);
             out.end_record();
         }
-        run();
+        qc_pass.join();
         uint64_t qnw = 0; int32_t qbc = 0; uint32_t qnb = 0;
         L.counters_len(qctx, &qnw, &qbc, &qnb);
         down_t.resize(qnw);
