@@ -33,7 +33,7 @@ for extra in (["-p", "100", "-k", "11"], ["-p", "100", "-k", "11", "-r", str(n /
         res[tag] = (ms, info)
         print("%-9s wall %.2f s -> %.2f Gbases/s, output %s" % (tag, best, bases / best / 1e9, ms))
         for l in p.stderr.decode().splitlines():
-            if l.startswith("TIMING"): print("   ", l[:700])
+            if l.startswith("TIMING") or l.startswith("DOWN"): print("   ", l[:1200])
     print("same output multiset:", res["ours"][0] == res["reference"][0], " same INFO lines:", res["ours"][1] == res["reference"][1])
     if res["ours"][1] != res["reference"][1]:
         for a, b in zip(res["ours"][1], res["reference"][1]):

@@ -23,6 +23,14 @@ def test_cli_golden(binary, golden_dir, name):
     cli_check.run_case(binary, golden_dir, name)
 
 
+@pytest.mark.parametrize("name", ["down_gd", "down_r", "down_R", "down_F", "fasta_down"])
+@pytest.mark.parametrize("how", ["text", "packed"])
+def test_cli_downsampling_qc_pass_both_ways(binary, golden_dir, name, how, monkeypatch):
+    """The QC pass over the kept reads reads them in place from the text or packs them first (TGSF_DOWN_QC): same files, same report."""
+    monkeypatch.setenv("TGSF_DOWN_QC", how)
+    cli_check.run_case(binary, golden_dir, name)
+
+
 def test_cli_gz_output_and_fasta(binary, golden_dir, tmp_path):
     """-o *.fq.gz (per-record gzip members) inflates to the reference's output; -o *.fa keeps the bases."""
     import gzip

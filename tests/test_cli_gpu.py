@@ -10,6 +10,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.mark.parametrize("name", ["down_gd", "down_r", "down_F", "fasta_down"])
+@pytest.mark.parametrize("how", ["text", "packed"])
+def test_cli_gpu_downsampling_qc_pass_both_ways(golden_dir, name, how, monkeypatch):
+    """The QC pass over the kept reads reads them in place from the text or packs them first (TGSF_DOWN_QC): same files, same report."""
+    monkeypatch.setenv("TGSF_DOWN_QC", how)
+    cli_check.run_case(os.path.join(ROOT, "tgsfilter_amd", "bin", "tgsfilter"), golden_dir, name)
+
+
 @pytest.mark.parametrize("name", hostmodel.GOLDEN_CASES + hostmodel.GOLDEN_CLI_ONLY)
 def test_cli_gpu_golden(golden_dir, name):
     binary = os.path.join(ROOT, "tgsfilter_amd", "bin", "tgsfilter")

@@ -580,6 +580,7 @@ int main(int argc, char** argv)
     uint64_t down_bases = 0;
     std::vector<int> down_lens;
     std::vector<uint64_t> down_t;
+    double t_d0 = now_s(), t_dsel = 0, t_dcreate = 0, t_dqc = 0, t_dwrite = 0, t_dclose = 0, t_dsubmit = 0, t_dfirst = 0, d_kept = 0, d_span = 0; int n_dsubmit = 0; bool d_in_place = false;
     if (o.downsample) {
         // Selection as the reference makes it (:2297-2344), container for container, so that ties at the cut fall
         // the same way when both programs are built with the same standard library: lengths keyed by record name
@@ -613,6 +614,7 @@ int main(int argc, char** argv)
         }
         std::vector<char> keep(clean_recs.size(), 0);
         for (size_t i = 0; i < clean_recs.size(); i++) keep[i] = chosen.count(full_name(clean_recs[i])) ? 1 : 0;
+        t_dsel = now_s() - t_d0;
         tgsf_params qp = p;
         qp.filter = 0; qp.only_qc = 1; qp.n_adapters = 0; qp.min_repeat = 0;
         // The reference's second pass re-reads what the filter pass wrote (:3129-3137): after a FASTA output
@@ -631,24 +633,83 @@ int main(int argc, char** argv)
             bi.seq = bs.data(); bi.qual = bq.data(); bi.offsets = boff.data(); bi.lengths = blen.data();
             bi.n_reads = (uint32_t)blen.size(); bi.n_bytes = bs.size() - 64;
             tgsf_batch_out bo{bres.data(), bfr.data(), (uint32_t)bfr.size(), 0};
+            const double s0 = now_s();
             if (L.submit(qctx, &bi, &bo) != TGSF_OK) die(L.last_error(qctx));
+            t_dsubmit += now_s() - s0; if (!n_dsubmit++) t_dfirst = now_s() - s0;
             bs.clear(); bq.clear(); boff.clear(); blen.clear();
         };
-        // the kept records go to the device (packed, in input order) on a thread of their own while this one writes them
+        // The kept records go to the device on a thread of their own while this one writes them.  Where they make up a fair
+        // part of the text between them they are read in place (the text itself is the batch, as in the filter pass: one
+        // copy to the device, none on the host); a very thin selection is packed first.
+        // (the writer took the batches as they came back from the feeders: the kept records are sorted by address first)
+        std::vector<uint32_t> by_addr;
+        uint64_t kept_bytes = 0, kept_span = 0;
+        for (size_t i = 0; i < clean_recs.size(); i++) {
+            if (!keep[i]) continue;
+            by_addr.push_back((uint32_t)i);
+            kept_bytes += (down_no_qual ? 1u : 2u) * (uint64_t)clean_recs[i].len;
+        }
+        std::sort(by_addr.begin(), by_addr.end(), [&](uint32_t x, uint32_t y) { return clean_recs[x].seq < clean_recs[y].seq; });
+        if (!by_addr.empty()) {
+            const CleanRec& a = clean_recs[by_addr.front()];
+            const CleanRec& z = clean_recs[by_addr.back()];
+            kept_span = (uint64_t)((down_no_qual ? z.seq : std::max(z.seq, z.qual)) + z.len - a.seq);
+            for (uint32_t i : by_addr) if (!down_no_qual && clean_recs[i].qual < clean_recs[i].seq) kept_span = 0;   // (never: FASTQ text)
+        }
+        const char* force = getenv("TGSF_DOWN_QC");                     // "text" / "packed": tests run both ways
+        const bool in_place = kept_span > 0 && (force ? !strcmp(force, "text") : kept_bytes * 12 >= kept_span);   // (packing runs at a tenth of the copy to the device)
+        d_in_place = in_place; d_kept = (double)kept_bytes; d_span = (double)kept_span;
         std::thread qc_pass([&] {
+            const double q0 = now_s();
             if (L.create(&qp, o.devices[0], &qctx) != TGSF_OK) die(L.last_error(nullptr));
-            for (size_t i = 0; i < clean_recs.size(); i++) {
-                if (!keep[i]) continue;
-                const CleanRec& c = clean_recs[i];
-                if (bs.size() + c.len > qp.max_batch_bases - (1u << 20) || blen.size() >= qp.max_batch_reads) run();
-                const size_t o0 = (bs.size() + 15) & ~size_t(15);
-                bs.resize(o0); bq.resize(o0);
-                bs.insert(bs.end(), c.seq, c.seq + c.len);
-                if (!down_no_qual) bq.insert(bq.end(), c.qual, c.qual + c.len); else bq.resize(bs.size());
-                boff.push_back(o0); blen.push_back(c.len);
+            t_dcreate = now_s() - q0;
+            if (in_place) {
+                std::vector<uint64_t> bqoff;
+                const char* base = nullptr;
+                uint64_t span = 0;
+                auto run_text = [&] {
+                    if (blen.empty()) return;
+                    bres.resize(blen.size());
+                    tgsf_batch_in bi; memset(&bi, 0, sizeof bi);
+                    bi.seq = bi.qual = reinterpret_cast<const uint8_t*>(base);
+                    bi.offsets = boff.data(); bi.qual_offsets = bqoff.data(); bi.lengths = blen.data();
+                    bi.n_reads = (uint32_t)blen.size(); bi.n_bytes = span;
+                    tgsf_batch_out bo{bres.data(), bfr.data(), (uint32_t)bfr.size(), 0};
+                    const double s0 = now_s();
+                    if (L.submit(qctx, &bi, &bo) != TGSF_OK) die(L.last_error(qctx));
+                    t_dsubmit += now_s() - s0; if (!n_dsubmit++) t_dfirst = now_s() - s0;
+                    boff.clear(); bqoff.clear(); blen.clear(); base = nullptr; span = 0;
+                };
+                for (uint32_t i : by_addr) {
+                    const CleanRec& c = clean_recs[i];
+                    const char* e = down_no_qual ? c.seq + c.len : c.qual + c.len;
+                    if (base && ((uint64_t)(e - base) > qp.max_batch_bases - (1u << 20) || blen.size() >= qp.max_batch_reads)) run_text();
+                    if (!base) base = c.seq;
+                    boff.push_back((uint64_t)(c.seq - base));
+                    bqoff.push_back((uint64_t)((down_no_qual ? c.seq : c.qual) - base));
+                    blen.push_back(c.len);
+                    span = std::max(span, (uint64_t)(e - base));
+                    if (span > qp.max_batch_bases) die("record larger than a batch");
+                }
+                run_text();
+            } else {
+                const size_t room = (size_t)std::min<uint64_t>(qp.max_batch_bases, kept_bytes / (down_no_qual ? 1 : 2) + 16 * by_addr.size() + 128);
+                bs.reserve(room); bq.reserve(room);
+                for (size_t i = 0; i < clean_recs.size(); i++) {
+                    if (!keep[i]) continue;
+                    const CleanRec& c = clean_recs[i];
+                    if (bs.size() + c.len > qp.max_batch_bases - (1u << 20) || blen.size() >= qp.max_batch_reads) run();
+                    const size_t o0 = (bs.size() + 15) & ~size_t(15);
+                    bs.resize(o0); bq.resize(o0);
+                    bs.insert(bs.end(), c.seq, c.seq + c.len);
+                    if (!down_no_qual) bq.insert(bq.end(), c.qual, c.qual + c.len); else bq.resize(bs.size());
+                    boff.push_back(o0); blen.push_back(c.len);
+                }
+                run();
             }
-            run();
+            t_dqc = now_s() - q0 - t_dcreate;
         });
+        const double w0 = now_s();
         const std::string lead(1, fastq_out ? '@' : '>'), nl("\n"), sep("\n+\n");
         std::string name;
         for (size_t i = 0; i < clean_recs.size(); i++) {
@@ -663,6 +724,7 @@ int main(int argc, char** argv)
             out.text(nl);
             out.end_record();
         }
+        t_dwrite = now_s() - w0;
         qc_pass.join();
         uint64_t qnw = 0; int32_t qbc = 0; uint32_t qnb = 0;
         L.counters_len(qctx, &qnw, &qbc, &qnb);
@@ -670,7 +732,7 @@ int main(int argc, char** argv)
         if (L.counters(qctx, down_t.data(), qnw) != TGSF_OK) die(L.last_error(qctx));
         L.destroy(qctx);
     }
-    if (!o.only_qc && !mapped_out) out.close();
+    { const double c0 = now_s(); if (!o.only_qc && !mapped_out) out.close(); t_dclose = now_s() - c0; }
 
     // ---- statistics, stderr, report: :3146-3235, :3240-3279, :3285-3328 ----
     uint64_t nw = 0; int32_t bc = 0; uint32_t nbins = 0;
@@ -759,6 +821,9 @@ int main(int argc, char** argv)
                 now_s() - t_start, t_prepass, t_libwait, t_load, t_dev, t_pipe, t_parse, ctxs.size(), t_gpu, t_write, t_widle, t_first,
                 t_fill_tail, t_close, now_s() - t_p0 - t_pipe, mapped_out ? "output: fallocate + mapped fill" : "output: writev", sink.t_falloc, t_drain, t_busy);
     }
+    if (timing && o.downsample)
+        fprintf(stderr, "DOWN: selection %.3f | QC pass over the kept reads (%s, %.2f GB of them in %.2f GB of text): context %.3f, batches + submits %.3f (its own thread; %d submits %.3f, the first %.3f) | writing them %.3f | closing the output %.3f\n",
+                t_dsel, d_in_place ? "read in place" : "packed", d_kept * 1e-9, d_span * 1e-9, t_dcreate, t_dqc, n_dsubmit, t_dsubmit, t_dfirst, t_dwrite, t_dclose);
     // everything is written and closed: skip the teardown of multi-GB mappings and of the HIP runtime
     if (timing) {
         struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts);
