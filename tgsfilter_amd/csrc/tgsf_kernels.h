@@ -889,6 +889,38 @@ TGSF_D int path_len_bv(const uint64_t* pf /*[256][2]*/, int Q, const uint8_t* t,
     return len + i + j;        // straight along the border (edlib.cpp:1028-1032, :1062-1067)
 }
 
+
+// The bytes of a window, sixteen per load (any alignment; whole chunks only, the tail byte by byte): fn(j, byte).
+// One lane walks its own window, so a load per byte would put the memory latency on every column.  (Fetching the
+// sixteen Eq rows of a chunk ahead as well was measured slower: 1.9 ms against 0.8 for k_end_windows.)
+template <class F>
+TGSF_D void each_byte_fwd(const uint8_t* t, int T, F fn)
+{
+    int j = 0;
+    for (; j + 16 <= T; j += 16) {
+        uint4 v;
+        __builtin_memcpy(&v, t + j, 16);
+        const uint32_t c[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 16; q++) fn(j + q, (c[q >> 2] >> (8 * (q & 3))) & 0xFFu);
+    }
+    for (; j < T; j++) fn(j, (uint32_t)t[j]);
+}
+// the same backwards: fn(l, t[end - l]) for l = 0 .. n-1
+template <class F>
+TGSF_D void each_byte_bwd(const uint8_t* t, int end, int n, F fn)
+{
+    int l = 0;
+    for (; l + 16 <= n; l += 16) {
+        uint4 v;
+        __builtin_memcpy(&v, t + end - l - 15, 16);
+        const uint32_t c[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 16; q++) fn(l + q, (c[(15 - q) >> 2] >> (8 * ((15 - q) & 3))) & 0xFFu);
+    }
+    for (; l < n; l++) fn(l, (uint32_t)t[end - l]);
+}
+
 template <int NW>
 TGSF_D int start_of(const DevParams& P, int a, const uint8_t* t, int end, int best)
 {
@@ -899,9 +931,16 @@ TGSF_D int start_of(const DevParams& P, int a, const uint8_t* t, int end, int be
     int maxl = end + 1;
     if (maxl > Q + best) maxl = Q + best;
     int best_l = 1;
-    for (int l = 1; l <= maxl; l++) {
-        bv_step<NW>(b, pr + (size_t)t[end - (l - 1)] * kPeqW, 1, Q);
-        if (b.score == best) best_l = l;
+    if constexpr (NW == 1) {
+        each_byte_bwd(t, end, maxl, [&](int l, uint32_t sym) TGSF_INLINE_LAMBDA {
+            bv_step<NW>(b, pr + (size_t)sym * kPeqW, 1, Q);
+            if (b.score == best) best_l = l + 1;
+        });
+    } else {
+        for (int l = 1; l <= maxl; l++) {
+            bv_step<NW>(b, pr + (size_t)t[end - (l - 1)] * kPeqW, 1, Q);
+            if (b.score == best) best_l = l;
+        }
     }
     return end - best_l + 1;
 }
@@ -935,11 +974,13 @@ TGSF_D WinAln align_window(const DevParams& P, int a, const uint8_t* t, int T, i
     Bv<NW> s;
     bv_init(s, Q);
     int cur = kk + 1;
-    for (int j = 0; j < T; j++) {
-        bv_step<NW>(s, pf + (size_t)t[j] * kPeqW, 0, Q);
+    auto column = [&](int j, uint32_t sym) TGSF_INLINE_LAMBDA {
+        bv_step<NW>(s, pf + (size_t)sym * kPeqW, 0, Q);
         if (s.score < cur) { cur = s.score; r.first_end = j; r.n = 0; }
         if (s.score == cur && cur <= kk) { r.last_end = j; r.n++; }
-    }
+    };
+    if constexpr (NW == 1) each_byte_fwd(t, T, column);
+    else for (int j = 0; j < T; j++) column(j, (uint32_t)t[j]);
     if (cur > kk) return r;
     r.best = cur;
     r.start0 = start_of<NW>(P, a, t, r.first_end, cur);          // edlib.cpp:246-255
