@@ -4,6 +4,7 @@
 cd $GRAFT_REPO_ROOT
 python -m pytest tests -x -q -m gpu --durations=10 > gpurun_out/gpu_suite.txt 2>&1; tail -4 gpurun_out/gpu_suite.txt
 bash tools/profile_round.sh r02 > gpurun_out/profile_round.log 2>&1; tail -2 gpurun_out/profile_round.log
+cp gpurun_out/prof_r02/traffic.json profiles/traffic.json      # (on the box: the bench line below quotes the traffic of THIS build)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for k in 11 21; do
