@@ -29,7 +29,7 @@ for tag, exe in (("ours", os.path.join(ROOT, "tgsfilter_amd", "bin", "tgsfilter"
     res[tag] = (ms, info)
     print("%-9s wall %.2f s -> %.2f Gbases/s, output %s" % (tag, best, bases / best / 1e9, ms))
     for l in p.stderr.decode().splitlines():
-        if l.startswith("TIMING"): print("   ", l[:700])
+        if l.startswith("TIMING") or l.startswith("PREPASS"): print("   ", l[:700])
 print("same output multiset:", res["ours"][0] == res["reference"][0], " same INFO lines:", res["ours"][1] == res["reference"][1])
 if res["ours"][1] != res["reference"][1]:
     for a, b in zip(res["ours"][1], res["reference"][1]):

@@ -1,4 +1,6 @@
 #include "prepass.h"
+#include <chrono>
+#include <cstdio>
 
 #include <unistd.h>
 
@@ -59,19 +61,15 @@ std::string rev_comp(const std::string& s)
 // CheckBaseContent, :1079-1146
 static int check_base_content(const std::vector<std::string>& ends, int check_len, int seq_num, float end_bias)
 {
+    // column of a base in the tallies (4 = not counted): a table instead of a switch, the bases being random
+    static const struct Col { uint8_t of[256]; Col() { memset(of, 4, sizeof of); of['A'] = of['a'] = 0; of['T'] = of['t'] = 1; of['G'] = of['g'] = 2; of['C'] = of['c'] = 3; } } col;
+    std::vector<int> cnt5((size_t)check_len * 5, 0);
+    for (const std::string& s : ends) {
+        const size_t n = std::min(s.size(), (size_t)check_len);
+        for (size_t i = 0; i < n; i++) cnt5[i * 5 + col.of[(unsigned char)s[i]]]++;
+    }
     std::vector<int> cnt((size_t)check_len * 4, 0);
-    for (const std::string& s : ends)
-        for (size_t i = 0; i < s.size(); i++) {
-            int c;
-            switch (s[i]) {
-            case 'A': case 'a': c = 0; break;
-            case 'T': case 't': c = 1; break;
-            case 'G': case 'g': c = 2; break;
-            case 'C': case 'c': c = 3; break;
-            default: continue;
-            }
-            cnt[i * 4 + c]++;
-        }
+    for (int i = 0; i < check_len; i++) for (int j = 0; j < 4; j++) cnt[(size_t)i * 4 + j] = cnt5[(size_t)i * 5 + j];
     const int max_diff = (int)((seq_num * end_bias) / 100);          // :1097 int(float)
     int trim = 0;
     for (int i = 1; i < check_len - 1; i++) {
@@ -87,6 +85,9 @@ static int check_base_content(const std::vector<std::string>& ends, int check_le
     }
     return trim;
 }
+
+static double pp_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static double g_pp_create = 0, g_pp_align = 0; static int g_pp_calls = 0;
 
 // adapterSearch, :1148-1209, with the 22 x N alignments done by the library.
 static void adapter_search(const Options& o, const std::vector<std::string>& ends, std::string& adapter, float& depth)
@@ -116,8 +117,10 @@ static void adapter_search(const Options& o, const std::vector<std::string>& end
     p.max_batch_reads = (uint32_t)(per_call * 22 / (22 * 2) + 64);      // n problems <= cap_reads * A * 2
     p.max_batch_bases = 1 << 20; p.max_read_len = 1 << 16;
     tgsf_ctx* ctx = nullptr;
+    const double c0 = pp_now();
     if (lib().create(&p, o.devices.empty() ? o.device : o.devices[0], &ctx) != TGSF_OK) { std::cerr << "Error: " << lib().last_error(nullptr) << std::endl; fflush(nullptr); _exit(255); }
 
+    g_pp_create += pp_now() - c0;
     // totals per adapter in the reference's own container (:1150, :1171): the winner among equal totals is
     // whatever its iteration order and std::sort make of it, reproduced here by using the same ones
     std::unordered_map<int, int> maps;
@@ -135,9 +138,11 @@ static void adapter_search(const Options& o, const std::vector<std::string>& end
         const uint32_t n = (uint32_t)off.size();
         if (!n) continue;
         res.assign((size_t)n * 4, 0); eds.assign((size_t)n * 2, 0);
+        const double a0 = pp_now();
         if (lib().align_windows(ctx, buf.data(), buf.size(), off.data(), len.data(), aid.data(), kk.data(), n, res.data(), eds.data()) != TGSF_OK) {
             std::cerr << "Error: " << lib().last_error(ctx) << std::endl; fflush(nullptr); _exit(255);
         }
+        g_pp_align += pp_now() - a0; g_pp_calls++;
         for (uint32_t i = 0; i < n; i++)
             if (res[(size_t)i * 4 + 1] > 0)                             // numAln > 0, :1170 (problems are read-major, as :1156-1158)
                 maps[(int)aid[i]] += res[(size_t)i * 4 + 2] - res[(size_t)i * 4 + 0];   // mlen = alignmentLength - editDistance
@@ -155,6 +160,7 @@ static void adapter_search(const Options& o, const std::vector<std::string>& end
 PrepassResult run_prepass(Options& o, const std::function<bool(Rec&)>& next_record)
 {
     PrepassResult R;
+    const double t0 = pp_now();
     int check_len = std::max(std::max(o.end_len, o.bc_len), 100);       // :897-904
     int min_len = std::max(o.min_len, 2 * check_len);                   // :906-909
     const int max_seq = std::max(o.ad_num, o.bc_num);                   // :911-914
@@ -177,6 +183,7 @@ PrepassResult run_prepass(Options& o, const std::function<bool(Rec&)>& next_reco
                 for (int i = 0; i < check_len; i++) { const char c = r.qual[i]; if (min_qc > c) min_qc = c; if (max_qc < c) max_qc = c; }
         }
     }
+    const double t_read = pp_now() - t0;
     if (o.in_type == 1 || o.in_type == 2) {                             // Get_qType, :1042-1077
         if (min_qc >= 33 && min_qc <= 78 && max_qc >= 33 && max_qc <= 127) R.qtype = 33;
         else if (min_qc >= 64 && min_qc <= 108 && max_qc >= 64 && max_qc <= 127) R.qtype = 64;
@@ -196,19 +203,29 @@ PrepassResult run_prepass(Options& o, const std::function<bool(Rec&)>& next_reco
             else o.min_q = 0;
         }
     }
+    const double t1 = pp_now();
+    double t_bc = 0;
     if (o.filter) {                                                     // :926-945
-        if (o.head_trim < 0) R.trim5p = check_base_content(ends5, check_len, seq_num, o.end_bias);
-        if (o.tail_trim < 0) R.trim3p = check_base_content(ends3, check_len, seq_num, o.end_bias);
+        {   // the two checks side by side, as the reference runs them (:930-936)
+            std::thread t3;
+            if (o.tail_trim < 0) t3 = std::thread([&] { R.trim3p = check_base_content(ends3, check_len, seq_num, o.end_bias); });
+            if (o.head_trim < 0) R.trim5p = check_base_content(ends5, check_len, seq_num, o.end_bias);
+            if (t3.joinable()) t3.join();
+        }
         // :1135-1137 clamps trim5p to -e BEFORE the result of the running check is stored, and the 5' and the 3'
         // check run as two threads (:930-936): what the clamp sees is the 5' result when the 3' thread gets there
         // after the 5' thread has stored it -- the order observed in practice (the 5' thread starts first).  So the
         // 5' trim is clamped exactly when both checks run; the 3' trim never is.
         if (o.head_trim < 0 && o.tail_trim < 0 && R.trim5p > o.bc_len) R.trim5p = o.bc_len;
+        t_bc = pp_now() - t1;
         if (o.adapter_file.empty()) {
             adapter_search(o, ends5, R.adapter5p, R.depth5p);
             adapter_search(o, ends3, R.adapter3p, R.depth3p);
         }
     }
+    if (getenv("TGSF_TIMING"))
+        fprintf(stderr, "PREPASS: %d reads looked at in %.3f s | base content %.3f | adapter search %.3f (contexts %.3f, %d alignment calls %.3f)\n",
+                seq_num, t_read, t_bc, pp_now() - t1 - t_bc, g_pp_create, g_pp_calls, g_pp_align);
     return R;
 }
 
