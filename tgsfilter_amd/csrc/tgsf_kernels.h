@@ -12,7 +12,7 @@
 //   k_mid_scan*      GetEditDistance middle: Myers infix scan, 1 lane = 1024 columns  [VALU-bound, dominant]
 //   k_mid_resolve    start locations + path of the first location + similarity gates
 //   k_regions<count|emit>   adapterMap: merge drop regions, keep regions, DropInfo
-//   k_repeat         GetKmerCount gate (-p/-k), only when asked for
+//   k_repeat / k_repeat_keys   GetKmerCount gate (-p/-k), only when asked for: LDS bitmap (k <= 12) / hashed maps + keys (13..32)
 //   k_clean_plan     reads kept whole; which way the clean tables are cheaper to tally
 //   k_frag_prepare + sort + k_stats<clean> + k_gate_frags + k_end_tables<clean>
 //   k_finalize       tgsf_read_result / tgsf_fragment records
@@ -1500,7 +1500,8 @@ TGSF_KERNEL k_regions(DevParams P, DevBatch B)
 }
 
 // ---------------------------------------------------------------------------
-// k_repeat: the repeat gate, GetKmerCount (src/TGSFilter.cpp:1703-1753, :1982-1989), for k <= 13.
+// k_repeat: the repeat gate, GetKmerCount (src/TGSFilter.cpp:1703-1753, :1982-1989), for k <= 13 (launched for k <= 12:
+// from 13 on k_repeat_keys is faster).
 // repeat = (#k-mers) - (#distinct k-mers) of a fragment; fragments below -p are dropped before any
 // clean statistics.  k-mers are 2-bit codes (A0 C1 G2 T3, every other byte 0), first base in the top bits.
 //
