@@ -2,6 +2,8 @@
 parameters inside the supported domain, random read sets, full comparison with the oracle."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from tests import parity
@@ -45,8 +47,8 @@ def random_case(seed: int, n_reads: int):
         filter=bool(rng.random() < 0.9),
         qtype=33,
     )
-    if rng.random() < 0.2:
-        kw.update(min_repeat=int(rng.choice([50, 400])), kmer=int(rng.choice([7, 11, 12, 14, 20, 32])))
+    if rng.random() < float(os.environ.get("TGSF_FUZZ_GATE_P", "0.2")):      # (a campaign can ask for the repeat gate more often)
+        kw.update(min_repeat=int(rng.choice([50, 400, 1, 5])), kmer=int(rng.choice([7, 11, 12, 14, 20, 32, 9, 13, 15, 16, 17, 31])))
     if rng.random() < 0.15:
         kw.update(no_qual=True)
     return kind, reads, kw

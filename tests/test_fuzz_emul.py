@@ -8,3 +8,11 @@ from tests.test_emul_parity import emul  # noqa: F401  (fixture)
 @pytest.mark.parametrize("seed", range(100, 160))
 def test_fuzz_emul(emul, seed):  # noqa: F811
     fuzz.run_case(emul, seed, 24)
+
+
+@pytest.mark.parametrize("seed", [20081, 20104])
+def test_fuzz_emul_loose_thresholds_long_adapters(emul, seed, monkeypatch):  # noqa: F811
+    """Cases a wider campaign found: -M 20..25 with 150- and 241-bp adapters makes every lane list candidates (the first lane
+    of a read one per new low while the score comes down from Q); the candidate pool has room for that."""
+    monkeypatch.setenv("TGSF_FUZZ_GATE_P", "0.6")
+    fuzz.run_case(emul, seed, 150)

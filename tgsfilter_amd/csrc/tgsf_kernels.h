@@ -1272,6 +1272,7 @@ template <int NW>
 TGSF_KERNEL k_mid_scanw(DevParams P, DevBatch B, int a)
 {
     TGSF_SHARED uint64_t eqt[256][NW];
+    TGSF_SHARED int32_t tie_col[256][4];
     for (uint32_t i = TGSF_COOP_BEGIN; i < 256u * NW; i += TGSF_COOP_STRIDE)
         eqt[i / NW][i % NW] = P.peq_fwd[(size_t)a * 256 * kPeqW + (size_t)(i / NW) * kPeqW + (i % NW)];
     TGSF_BLOCK_SYNC();
@@ -1294,14 +1295,24 @@ TGSF_KERNEL k_mid_scanw(DevParams P, DevBatch B, int a)
     if (c1 > ML) c1 = ML;
     Bv<NW> s;
     bv_init(s, Q);
-    int lim = P.k_mid[a];
+    // As in k_mid_scan1: only the columns at the read's global minimum matter, so the lane keeps the columns tying ITS best
+    // value (a 4-slot buffer, void as soon as a column does strictly better) and hands them over when the buffer fills or
+    // the block ends -- with k close to Q every new low on the way down from Q would otherwise be a candidate.
+    int32_t* ties = tie_col[threadIdx.x];
+    int ntie = 0;
+    int lim = P.k_mid[a] + 1;                                          // nothing at or below k yet
     int c = c0 - (Q + P.k_mid[a]);
     if (c < 0) c = 0;
     for (; c < c0; c++) bv_step<NW>(s, eqt[mid[c]], 0, Q);
     for (; c < c1; c++) {
         bv_step<NW>(s, eqt[mid[c]], 0, Q);
-        if (s.score <= lim) { lim = s.score; push_candidate(B, r, c, s.score, a); }
+        if (s.score < lim) { lim = s.score; ntie = 0; }
+        if (s.score == lim && lim <= P.k_mid[a]) {
+            if (ntie == 4) { for (int i = 0; i < 4; i++) push_candidate(B, r, ties[i], lim, a); ntie = 0; }
+            ties[ntie++] = c;
+        }
     }
+    for (int i = 0; i < ntie; i++) push_candidate(B, r, ties[i], lim, a);
 }
 
 // ---------------------------------------------------------------------------

@@ -420,7 +420,9 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     if (fcap64 < n + 16 && !p->filter) fcap64 = n + 16;
     B.fcap = (uint32_t)std::min<uint64_t>(fcap64, 0x7FFFFFF0ull);
     B.max_tiles = (c->max_read_len + kTileBases - 1) / kTileBases;
-    uint64_t pool = c->cap_bases / 64 + 65536;
+    // candidates are rare at sensible thresholds (1e-6 per column), and a lane only hands over the columns tying its best
+    // value (4 at a time): the pool stays small for any threshold; some room per read and adapter on top
+    uint64_t pool = c->cap_bases / 64 + 65536 + (uint64_t)n * 16u * (uint64_t)std::max(p->n_adapters, 1);
     B.pool_cap = (uint32_t)std::min<uint64_t>(pool, 1ull << 28);
     const size_t nitems = n + (size_t)B.fcap;         // clean pass: fragments, and reads to take back out
     if (!e) e = dev_alloc(c, &c->d_seq, cap_bytes);
