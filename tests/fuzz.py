@@ -24,7 +24,10 @@ def random_case(seed: int, n_reads: int):
     na = int(rng.choice([1, 2, 2, 3, 4]))
     ads = [LIB_ADAPTERS[i] for i in rng.choice(len(LIB_ADAPTERS), na, replace=False)]
     planted = ads[0] if rng.random() < 0.8 else None
-    reads = synth.make_reads(int(rng.integers(1, 1 << 30)), n_reads, kind, mean_len=float(rng.choice([800, 2500, 6000])),
+    mean_len = float(rng.choice([800, 2500, 6000]))
+    if os.environ.get("TGSF_FUZZ_MEAN_LEN"):                          # (a campaign can ask for long reads: windows of the repeat gate, many scan blocks)
+        mean_len = float(os.environ["TGSF_FUZZ_MEAN_LEN"])
+    reads = synth.make_reads(int(rng.integers(1, 1 << 30)), n_reads, kind, mean_len=mean_len,
                              zoo=bool(rng.random() < 0.7), pmid=float(rng.choice([0.0, 0.05, 0.3])),
                              **({"adapter": planted} if planted else {}))
     end_len = int(rng.choice([150, 60, 300]))
