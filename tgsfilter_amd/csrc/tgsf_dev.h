@@ -56,6 +56,7 @@ struct DevBatch {
     int32_t*  clip5;           // [n*A] 5' hit: end of drop region (0 = no hit)
     int32_t*  clip3;           // [n*A] 3' hit: start of drop region (-1 = no hit)
     int32_t*  mid_head;        // [n] head of the candidate list, -1
+    int32_t*  mid_best;        // [n*A] best middle-scan value any lane has handed over so far (prunes the hand-overs)
     MidCand*  pool;            // candidate / region pool
     uint32_t  pool_cap;
     uint32_t* pool_n;          // number of slots used

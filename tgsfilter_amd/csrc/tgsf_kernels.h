@@ -186,7 +186,7 @@ TGSF_KERNEL k_prepare(DevParams P, DevBatch B, uint32_t max_read_len)
         B.trimmed[r] = 0;
         B.seg_cnt[r] = 0;
         B.nfr[r] = 0;
-        for (int a = 0; a < A; a++) { B.clip5[(size_t)r * A + a] = 0; B.clip3[(size_t)r * A + a] = -1; }
+        for (int a = 0; a < A; a++) { B.clip5[(size_t)r * A + a] = 0; B.clip3[(size_t)r * A + a] = -1; B.mid_best[(size_t)r * A + a] = 0x7FFFFFFF; }
         if (L == 0 || L > max_read_len) { set_status(B, DS_BAD_LEN, r); B.len[r] = 0; continue; }
         const uint32_t v = (L + kTileBases - 1) / kTileBases;
         if (use_lds) atomicAdd(&h[v], 1u); else atomicAdd(&B.tile_hist[v], 1u);
@@ -1108,6 +1108,14 @@ TGSF_KERNEL k_end_windows(DevParams P, DevBatch B)
 // of sequence.  Peq rows live in LDS ([symbol][adapter]), sequence bytes are
 // fetched 16 at a time per lane.
 // ---------------------------------------------------------------------------
+// Only the columns at the read's GLOBAL minimum matter.  A lane about to hand over the columns tying its own best value
+// first compares that value with the best any lane of the read has handed over so far (one atomicMin): worse, and the
+// columns are dropped here.  With thresholds close to Q every lane has a "best" at or below k; this keeps the pool to
+// the lanes that tie or improve the read's running minimum.
+TGSF_D bool worth_handing_over(const DevBatch& B, uint32_t r, int a, int A, int score)
+{
+    return score <= atomicMin(&B.mid_best[(size_t)r * A + a], score);
+}
 TGSF_D void push_candidate(const DevBatch& B, uint32_t r, int pos, int score, int a)
 {
     uint32_t idx = atomicAdd(B.pool_n, 1u);
@@ -1183,7 +1191,8 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
     // list when the buffer fills or the block ends: the pool stays small for any threshold.
     int32_t (*ties)[4] = tie_col[threadIdx.x];
     auto flush_ties = [&](int j) {
-        for (int i = 0; i < ntie[j]; i++) push_candidate(B, r, ties[j][i], lim[j], a0 + j);
+        if (ntie[j] > 0 && worth_handing_over(B, r, a0 + j, P.n_adapters, lim[j]))
+            for (int i = 0; i < ntie[j]; i++) push_candidate(B, r, ties[j][i], lim[j], a0 + j);
         ntie[j] = 0;
     };
     auto note = [&](int j, int sc, int col) {
@@ -1308,11 +1317,14 @@ TGSF_KERNEL k_mid_scanw(DevParams P, DevBatch B, int a)
         bv_step<NW>(s, eqt[mid[c]], 0, Q);
         if (s.score < lim) { lim = s.score; ntie = 0; }
         if (s.score == lim && lim <= P.k_mid[a]) {
-            if (ntie == 4) { for (int i = 0; i < 4; i++) push_candidate(B, r, ties[i], lim, a); ntie = 0; }
+            if (ntie == 4) {
+                if (worth_handing_over(B, r, a, P.n_adapters, lim)) for (int i = 0; i < 4; i++) push_candidate(B, r, ties[i], lim, a);
+                ntie = 0;
+            }
             ties[ntie++] = c;
         }
     }
-    for (int i = 0; i < ntie; i++) push_candidate(B, r, ties[i], lim, a);
+    if (ntie > 0 && worth_handing_over(B, r, a, P.n_adapters, lim)) for (int i = 0; i < ntie; i++) push_candidate(B, r, ties[i], lim, a);
 }
 
 // ---------------------------------------------------------------------------

@@ -436,6 +436,7 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     if (!e) e = dev_alloc(c, &B.clip5, n * A);
     if (!e) e = dev_alloc(c, &B.clip3, n * A);
     if (!e) e = dev_alloc(c, &B.mid_head, n);
+    if (!e) e = dev_alloc(c, &B.mid_best, n * A);
     if (!e) e = dev_alloc(c, &B.pool, (size_t)B.pool_cap);
     if (!e) e = dev_alloc(c, &B.pool_n, 4);
     if (!e) e = dev_alloc(c, &B.seg_cnt, n + 1);
