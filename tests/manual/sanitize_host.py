@@ -13,7 +13,7 @@ THREADED = {"TGSF_BATCH_BYTES": "30000", "TGSF_CTX_PER_DEVICE": "3", "TGSF_FILL_
 STREAMED = {"TGSF_STREAM_MIN_BYTES": "1", "TGSF_CHUNK_BYTES": "20000", "TGSF_FILL_MIN_BYTES": "1", "TGSF_STRIDE_BYTES": "50000",
             "TGSF_CTX_PER_DEVICE": "3"}
 CASES = [("ont_zoo", None), ("hifi_zoo", None), ("hifi_bam", None), ("ont_sam", None), ("ont_zoo", "gzip"), ("ont_fasta", "bgzf"),
-         ("down_r", None), ("hifi_auto", None), ("repeat_k21", None), ("huge_adapter", None), ("hifi_bam_auto", None)]
+         ("down_r", None), ("down_gd", None), ("down_F", None), ("fasta_down", None), ("hifi_auto", None), ("ont_auto", None), ("repeat_k21", None), ("huge_adapter", None), ("hifi_bam_auto", None)]
 bad = 0
 for kind, target, opts in (("asan", "tgsfilter_asan", {"ASAN_OPTIONS": "detect_leaks=0:halt_on_error=1", "UBSAN_OPTIONS": "halt_on_error=1:print_stacktrace=1"}),
                            ("tsan", "tgsfilter_tsan", {"TSAN_OPTIONS": "halt_on_error=1:report_thread_leaks=0"})):   # the program leaves with _exit: threads are not joined
