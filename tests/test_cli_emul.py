@@ -26,9 +26,11 @@ def test_cli_golden(binary, golden_dir, name):
 @pytest.mark.parametrize("name", ["down_gd", "down_r", "down_R", "down_F", "fasta_down"])
 @pytest.mark.parametrize("how", ["text", "packed"])
 def test_cli_downsampling_qc_pass_both_ways(binary, golden_dir, name, how, monkeypatch):
-    """The QC pass over the kept reads reads them in place from the text or packs them first (TGSF_DOWN_QC): same files, same report."""
+    """The QC pass over the kept reads reads them in place from the text or packs them first (TGSF_DOWN_QC): same files, same report.
+    The records are written by threads into a mapping of the file (forced here: TGSF_DOWN_MAP_MIN) or by the single-stream writer."""
     monkeypatch.setenv("TGSF_DOWN_QC", how)
-    cli_check.run_case(binary, golden_dir, name)
+    monkeypatch.setenv("TGSF_DOWN_MAP_MIN", "1" if how == "text" else "1000000000000")
+    cli_check.run_case(binary, golden_dir, name, extra_args=["-t", "5"])
 
 
 def test_cli_gz_output_and_fasta(binary, golden_dir, tmp_path):

@@ -15,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_cli_gpu_downsampling_qc_pass_both_ways(golden_dir, name, how, monkeypatch):
     """The QC pass over the kept reads reads them in place from the text or packs them first (TGSF_DOWN_QC): same files, same report."""
     monkeypatch.setenv("TGSF_DOWN_QC", how)
-    cli_check.run_case(os.path.join(ROOT, "tgsfilter_amd", "bin", "tgsfilter"), golden_dir, name)
+    monkeypatch.setenv("TGSF_DOWN_MAP_MIN", "1" if how == "text" else "1000000000000")      # threads into a mapping / the single-stream writer
+    cli_check.run_case(os.path.join(ROOT, "tgsfilter_amd", "bin", "tgsfilter"), golden_dir, name, extra_args=["-t", "5"])
 
 
 @pytest.mark.parametrize("name", hostmodel.GOLDEN_CASES + hostmodel.GOLDEN_CLI_ONLY)

@@ -580,7 +580,7 @@ int main(int argc, char** argv)
     uint64_t down_bases = 0;
     std::vector<int> down_lens;
     std::vector<uint64_t> down_t;
-    double t_d0 = now_s(), t_dsel = 0, t_dcreate = 0, t_dqc = 0, t_dwrite = 0, t_dclose = 0, t_dsubmit = 0, t_dfirst = 0, d_kept = 0, d_span = 0; int n_dsubmit = 0; bool d_in_place = false;
+    double t_d0 = now_s(), t_dsel = 0, t_dcreate = 0, t_dqc = 0, t_dwrite = 0, t_dclose = 0, t_dsubmit = 0, t_dfirst = 0, d_kept = 0, d_span = 0; int n_dsubmit = 0; bool d_in_place = false, d_mapped = false;
     if (o.downsample) {
         // Selection as the reference makes it (:2297-2344), container for container, so that ties at the cut fall
         // the same way when both programs are built with the same standard library: lengths keyed by record name
@@ -712,7 +712,61 @@ int main(int argc, char** argv)
         const double w0 = now_s();
         const std::string lead(1, fastq_out ? '@' : '>'), nl("\n"), sep("\n+\n");
         std::string name;
-        for (size_t i = 0; i < clean_recs.size(); i++) {
+        // A regular file of some size is written as the filter pass writes its own (MappedSink): every record's place is
+        // known, so the pages are instantiated in one go and threads copy the records in -- a single writev stream is a
+        // 6-GB/s copy under the inode lock.
+        bool down_mapped = false;
+        {
+            const char* w = getenv("TGSF_WRITER");
+            const char* mn = getenv("TGSF_DOWN_MAP_MIN");              // tests force the mapped way on small outputs
+            const uint64_t map_min = mn ? strtoull(mn, nullptr, 10) : (256ull << 20);
+            std::vector<uint32_t> kept;
+            std::vector<uint64_t> at;
+            uint64_t total_out = 0;
+            if (!o.out_gz && !o.out_file.empty() && !(w && !strcmp(w, "writev"))) {
+                for (size_t i = 0; i < clean_recs.size(); i++) {
+                    if (!keep[i]) continue;
+                    const CleanRec& c = clean_recs[i];
+                    size_t nm = c.name.size();
+                    if (c.pass_num >= 2) { name.clear(); append_name(name, c.name, c.pass_num); nm = name.size(); }
+                    kept.push_back((uint32_t)i); at.push_back(total_out);
+                    total_out += 1 + nm + 1 + c.len + (fastq_out ? 3 + (uint64_t)c.len : 0) + 1;
+                }
+            }
+            MappedSink dsink;
+            if (total_out >= std::max<uint64_t>(map_min, 1) && dsink.open(o.out_file, total_out)) {
+                dsink.reserve_to(total_out);
+                const int T = std::max(1, std::min(o.n_thread, 16));
+                char* const base = dsink.place(0);
+                std::vector<std::thread> team;
+                for (int t = 0; t < T; t++) team.emplace_back([&, t] {
+                    const uint64_t lo = total_out / T * t, hi = t + 1 == T ? total_out : total_out / T * (t + 1);
+                    const size_t r0 = (size_t)(std::lower_bound(at.begin(), at.end(), lo) - at.begin());
+                    const size_t r1 = (size_t)(std::lower_bound(at.begin(), at.end(), hi) - at.begin());
+                    if (r0 >= r1) return;
+                    const uint64_t b0 = at[r0], b1 = r1 < at.size() ? at[r1] : total_out;
+                    dsink.populate(b0, b1 - b0);                       // (no fallocate runs beside these faults)
+                    std::string nm;
+                    for (size_t r = r0; r < r1; r++) {
+                        const CleanRec& c = clean_recs[kept[r]];
+                        char* p = base + at[r];
+                        *p++ = fastq_out ? '@' : '>';
+                        if (c.pass_num < 2) { memcpy(p, c.name.data(), c.name.size()); p += c.name.size(); }
+                        else { nm.clear(); append_name(nm, c.name, c.pass_num); memcpy(p, nm.data(), nm.size()); p += nm.size(); }
+                        *p++ = '\n';
+                        stream_copy(p, c.seq, c.len); p += c.len;
+                        if (fastq_out) { memcpy(p, "\n+\n", 3); p += 3; stream_copy(p, c.qual, c.len); p += c.len; }
+                        *p++ = '\n';
+                    }
+                    stream_fence();
+                });
+                for (std::thread& th : team) th.join();
+                dsink.place(total_out);
+                dsink.close();
+                down_mapped = true;
+            }
+        }
+        for (size_t i = 0; i < clean_recs.size() && !down_mapped; i++) {
             if (!keep[i]) continue;
             const CleanRec& c = clean_recs[i];
             out.text(lead);
@@ -724,7 +778,7 @@ int main(int argc, char** argv)
             out.text(nl);
             out.end_record();
         }
-        t_dwrite = now_s() - w0;
+        t_dwrite = now_s() - w0; d_mapped = down_mapped;
         qc_pass.join();
         uint64_t qnw = 0; int32_t qbc = 0; uint32_t qnb = 0;
         L.counters_len(qctx, &qnw, &qbc, &qnb);
@@ -822,8 +876,8 @@ int main(int argc, char** argv)
                 t_fill_tail, t_close, now_s() - t_p0 - t_pipe, mapped_out ? "output: fallocate + mapped fill" : "output: writev", sink.t_falloc, t_drain, t_busy);
     }
     if (timing && o.downsample)
-        fprintf(stderr, "DOWN: selection %.3f | QC pass over the kept reads (%s, %.2f GB of them in %.2f GB of text): context %.3f, batches + submits %.3f (its own thread; %d submits %.3f, the first %.3f) | writing them %.3f | closing the output %.3f\n",
-                t_dsel, d_in_place ? "read in place" : "packed", d_kept * 1e-9, d_span * 1e-9, t_dcreate, t_dqc, n_dsubmit, t_dsubmit, t_dfirst, t_dwrite, t_dclose);
+        fprintf(stderr, "DOWN: selection %.3f | QC pass over the kept reads (%s, %.2f GB of them in %.2f GB of text): context %.3f, batches + submits %.3f (its own thread; %d submits %.3f, the first %.3f) | writing them %.3f (%s) | closing the output %.3f\n",
+                t_dsel, d_in_place ? "read in place" : "packed", d_kept * 1e-9, d_span * 1e-9, t_dcreate, t_dqc, n_dsubmit, t_dsubmit, t_dfirst, t_dwrite, d_mapped ? "fallocate + threads into a mapping" : "writev", t_dclose);
     // everything is written and closed: skip the teardown of multi-GB mappings and of the HIP runtime
     if (timing) {
         struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts);
