@@ -40,6 +40,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 CLI = os.environ.get("TGSF_BENCH_CLI") or os.path.join(ROOT, "tgsfilter_amd", "bin", "tgsfilter")   # override: tests only
 REF = os.path.join(ROOT, "oracle", "_ref", "tgsfilter_ref")
+# How the command line ends (host/main.cpp): by default one process, every mapping and GPU context taken down before it
+# returns ("sync"); TGSF_DETACH=1 makes it work in a child whose teardown goes on after the caller has its status.
+DEFAULT_EXIT_MODE = "sync"
+OTHER_EXIT_MODE_ENV = {"TGSF_DETACH": "1"}
+OTHER_EXIT_MODE_KEY = "detached_wall_s"
 FQ_MULTISET = os.path.join(ROOT, "tools", "fq_multiset")
 
 
@@ -68,92 +73,300 @@ def info_lines(stderr_text):
 
 def multiset(path):
     if not os.path.exists(FQ_MULTISET):
-        subprocess.run(["gcc", "-O2", "-o", FQ_MULTISET, FQ_MULTISET + ".c"], check=True)
+        subprocess.run(["gcc", "-O2", "-pthread", "-o", FQ_MULTISET, FQ_MULTISET + ".c"], check=True)
     return subprocess.run([FQ_MULTISET, path], capture_output=True, check=True).stdout.decode().split()
 
 
+def cli_processes():
+    """PIDs still running the command line under test, INCLUDING one that is on its way out: a process taking down
+    hundreds of GB of mappings in exit has no /proc/<pid>/exe any more (its mm is detached first) but keeps its
+    name and is not a zombie yet -- and still holds the tmpfs pages of a deleted output file."""
+    real = os.path.realpath(CLI)
+    comm = os.path.basename(CLI)[:15]
+    me = os.getpid()
+    out = []
+    for d in os.listdir("/proc"):
+        if not d.isdigit() or int(d) == me:
+            continue
+        try:
+            stat = open("/proc/%s/stat" % d).read()
+            name, state = stat[stat.index("(") + 1:stat.rindex(")")], stat[stat.rindex(")") + 2]
+            if state in "ZX":
+                continue
+            try:
+                if os.path.realpath(os.readlink("/proc/%s/exe" % d)) == real:
+                    out.append(int(d))
+                    continue
+            except OSError:
+                if name == comm:              # exiting: no exe link any more
+                    out.append(int(d))
+        except (OSError, ValueError, IndexError):
+            pass
+    return out
+
+
+def wait_cli_gone(limit_s=180.0):
+    """Nothing of an earlier run may overlap the next timed run (neither ours nor the reference's): wait until no
+    process runs the command line any more (with TGSF_DETACH=1 a child takes its mappings down after the parent
+    returned).  Returns the seconds waited (not part of any run's wall time)."""
+    t0 = time.perf_counter()
+    while cli_processes() and time.perf_counter() - t0 < limit_s:
+        time.sleep(0.02)
+    return time.perf_counter() - t0
+
+
+def cgroup_cpu():
+    """CPU seconds used / throttled so far by this box's control group (cgroup v2), or None."""
+    try:
+        d = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat").read().splitlines())
+        return {"usage_s": int(d["usage_usec"]) * 1e-6, "throttled_s": int(d.get("throttled_usec", 0)) * 1e-6,
+                "nr_throttled": int(d.get("nr_throttled", 0))}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def cgroup_limits():
+    """What the box's control group allows: CPUs' worth of time per second (cpu.max) and bytes of memory (memory.max)
+    -- tmpfs pages count as memory of the group that wrote them."""
+    out = {"cpus": None, "memory_bytes": None, "memory_used_bytes": None}
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            out["cpus"] = int(q) / int(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        m = open("/sys/fs/cgroup/memory.max").read().strip()
+        if m != "max":
+            out["memory_bytes"] = int(m)
+        out["memory_used_bytes"] = int(open("/sys/fs/cgroup/memory.current").read().strip())
+    except (OSError, ValueError):
+        pass
+    return out
+
+
+LAST_RUN_CPU = {}
+
+
 def run_cmd(cmd, env=None):
+    wait_cli_gone()
+    c0 = cgroup_cpu()
     t0 = time.perf_counter()
     p = subprocess.run(cmd, capture_output=True, env=env)
     dt = time.perf_counter() - t0
+    c1 = cgroup_cpu()
+    LAST_RUN_CPU.clear()
+    if c0 and c1:
+        LAST_RUN_CPU.update({"cpu_s": c1["usage_s"] - c0["usage_s"], "throttled_thread_s": c1["throttled_s"] - c0["throttled_s"],
+                             "throttled_periods": c1["nr_throttled"] - c0["nr_throttled"], "wall_s": dt})
     if p.returncode != 0:
         raise SystemExit("command failed (%d): %s\n%s" % (p.returncode, " ".join(cmd), p.stderr.decode()[-3000:]))
     return dt, p.stderr.decode()
 
 
+def parse_timing(err):
+    """Numbers of the command line's TGSF_TIMING lines: where the wall time went."""
+    import re
+    t = {}
+    for l in err.splitlines():
+        if l.startswith("TIMING:"):
+            for key, pat in (("total_s", r"total ([0-9.]+) s"), ("index_prepass_s", r"index\+prepass ([0-9.]+)"),
+                             ("library_wait_s", r"waiting for the library ([0-9.]+)"), ("pipeline_s", r"pipeline ([0-9.]+)"),
+                             ("fallocate_s", r"\(fallocate ([0-9.]+)"), ("populate_s", r"mapping the reserved pages ([0-9.]+)"),
+                             ("submit_summed_s", r"feeders ([0-9.]+)"), ("release_tail_s", r"dropping the mappings ([0-9.]+)")):
+                m = re.search(pat, l)
+                if m:
+                    t[key] = float(m.group(1))
+        elif l.startswith("GPU:"):
+            m = re.search(r"kernels ([0-9.]+) s", l)
+            if m:
+                t["gpu_kernel_s_summed"] = float(m.group(1))
+    return t
+
+
+class Budget:
+    """The driver gives a bench run a time limit: optional legs are dropped (and named) when the time runs short;
+    the K timed steps of the headline never are."""
+    def __init__(self, limit_s):
+        self.t0, self.limit, self.skipped = time.perf_counter(), limit_s, []
+
+    def left(self):
+        return self.limit - (time.perf_counter() - self.t0)
+
+    def allows(self, name, need_s):
+        if self.left() >= need_s:
+            return True
+        self.skipped.append("%s (needs ~%.0f s, %.0f s left of --e2e-budget-s)" % (name, need_s, self.left()))
+        log("bench: skipping %s" % self.skipped[-1])
+        return False
+
+
 def e2e_leg(args, n_gpus):
+    """The command line end to end on config C2's file.  Legs, in this order:
+      main     C2's own flags (-x ont -l 1000 -q 10: automatic trims, automatic adapter identification), tmpfs file sink:
+               W warm-up runs + K timed runs (the headline), 3 runs of the other exit mode, the reference ONCE on the same
+               file with the same flags and sink (cpu_baseline), outputs compared as multisets, INFO lines compared;
+      dev_null the same command writing to /dev/null (the sink that can scale with the GPUs: no page instantiation);
+      pinned   the pre-pass pinned (-5 0 -3 0 -a rapid.fa) on a 400 000-read file (round 2's headline, for continuity),
+               with the reference beside it."""
     from tgsfilter_amd import synth
     if not os.path.exists(CLI):
         raise SystemExit("bench.py: %s is missing -- run __graft_entry__.build() (there is no fallback path)" % CLI)
+    budget = Budget(float(getattr(args, "e2e_budget_s", 1500.0)))
     shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
-    n_reads = args.e2e_reads
-    need = n_reads * 92_000 * 2.3                     # input + two outputs
+    n_want = n_reads = args.e2e_reads
+    per_read = 90_300                                 # bytes of text per C2 read (2 x 45 kb + header)
+    # Room for the staging: the input and ONE output at a time live on tmpfs (ours is digested and removed before the
+    # reference writes its own); an output is never larger than its input.  tmpfs pages are memory of the box's control
+    # group: a group that outgrows memory.max loses the whole box, so stay well inside it.
+    lim = cgroup_limits()
     free = shutil.disk_usage(shm or tempfile.gettempdir()).free
-    if need > 0.6 * free:
-        n_reads = max(2000, int(n_reads * 0.6 * free / need))
-        log("bench: only %.0f GB free on the staging file system: end-to-end file reduced to %d reads" % (free / 1e9, n_reads))
+    why = "free space on %s" % (shm or tempfile.gettempdir())
+    if shm and lim["memory_bytes"]:
+        room = lim["memory_bytes"] - (lim["memory_used_bytes"] or 0)
+        if room < free:
+            free, why = room, "the box's memory control group (memory.max %.0f GiB; tmpfs pages count)" % (lim["memory_bytes"] / 2**30)
+    try:
+        avail = int([l for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0].split()[1]) * 1024
+        if shm and avail < free:
+            free, why = avail, "available memory"
+    except (OSError, IndexError, ValueError):
+        pass
+    need = n_reads * per_read * 2.0
+    reduced = None
+    if need > 0.85 * free:
+        n_reads = max(2000, int(n_reads * 0.85 * free / need) // 1000 * 1000 or 2000)
+        reduced = "%s holds %.0f GB: the file is %d of config C2's %d reads (input + one output, <= 2 x %.0f GB, kept under 85 %% of that)" % (
+            why, free / 1e9, n_reads, n_want, n_reads * per_read / 1e9)
+        log("bench: " + reduced)
     td = tempfile.mkdtemp(prefix="tgsf_bench_", dir=shm)
+    cores = max(1, min((os.cpu_count() or 2) - 1, 32))      # the reference clamps -t to min(hw-1, 32), :488-499
+    gen_procs = max(1, min((os.cpu_count() or 2) - 1, int(2 * (lim["cpus"] or 16)), 64))
+    devs = ",".join(str(d) for d in range(n_gpus))
+    env = dict(os.environ, TGSF_TIMING="1")
+    env.pop("TGSF_SYNC_EXIT", None)
+    env.pop("TGSF_DETACH", None)
+    env_other = dict(env, **OTHER_EXIT_MODE_ENV)
+    have_ref = os.path.exists(REF) and not args.no_cpu_baseline
     res = {}
+
+    def rm(path):
+        if os.path.isfile(path) and not os.path.islink(path):
+            os.remove(path)           # dropping a previous run's GBs of tmpfs pages is not part of a run
+
+    def ours(fq, out, flags, e=env):
+        rm(out)
+        return run_cmd([CLI, "-i", fq, "-o", out, "-t", str(cores), "--devices", devs] + flags, e)
+
+    def theirs(fq, out, flags):
+        rm(out)
+        return run_cmd([REF, "-i", fq, "-o", out, "-t", str(cores)] + flags)
+
+    def timed(fq, out, flags, warm, k, e=env):
+        for _ in range(warm):
+            ours(fq, out, flags, e)
+        walls, err = [], ""
+        for _ in range(k):
+            dt, err = ours(fq, out, flags, e)
+            walls.append(dt)
+        return walls, err
+
+    def file_sink_leg(fq, bases, flags, warm, k, other_runs, tag):
+        """Ours W + K on a tmpfs file, the other exit mode, then the reference once; everything compared."""
+        out_o, out_r = os.path.join(td, tag + "_ours.fq"), os.path.join(td, tag + "_ref.fq")
+        walls, err = timed(fq, out_o, flags, warm, k)
+        s = {"runs": k, "exit_mode": DEFAULT_EXIT_MODE, "wall_s": walls, "wall_s_mean": sum(walls) / len(walls),
+             "gbases_per_s": bases * len(walls) / sum(walls) / 1e9,
+             "timing_line": [l for l in err.splitlines() if l.startswith("TIMING")][-1:],
+             "timing": parse_timing(err), "cpu_last_run": dict(LAST_RUN_CPU)}
+        t = s["timing"]
+        if t.get("total_s"):
+            parts = {"fallocate (tmpfs page instantiation, one thread, inode lock)": t.get("fallocate_s", 0.0),
+                     "mapping the reserved pages": t.get("populate_s", 0.0),
+                     "index + pre-pass": t.get("index_prepass_s", 0.0), "waiting for the library/device": t.get("library_wait_s", 0.0)}
+            top = max(parts, key=parts.get)
+            s["bound"] = "%s: %.2f s of %.2f s" % (top, parts[top], t["total_s"])
+            if "gpu_kernel_s_summed" in t:
+                s["gpu_busy_frac"] = t["gpu_kernel_s_summed"] / t["total_s"]      # upper bound: contexts overlap
+        info = info_lines(err)
+        mine = multiset(out_o) if have_ref else None
+        if other_runs and budget.allows("%s: %d runs in the other exit mode" % (tag, other_runs), (other_runs + 1) * 2.0 * s["wall_s_mean"] + 5):
+            w2, err2 = timed(fq, out_o, flags, 1 if warm else 0, other_runs, env_other)
+            s[OTHER_EXIT_MODE_KEY] = w2
+            s[OTHER_EXIT_MODE_KEY + "_mean"] = sum(w2) / len(w2)
+            s[OTHER_EXIT_MODE_KEY + "_timing"] = parse_timing(err2)
+            if info_lines(err2) != info:
+                raise SystemExit("bench: INFO lines differ between the two exit modes")
+        rm(out_o)
+        if have_ref:
+            dt, rerr = theirs(fq, out_r, flags)
+            s["reference_wall_s"] = dt
+            s["reference_gbases_per_s"] = bases / dt / 1e9
+            s["speedup_vs_reference"] = s["gbases_per_s"] / (bases / dt / 1e9)
+            if OTHER_EXIT_MODE_KEY + "_mean" in s:
+                s["speedup_vs_reference_" + OTHER_EXIT_MODE_KEY.replace("_wall_s", "")] = dt / s[OTHER_EXIT_MODE_KEY + "_mean"]
+            s["same_counters"] = info_lines(rerr) == info
+            if not s["same_counters"]:
+                raise SystemExit("bench: INFO lines differ from the reference's:\n%s\n---\n%s" % ("\n".join(info), "\n".join(info_lines(rerr))))
+            theirs_ms = multiset(out_r)
+            s["same_output_multiset"] = mine == theirs_ms
+            s["output_records"], s["output_bytes"] = int(mine[0]), int(mine[3])
+            if mine != theirs_ms:
+                raise SystemExit("bench: output differs from the reference's (records sum xor bytes): %s vs %s" % (mine, theirs_ms))
+            rm(out_r)
+        s["_info"] = info
+        s["info_prepass"] = [l for l in info if any(w in l for w in ("trim 5'", "trim 3'", "5' adapter", "3' adapter", "min Phred"))]
+        log("bench: e2e %s: %s" % (tag, json.dumps({k2: v for k2, v in s.items() if k2 not in ("timing_line", "_info")})))
+        return s
+
     try:
         fq = os.path.join(td, "c2.fq")
         t0 = time.perf_counter()
-        bases, nbytes = synth.write_ont_fastq(fq, n_reads, seed=2)
-        log("bench: %d reads / %.2f Gbases / %.2f GB of FASTQ text written to %s in %.1f s"
-            % (n_reads, bases / 1e9, nbytes / 1e9, fq, time.perf_counter() - t0))
-        fa = os.path.join(td, "rapid.fa")
-        open(fa, "wb").write(b">rapid\n" + synth.ONT_RAPID + b"\n")
-        flags = ["-x", "ont", "-l", "1000", "-q", "10", "-5", "0", "-3", "0", "-a", fa]
-        cores = max(1, min((os.cpu_count() or 2) - 1, 32))      # the reference clamps -t to min(hw-1, 32), :488-499
-        devs = ",".join(str(d) for d in range(n_gpus))
-        null_out = os.path.join(td, "null.fq")                  # the suffix decides the format: a symlink to /dev/null
-        os.symlink("/dev/null", null_out)
-        env = dict(os.environ, TGSF_TIMING="1")
-
-        def ours(out):
-            if os.path.isfile(out) and not os.path.islink(out):
-                os.remove(out)             # dropping the previous run's GBs of tmpfs pages is not part of a run
-            return run_cmd([CLI, "-i", fq, "-o", out, "-t", str(cores), "--devices", devs] + flags, env)
-
-        def theirs(out):
-            if os.path.isfile(out) and not os.path.islink(out):
-                os.remove(out)
-            return run_cmd([REF, "-i", fq, "-o", out, "-t", str(cores)] + flags)
-
+        bases, nbytes = synth.write_ont_fastq(fq, n_reads, seed=2, procs=gen_procs)
+        log("bench: %d reads / %.2f Gbases / %.2f GB of FASTQ text written to %s in %.1f s by %d processes"
+            % (n_reads, bases / 1e9, nbytes / 1e9, fq, time.perf_counter() - t0, gen_procs))
+        flags = ["-x", "ont", "-l", "1000", "-q", "10"]          # configs[1] as written: automatic trims and adapter
         sinks = {}
-        for sink, out_o, out_r, k in (("tmpfs_file", os.path.join(td, "ours.fq"), os.path.join(td, "ref.fq"), args.steps),
-                                      ("dev_null", null_out, null_out, min(args.steps, 3))):
-            for _ in range(args.warmup):
-                ours(out_o)
-            walls, err = [], ""
-            for _ in range(k):
-                dt, err = ours(out_o)
-                walls.append(dt)
-            s = {"runs": k, "wall_s": walls, "wall_s_mean": sum(walls) / len(walls), "gbases_per_s": bases * len(walls) / sum(walls) / 1e9,
-                 "timing": [l for l in err.splitlines() if l.startswith("TIMING")][-1:]}
-            s["info"] = info_lines(err)
-            if os.path.exists(REF) and not args.no_cpu_baseline:
-                dt, rerr = theirs(out_r)
-                s["reference_wall_s"] = dt
-                s["reference_gbases_per_s"] = bases / dt / 1e9
-                s["speedup_vs_reference"] = s["gbases_per_s"] / (bases / dt / 1e9)
-                s["same_counters"] = info_lines(rerr) == s["info"]
-                if not s["same_counters"]:
-                    raise SystemExit("bench: INFO counters differ from the reference's:\n%s\n---\n%s" % ("\n".join(s["info"]), "\n".join(info_lines(rerr))))
-                if sink == "tmpfs_file":
-                    a, b = multiset(out_o), multiset(out_r)
-                    s["same_output_multiset"] = a == b
-                    s["output_records"], s["output_bytes"] = int(a[0]), int(a[3])
-                    if a != b:
-                        raise SystemExit("bench: output differs from the reference's (records sum xor bytes): %s vs %s" % (a, b))
-            del s["info"]
-            sinks[sink] = s
-            log("bench: e2e %s: %s" % (sink, json.dumps({k2: v for k2, v in s.items() if k2 != "timing"})))
-            for o_ in (out_o, out_r):
-                if os.path.isfile(o_) and not os.path.islink(o_):
-                    os.remove(o_)
-        res = {"reads": n_reads, "bases": bases, "fastq_bytes": nbytes, "flags": " ".join(flags[:-1]) + " rapid.fa", "threads": cores,
-               "devices": devs, "staging": "synthetic FASTQ text written to tmpfs (%s) by tgsfilter_amd/synth.write_ont_fastq before timing; "
+        sinks["tmpfs_file"] = file_sink_leg(fq, bases, flags, args.warmup, args.steps, min(3, args.steps), "c2")
+        s_file = sinks["tmpfs_file"]
+        # /dev/null through a symlink (the suffix decides the format): no page instantiation, PCIe-bound at one GPU
+        null_out = os.path.join(td, "null.fq")
+        os.symlink("/dev/null", null_out)
+        k_null = min(args.steps, 3)
+        if budget.allows("dev_null sink", (k_null + 1) * s_file["wall_s_mean"] + 5):
+            walls, err = timed(fq, null_out, flags, min(args.warmup, 1), k_null)
+            s = {"runs": k_null, "exit_mode": DEFAULT_EXIT_MODE, "wall_s": walls, "wall_s_mean": sum(walls) / len(walls),
+                 "gbases_per_s": bases * len(walls) / sum(walls) / 1e9,
+                 "timing_line": [l for l in err.splitlines() if l.startswith("TIMING")][-1:], "timing": parse_timing(err)}
+            if "reference_wall_s" in s_file:
+                s["same_counters_as_the_file_run"] = info_lines(err) == s_file["_info"]
+                if not s["same_counters_as_the_file_run"]:
+                    raise SystemExit("bench: INFO lines of the /dev/null run differ from the file run's")
+                s["speedup_vs_reference_file_run"] = s_file["reference_wall_s"] / s["wall_s_mean"]
+                s["note"] = "the reference was timed once, writing the tmpfs file (its /dev/null run is within 5 % of that: BENCH_r02)"
+            sinks["dev_null"] = s
+            log("bench: e2e dev_null: %s" % json.dumps({k2: v for k2, v in s.items() if k2 != "timing_line"}))
+        res = {"box": {"cgroup_cpus": lim["cpus"], "cgroup_memory_gib": (lim["memory_bytes"] or 0) / 2**30 or None, "hw_threads": os.cpu_count()},
+               "reads": n_reads, "bases": bases, "fastq_bytes": nbytes, "flags": " ".join(flags), "threads": cores, "devices": devs,
+               "reduced": reduced,
+               "staging": "synthetic FASTQ text written to tmpfs (%s) by tgsfilter_amd/synth.write_ont_fastq before timing; "
                "read by both programs through the page cache" % (shm or "tmp"), "sinks": sinks}
+        os.remove(fq)
+        # the pinned pre-pass on round 2's file, the reference beside it
+        n_pin = min(400_000, n_reads)
+        if not getattr(args, "no_pinned_variant", False) and budget.allows("pinned-pre-pass variant", 45 + n_pin * 1.1e-4):
+            fq2 = os.path.join(td, "c2_400k.fq")
+            bases2, nbytes2 = synth.write_ont_fastq(fq2, n_pin, seed=2, procs=gen_procs)
+            fa = os.path.join(td, "rapid.fa")
+            open(fa, "wb").write(b">rapid\n" + synth.ONT_RAPID + b"\n")
+            pflags = ["-x", "ont", "-l", "1000", "-q", "10", "-5", "0", "-3", "0", "-a", fa]
+            v = file_sink_leg(fq2, bases2, pflags, 1, 3, 0, "pinned")
+            v.update({"reads": n_pin, "bases": bases2, "fastq_bytes": nbytes2, "flags": " ".join(pflags[:-1]) + " rapid.fa"})
+            res["variants"] = {"pinned_prepass": v}
+        for leg in list(sinks.values()) + list(res.get("variants", {}).values()):
+            leg.pop("_info", None)
+        res["skipped"] = budget.skipped
+        res["seconds"] = time.perf_counter() - budget.t0
     finally:
         shutil.rmtree(td, ignore_errors=True)
     return res

@@ -17,11 +17,16 @@ def test_e2e_leg_with_the_emulated_cli(monkeypatch):
     monkeypatch.setattr(bench, "CLI", os.path.join(ROOT, "tests", "emul", "tgsfilter_emul"))
     args = types.SimpleNamespace(e2e_reads=16, steps=1, warmup=0, no_cpu_baseline=False)
     r = bench.e2e_leg(args, 1)
-    for sink in ("tmpfs_file", "dev_null"):
-        s = r["sinks"][sink]
-        assert s["same_counters"] and s["gbases_per_s"] > 0 and s["reference_gbases_per_s"] > 0
-    assert r["sinks"]["tmpfs_file"]["same_output_multiset"] and r["sinks"]["tmpfs_file"]["output_records"] > 0
-    assert r["reads"] == 16 and r["bases"] > 0
+    s = r["sinks"]["tmpfs_file"]
+    assert s["same_counters"] and s["gbases_per_s"] > 0 and s["reference_gbases_per_s"] > 0
+    assert s["same_output_multiset"] and s["output_records"] > 0
+    assert s["exit_mode"] == "sync" and len(s["detached_wall_s"]) == 1 and s["speedup_vs_reference_detached"] > 0
+    assert any("5' adapter: GTTTTCGC" in l for l in s["info_prepass"])          # the automatic pre-pass ran (configs[1] as written)
+    d = r["sinks"]["dev_null"]
+    assert d["same_counters_as_the_file_run"] and d["gbases_per_s"] > 0
+    v = r["variants"]["pinned_prepass"]
+    assert v["same_counters"] and v["same_output_multiset"] and "-5 0 -3 0 -a rapid.fa" in v["flags"]
+    assert r["reads"] == 16 and r["bases"] > 0 and r["flags"] == "-x ont -l 1000 -q 10" and not r["skipped"]
 
 
 def test_write_ont_fastq_is_deterministic(tmp_path):

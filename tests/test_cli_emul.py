@@ -133,18 +133,20 @@ def test_cli_corrupt_gzip(binary, golden_dir, tmp_path, stream_min, monkeypatch)
 
 
 @pytest.mark.parametrize("name", ["ont_zoo", "hifi_bam", "down_r"])
-def test_cli_single_process_exit(binary, golden_dir, name, monkeypatch):
-    """TGSF_SYNC_EXIT=1: no child process, mappings dropped piece by piece during the run, everything on the clock --
-    same results as the default (work in a child, address space taken down in the background after the status is out)."""
-    monkeypatch.setenv("TGSF_SYNC_EXIT", "1")
+def test_cli_detached_exit(binary, golden_dir, name, monkeypatch):
+    """TGSF_DETACH=1: the work happens in a child process whose address space is taken down in the background after the
+    status is out -- same results as the default (one process, mappings dropped piece by piece during the run,
+    everything on the caller's clock)."""
+    monkeypatch.setenv("TGSF_DETACH", "1")
     monkeypatch.setenv("TGSF_BATCH_BYTES", "30000")
     monkeypatch.setenv("TGSF_FILL_MIN_BYTES", "1")
     cli_check.run_case(binary, golden_dir, name, extra_args=["-t", "4"])
 
 
-def test_cli_exit_status_comes_through_the_parent(binary, tmp_path):
-    """Fatal paths of the working child (here: an output file that cannot be opened, after threads exist) reach the caller
+def test_cli_exit_status_comes_through_the_parent(binary, tmp_path, monkeypatch):
+    """(TGSF_DETACH=1) Fatal paths of the working child (here: an output file that cannot be opened, after threads exist) reach the caller
     as the reference's exit status, and the caller's pipes close when the work is done."""
+    monkeypatch.setenv("TGSF_DETACH", "1")
     f = tmp_path / "a.fq"
     f.write_bytes(b"@r\n" + b"ACGT" * 400 + b"\n+\n" + b"I" * 1600 + b"\n")
     p = subprocess.run([binary, "-i", str(f), "-x", "ont", "-o", str(tmp_path / "no_such_dir" / "o.fq")], capture_output=True, timeout=120)

@@ -133,3 +133,60 @@ def test_emul_align_windows_random(emul):
 
 def test_emul_more_than_64_drop_regions(emul):
     parity.many_regions(emul)
+
+
+def _tie_reads():
+    """Reads whose middle-scan minimum is tied column after column: homopolymers against homopolymer
+    adapters, a (CT)n read against the PacBio blunt adapter, beside ordinary reads."""
+    rng = np.random.default_rng(77)
+    q = lambda n: bytes((rng.integers(15, 35, n) + 33).astype(np.uint8))
+    reads = synth.make_reads(9, 6, "ont", mean_len=3000, zoo=True, pmid=0.5)
+    reads.append((b"polyA", b"A" * 100000, q(100000)))      # 100 000 tied columns: beyond the 65 536 + ... slots of a small context
+    reads.append((b"polyT_ends", b"ACGT" * 100 + b"T" * 9000 + b"GATTACA" * 60, q(400 + 9000 + 420)))
+    reads.append((b"ct", b"CT" * 6000, q(12000)))
+    reads.append((b"polyA_short", b"A" * 700, q(700)))
+    return reads
+
+
+@pytest.mark.parametrize("adapters,m_mid", [([b"A" * 50, b"T" * 50], 35), ([synth.PACBIO_BLUNT, synth.PACBIO_BLUNT_RC], 1),
+                                            ([b"A" * 50, b"T" * 50, b"AC" * 45 + b"G"], 35)])
+def test_emul_candidate_pool_overflow_is_handled(emul, adapters, m_mid, monkeypatch, capfd):
+    """With the sizing hints a minimal caller passes, reads whose minimum is tied everywhere used to end in TGSF_E_CAPACITY
+    ("candidate pool overflow"); the reference completes them (include/edlib.cpp:660-672: every column at the global
+    minimum is a location).  The library now re-runs the scan with a pool that fits: same records, same tallies as the oracle."""
+    monkeypatch.setenv("TGSF_TRACE_POOL", "1")
+    reads = _tie_reads()
+    p = parity.sized(abi.make_params("ont", adapters=adapters, min_q=7.0, mid_match_len=m_mid, end_match_len=4), reads)
+    ctx = capi.Context(p, 0, emul)
+    parity.compare_batch(ctx, p, reads)
+    err = capfd.readouterr().err
+    assert "candidate pool overflow" in err and "(grown)" in err      # the fallback DID run, and had to grow the pool
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", ["ont_zoo", "hifi_zoo", "ont_m1", "huge_adapter"])
+def test_emul_golden_through_the_overflow_path(emul, golden_dir, name, monkeypatch, capfd):
+    """A pool of 2 slots: every batch with more than two candidates takes the count-and-rescan path; the goldens must not notice."""
+    monkeypatch.setenv("TGSF_POOL_CAP", "2")
+    monkeypatch.setenv("TGSF_TRACE_POOL", "1")
+    parity.golden_case(emul, golden_dir, name)
+    assert "candidate pool overflow" in capfd.readouterr().err
+
+
+def test_emul_pool_overflow_over_several_batches(emul, monkeypatch):
+    """Tallies accumulate correctly when some batches of a run take the overflow path and others do not; a batch submitted
+    asynchronously is completed by tgsf_wait; two batches enqueued without a wait between them report the overflow."""
+    monkeypatch.setenv("TGSF_POOL_CAP", "3")
+    plain = synth.make_reads(21, 10, "ont", mean_len=2500, zoo=False, pmid=0.0, p5=0.0)
+    busy = synth.make_reads(22, 10, "ont", mean_len=2500, zoo=True, pmid=1.0)
+    p = parity.sized(abi.make_params("ont", adapters=[synth.ONT_RAPID, synth.ONT_RAPID_RC], min_q=7.0), plain + busy)
+    ctx = capi.Context(p, 0, emul)
+    exp = np.zeros(ctx.ctr_words, dtype=np.uint64)
+    from oracle import orc
+    for reads in (plain, busy, plain, busy):
+        seq, qual, offsets, lengths = synth.pack(reads)
+        got_r, got_f = ctx.submit(seq, qual, offsets[:-1].copy(), lengths)
+        exp_r, exp_f, exp = orc.filter_batch(p, seq, qual, offsets, lengths, n_bins=ctx.n_bins, ctr=exp)
+        assert np.array_equal(got_r, exp_r) and np.array_equal(got_f, exp_f)
+    assert np.array_equal(ctx.counters(), exp)
+    ctx.close()

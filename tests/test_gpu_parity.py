@@ -202,3 +202,81 @@ def test_gpu_align_windows_random():
 
 def test_gpu_more_than_64_drop_regions():
     parity.many_regions(None)
+
+
+def _tie_reads(long_len):
+    """Reads whose middle-scan minimum is tied column after column."""
+    rng = np.random.default_rng(77)
+    q = lambda n: bytes((rng.integers(15, 35, n) + 33).astype(np.uint8))
+    reads = synth.make_reads(9, 6, "ont", mean_len=3000, zoo=True, pmid=0.5)
+    reads.append((b"polyA", b"A" * long_len, q(long_len)))
+    reads.append((b"polyT_ends", b"ACGT" * 100 + b"T" * 9000 + b"GATTACA" * 60, q(400 + 9000 + 420)))
+    reads.append((b"ct", b"CT" * 40000, q(80000)))
+    reads.append((b"polyA_short", b"A" * 700, q(700)))
+    return reads
+
+
+@pytest.mark.parametrize("adapters,m_mid,long_len", [([b"A" * 50, b"T" * 50], 35, 200_000),
+                                                     ([synth.PACBIO_BLUNT, synth.PACBIO_BLUNT_RC], 1, 200_000),
+                                                     ([b"A" * 50, b"T" * 50], 35, 2_000_000)])
+def test_gpu_candidate_pool_overflow_is_handled(adapters, m_mid, long_len, monkeypatch, capfd):
+    """With the sizing hints a minimal caller passes, a 200-kb (2-Mb) homopolymer read against a homopolymer adapter, or a
+    (CT)n read against the PacBio blunt adapter at -M 1, used to end in TGSF_E_CAPACITY; the reference completes them
+    (every column at the global minimum is a location, include/edlib.cpp:660-672).  The library re-runs the scan with a pool
+    that fits: records and tallies equal the oracle's."""
+    monkeypatch.setenv("TGSF_TRACE_POOL", "1")
+    reads = _tie_reads(long_len)
+    p = parity.sized(abi.make_params("ont", adapters=adapters, min_q=7.0, mid_match_len=m_mid, end_match_len=4), reads)
+    ctx = capi.Context(p, 0)
+    parity.compare_batch(ctx, p, reads)
+    err = capfd.readouterr().err
+    assert "candidate pool overflow" in err and "(grown)" in err
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", ["ont_zoo", "hifi_zoo", "ont_m1", "huge_adapter", "ont_trim"])
+def test_gpu_golden_through_the_overflow_path(golden_dir, name, monkeypatch, capfd):
+    monkeypatch.setenv("TGSF_POOL_CAP", "2")
+    monkeypatch.setenv("TGSF_TRACE_POOL", "1")
+    parity.golden_case(None, golden_dir, name)
+    assert "candidate pool overflow" in capfd.readouterr().err
+
+
+def test_gpu_pool_overflow_device_batches(monkeypatch):
+    """tgsf_submit_device: one batch + tgsf_wait takes the fallback (results as without the overflow); two batches
+    enqueued without a wait between them cannot be recovered (the context's buffers hold the second one) and say so."""
+    import torch
+    reads = synth.make_reads(22, 40, "ont", mean_len=2500, zoo=True, pmid=1.0)
+    p = parity.sized(abi.make_params("ont", adapters=[synth.ONT_RAPID, synth.ONT_RAPID_RC], min_q=7.0), reads)
+    seq, qual, offsets, lengths = synth.pack(reads)
+    ref = capi.Context(p, 0)
+    exp_r, exp_f = ref.submit(seq, qual, offsets[:-1].copy(), lengths)
+    exp_ctr = ref.counters()
+    ref.close()
+    monkeypatch.setenv("TGSF_POOL_CAP", "2")
+    ctx = capi.Context(p, 0)
+    dev = torch.device("cuda", 0)
+    d = {k: torch.from_numpy(v).to(dev) for k, v in (("seq", seq), ("qual", qual), ("off", offsets[:-1].astype(np.int64)), ("len", lengths.astype(np.int32)))}
+    n, fcap = len(reads), len(exp_f) + 64
+    d_reads = torch.zeros(n * 32, dtype=torch.uint8, device=dev)
+    d_frags = torch.zeros(fcap * 24, dtype=torch.uint8, device=dev)
+    d_nf = torch.zeros(4, dtype=torch.int32, device=dev)
+    st = torch.cuda.Stream(device=dev)
+
+    def go():
+        ctx.submit_device(d["seq"].data_ptr(), d["qual"].data_ptr(), d["off"].data_ptr(), d["len"].data_ptr(), n, seq.size,
+                          d_reads.data_ptr(), d_frags.data_ptr(), fcap, d_nf.data_ptr(), st.cuda_stream)
+    go()
+    st.synchronize()
+    ctx.wait()
+    st.synchronize()
+    got_r = d_reads.cpu().numpy().view(abi.READ_RESULT_DTYPE)
+    got_f = d_frags.cpu().numpy().view(abi.FRAGMENT_DTYPE)[:int(d_nf[0].item())]
+    assert np.array_equal(got_r, exp_r) and np.array_equal(got_f, exp_f) and np.array_equal(ctx.counters(), exp_ctr)
+    go()
+    go()
+    st.synchronize()
+    with pytest.raises(capi.TgsfError) as e:
+        ctx.wait()
+    assert "without tgsf_wait between them" in str(e.value)
+    ctx.close()

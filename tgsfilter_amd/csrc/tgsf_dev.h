@@ -60,6 +60,9 @@ struct DevBatch {
     MidCand*  pool;            // candidate / region pool
     uint32_t  pool_cap;
     uint32_t* pool_n;          // number of slots used
+    uint32_t  mid_mode;        // middle scan: 0 = one pass (the pool usually holds every candidate); after an overflow
+                               // (status[2]) the scan runs twice more with mid_best known: 1 = count the columns at each
+                               // (read, adapter)'s minimum, 2 = hand exactly those over (the pool has been grown to fit)
     uint32_t* seg_cnt;         // [n+1] middle segments per read, scanned in place to bases
     uint32_t* nfr;             // [n+1] fragments per read, scanned in place to frag_begin
     uint32_t* scan_part;       // [n / kScanTile + 2] per-tile totals of the prefix scans
@@ -98,7 +101,8 @@ struct DevBatch {
     size_t    scratch_mid_wave0; // first wave region of k_mid_resolve (after those of k_end_windows)
 
     uint64_t* ctr;             // the flat tally vector (include/tgsf.h layout)
-    uint32_t* status;          // [4] device-side error words: [0] code, [1] detail
+    uint32_t* status;          // [4] device-side words: [0] error code, [1] detail, [2] the candidate pool overflowed (the
+                               // kernels behind the middle scan then leave the batch alone: tgsf_wait runs them again, see mid_mode)
 };
 
 // include/tgsf.h layout of the tally vector, callable from device code
@@ -115,6 +119,7 @@ enum DevStatus : uint32_t {
     DS_TOO_MANY_REGIONS = 4,
     DS_FRAG_CAP = 5,
     DS_BAD_MEANQ = 6,      // mean quality outside [0,256): the reference indexes out of bounds
+    DS_REPEAT_TABLE = 7,   // repeat gate: a pass's table of full keys cannot hold the fragment's duplicated k-mers
 };
 
 }  // namespace tgsf

@@ -117,6 +117,10 @@ TGSF_D void set_status(const DevBatch& B, uint32_t code, uint32_t detail) {
     if (atomicMax(&B.status[0], code) < code) B.status[1] = detail;
 }
 
+// The candidate pool of the middle scan overflowed: everything behind the scan leaves this batch alone (no tally, no
+// record is written), and tgsf_wait runs the scan and those kernels again with a pool grown to fit (mid_mode).
+TGSF_D bool pool_overflowed(const DevBatch& B) { return B.status[2] != 0u; }
+
 // fragments actually stored (the count may exceed the capacity: DS_FRAG_CAP)
 TGSF_D uint32_t stored_frags(const DevBatch& B) { uint32_t nf = B.nfr[B.n]; return nf < B.fcap ? nf : B.fcap; }
 
@@ -207,6 +211,7 @@ TGSF_KERNEL k_prepare(DevParams P, DevBatch B, uint32_t max_read_len)
 // k_clean_plan: which reads are kept whole, and the bases each clean-table strategy would scan.
 TGSF_KERNEL k_clean_plan(DevParams P, DevBatch B)
 {
+    if (pool_overflowed(B)) return;
     uint64_t direct = 0, diff = 0;
     for (uint32_t r0 = blockIdx.x * blockDim.x; r0 < B.n; r0 += gsize()) {
         const uint32_t r = r0 + threadIdx.x;
@@ -235,6 +240,7 @@ TGSF_KERNEL k_clean_plan(DevParams P, DevBatch B)
 template <bool CLEAN>
 TGSF_KERNEL k_fold_raw(DevParams P, DevBatch B)
 {
+    if (CLEAN && pool_overflowed(B)) return;           // (the clean instance runs behind the middle scan)
     const bool add = !CLEAN || clean_by_difference(B);
     uint64_t rows = B.plan[0];
     if (rows > P.n_bins) rows = P.n_bins;
@@ -251,6 +257,7 @@ TGSF_KERNEL k_fold_raw(DevParams P, DevBatch B)
 // Items of the clean stats pass: the fragments (keep regions), plus -- by difference -- the reads to take out.
 TGSF_KERNEL k_frag_prepare(DevParams P, DevBatch B)
 {
+    if (pool_overflowed(B)) return;
     TGSF_SHARED uint32_t h[kHistLds];
     const uint32_t nbuck = B.max_tiles + 2;
     const bool use_lds = nbuck <= kHistLds;
@@ -321,6 +328,7 @@ TGSF_KERNEL k_tile_scan(DevBatch B)
 template <bool CLEAN>
 TGSF_KERNEL k_tile_scatter(DevBatch B)
 {
+    if (CLEAN && pool_overflowed(B)) return;
     TGSF_SHARED uint32_t h[kHistLds];
     TGSF_SHARED uint32_t hb[kHistLds];
     const uint32_t nbuck = B.max_tiles + 2;
@@ -376,6 +384,7 @@ constexpr int kLaneChunks = (kTileChunks + 63) / 64;   // 16-byte chunks a lane 
 template <bool CLEAN>
 TGSF_KERNEL k_build_work(DevBatch B)
 {
+    if (CLEAN && pool_overflowed(B)) return;
     const uint32_t mt = B.max_tiles;
     const uint32_t W = B.tile_base[mt + 1];
     for (uint32_t w = gtid(); w < W && w < B.work_cap; w += gsize()) {
@@ -426,6 +435,7 @@ TGSF_D int32_t wave_sum_i32(int32_t v) {
 template <bool CLEAN>
 TGSF_KERNEL TGSF_BOUNDS(256, 3) k_stats(DevParams P, DevBatch B)
 {
+    if (CLEAN && pool_overflowed(B)) return;
     TGSF_SHARED uint4 lds[kStatsWaves][2][kTileChunks];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t gw = blockIdx.x * kStatsWaves + wave, nw = gridDim.x * kStatsWaves;
@@ -749,6 +759,7 @@ TGSF_D int base_col(uint32_t b) {
 template <bool CLEAN>
 TGSF_KERNEL k_end_tables(DevParams P, DevBatch B)
 {
+    if (CLEAN && pool_overflowed(B)) return;
     // [end][slot][10][lane]: 5 counts, 5 quality sums; position = slot*64 + lane
     TGSF_SHARED uint32_t acc[2][kMaxBcLen / 64][10][64];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -1119,13 +1130,19 @@ TGSF_D bool worth_handing_over(const DevBatch& B, uint32_t r, int a, int A, int 
 TGSF_D void push_candidate(const DevBatch& B, uint32_t r, int pos, int score, int a)
 {
     uint32_t idx = atomicAdd(B.pool_n, 1u);
-    if (idx >= B.pool_cap) { set_status(B, DS_POOL_FULL, r); return; }
+    if (idx >= B.pool_cap) { B.status[2] = 1u; (void)r; return; }     // not an error: tgsf_wait re-runs the scan with a pool that fits
     MidCand c;
     c.pos = pos;
     c.aux = score | (a << 8);
     c.state = 0;
     c.next = atomicExch(&B.mid_head[r], (int32_t)idx);
     B.pool[idx] = c;
+}
+
+// before the scans that follow a pool overflow: empty candidate lists (mid_best keeps the minima of the first scan)
+TGSF_KERNEL k_mid_reset(DevBatch B)
+{
+    for (uint32_t r = gtid(); r < B.n; r += gsize()) B.mid_head[r] = -1;
 }
 
 template <int AT>
@@ -1163,16 +1180,27 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
                               // BELOW lim counts then), lim + 3 afterwards (ties count too)
     int ntie[AT];             // buffered columns attaining it
     int wu = 0;
+    bool any_on = false;
 #pragma unroll
     for (int j = 0; j < AT; j++) {
         const int a = a0 + j;
-        const bool on = j < na && ML >= P.Q[a] && P.k_mid[a] >= 0;    // :1237 tsmLen >= qLen
+        bool on = j < na && ML >= P.Q[a] && P.k_mid[a] >= 0;          // :1237 tsmLen >= qLen
+        int first_lim = on ? P.k_mid[a] + 1 : 0;
+        if (on && B.mid_mode) {
+            // second and third scan after a pool overflow: the (read, adapter)'s minimum is known from the first one
+            // (every lane's best went through atomicMin whether or not its columns found room), so only the columns
+            // AT that minimum are counted / handed over, and a lane whose pairs have nothing within k has nothing to do
+            const int gmin = B.mid_best[(size_t)r * P.n_adapters + a];
+            if (gmin > P.k_mid[a]) on = false; else first_lim = gmin + 1;
+        }
+        any_on |= on;
         hot_init(st[j], j < na ? P.Q[a] : 1);
-        lim[j] = on ? P.k_mid[a] + 1 : -1000;
+        lim[j] = on ? first_lim : -1000;
         lim3[j] = lim[j] + 2;
         ntie[j] = 0;
         if (on) { int w = P.Q[a] + P.k_mid[a]; wu = w > wu ? w : wu; }
     }
+    if (B.mid_mode && !any_on) continue;
     int c = c0 - wu;
     if (c < 0) c = 0;
     else if (c > 0) {
@@ -1191,8 +1219,11 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
     // list when the buffer fills or the block ends: the pool stays small for any threshold.
     int32_t (*ties)[4] = tie_col[threadIdx.x];
     auto flush_ties = [&](int j) {
-        if (ntie[j] > 0 && worth_handing_over(B, r, a0 + j, P.n_adapters, lim[j]))
-            for (int i = 0; i < ntie[j]; i++) push_candidate(B, r, ties[j][i], lim[j], a0 + j);
+        if (ntie[j] > 0) {
+            if (B.mid_mode == 1u) atomicAdd(B.pool_n, (uint32_t)ntie[j]);     // counting pass: how large the pool has to be
+            else if (worth_handing_over(B, r, a0 + j, P.n_adapters, lim[j]))
+                for (int i = 0; i < ntie[j]; i++) push_candidate(B, r, ties[j][i], lim[j], a0 + j);
+        }
         ntie[j] = 0;
     };
     auto note = [&](int j, int sc, int col) {
@@ -1310,6 +1341,15 @@ TGSF_KERNEL k_mid_scanw(DevParams P, DevBatch B, int a)
     int32_t* ties = tie_col[threadIdx.x];
     int ntie = 0;
     int lim = P.k_mid[a] + 1;                                          // nothing at or below k yet
+    if (B.mid_mode) {                                                  // after a pool overflow: see k_mid_scan1
+        const int gmin = B.mid_best[(size_t)r * P.n_adapters + a];
+        if (gmin > P.k_mid[a]) return;
+        lim = gmin + 1;
+    }
+    auto hand_over = [&](int n) {
+        if (B.mid_mode == 1u) atomicAdd(B.pool_n, (uint32_t)n);
+        else if (worth_handing_over(B, r, a, P.n_adapters, lim)) for (int i = 0; i < n; i++) push_candidate(B, r, ties[i], lim, a);
+    };
     int c = c0 - (Q + P.k_mid[a]);
     if (c < 0) c = 0;
     for (; c < c0; c++) bv_step<NW>(s, eqt[mid[c]], 0, Q);
@@ -1317,14 +1357,11 @@ TGSF_KERNEL k_mid_scanw(DevParams P, DevBatch B, int a)
         bv_step<NW>(s, eqt[mid[c]], 0, Q);
         if (s.score < lim) { lim = s.score; ntie = 0; }
         if (s.score == lim && lim <= P.k_mid[a]) {
-            if (ntie == 4) {
-                if (worth_handing_over(B, r, a, P.n_adapters, lim)) for (int i = 0; i < 4; i++) push_candidate(B, r, ties[i], lim, a);
-                ntie = 0;
-            }
+            if (ntie == 4) { hand_over(4); ntie = 0; }
             ties[ntie++] = c;
         }
     }
-    if (ntie > 0 && worth_handing_over(B, r, a, P.n_adapters, lim)) for (int i = 0; i < ntie; i++) push_candidate(B, r, ties[i], lim, a);
+    if (ntie > 0) hand_over(ntie);
 }
 
 // ---------------------------------------------------------------------------
@@ -1338,7 +1375,7 @@ TGSF_KERNEL k_mid_resolve(DevParams P, DevBatch B)
 {
     const int A = P.n_adapters;
     const uint32_t idx = gtid();
-    if (idx >= B.n * (uint32_t)A || !P.filter) return;
+    if (idx >= B.n * (uint32_t)A || !P.filter || pool_overflowed(B)) return;
     const uint32_t r = idx / (uint32_t)A;
     const int a = (int)(idx % (uint32_t)A);
     const int32_t head = B.mid_head[r];
@@ -1412,6 +1449,7 @@ TGSF_D void reg_insert(RegList& R, int s, int e)
 template <bool EMIT>
 TGSF_KERNEL k_regions(DevParams P, DevBatch B)
 {
+    if (pool_overflowed(B)) return;
     const int A = P.n_adapters;
     uint64_t d[TGSF_N_DROPINFO];
 #pragma unroll
@@ -1587,6 +1625,7 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat(DevParams P, DevBatch B)
     const uint32_t part_q = (((1u << part_log2) + 31u) / 32u + 3u) / 4u;   // uint4s of a partition
     const uint32_t nf = stored_frags(B);
     uint64_t drop_n = 0, drop_b = 0;
+    if (pool_overflowed(B)) return;
 #if defined(TGSF_EMUL)
     const int NT = 1, tid = 0;                                         // emulation: one lane does the whole fragment
     if (threadIdx.x != 0) return;
@@ -1744,6 +1783,7 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
     const int k = P.kmer;
     const uint32_t nf = stored_frags(B);
     uint64_t drop_n = 0, drop_b = 0;
+    if (pool_overflowed(B)) return;
 #if defined(TGSF_EMUL)
     const int NT = 1, tid = 0;
     if (threadIdx.x != 0) return;
@@ -1930,7 +1970,8 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
                 if (!over_s) break;
                 TGSF_BLOCK_SYNC();
                 if (tid == 0) over_s = 0;
-                if (PB >= k - 1) { set_status(B, DS_POOL_FULL, B.frag_read[f]); mine = 0; TGSF_BLOCK_SYNC(); break; }   // (cannot happen: 4 keys)
+                // the chunk words a lane holds (w0..w3) serve keys that start up to 16 bases behind a pass's leading bases
+                if (PB >= k - 1 || PB >= 16) { set_status(B, DS_REPEAT_TABLE, B.frag_read[f]); mine = 0; TGSF_BLOCK_SYNC(); break; }
                 PB++;
 #if defined(TGSF_EMUL) && defined(TGSF_REP_TRACE)
                 fprintf(stderr, "k_repeat_keys: fragment %u (%d k-mers) starts over with %d leading bases\n", f, total, PB);
@@ -1961,6 +2002,7 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
 // ---------------------------------------------------------------------------
 TGSF_KERNEL k_gate_frags(DevParams P, DevBatch B)
 {
+    if (pool_overflowed(B)) return;
     TGSF_SHARED ull hq[TGSF_N_QBINS];
     for (uint32_t i = TGSF_COOP_BEGIN; i < (uint32_t)TGSF_N_QBINS; i += TGSF_COOP_STRIDE) hq[i] = 0;
     TGSF_BLOCK_SYNC();
@@ -2008,6 +2050,7 @@ TGSF_KERNEL k_ctr_merge(uint64_t* dst, const uint64_t* src, uint64_t n)
 TGSF_KERNEL k_finalize(DevBatch B, tgsf_read_result* out_reads, tgsf_fragment* out_frags,
                        uint32_t out_fcap, uint32_t* out_nfrags)
 {
+    if (pool_overflowed(B)) return;
     const uint32_t nf = B.nfr[B.n];
     if (gtid() == 0) {
         if (out_nfrags) *out_nfrags = nf;

@@ -84,6 +84,16 @@ struct tgsf_ctx {
     uint32_t* pend_nf_p;       // fragment count of the pending batch       } into it are truly asynchronous
     // batch enqueued by tgsf_submit_async, completed by tgsf_wait
     tgsf_batch_out* pend_out = nullptr;
+    // the most recent batch as the pipeline saw it (device pointers), and how many were enqueued since the last
+    // tgsf_wait: when the candidate pool of the middle scan overflows (DevBatch::status[2]) tgsf_wait runs the scan and
+    // everything behind it again with a pool grown to fit -- possible while the batch's buffers still hold ITS data
+    tgsf_batch_in last_in;
+    tgsf_read_result* last_reads = nullptr;
+    tgsf_fragment* last_frags = nullptr;
+    uint32_t last_fcap = 0;
+    uint32_t* last_nfrags = nullptr;
+    uint32_t batches_since_wait = 0;
+    uint32_t pool_regrown = 0;            // times the pool had to grow (tests look at it through tgsf_last_error's sibling below)
 
 };
 
@@ -424,6 +434,7 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     // value (4 at a time): the pool stays small for any threshold; some room per read and adapter on top
     uint64_t pool = c->cap_bases / 64 + 65536 + (uint64_t)n * 16u * (uint64_t)std::max(p->n_adapters, 1);
     B.pool_cap = (uint32_t)std::min<uint64_t>(pool, 1ull << 28);
+    if (const char* e = getenv("TGSF_POOL_CAP")) { const long long v = atoll(e); if (v >= 1 && v < (1ll << 28)) B.pool_cap = (uint32_t)v; }   // test knob: force the overflow path
     const size_t nitems = n + (size_t)B.fcap;         // clean pass: fragments, and reads to take back out
     if (!e) e = dev_alloc(c, &c->d_seq, cap_bytes);
     if (!e) e = dev_alloc(c, &c->d_qual, cap_bytes);
@@ -538,9 +549,17 @@ static void scan_u32(const DevBatch& B, uint32_t* a, uint32_t n, rt_stream st)
     TGSF_LAUNCH_COOP(k_scan_add, nb, 256, st, a, n, (const uint32_t*)B.scan_part);
 }
 
+// redo = false: the whole pipeline of one batch, enqueued without a host round trip.
+// redo = true (from tgsf_wait, after a pool overflow): the middle scan again -- first counting the columns at each
+// (read, adapter)'s minimum, then, with the pool grown to that many slots, handing them over -- and everything behind it.
 static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* d_reads, tgsf_fragment* d_frags,
-                        uint32_t out_fcap, uint32_t* d_nfrags, rt_stream st)
+                        uint32_t out_fcap, uint32_t* d_nfrags, rt_stream st, bool redo = false)
 {
+    if (!redo) {
+        c->last_in = *in; c->last_reads = d_reads; c->last_frags = d_frags; c->last_fcap = out_fcap; c->last_nfrags = d_nfrags;
+        c->batches_since_wait++;
+    }
+    const bool profile = c->profile && !redo;
     DevBatch B = c->B;
     const DevParams& P = c->P;
     B.seq = in->seq; B.qual = in->qual; B.off = in->offsets; B.len_in = in->lengths;
@@ -556,19 +575,29 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     const unsigned gfold = grid_cap(std::min(blocks_for((uint64_t)P.n_bins * 5, T), 1024u));
     int stage = 0;
 #if !defined(TGSF_EMUL)
-    if (c->profile && c->prof_pending == tgsf_ctx::kProfRing) { int e = harvest_profile(c, st); if (e) return e; }
-    hipEvent_t* evs = c->ev[c->profile ? c->prof_pending : 0];
-    hipEvent_t* evx = c->ev_aux[c->profile ? c->prof_pending : 0];
-    if (c->profile) {
+    if (profile && c->prof_pending == tgsf_ctx::kProfRing) { int e = harvest_profile(c, st); if (e) return e; }
+    hipEvent_t* evs = c->ev[profile ? c->prof_pending : 0];
+    hipEvent_t* evx = c->ev_aux[profile ? c->prof_pending : 0];
+    if (profile) {
         for (int i = 0; i <= TGSF_N_STAGES; i++) if (!evs[i]) (void)hipEventCreate(&evs[i]);
         for (int i = 0; i < 3; i++) if (!evx[i]) (void)hipEventCreate(&evx[i]);
     }
     hipStream_t ax = c->aux;
-#define STAGE_MARK() do { if (c->profile) (void)hipEventRecord(evs[stage], st); stage++; } while (0)
+#define STAGE_MARK() do { if (profile) (void)hipEventRecord(evs[stage], st); stage++; } while (0)
 #else
 #define STAGE_MARK() do { stage++; } while (0)
 #endif
     STAGE_MARK();
+    const unsigned gwork = grid_cap(std::min(blocks_for(in->n_bytes / kTileBases + n + 1, T), 4096u));
+    rt_stream ss = st;
+    (void)ss;
+#if !defined(TGSF_EMUL)
+    if (c->hp) ss = c->hp;
+#else
+    rt_stream ax = st;
+    (void)ax;
+#endif
+    if (!redo) {
     // -- prepare + counting sort of reads by tile count
     rt_memset(B.tile_hist, 0, tl, st);
     rt_memset(B.tile_fill, 0, tl, st);
@@ -577,14 +606,11 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     TGSF_LAUNCH(k_prepare, gsmall, T, st, P, B, c->max_read_len);
     TGSF_LAUNCH_COOP(k_tile_scan, 1, 64, st, B);       // a few hundred buckets: one wave
     TGSF_LAUNCH(k_tile_scatter<false>, gsmall, T, st, B);
-    const unsigned gwork = grid_cap(std::min(blocks_for(in->n_bytes / kTileBases + n + 1, T), 4096u));
     TGSF_LAUNCH(k_build_work<false>, gwork, T, st, B);
     STAGE_MARK();
     // -- raw stats
-    rt_stream ss = st;
-    (void)ss;
 #if !defined(TGSF_EMUL)
-    if (c->hp) { ss = c->hp; (void)hipEventRecord(c->ev_hp[0], st); (void)hipStreamWaitEvent(ss, c->ev_hp[0], 0); }
+    if (c->hp) { (void)hipEventRecord(c->ev_hp[0], st); (void)hipStreamWaitEvent(ss, c->ev_hp[0], 0); }
 #endif
     TGSF_LAUNCH(k_stats<false>, gstats, 64 * kStatsWaves, ss, P, B);
 #if !defined(TGSF_EMUL)
@@ -599,14 +625,11 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
 #if !defined(TGSF_EMUL)
     (void)hipEventRecord(c->ev_fork, st);
     (void)hipStreamWaitEvent(ax, c->ev_fork, 0);
-    if (c->profile) (void)hipEventRecord(evx[0], ax);
-#else
-    rt_stream ax = st;
-    (void)ax;
+    if (profile) (void)hipEventRecord(evx[0], ax);
 #endif
     if (P.bc_len > 0) TGSF_LAUNCH(k_end_tables<false>, grid_cap(c->endtab_grid), 64 * kEndWaves, ax, P, B);
 #if !defined(TGSF_EMUL)
-    if (c->profile) (void)hipEventRecord(evx[1], ax);
+    if (profile) (void)hipEventRecord(evx[1], ax);
 #endif
     if (P.filter && A > 0) {
         const uint64_t nw = (uint64_t)n * A * 2;
@@ -614,13 +637,16 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
         else TGSF_LAUNCH(k_end_windows<2>, blocks_for(nw, 64), 64, ax, P, B);
     }
 #if !defined(TGSF_EMUL)
-    if (c->profile) (void)hipEventRecord(evx[2], ax);
+    if (profile) (void)hipEventRecord(evx[2], ax);
     (void)hipEventRecord(c->ev_join, ax);
 #endif
+    } else {
+        stage = 4;                                      // (the stage events of a redo are not recorded)
+    }
     STAGE_MARK();
     STAGE_MARK();
     if (P.filter && A > 0) {
-        scan_u32(B, B.seg_cnt, n, st);
+        if (!redo) scan_u32(B, B.seg_cnt, n, st);       // (in place: a redo finds the prefix sums of the first run)
         // upper bound of the segment count, known on the host: no device round trip
         const uint64_t max_segs = in->n_bytes / (uint64_t)P.seg_cols + 2ull * n + 1;
         const unsigned gseg = blocks_for(max_segs, T);
@@ -630,20 +656,54 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
 #if !defined(TGSF_EMUL)
         if (c->hp && c->side_mid) { ms = c->hp; (void)hipEventRecord(c->ev_hp[0], st); (void)hipStreamWaitEvent(ms, c->ev_hp[0], 0); }
 #endif
-        int a = 0;
-        while (a < A) {
-            if (P.Q[a] > 192) { TGSF_LAUNCH(k_mid_scanw<4>, gseg, T, ms, P, B, a); a++; continue; }
-            if (P.Q[a] > 128) { TGSF_LAUNCH(k_mid_scanw<3>, gseg, T, ms, P, B, a); a++; continue; }
-            if (P.Q[a] > 64) { TGSF_LAUNCH(k_mid_scanw<2>, gseg, T, ms, P, B, a); a++; continue; }
-            int na = 0;
-            while (a + na < A && na < 4 && P.Q[a + na] <= 64) na++;
-            switch (na) {
-            case 1: TGSF_LAUNCH(k_mid_scan1<1>, gmid, T, ms, P, B, a, na); break;
-            case 2: TGSF_LAUNCH(k_mid_scan1<2>, gmid, T, ms, P, B, a, na); break;
-            case 3: TGSF_LAUNCH(k_mid_scan1<3>, gmid, T, ms, P, B, a, na); break;
-            default: TGSF_LAUNCH(k_mid_scan1<4>, gmid, T, ms, P, B, a, na); break;
+        auto launch_scans = [&](uint32_t mode) {
+            DevBatch Bm = B;
+            Bm.mid_mode = mode;
+            int a = 0;
+            while (a < A) {
+                if (P.Q[a] > 192) { TGSF_LAUNCH(k_mid_scanw<4>, gseg, T, ms, P, Bm, a); a++; continue; }
+                if (P.Q[a] > 128) { TGSF_LAUNCH(k_mid_scanw<3>, gseg, T, ms, P, Bm, a); a++; continue; }
+                if (P.Q[a] > 64) { TGSF_LAUNCH(k_mid_scanw<2>, gseg, T, ms, P, Bm, a); a++; continue; }
+                int na = 0;
+                while (a + na < A && na < 4 && P.Q[a + na] <= 64) na++;
+                switch (na) {
+                case 1: TGSF_LAUNCH(k_mid_scan1<1>, gmid, T, ms, P, Bm, a, na); break;
+                case 2: TGSF_LAUNCH(k_mid_scan1<2>, gmid, T, ms, P, Bm, a, na); break;
+                case 3: TGSF_LAUNCH(k_mid_scan1<3>, gmid, T, ms, P, Bm, a, na); break;
+                default: TGSF_LAUNCH(k_mid_scan1<4>, gmid, T, ms, P, Bm, a, na); break;
+                }
+                a += na;
             }
-            a += na;
+        };
+        if (!redo) launch_scans(0);
+        else {
+            // The first scan left every (read, adapter)'s minimum in mid_best.  Count the columns AT those minima (what
+            // edlib reports, include/edlib.cpp:660-672), make room for exactly them, hand them over.
+            TGSF_LAUNCH(k_mid_reset, gsmall, T, ms, B);
+            rt_memset(B.pool_n, 0, 4, ms);
+            launch_scans(1);
+            uint32_t need = 0;
+            int he = rt_d2h(&need, B.pool_n, 4, ms);
+            if (!he) he = rt_sync(ms);
+            if (he) return fail(c, TGSF_E_HIP, "middle scan (counting pass) failed: %s", rt_errstr(he));
+            if (need > B.pool_cap) {
+                const uint64_t want = (uint64_t)need + need / 16 + 1024;
+                if (want > 0x7FFFFFF0ull) return fail(c, TGSF_E_CAPACITY, "middle-adapter candidates: %u columns tie their reads' minima, more than one batch can list", need);
+                void* np = nullptr;
+                if (rt_malloc(&np, (size_t)want * sizeof(MidCand) + 64))
+                    return fail(c, TGSF_E_CAPACITY, "middle-adapter candidates: no device memory for %llu slots (%.1f GB)", (unsigned long long)want, (double)want * sizeof(MidCand) * 1e-9);
+                for (void*& q : c->allocs) if (q == (void*)c->B.pool) q = np;
+                rt_free(c->B.pool);
+                c->B.pool = (MidCand*)np; c->B.pool_cap = (uint32_t)want;
+                B.pool = c->B.pool; B.pool_cap = c->B.pool_cap;
+                c->pool_regrown++;
+            }
+            if (getenv("TGSF_TRACE_POOL"))
+                fprintf(stderr, "tgsf: candidate pool overflow: %u columns at their reads' minima, pool of %u slots%s; scanning again\n", need, B.pool_cap,
+                        c->pool_regrown ? " (grown)" : "");
+            rt_memset(B.pool_n, 0, 4, ms);
+            rt_memset(B.status + 2, 0, 4, ms);
+            launch_scans(2);
         }
 #if !defined(TGSF_EMUL)
         if (c->hp && c->side_mid) { (void)hipEventRecord(c->ev_hp[1], ms); (void)hipStreamWaitEvent(st, c->ev_hp[1], 0); }
@@ -695,7 +755,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
 #if !defined(TGSF_EMUL)
     hipError_t he = hipGetLastError();
     if (he != hipSuccess) return fail(c, TGSF_E_HIP, "kernel launch failed: %s", hipGetErrorString(he));
-    if (c->profile) { c->prof_batches++; c->prof_pending++; }
+    if (profile) { c->prof_batches++; c->prof_pending++; }
 #endif
     return TGSF_OK;
 }
@@ -745,7 +805,7 @@ static int check_status(tgsf_ctx* c)
     switch (code) {
     case DS_BAD_LEN: return fail(c, TGSF_E_DATA, "read %u: length 0 or above max_read_len %u", detail, c->max_read_len);
     case DS_BAD_QUAL: return fail(c, TGSF_E_DATA, "quality byte >= 128 in the batch (outside the supported domain)");
-    case DS_POOL_FULL: return fail(c, TGSF_E_CAPACITY, "middle-adapter candidate pool overflow (read %u)", detail);
+    case DS_REPEAT_TABLE: return fail(c, TGSF_E_CAPACITY, "read %u: the repeat gate's table cannot hold the duplicated k-mers of a fragment (thousands of them sharing their first 16 bases)", detail);
     case DS_TOO_MANY_REGIONS: return fail(c, TGSF_E_CAPACITY, "read %u has more than %d disjoint drop regions", detail, kMaxRegions);
     case DS_FRAG_CAP: return fail(c, TGSF_E_CAPACITY, "fragment capacity exceeded (%u)", detail);
     case DS_BAD_MEANQ: return fail(c, TGSF_E_DATA, "read %u: mean quality outside [0,256)", detail);
@@ -783,9 +843,38 @@ extern "C" int tgsf_wait(tgsf_ctx* c)
 #endif
     if (!e) e = rt_d2h(c->h_status, c->B.status, 16, c->stream);
     if (!e) e = rt_sync(c->stream);
+    const uint32_t enqueued = c->batches_since_wait;
+    c->batches_since_wait = 0;
     if (e) { c->pend_out = nullptr; return fail(c, TGSF_E_HIP, "stream synchronize failed: %s", rt_errstr(e)); }
     e = check_status(c);
     if (e) { c->pend_out = nullptr; return e; }
+    if (c->h_status[2]) {
+        // The candidate pool of the middle scan overflowed (a read whose minimum is tied column after column, e.g. a
+        // homopolymer against a homopolymer adapter): nothing behind the scan has touched the batch.  Its buffers still
+        // hold it if it was the only batch enqueued since the last wait -- then the scan runs again, sized to fit.
+        if (enqueued != 1) {
+            rt_memset(c->B.status, 0, 16, c->stream);
+            rt_sync(c->stream);
+            c->pend_out = nullptr;
+            return fail(c, TGSF_E_CAPACITY, "middle-adapter candidate pool overflow in one of %u batches enqueued without tgsf_wait between them "
+                                            "(call tgsf_wait after each batch and the library re-runs the scan with a pool that fits)", enqueued);
+        }
+        rt_stream st = c->last_stream;
+        e = run_pipeline(c, &c->last_in, c->last_reads, c->last_frags, c->last_fcap, c->last_nfrags, st, true);
+        if (!e && c->pend_out) {
+            int he = rt_d2h(c->pend_nf_p, c->d_out_nfrags, 4, st);
+            he |= rt_d2h(c->pend_out->reads, c->d_out_reads, (size_t)c->last_in.n_reads * sizeof(tgsf_read_result), st);
+            if (he) e = fail(c, TGSF_E_HIP, "device to host copy failed");
+        }
+        if (!e) {
+            int he = rt_d2h(c->h_status, c->B.status, 16, st);
+            if (!he) he = rt_sync(st);
+            if (he) e = fail(c, TGSF_E_HIP, "stream synchronize failed: %s", rt_errstr(he));
+        }
+        if (!e) e = check_status(c);
+        if (!e && c->h_status[2]) e = fail(c, TGSF_E_HIP, "middle-adapter candidate pool overflowed again after it was sized to fit");
+        if (e) { c->pend_out = nullptr; return e; }
+    }
     return finish_pending(c);
 }
 

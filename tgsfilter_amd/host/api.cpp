@@ -56,6 +56,9 @@ void load(std::vector<int> devices)
     BIND(counters_used, "tgsf_counters_used")
     BIND(align_windows, "tgsf_align_windows")
     BIND(last_error, "tgsf_last_error")
+    BIND(profile, "tgsf_profile")
+    BIND(stage_times, "tgsf_stage_times")
+    BIND(stage_name, "tgsf_stage_name")
 #undef BIND
     if (g_api.abi_version() != TGSF_ABI_VERSION) { g_error = path + ": ABI version mismatch"; return; }
     g_load_s = now_s() - t0;

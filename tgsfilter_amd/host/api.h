@@ -22,6 +22,9 @@ struct Api {
     decltype(&tgsf_counters_used) counters_used;
     decltype(&tgsf_align_windows) align_windows;
     decltype(&tgsf_last_error) last_error;
+    decltype(&tgsf_profile) profile;              // stage timing (TGSF_TIMING only)
+    decltype(&tgsf_stage_times) stage_times;
+    decltype(&tgsf_stage_name) stage_name;
 };
 
 // Starts the helper thread: dlopen + tgsf_prepare_device on each device.  Call once, early.

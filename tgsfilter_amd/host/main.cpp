@@ -18,12 +18,12 @@
 using namespace host;
 
 // How the program ends.  A run maps tens of GB (the input text, the output file) and holds GPU contexts: taking all
-// that down is ~1.3 s of kernel work per 57 GB of mappings, AFTER every output byte is written and every file is
-// closed.  Done synchronously it is the last 0.2-1 s of the command; done piecemeal during the run (MADV_DONTNEED) it
-// disturbs the run itself (TLB shootdowns: fallocate of the output 1.27 -> 1.6 s).  So, like linkers that map whole
-// outputs (mold), the program works in a child process: when the child has written and closed everything it hands its exit
-// status to the waiting parent, which returns to the caller at once, and the child's address space is taken down in the
-// background.  TGSF_SYNC_EXIT=1: one process, everything on the clock.
+// that down is ~1.3 s of kernel work per 57 GB of mappings.  By default the program is ONE process and everything is on
+// the caller's clock: the mappings of written batches are dropped piece by piece during the run by a background thread
+// (see the releaser in main), the rest at exit.  TGSF_DETACH=1 (opt-in) works in a child process instead, as linkers
+// that map whole outputs do (mold): when the child has written and closed everything it hands its exit status to the
+// waiting parent, which returns to the caller at once, and the child's address space is taken down in the background --
+// the caller then shares the machine with that teardown for a moment (and schedulers see a short-lived orphan).
 static int g_done_fd = -1;
 
 [[noreturn]] static void leave(int code)
@@ -38,7 +38,8 @@ static int g_done_fd = -1;
 
 static void work_in_a_child()
 {
-    if (getenv("TGSF_SYNC_EXIT")) return;
+    const char* d = getenv("TGSF_DETACH");
+    if (!d || !*d || *d == '0' || getenv("TGSF_SYNC_EXIT")) return;
     int fds[2];
     if (pipe(fds) != 0) return;
     const pid_t pid = fork();                          // before any thread or GPU state exists
@@ -224,18 +225,6 @@ int main(int argc, char** argv)
                                                      : (uint64_t)in.size() + in.size() / 4 + (16u << 20));
         if (!o.only_qc && !sink.is_open() && !out.open(o)) leave(1);
     }
-    // While the library loads and the device comes up nothing else needs this thread's core: pages of the output file
-    // are instantiated meanwhile, up to a quarter of the input's size (what a run keeps is not known yet; a surplus is
-    // cut off at the end).  Stops as soon as the planner has its first batch.
-    std::atomic<bool> spec_stop{false};
-    std::thread spec;
-    if (sink.is_open() && !streaming && in.size() > (256u << 20) && !getenv("TGSF_NO_EARLY_RESERVE"))
-        spec = std::thread([&] {
-            const uint64_t limit = (uint64_t)in.size() / 4;
-            while (!spec_stop.load() && sink.reserved() < limit)
-                if (!sink.reserve_to(std::min<uint64_t>(limit, sink.reserved() + (128u << 20)), false)) break;   // e.g. a nearly full file system: not this thread's call
-        });
-    auto end_spec = [&] { if (spec.joinable()) { spec_stop = true; spec.join(); } };
     const Api& L = lib();                                              // joins the loader thread
     double t_load = 0, t_dev = 0;
     lib_times(t_load, t_dev);
@@ -353,6 +342,7 @@ int main(int argc, char** argv)
     auto feed = [&](size_t k) {                                        // filter_sequence, :1919-2064, one batch per call
         if (L.create(&p, ctx_dev[k], &ctxs[k]) != TGSF_OK) die(L.last_error(nullptr));
         tgsf_ctx* fctx = ctxs[k];
+        if (timing) (void)L.profile(fctx, 1);                          // HIP events around the stages of every batch (GPU: line)
         for (;;) {
             std::shared_ptr<Batch> b = to_gpu.get();
             if (!b) break;
@@ -387,17 +377,27 @@ int main(int argc, char** argv)
     Pool pool(sink.is_open() ? fill_threads : 1);
     int populate_threads = std::max(1, std::min(o.n_thread, 32));      // short bursts between two fallocates: the more the shorter
     if (const char* e = getenv("TGSF_POPULATE_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) populate_threads = v; }   // tuning knob
-    Pool populate(sink.is_open() ? populate_threads : 0);              // maps the pages of a reserved stride (between two fallocates)
+    // Mapping the pages of a reserved stride: by many threads between two fallocates, or (TGSF_POPULATE_BESIDE=n) by n
+    // threads beside the next stride's fallocate.
+    int populate_beside = 0;
+    if (const char* e = getenv("TGSF_POPULATE_BESIDE")) { const int v = atoi(e); if (v >= 0 && v <= 64) populate_beside = v; }
+    if (populate_beside > 0) populate_threads = populate_beside;
+    Pool populate(sink.is_open() ? populate_threads : 0);
     // (a streamed input is decoder-bound: small strides keep the mapped part of the output -- it counts as resident -- small)
     uint64_t stride_bytes = streaming ? (128ull << 20) : (2ull << 30);
     if (const char* e = getenv("TGSF_STRIDE_BYTES")) { const long long v = atoll(e); if (v > 0) stride_bytes = (uint64_t)v; }   // tuning / test knob
+    // While the library loads and the device comes up pages of the output file are instantiated already, up to a quarter
+    // of the input's size (what a run keeps is not known yet; a surplus is cut off at the end).
+    Reserver reserver(sink, populate, stride_bytes, populate_beside > 0);
+    if (sink.is_open())
+        reserver.start((!streaming && in.size() > (256u << 20) && !getenv("TGSF_NO_EARLY_RESERVE")) ? (uint64_t)in.size() / 4 : 0);
     // Mappings of written batches (input text, output file).  By default nothing is dropped during the run: the program
     // works in a child process and its address space is taken down in the background after the caller has its status
     // (see work_in_a_child).  They are dropped piece by piece -- by ONE background thread: several only get in each
     // other's way -- where the teardown is on the clock (TGSF_SYNC_EXIT: 90 ns per page of the input, ~200 ns per dirty
     // page of the output otherwise wait at exit) or where the resident size matters (a streamed input: the mapped part
     // of the output counts as resident).
-    const bool sync_exit = getenv("TGSF_SYNC_EXIT") != nullptr;
+    const bool sync_exit = g_done_fd < 0;                              // one process (the default): the teardown is on the clock
     const bool release_input = sync_exit && !streaming && in.mapped() && !o.downsample;
     const bool release_output = sync_exit || streaming;
     Channel<std::pair<const char*, uint64_t>> to_release(1 << 16);
@@ -421,7 +421,6 @@ int main(int argc, char** argv)
         std::string name;
         std::map<uint64_t, std::shared_ptr<Batch>> held;               // batches that arrived ahead of their turn
         uint64_t want = 0, in_seen = 0;
-        uint64_t ready_end = 0;                                        // bytes of the output file instantiated AND mapped
         size_t open_feeders = ctxs.size();
         for (;;) {
             std::shared_ptr<Batch> b;
@@ -438,7 +437,6 @@ int main(int argc, char** argv)
             want++;
             const double w0 = now_s();
             const bool fill = sink.is_open();
-            end_spec();
             uint64_t at = 0;
             for (size_t r = 0; r < b->recs.size(); r++) {
                 int pass_num = 1;
@@ -482,36 +480,19 @@ int main(int argc, char** argv)
             in_seen += b->span;
             if (fill && at) {
                 if (sink.planned() + at > sink.capacity()) die("output larger than the space mapped for it");
-                if (sink.planned() + at > ready_end) {
-                    // Make more of the file ready, stride by stride: (1) fallocate instantiates the stride's pages --
-                    // fill jobs of earlier strides keep running meanwhile, they only store into pages that are already
-                    // mapped; (2) the pool's populate threads map the stride's pages (page faults and fallocate do not
-                    // mix, so this runs between two fallocates, in parallel, and is waited for).  How far: what is left
-                    // of the input times the share of it that was written so far (plus a little).
+                {
+                    // How far the file will go: what is left of the input times the share of it that was written so far
+                    // (plus a little).  (A streamed input's text size is estimated from the share of the file decoded so far.)
                     const double share = in_seen ? (double)(sink.planned() + at) / (double)in_seen : 1.0;
-                    // (a streamed input's text size is estimated from the share of the file decoded so far)
                     const double sh = stream_share.load();
                     const uint64_t in_total = !streaming ? (uint64_t)in.size()
                                             : (uint64_t)((double)stream_text.load() / (sh > 1e-6 ? sh : 1e-6));
                     uint64_t goal = sink.planned() + at + (uint64_t)(share * 1.02 * (double)(in_total - std::min<uint64_t>(in_seen, in_total)));
                     goal = std::min<uint64_t>(std::max<uint64_t>(goal, sink.planned() + at), sink.capacity());
-                    while (ready_end < sink.planned() + at) {
-                        uint64_t upto = std::min<uint64_t>(goal, std::max<uint64_t>(ready_end + stride_bytes, sink.planned() + at));
-                        if (upto < sink.reserved()) upto = sink.reserved();      // what the early reserve already holds
-                        if (!sink.reserve_to(upto, false)) {                     // no room for the estimate: exactly what this batch needs
-                            upto = std::max<uint64_t>(sink.planned() + at, sink.reserved());
-                            sink.reserve_to(upto);
-                        }
-                        const double d0 = now_s();
-                        const uint64_t lo = ready_end & ~uint64_t(4095), piece = 32u << 20;
-                        for (uint64_t o2 = lo; o2 < upto; o2 += piece) {
-                            const uint64_t n2 = std::min<uint64_t>(piece, upto - o2);
-                            populate.add([&sink, o2, n2] { sink.populate(o2, n2); });
-                        }
-                        populate.drain();
-                        t_drain += now_s() - d0;
-                        ready_end = upto;
-                    }
+                    reserver.want(goal, sink.planned() + at);
+                    const double d0 = now_s();
+                    reserver.wait_ready(sink.planned() + at);            // instantiated AND mapped: the fill jobs take no fault
+                    t_drain += now_s() - d0;
                 }
                 b->dst = sink.place(at);
                 b->out_bytes = at;
@@ -560,7 +541,7 @@ int main(int argc, char** argv)
     reader.join();
     for (std::thread& f : feeders) f.join();
     writer.join();
-    end_spec();
+    reserver.finish();
     const bool mapped_out = sink.is_open();
     const double t_f0 = now_s();
     pool.finish();
@@ -873,7 +854,24 @@ int main(int argc, char** argv)
                         "pipeline %.3f (batching %.3f, tgsf_submit summed over %zu feeders %.3f, plan+write %.3f, planner waiting %.3f, "
                         "first batch filtered after %.3f, fill tail %.3f, closing the output %.3f; stages overlap) | stats+report %.3f | %s (fallocate %.3f, mapping the reserved pages %.3f, fill threads busy %.3f summed)\n",
                 now_s() - t_start, t_prepass, t_libwait, t_load, t_dev, t_pipe, t_parse, ctxs.size(), t_gpu, t_write, t_widle, t_first,
-                t_fill_tail, t_close, now_s() - t_p0 - t_pipe, mapped_out ? "output: fallocate + mapped fill" : "output: writev", sink.t_falloc, t_drain, t_busy);
+                t_fill_tail, t_close, now_s() - t_p0 - t_pipe, mapped_out ? (populate_beside > 0 ? "output: fallocate + mapped fill, pages mapped beside the fallocate" : "output: fallocate + mapped fill") : "output: writev", sink.t_falloc, reserver.t_populate_wait, t_busy);
+        fprintf(stderr, "RESERVE: planner waited %.3f s for pages of the output file\n", t_drain);
+    }
+    if (timing) {
+        // kernel time of the run: the stage durations of every batch (HIP events inside the library), summed over the
+        // contexts -- batches of different contexts overlap, so this is an upper bound of the time the GPU was busy
+        float tot[TGSF_N_STAGES] = {0};
+        uint32_t nb = 0;
+        for (tgsf_ctx* c : ctxs) {
+            float ms[TGSF_N_STAGES]; uint32_t n1 = 0;
+            if (c && L.stage_times(c, ms, &n1) == TGSF_OK) { nb += n1; for (int i = 0; i < TGSF_N_STAGES; i++) tot[i] += ms[i]; }
+        }
+        double sum = 0;
+        for (int i = 0; i < TGSF_N_STAGES; i++) sum += tot[i];
+        fprintf(stderr, "GPU: kernels %.3f s summed over %zu contexts and %u batches (upper bound of the busy time: contexts overlap) = %.4f of the run |", sum * 1e-3, ctxs.size(), nb,
+                sum * 1e-3 / std::max(1e-9, now_s() - t_start));
+        for (int i = 0; i < TGSF_N_STAGES; i++) if (tot[i] > 0) fprintf(stderr, " %s %.1f ms", L.stage_name(i), tot[i]);
+        fprintf(stderr, "\n");
     }
     if (timing && o.downsample)
         fprintf(stderr, "DOWN: selection %.3f | QC pass over the kept reads (%s, %.2f GB of them in %.2f GB of text): context %.3f, batches + submits %.3f (its own thread; %d submits %.3f, the first %.3f) | writing them %.3f (%s) | closing the output %.3f\n",

@@ -460,5 +460,88 @@ private:
     bool stop_ = false;
 };
 
+// The output file's pages, made ready ahead of the planner by a thread of its own.  A stride of the file is instantiated
+// (fallocate: one thread, 13-16 GB/s, the critical path of a run that writes a tmpfs file) and then its pages are mapped
+// (MADV_POPULATE_WRITE on the populate pool) -- either between two fallocates (page faults on a file take its inode's
+// i_lock while a fallocate is in progress on it, shmem_falloc_wait: dozens of faulting threads beside a fallocate drag
+// both down), or, `beside` > 0, by a FEW threads while the next stride is being instantiated.  The planner says how far
+// the file will probably go (want) and waits for the part it is about to hand to the fill threads (wait_ready).
+class Reserver {
+public:
+    Reserver(MappedSink& sink, Pool& populate, uint64_t stride, bool beside) : sink_(sink), pop_(populate), stride_(stride), beside_(beside) {}
+    ~Reserver() { finish(); }
+    // speculative: up to `limit` while nothing else is known (a failure just ends the speculation)
+    void start(uint64_t speculative_limit) {
+        goal_ = speculative_limit;
+        th_ = std::thread([this] { run(); });
+    }
+    // the file will probably reach `estimate`; [0, need) is needed for certain (its reservation failing ends the run)
+    void want(uint64_t estimate, uint64_t need) {
+        std::lock_guard<std::mutex> l(m_);
+        if (need > need_) need_ = need;
+        if (estimate > goal_) goal_ = estimate;
+        if (need_ > goal_) goal_ = need_;
+        cv_.notify_all();
+    }
+    void wait_ready(uint64_t upto) {
+        std::unique_lock<std::mutex> l(m_);
+        ready_cv_.wait(l, [&] { return ready_ >= upto; });
+    }
+    void finish() {
+        { std::lock_guard<std::mutex> l(m_); stop_ = true; }
+        cv_.notify_all();
+        if (th_.joinable()) th_.join();
+    }
+    double t_populate_wait = 0;                 // fallocate waiting for the mapping of the stride before (serial mode)
+private:
+    void piece_done(size_t k) {
+        std::lock_guard<std::mutex> l(m_);
+        done_[k] = 1;
+        while (next_ < done_.size() && done_[next_]) { ready_ = ends_[next_]; next_++; }
+        ready_cv_.notify_all();
+    }
+    void run() {
+        uint64_t at = 0;                        // pages of [0, at) are instantiated and their mapping is under way or done
+        for (;;) {
+            uint64_t goal, need;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [&] { return stop_ || goal_ > at; });
+                if (goal_ <= at) return;        // stopped with nothing left to do
+                goal = goal_; need = need_;
+            }
+            uint64_t upto = std::min<uint64_t>(goal, at + stride_);
+            if (upto < sink_.reserved()) upto = sink_.reserved();
+            if (!sink_.reserve_to(upto, false)) {                    // no room for the estimate: exactly what is needed
+                if (need > at) { upto = need; sink_.reserve_to(upto); }
+                else { std::lock_guard<std::mutex> l(m_); goal_ = at; continue; }   // the speculation ends here
+            }
+            const uint64_t lo = at & ~uint64_t(4095), piece = 32u << 20;
+            const double d0 = now_s();
+            for (uint64_t o = lo; o < upto; o += piece) {
+                const uint64_t n = std::min<uint64_t>(piece, upto - o);
+                size_t k;
+                { std::lock_guard<std::mutex> l(m_); k = done_.size(); done_.push_back(0); ends_.push_back(o + n); }
+                pop_.add([this, o, n, k] { sink_.populate(o, n); piece_done(k); });
+            }
+            if (!beside_) { pop_.drain(); t_populate_wait += now_s() - d0; }
+            at = upto;
+        }
+    }
+    MappedSink& sink_;
+    Pool& pop_;
+    const uint64_t stride_;
+    const bool beside_;
+    std::mutex m_;
+    std::condition_variable cv_, ready_cv_;
+    uint64_t goal_ = 0, need_ = 0, ready_ = 0;
+    std::vector<char> done_;
+    std::vector<uint64_t> ends_;
+    size_t next_ = 0;
+    bool stop_ = false;
+    std::thread th_;
+};
+
+
 
 }  // namespace host
