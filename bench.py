@@ -201,8 +201,21 @@ class Budget:
         return False
 
 
+# The BASELINE.json configurations the end-to-end leg can run (`--config`).  C5 as written: ONT ultra-long reads (lognormal,
+# mean 150 kb, max 2 Mb) through the repeat gate (-p/-k; `-k` only acts with `-p` > 0, src/TGSFilter.cpp:1982: -p 100 is
+# this bench's choice, said in SURVEY 8d) and the longest-first downsampling (-g 3g -d 40).  The reference keeps a copy of
+# the filtered reads (<inprefix>.tmp.XXXXX.fq, :3129-3137) beside its output: three files on tmpfs at once.
+E2E_CONFIGS = {
+    "c2": {"name": "C2 (BASELINE.json configs[1])", "reads": 4_000_000, "mean_len": 45000.0, "max_len": 2_000_000, "per_read": 90_300, "files": 2.0,
+           "flags": ["-x", "ont", "-l", "1000", "-q", "10"], "seed": 2, "what": "automatic trims and adapter identification"},
+    "c5": {"name": "C5 (BASELINE.json configs[4]) at one GPU", "reads": 1_000_000, "mean_len": 150000.0, "max_len": 2_000_000, "per_read": 300_100, "files": 3.0,
+           "flags": ["-x", "ont", "-l", "1000", "-q", "10", "-g", "3g", "-d", "40", "-p", "100", "-k", "11"], "seed": 5,
+           "what": "automatic pre-pass, repeat gate -p 100 -k 11 on the GPU, longest-first downsampling to 3 Gb x 40"},
+}
+
+
 def e2e_leg(args, n_gpus):
-    """The command line end to end on config C2's file.  Legs, in this order:
+    """The command line end to end on the configuration's file (default: C2's).  Legs, in this order:
       main     C2's own flags (-x ont -l 1000 -q 10: automatic trims, automatic adapter identification), tmpfs file sink:
                W warm-up runs + K timed runs (the headline), 3 runs of the other exit mode, the reference ONCE on the same
                file with the same flags and sink (cpu_baseline), outputs compared as multisets, INFO lines compared;
@@ -214,8 +227,9 @@ def e2e_leg(args, n_gpus):
         raise SystemExit("bench.py: %s is missing -- run __graft_entry__.build() (there is no fallback path)" % CLI)
     budget = Budget(float(getattr(args, "e2e_budget_s", 1500.0)))
     shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
-    n_want = n_reads = args.e2e_reads
-    per_read = 90_300                                 # bytes of text per C2 read (2 x 45 kb + header)
+    cfg = E2E_CONFIGS[getattr(args, "config", "c2") or "c2"]
+    n_want = n_reads = args.e2e_reads if getattr(args, "e2e_reads", None) else cfg["reads"]
+    per_read = cfg["per_read"]                        # bytes of text per read (2 x mean length + header)
     # Room for the staging: the input and ONE output at a time live on tmpfs (ours is digested and removed before the
     # reference writes its own); an output is never larger than its input.  tmpfs pages are memory of the box's control
     # group: a group that outgrows memory.max loses the whole box, so stay well inside it.
@@ -232,12 +246,13 @@ def e2e_leg(args, n_gpus):
             free, why = avail, "available memory"
     except (OSError, IndexError, ValueError):
         pass
-    need = n_reads * per_read * 2.0
+    need = n_reads * per_read * cfg["files"]
     reduced = None
     if need > 0.85 * free:
         n_reads = max(2000, int(n_reads * 0.85 * free / need) // 1000 * 1000 or 2000)
-        reduced = "%s holds %.0f GB: the file is %d of config C2's %d reads (input + one output, <= 2 x %.0f GB, kept under 85 %% of that)" % (
-            why, free / 1e9, n_reads, n_want, n_reads * per_read / 1e9)
+        reduced = "%s holds %.0f GB: the file is %d of the configuration's %d reads (input + %s, <= %.0f x %.0f GB, kept under 85 %% of that)" % (
+            why, free / 1e9, n_reads, n_want, "one output" if cfg["files"] == 2.0 else "the reference's temporary copy and its output",
+            cfg["files"], n_reads * per_read / 1e9)
         log("bench: " + reduced)
     td = tempfile.mkdtemp(prefix="tgsf_bench_", dir=shm)
     cores = max(1, min((os.cpu_count() or 2) - 1, 32))      # the reference clamps -t to min(hw-1, 32), :488-499
@@ -322,10 +337,10 @@ def e2e_leg(args, n_gpus):
     try:
         fq = os.path.join(td, "c2.fq")
         t0 = time.perf_counter()
-        bases, nbytes = synth.write_ont_fastq(fq, n_reads, seed=2, procs=gen_procs)
+        bases, nbytes = synth.write_ont_fastq(fq, n_reads, seed=cfg["seed"], procs=gen_procs, mean_len=cfg["mean_len"], max_len=cfg["max_len"])
         log("bench: %d reads / %.2f Gbases / %.2f GB of FASTQ text written to %s in %.1f s by %d processes"
             % (n_reads, bases / 1e9, nbytes / 1e9, fq, time.perf_counter() - t0, gen_procs))
-        flags = ["-x", "ont", "-l", "1000", "-q", "10"]          # configs[1] as written: automatic trims and adapter
+        flags = list(cfg["flags"])                               # the configuration as BASELINE.json writes it
         sinks = {}
         sinks["tmpfs_file"] = file_sink_leg(fq, bases, flags, args.warmup, args.steps, min(3, args.steps), "c2")
         s_file = sinks["tmpfs_file"]
@@ -346,7 +361,7 @@ def e2e_leg(args, n_gpus):
                 s["note"] = "the reference was timed once, writing the tmpfs file (its /dev/null run is within 5 % of that: BENCH_r02)"
             sinks["dev_null"] = s
             log("bench: e2e dev_null: %s" % json.dumps({k2: v for k2, v in s.items() if k2 != "timing_line"}))
-        res = {"box": {"cgroup_cpus": lim["cpus"], "cgroup_memory_gib": (lim["memory_bytes"] or 0) / 2**30 or None, "hw_threads": os.cpu_count()},
+        res = {"config": cfg["name"], "config_what": cfg["what"], "box": {"cgroup_cpus": lim["cpus"], "cgroup_memory_gib": (lim["memory_bytes"] or 0) / 2**30 or None, "hw_threads": os.cpu_count()},
                "reads": n_reads, "bases": bases, "fastq_bytes": nbytes, "flags": " ".join(flags), "threads": cores, "devices": devs,
                "reduced": reduced,
                "staging": "synthetic FASTQ text written to tmpfs (%s) by tgsfilter_amd/synth.write_ont_fastq before timing; "
@@ -354,7 +369,7 @@ def e2e_leg(args, n_gpus):
         os.remove(fq)
         # the pinned pre-pass on round 2's file, the reference beside it
         n_pin = min(400_000, n_reads)
-        if not getattr(args, "no_pinned_variant", False) and budget.allows("pinned-pre-pass variant", 45 + n_pin * 1.1e-4):
+        if cfg is E2E_CONFIGS["c2"] and not getattr(args, "no_pinned_variant", False) and budget.allows("pinned-pre-pass variant", 45 + n_pin * 1.1e-4):
             fq2 = os.path.join(td, "c2_400k.fq")
             bases2, nbytes2 = synth.write_ont_fastq(fq2, n_pin, seed=2, procs=gen_procs)
             fa = os.path.join(td, "rapid.fa")
@@ -486,6 +501,7 @@ def kernel_leg(args, torch, dist, world, rank, local_rank, device, xdev, host_gr
     NS = max(1, args.streams)
     ctxs = [capi.Context(p, local_rank) for _ in range(NS)]
     comm = None
+    state_rccl_ranks = None
     if world > 1:
         tdist.check_layout(ctxs[0].ctr_words, group=host_group)     # setup: same tally layout on every rank
         if args.backend == "nccl":
@@ -493,6 +509,7 @@ def kernel_leg(args, torch, dist, world, rank, local_rank, device, xdev, host_gr
             box = [rccl.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0, group=host_group)
             comm = rccl.comm_init_rank(box[0], rank, world)
+            state_rccl_ranks = rccl.comm_count(comm)
     fcap = max_bases // 1000 + args.reads + 16
     # every context gets a stream of its own (never torch's null stream: the library's streams are non-blocking,
     # nothing orders the null stream against them)
@@ -613,7 +630,10 @@ def kernel_leg(args, torch, dist, world, rank, local_rank, device, xdev, host_gr
 
     dom = "mid_scan"
     t_dom = excl_stage_ms[dom] / 1e3
-    t_all = sum(v for k, v in excl_stage_ms.items() if k not in ("end_tables_raw", "end_windows")) / 1e3
+    # every kernel of a batch (one batch in flight): the two stages that run on the auxiliary stream, beside the middle
+    # scan, count in the SUM; the critical path leaves them out
+    t_all = sum(excl_stage_ms.values()) / 1e3
+    t_crit = sum(v for k, v in excl_stage_ms.items() if k not in ("end_tables_raw", "end_windows")) / 1e3
     steps_mine = max(len(my_steps), 1)
     alg_bytes = 2.0 * (bases / steps_mine) + 32.0 * (reads / steps_mine)    # 2 B/base + 32 B/read
     contract = alg_bytes / t_dom / 1e9 if t_dom > 0 else 0.0
@@ -637,7 +657,7 @@ def kernel_leg(args, torch, dist, world, rank, local_rank, device, xdev, host_gr
         "traffic": traffic, "stale_profile": stale,
         "fractions_of_hbm_peak": {
             "dominant_kernel_contract": contract / HBM_PEAK_GBS,                      # (2 B/base + 32 B/read) / scan time
-            "pipeline": (alg_bytes / t_all / 1e9 / HBM_PEAK_GBS) if t_all > 0 else 0.0,  # same bytes / sum of kernel time
+            "pipeline": (alg_bytes / t_all / 1e9 / HBM_PEAK_GBS) if t_all > 0 else 0.0,  # same bytes / sum of ALL kernel time
             "dominant_kernel_actual_hbm": (traffic / t_dom / 1e9 / HBM_PEAK_GBS) if traffic and t_dom > 0 else None,  # PMC bytes / scan time
             "whole_job": (2.0 * bases_all / world + 32.0 * reads_all / world) / dt / 1e9 / HBM_PEAK_GBS,
         },
@@ -648,7 +668,7 @@ def kernel_leg(args, torch, dist, world, rank, local_rank, device, xdev, host_gr
                     "profiles/ and are reported only while profiles/traffic.json carries the hash of today's kernel "
                     "sources (stale_profile says so)" % (nprof, NS),
         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": excl_stage_ms[dom],
-        "sum_kernel_ms": t_all * 1e3,
+        "sum_kernel_ms": t_all * 1e3, "critical_path_ms": t_crit * 1e3,
         "stage_ms_per_step": excl_stage_ms, "timed_region_stage_ms": timed_stage_ms,
     }
     kp = {
@@ -660,6 +680,12 @@ def kernel_leg(args, torch, dist, world, rank, local_rank, device, xdev, host_gr
                     ("C2: synthetic ONT reads, lognormal mean %.0f bp, %s, adapters ONT rapid + reverse complement" % (mean_len, flags)),
         "reads_per_step": args.reads, "gbases_per_step": bases / steps_mine / 1e9, "batches_in_flight_per_gpu": NS,
         "oracle_check": oracle_note,
+        "tally_exchange": ("one SUM all-reduce of the tally vector over RCCL (libtgsf_rccl), inside the timed region" if comm is not None else
+                           ("one SUM all-reduce through torch.distributed/%s (validation path)" % args.backend if world > 1 else "none (one rank)")),
+        "rccl_ranks": state_rccl_ranks,
+        # the job's merged tallies: the same fixed job must give the same vector whatever the number of ranks
+        "tallies": {"dropinfo": [int(x) for x in drop], "sha256_16": hashlib.sha256(np.ascontiguousarray(total_ctr).tobytes()).hexdigest()[:16],
+                    "reads": reads_all, "bases": bases_all},
     }
     for c in ctxs:
         c.close()
@@ -673,7 +699,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3, help="timed end-to-end runs of the command line")
     ap.add_argument("--warmup", type=int, default=1, help="untimed end-to-end runs before them")
-    ap.add_argument("--e2e-reads", type=int, default=400_000, help="reads in the end-to-end FASTQ file (C2 shape, ~90 KB of text each)")
+    ap.add_argument("--config", choices=sorted(E2E_CONFIGS), default="c2", help="BASELINE.json configuration of the end-to-end leg (c2: the headline; "
+                    "c5: ultra-long reads, repeat gate and downsampling)")
+    ap.add_argument("--e2e-reads", type=int, default=None, help="reads in the end-to-end FASTQ file (default: the configuration's -- C2: 4 M reads, ~90 KB "
+                    "of text each); reduced -- and said so in config.workload -- to what the staging file system / the box's memory control group holds")
+    ap.add_argument("--e2e-budget-s", type=float, default=1500.0, help="seconds the end-to-end leg may take: optional legs are dropped (and named in "
+                    "e2e.skipped) when it runs short; the K timed steps never are")
+    ap.add_argument("--no-pinned-variant", action="store_true", help="skip the pinned-pre-pass variant (-5 0 -3 0 -a rapid.fa on 400 000 reads)")
     ap.add_argument("--no-e2e", action="store_true", help="kernel path only (profiling runs); the headline is then the kernel path")
     ap.add_argument("--no-kernel-path", action="store_true")
     ap.add_argument("--kernel-steps", type=int, default=24)
@@ -691,6 +723,11 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="validation on a 1-GPU box: every rank uses device 0")
     ap.add_argument("--streams", type=int, default=3, help="kernel path: batches in flight per GPU")
     args = ap.parse_args()
+    if args.config == "c5":                # the kernel path in C5's shape: ultra-long reads through the repeat gate
+        args.mean_len = args.mean_len or 150000.0
+        args.min_repeat = args.min_repeat or 100
+        if args.reads == 131072:
+            args.reads = 32768             # (4.9 Gbases a step, as C2's steps)
     # stdout carries exactly one line, the result: whatever libraries print there meanwhile goes to stderr
     sys.stdout.flush()
     real_stdout = os.dup(1)
@@ -736,11 +773,14 @@ def main():
             s = e2e["sinks"]["tmpfs_file"]
             value, ms, steps, warmup = s["gbases_per_s"], s["wall_s_mean"] * 1e3, s["runs"], args.warmup
             metric = "filtered Gbases/sec (end-to-end, excl. gzip I/O)"
-            workload = ("C2 (BASELINE.json configs[1]) END-TO-END: %d synthetic ONT reads (lognormal mean 45 kb, %.2f Gbases, %.1f GB of "
-                        "FASTQ text on tmpfs) -> tgsfilter_amd/bin/tgsfilter %s -t %d -> FASTQ file on tmpfs (%.1f GB) + report; "
-                        "a step = one whole run of the command line; the 4M-read job is %.0f such files"
-                        % (e2e["reads"], e2e["bases"] / 1e9, e2e["fastq_bytes"] / 1e9, e2e["flags"], e2e["threads"],
-                           s.get("output_bytes", 0) / 1e9, 4_000_000 / e2e["reads"]))
+            cfg = E2E_CONFIGS[args.config]
+            workload = ("%s END-TO-END: %d of its %d synthetic ONT reads (lognormal mean %.0f kb, max 2 Mb; %.2f Gbases, "
+                        "%.1f GB of FASTQ text on tmpfs%s) -> tgsfilter_amd/bin/tgsfilter %s -t %d (%s; "
+                        "one process, every mapping taken down before it returns) -> FASTQ file on tmpfs (%.1f GB) + report; a step = one whole "
+                        "run of the command line"
+                        % (cfg["name"], e2e["reads"], cfg["reads"], cfg["mean_len"] / 1e3, e2e["bases"] / 1e9, e2e["fastq_bytes"] / 1e9,
+                           ("; REDUCED: " + e2e["reduced"]) if e2e.get("reduced") else "", e2e["flags"], e2e["threads"], cfg["what"],
+                           s.get("output_bytes", 0) / 1e9))
         else:
             value, ms, steps, warmup = kp["value"], kp["ms_per_step"], kp["steps"], kp["warmup"]
             metric = "device-resident filter throughput (Gbases/sec, inputs in HBM; NOT end-to-end)"
@@ -756,14 +796,23 @@ def main():
         if e2e:
             out["e2e"] = e2e
             s = e2e["sinks"]["tmpfs_file"]
+            if world > 1:
+                # what can and cannot scale with the GPUs: one tmpfs output file is instantiated by one kernel
+                # thread under the inode lock, whatever the number of GPUs; the /dev/null (pipe) sink is PCIe-bound per GPU
+                e2e["scaling_note"] = ("headline sink (one tmpfs file) is bound by the kernel's page instantiation (%s) and does not scale with "
+                                       "GPUs; the dev_null sink is the one that can" % s.get("bound", "fallocate"))
             if "reference_gbases_per_s" in s:
                 out["cpu_baseline"] = {
                     "value": s["reference_gbases_per_s"], "unit": "Gbases/s", "cores": e2e["threads"], "kind": "reference",
                     "sample": "the whole end-to-end file (%d reads, %.2f Gbases, %.1f GB FASTQ on tmpfs), same flags, same sink "
-                              "(tmpfs file), oracle/_ref/tgsfilter_ref -t %d, wall %.2f s; output multiset and INFO counters "
-                              "identical to ours (asserted)" % (e2e["reads"], e2e["bases"] / 1e9, e2e["fastq_bytes"] / 1e9,
-                                                               e2e["threads"], s["reference_wall_s"])}
-                out["e2e_speedup_vs_reference"] = {k: v.get("speedup_vs_reference") for k, v in e2e["sinks"].items()}
+                              "(tmpfs file), oracle/_ref/tgsfilter_ref -t %d, wall %.2f s; output multiset and INFO lines "
+                              "(automatic trims, identified adapter, depths, counters) identical to ours (asserted)"
+                              % (e2e["reads"], e2e["bases"] / 1e9, e2e["fastq_bytes"] / 1e9, e2e["threads"], s["reference_wall_s"])}
+                out["e2e_speedup_vs_reference"] = {
+                    "tmpfs_file": s.get("speedup_vs_reference"),
+                    "tmpfs_file_" + OTHER_EXIT_MODE_KEY.replace("_wall_s", ""): s.get("speedup_vs_reference_" + OTHER_EXIT_MODE_KEY.replace("_wall_s", "")),
+                    "dev_null_vs_reference_file_run": e2e["sinks"].get("dev_null", {}).get("speedup_vs_reference_file_run"),
+                    "pinned_prepass_variant": e2e.get("variants", {}).get("pinned_prepass", {}).get("speedup_vs_reference")}
         if kp:
             out["kernel_path"] = kp
             out["roofline"] = roofline

@@ -15,12 +15,14 @@ from tgsfilter_amd import synth  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 400000
 runs = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 print("box:", bench.cgroup_limits(), flush=True)
+DEFAULT_CLI = bench.CLI
 td = tempfile.mkdtemp(prefix="thr_", dir="/dev/shm")
 try:
     fq = os.path.join(td, "in.fq")
     bases, nbytes = synth.write_ont_fastq(fq, n, seed=2, procs=32)
     for setting in (sys.argv[3:] or [""]):
         env = dict(os.environ, TGSF_TIMING="1")
+        bench.CLI = DEFAULT_CLI
         out = os.path.join(td, "out.fq")
         extra = []
         for kv in setting.split():
@@ -29,6 +31,8 @@ try:
                 extra = v.replace(",", " ").split()
             elif k == "OUT":
                 out = v
+            elif k == "CLI":                      # another build of the command line (A/B in one sitting)
+                bench.CLI = v if os.path.isabs(v) else os.path.join(ROOT, v)
             else:
                 env[k] = v
         walls, cpus, thr, tim = [], [], [], {}

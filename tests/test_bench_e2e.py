@@ -29,6 +29,19 @@ def test_e2e_leg_with_the_emulated_cli(monkeypatch):
     assert r["reads"] == 16 and r["bases"] > 0 and r["flags"] == "-x ont -l 1000 -q 10" and not r["skipped"]
 
 
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/tgsfilter_ref not built (make -C oracle ref)")
+def test_e2e_leg_config_c5_with_the_emulated_cli(monkeypatch):
+    """--config c5: ultra-long reads, -g 3g -d 40 -p 100 -k 11 as BASELINE.json writes it, the reference beside it."""
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tgsfilter_amd", "host"), "emul"], check=True)
+    import bench
+    monkeypatch.setattr(bench, "CLI", os.path.join(ROOT, "tests", "emul", "tgsfilter_emul"))
+    args = types.SimpleNamespace(e2e_reads=10, steps=1, warmup=0, no_cpu_baseline=False, config="c5")
+    r = bench.e2e_leg(args, 1)
+    s = r["sinks"]["tmpfs_file"]
+    assert r["flags"] == "-x ont -l 1000 -q 10 -g 3g -d 40 -p 100 -k 11" and "C5" in r["config"]
+    assert s["same_counters"] and s["same_output_multiset"] and s["output_records"] > 0 and "variants" not in r
+
+
 def test_write_ont_fastq_is_deterministic(tmp_path):
     from tgsfilter_amd import synth
     a, b = str(tmp_path / "a.fq"), str(tmp_path / "b.fq")

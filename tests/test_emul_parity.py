@@ -148,13 +148,15 @@ def _tie_reads():
     return reads
 
 
+@pytest.mark.parametrize("order", ["forward", "reverse"])
 @pytest.mark.parametrize("adapters,m_mid", [([b"A" * 50, b"T" * 50], 35), ([synth.PACBIO_BLUNT, synth.PACBIO_BLUNT_RC], 1),
                                             ([b"A" * 50, b"T" * 50, b"AC" * 45 + b"G"], 35)])
-def test_emul_candidate_pool_overflow_is_handled(emul, adapters, m_mid, monkeypatch, capfd):
+def test_emul_candidate_pool_overflow_is_handled(emul, adapters, m_mid, order, monkeypatch, capfd):
     """With the sizing hints a minimal caller passes, reads whose minimum is tied everywhere used to end in TGSF_E_CAPACITY
     ("candidate pool overflow"); the reference completes them (include/edlib.cpp:660-672: every column at the global
     minimum is a location).  The library now re-runs the scan with a pool that fits: same records, same tallies as the oracle."""
     monkeypatch.setenv("TGSF_TRACE_POOL", "1")
+    monkeypatch.setenv("TGSF_EMUL_ORDER", order)          # reverse: the emulated lanes run last to first (a GPU's order is its own)
     reads = _tie_reads()
     p = parity.sized(abi.make_params("ont", adapters=adapters, min_q=7.0, mid_match_len=m_mid, end_match_len=4), reads)
     ctx = capi.Context(p, 0, emul)
@@ -164,11 +166,13 @@ def test_emul_candidate_pool_overflow_is_handled(emul, adapters, m_mid, monkeypa
     ctx.close()
 
 
+@pytest.mark.parametrize("order", ["forward", "reverse"])
 @pytest.mark.parametrize("name", ["ont_zoo", "hifi_zoo", "ont_m1", "huge_adapter"])
-def test_emul_golden_through_the_overflow_path(emul, golden_dir, name, monkeypatch, capfd):
+def test_emul_golden_through_the_overflow_path(emul, golden_dir, name, order, monkeypatch, capfd):
     """A pool of 2 slots: every batch with more than two candidates takes the count-and-rescan path; the goldens must not notice."""
     monkeypatch.setenv("TGSF_POOL_CAP", "2")
     monkeypatch.setenv("TGSF_TRACE_POOL", "1")
+    monkeypatch.setenv("TGSF_EMUL_ORDER", order)
     parity.golden_case(emul, golden_dir, name)
     assert "candidate pool overflow" in capfd.readouterr().err
 
@@ -190,3 +194,10 @@ def test_emul_pool_overflow_over_several_batches(emul, monkeypatch):
         assert np.array_equal(got_r, exp_r) and np.array_equal(got_f, exp_f)
     assert np.array_equal(ctx.counters(), exp)
     ctx.close()
+
+
+@pytest.mark.parametrize("name", ["ont_zoo", "hifi_zoo", "ont_discard", "long_adapter"])
+def test_emul_golden_with_lanes_in_reverse_order(emul, golden_dir, name, monkeypatch):
+    """The candidate lists of the one-pass scan are in whatever order the lanes append: results must not depend on it."""
+    monkeypatch.setenv("TGSF_EMUL_ORDER", "reverse")
+    parity.golden_case(emul, golden_dir, name)

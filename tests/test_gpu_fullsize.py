@@ -241,3 +241,27 @@ def test_hifi_full_size_invariances_and_oracle_slice(hifi_batch):
     must = rng.choice(split, size=150, replace=False)
     n_chk, _ = bench.oracle_slice_check(hifi_batch["torch"], hifi_batch, HIFI_KW, "hifi", reads, frags, m=350, seed=6, must_include=must)
     assert n_chk >= 350
+
+
+def test_bench_two_ranks_share_one_gpu_same_totals(tmp_path):
+    """bench.py's N > 1 bookkeeping on the 1-GPU box: the fixed job of K batches dealt over two ranks
+    (both on device 0, the tally exchange through torch.distributed/gloo -- RCCL refuses two ranks on one GPU), one
+    all-reduce, must end with the SAME merged tally vector as one rank running the K batches; strong scaling is declared."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--no-e2e", "--no-cpu-baseline", "--no-oracle-check", "--reads", "4096", "--kernel-warmup", "1", "--streams", "2"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--kernel-steps", "6"] + common, capture_output=True, timeout=900)
+    assert one.returncode == 0, one.stderr.decode()[-2000:]
+    j1 = json.loads(one.stdout.decode().strip().splitlines()[-1])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "gloo",
+                          "--job-steps", "6"] + common, capture_output=True, timeout=900, env=env)
+    assert two.returncode == 0, two.stderr.decode()[-2000:]
+    j2 = json.loads([l for l in two.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert j2["n_gpus"] == 2 and j2["scaling"] == "strong" and "strong" in j2["kernel_path"]["scaling"]
+    assert j2["kernel_path"]["tallies"] == j1["kernel_path"]["tallies"]
+    assert j2["kernel_path"]["tallies"]["reads"] == 6 * 4096
+    assert "all-reduce" in j2["kernel_path"]["tally_exchange"] and j2["kernel_path"]["rccl_ranks"] is None

@@ -273,6 +273,8 @@ def test_gpu_pool_overflow_device_batches(monkeypatch):
     got_r = d_reads.cpu().numpy().view(abi.READ_RESULT_DTYPE)
     got_f = d_frags.cpu().numpy().view(abi.FRAGMENT_DTYPE)[:int(d_nf[0].item())]
     assert np.array_equal(got_r, exp_r) and np.array_equal(got_f, exp_f) and np.array_equal(ctx.counters(), exp_ctr)
+    ctx.close()
+    ctx = capi.Context(p, 0)          # (the first context has grown its pool by now: a new one starts from the forced 2 slots)
     go()
     go()
     st.synchronize()

@@ -34,6 +34,7 @@ constexpr int kTileBins = 64;      // one bin per lane
 constexpr int kTileBases = kBin * kTileBins;   // 6400 bases per stats tile
 constexpr int kSegCols = 1024;     // columns of the read middle owned by one lane of the infix scan
 constexpr int kMaxRegions = 64;    // disjoint drop regions per read the region kernel can hold
+constexpr int kMidListMax = 1024;  // candidates of one read beyond which the scan is redone into position-ordered arrays
 
 // ---------------------------------------------------------------------------
 // small intrinsics with host stand-ins (emulation only)

@@ -60,9 +60,16 @@ struct DevBatch {
     MidCand*  pool;            // candidate / region pool
     uint32_t  pool_cap;
     uint32_t* pool_n;          // number of slots used
-    uint32_t  mid_mode;        // middle scan: 0 = one pass (the pool usually holds every candidate); after an overflow
-                               // (status[2]) the scan runs twice more with mid_best known: 1 = count the columns at each
-                               // (read, adapter)'s minimum, 2 = hand exactly those over (the pool has been grown to fit)
+    uint32_t  mid_mode;        // middle scan: 0 = one pass, candidates go to per-read lists in the order the lanes get to them
+                               // (the pool usually holds them all, and a read has a handful).  When the pool overflows or a
+                               // read collects more than kMidListMax of them (status[2]) the scan runs twice more with
+                               // mid_best known: 1 = every lane counts the columns at its (read, adapter)'s minimum into
+                               // seg_n, 2 = after a prefix sum over seg_n the lanes write exactly those columns at their
+                               // own offsets: the pool (grown to fit) then holds every read's candidates as one array,
+                               // in ascending order of position -- which the walks behind the scan rely on for long lists
+    uint32_t* mid_cnt;         // [n] candidates handed over per read (mode 0)
+    uint32_t* mid_gate;        // [n*A] (modes 1, 2) 1 = the first location's path passes the gates: every location counts
+    uint32_t* seg_n;           // [segments*A + 1] (modes 1, 2) per (lane, adapter): count, then first slot
     uint32_t* seg_cnt;         // [n+1] middle segments per read, scanned in place to bases
     uint32_t* nfr;             // [n+1] fragments per read, scanned in place to frag_begin
     uint32_t* scan_part;       // [n / kScanTile + 2] per-tile totals of the prefix scans

@@ -187,6 +187,7 @@ TGSF_KERNEL k_prepare(DevParams P, DevBatch B, uint32_t max_read_len)
         B.sumq[r] = 0;
         B.flags[r] = 0;
         B.mid_head[r] = -1;
+        B.mid_cnt[r] = 0;
         B.trimmed[r] = 0;
         B.seg_cnt[r] = 0;
         B.nfr[r] = 0;
@@ -432,7 +433,9 @@ TGSF_D int32_t wave_sum_i32(int32_t v) {
 
 // 51 KB of LDS per block already limits a CU to 3 blocks (3 waves per SIMD): take that register budget
 // (the 14 staging registers per stream plus the work-list words spill at the default 128).
-template <bool CLEAN>
+// NT: the text is fetched with non-temporal loads (each byte is wanted once by this kernel; what the later kernels of the
+// batch re-read has long left the caches by then: a batch is GBs, the caches are MBs)
+template <bool CLEAN, bool NT = false>
 TGSF_KERNEL TGSF_BOUNDS(256, 3) k_stats(DevParams P, DevBatch B)
 {
     if (CLEAN && pool_overflowed(B)) return;
@@ -499,9 +502,11 @@ TGSF_KERNEL TGSF_BOUNDS(256, 3) k_stats(DevParams P, DevBatch B)
 #pragma unroll
         for (int k = 0; k < kLaneChunks; k++) {
             const uint32_t cb = (lane + 64u * k) * 16u;
-            rs[k] = *reinterpret_cast<const u32x4*>(ps + (cb < lasts ? cb : lasts));
+            const u32x4* as = reinterpret_cast<const u32x4*>(ps + (cb < lasts ? cb : lasts));
+            const u32x4* aq4 = reinterpret_cast<const u32x4*>(pq + (cb < lastq ? cb : lastq));
+            rs[k] = NT ? __builtin_nontemporal_load(as) : *as;
             if (P.no_qual) { const uint32_t w = (uint32_t)P.qtype * 0x01010101u; rq[k] = u32x4{w, w, w, w}; }   // q - qType = 0
-            else rq[k] = *reinterpret_cast<const u32x4*>(pq + (cb < lastq ? cb : lastq));
+            else rq[k] = NT ? __builtin_nontemporal_load(aq4) : *aq4;
         }
 #else
         (void)a0; (void)aq; (void)nb;
@@ -1129,8 +1134,12 @@ TGSF_D bool worth_handing_over(const DevBatch& B, uint32_t r, int a, int A, int 
 }
 TGSF_D void push_candidate(const DevBatch& B, uint32_t r, int pos, int score, int a)
 {
+    if (B.status[2]) return;                                          // the scan will be redone anyway
     uint32_t idx = atomicAdd(B.pool_n, 1u);
-    if (idx >= B.pool_cap) { B.status[2] = 1u; (void)r; return; }     // not an error: tgsf_wait re-runs the scan with a pool that fits
+    // Not errors: tgsf_wait re-runs the scan into a pool that fits, in position order (mid_mode).  A long list in the
+    // order the lanes happened to reach it would cost the region kernel a pass over the list per out-of-order region.
+    if (idx >= B.pool_cap) { B.status[2] = 1u; return; }
+    if (atomicAdd(&B.mid_cnt[r], 1u) == (uint32_t)kMidListMax) B.status[2] = 1u;
     MidCand c;
     c.pos = pos;
     c.aux = score | (a << 8);
@@ -1140,9 +1149,33 @@ TGSF_D void push_candidate(const DevBatch& B, uint32_t r, int pos, int score, in
 }
 
 // before the scans that follow a pool overflow: empty candidate lists (mid_best keeps the minima of the first scan)
-TGSF_KERNEL k_mid_reset(DevBatch B)
+TGSF_KERNEL k_mid_reset(DevBatch B, int A)
 {
-    for (uint32_t r = gtid(); r < B.n; r += gsize()) B.mid_head[r] = -1;
+    for (uint32_t r = gtid(); r < B.n; r += gsize()) {
+        B.mid_head[r] = -1;
+        for (int a = 0; a < A; a++) B.mid_gate[(size_t)r * A + a] = 0u;
+    }
+}
+// a candidate written at its own slot (mode 2): the slots of a read are consecutive, in ascending order of position
+TGSF_D void place_candidate(const DevBatch& B, uint32_t idx, int pos, int score, int a)
+{
+    if (idx >= B.pool_cap) { B.status[2] = 1u; return; }              // (cannot happen: the pool was sized from the counts)
+    MidCand c;
+    c.pos = pos;
+    c.aux = score | (a << 8);
+    c.state = 0;
+    c.next = (int32_t)idx + 1;                                        // k_mid_link ends every read's list
+    B.pool[idx] = c;
+}
+// first slot of read r's candidates (mode 2, after the prefix sum over seg_n)
+TGSF_D uint32_t cand_begin(const DevBatch& B, uint32_t r, int A) { return B.seg_n[(size_t)B.seg_cnt[r] * (size_t)A]; }
+TGSF_KERNEL k_mid_link(DevBatch B, int A)
+{
+    for (uint32_t r = gtid(); r < B.n; r += gsize()) {
+        const uint32_t b = cand_begin(B, r, A), e = cand_begin(B, r + 1, A);
+        B.mid_head[r] = b < e ? (int32_t)b : -1;
+        if (b < e && e - 1u < B.pool_cap) B.pool[e - 1u].next = -1;
+    }
 }
 
 template <int AT>
@@ -1175,6 +1208,7 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
     if (c1 > ML) c1 = ML;
 
     Hot st[AT];
+    uint32_t slot[AT];        // mode 1: columns counted so far; mode 2: the next slot of this (lane, adapter)
     int lim[AT];              // best bottom-row value seen so far in the owned columns (k+1: none yet)
     int lim3[AT];             // the every-4th-column test: lim + 2 while nothing is recorded yet (only a value
                               // BELOW lim counts then), lim + 3 afterwards (ties count too)
@@ -1194,6 +1228,7 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
             if (gmin > P.k_mid[a]) on = false; else first_lim = gmin + 1;
         }
         any_on |= on;
+        slot[j] = (B.mid_mode == 2u && on) ? B.seg_n[(size_t)g * P.n_adapters + a] : 0u;
         hot_init(st[j], j < na ? P.Q[a] : 1);
         lim[j] = on ? first_lim : -1000;
         lim3[j] = lim[j] + 2;
@@ -1220,7 +1255,8 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
     int32_t (*ties)[4] = tie_col[threadIdx.x];
     auto flush_ties = [&](int j) {
         if (ntie[j] > 0) {
-            if (B.mid_mode == 1u) atomicAdd(B.pool_n, (uint32_t)ntie[j]);     // counting pass: how large the pool has to be
+            if (B.mid_mode == 1u) slot[j] += (uint32_t)ntie[j];               // counting pass
+            else if (B.mid_mode == 2u) for (int i = 0; i < ntie[j]; i++) place_candidate(B, slot[j]++, ties[j][i], lim[j], a0 + j);
             else if (worth_handing_over(B, r, a0 + j, P.n_adapters, lim[j]))
                 for (int i = 0; i < ntie[j]; i++) push_candidate(B, r, ties[j][i], lim[j], a0 + j);
         }
@@ -1303,7 +1339,10 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
     }
     while (c < c1) { step_all(mid[c]); if (c >= c0) check_col(c); c++; }
 #pragma unroll
-    for (int j = 0; j < AT; j++) flush_ties(j);
+    for (int j = 0; j < AT; j++) {
+        flush_ties(j);
+        if (B.mid_mode == 1u && j < na && slot[j]) B.seg_n[(size_t)g * P.n_adapters + a0 + j] = slot[j];
+    }
     }
 }
 
@@ -1346,8 +1385,10 @@ TGSF_KERNEL k_mid_scanw(DevParams P, DevBatch B, int a)
         if (gmin > P.k_mid[a]) return;
         lim = gmin + 1;
     }
+    uint32_t slot = B.mid_mode == 2u ? B.seg_n[(size_t)g * P.n_adapters + a] : 0u;
     auto hand_over = [&](int n) {
-        if (B.mid_mode == 1u) atomicAdd(B.pool_n, (uint32_t)n);
+        if (B.mid_mode == 1u) slot += (uint32_t)n;
+        else if (B.mid_mode == 2u) for (int i = 0; i < n; i++) place_candidate(B, slot++, ties[i], lim, a);
         else if (worth_handing_over(B, r, a, P.n_adapters, lim)) for (int i = 0; i < n; i++) push_candidate(B, r, ties[i], lim, a);
     };
     int c = c0 - (Q + P.k_mid[a]);
@@ -1362,6 +1403,7 @@ TGSF_KERNEL k_mid_scanw(DevParams P, DevBatch B, int a)
         }
     }
     if (ntie > 0) hand_over(ntie);
+    if (B.mid_mode == 1u && slot) B.seg_n[(size_t)g * P.n_adapters + a] = slot;
 }
 
 // ---------------------------------------------------------------------------
@@ -1386,6 +1428,7 @@ TGSF_KERNEL k_mid_resolve(DevParams P, DevBatch B)
         if ((aux >> 8) != a) continue;
         const int sc = aux & 0xFF, pos = B.pool[i].pos;
         if (sc < best || (sc == best && pos < e0)) { best = sc; e0 = pos; }
+        if (B.mid_mode) break;       // position-ordered arrays of columns AT the minimum: the first one is the first location
     }
     if (best == (1 << 30)) return;
     const int L = (int)B.len[r], E = P.end_len;
@@ -1396,6 +1439,7 @@ TGSF_KERNEL k_mid_resolve(DevParams P, DevBatch B)
     const int mlen = first_mlen_any<MAXNW>(P, a, win, s0, e0, best, need, sc, false);
     if (mlen < need) return;
     atomicOr(&B.flags[r], (uint32_t)TGSF_RF_ADMID);
+    if (B.mid_mode) { B.mid_gate[idx] = 1u; return; }                  // the locations themselves: k_mid_resolve_each, a lane each
     for (int32_t i = head; i >= 0; i = B.pool[i].next) {
         const int aux = B.pool[i].aux;
         if ((aux >> 8) != a || (aux & 0xFF) != best) continue;
@@ -1405,6 +1449,30 @@ TGSF_KERNEL k_mid_resolve(DevParams P, DevBatch B)
         if (ts < 0) ts = 0;
         if (te > L) te = L;
         // the slot is only ever touched by its own adapter's lane
+        B.pool[i].pos = ts;
+        B.pool[i].state = (te << 2) | 1;
+    }
+}
+
+// The same for the position-ordered arrays (mid_mode): one lane per candidate slot -- a read may have millions -- finds its
+// read by bisection over the reads' first slots and, if the (read, adapter)'s first location passed, its own start.
+template <int MAXNW>
+TGSF_KERNEL k_mid_resolve_each(DevParams P, DevBatch B)
+{
+    const int A = P.n_adapters;
+    const uint32_t total = B.seg_n[(size_t)B.seg_cnt[B.n] * (size_t)A];
+    for (uint32_t i = gtid(); i < total && i < B.pool_cap; i += gsize()) {
+        uint32_t lo = 0, hi = B.n;                                     // largest r with cand_begin(r) <= i
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cand_begin(B, mid, A) <= i) lo = mid; else hi = mid; }
+        const uint32_t r = lo;
+        const int aux = B.pool[i].aux, a = aux >> 8, best = aux & 0xFF, pos = B.pool[i].pos;
+        if (!B.mid_gate[(size_t)r * A + a]) continue;
+        const int L = (int)B.len[r], E = P.end_len;
+        const uint8_t* win = B.seq + B.off[r] + E;
+        const int st = start_of_any<MAXNW>(P, a, win, pos, best);
+        int ts = st + E - P.extra_len, te = pos + E + 1 + P.extra_len;   // :1248-1256
+        if (ts < 0) ts = 0;
+        if (te > L) te = L;
         B.pool[i].pos = ts;
         B.pool[i].state = (te << 2) | 1;
     }

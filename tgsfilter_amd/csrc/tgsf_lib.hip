@@ -48,6 +48,7 @@ struct tgsf_ctx {
     uint32_t cap_reads, max_read_len, n_bins;
     unsigned endtab_grid = 512;             // k_end_tables: LDS-atomic bound, 40 KB of LDS per block: two blocks per CU (128: 0.36 ms, 512: 0.19 ms)
     unsigned stats_grid = 768, mid_grid = 0;   // tuning knobs (TGSF_STATS_GRID, TGSF_MID_GRID; 0 = one lane per segment)
+    bool stats_nt = true;                     // k_stats fetches the text with non-temporal loads (2.24 -> 2.06 ms raw, 5.4 -> 5.8 TB/s; TGSF_STATS_NT=0: plain loads)
     uint64_t ctr_words;
     int scratch_cols;
     // internal input / output staging for tgsf_submit
@@ -121,8 +122,15 @@ static void emul_launch(unsigned grid, unsigned block, F f)
 {
     using namespace tgsf_emul;
     gridDim = {grid, 1, 1}; blockDim = {block, 1, 1};
-    for (unsigned b = 0; b < grid; b++)
-        for (unsigned t = 0; t < block; t++) { blockIdx = {b, 0, 0}; threadIdx = {t, 0, 0}; f(); }
+    // TGSF_EMUL_ORDER=reverse: lanes run last to first -- what they append to shared lists (the middle scan's candidates)
+    // then arrives in descending order, as unlike the usual order as a GPU's may be: results must not depend on it
+    const char* ord = getenv("TGSF_EMUL_ORDER");
+    const bool reverse = ord && !strcmp(ord, "reverse");
+    for (unsigned b0 = 0; b0 < grid; b0++)
+        for (unsigned t0 = 0; t0 < block; t0++) {
+            const unsigned b = reverse ? grid - 1 - b0 : b0, t = reverse ? block - 1 - t0 : t0;
+            blockIdx = {b, 0, 0}; threadIdx = {t, 0, 0}; f();
+        }
 }
 #define TGSF_LAUNCH(kernel, grid, block, stream, ...) emul_launch((grid), (block), [&] { kernel(__VA_ARGS__); })
 // block-cooperative kernels are written for any block size; emulate them with one thread
@@ -413,6 +421,7 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     c->ctr_words = tgsf_ctr_len(p->bc_len, c->n_bins);
     P.seg_cols = kSegCols;
     if (const char* e = getenv("TGSF_STATS_GRID")) { int v = atoi(e); if (v >= 1 && v <= 65536) c->stats_grid = (unsigned)v; }
+    if (const char* e = getenv("TGSF_STATS_NT")) c->stats_nt = atoi(e) > 0;
     if (const char* e = getenv("TGSF_ENDTAB_GRID")) { int v = atoi(e); if (v >= 1 && v <= 4096) c->endtab_grid = (unsigned)v; }
     if (const char* e = getenv("TGSF_MID_GRID")) { int v = atoi(e); if (v >= 1) c->mid_grid = (unsigned)v; }
     if (const char* e = getenv("TGSF_SEG_COLS")) { int v = atoi(e); if (v >= 256 && v <= 65536) P.seg_cols = v & ~15; }   // tuning knob
@@ -448,6 +457,8 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     if (!e) e = dev_alloc(c, &B.clip3, n * A);
     if (!e) e = dev_alloc(c, &B.mid_head, n);
     if (!e) e = dev_alloc(c, &B.mid_best, n * A);
+    if (!e) e = dev_alloc(c, &B.mid_cnt, n);
+    if (!e) e = dev_alloc(c, &B.mid_gate, n * A);
     if (!e) e = dev_alloc(c, &B.pool, (size_t)B.pool_cap);
     if (!e) e = dev_alloc(c, &B.pool_n, 4);
     if (!e) e = dev_alloc(c, &B.seg_cnt, n + 1);
@@ -541,12 +552,13 @@ static int harvest_profile(tgsf_ctx* c, rt_stream st)
 #endif
 
 // exclusive prefix sums of a[0..n) in place, a[n] = total
-static void scan_u32(const DevBatch& B, uint32_t* a, uint32_t n, rt_stream st)
+static void scan_u32(const DevBatch& B, uint32_t* a, uint32_t n, rt_stream st, uint32_t* part = nullptr)
 {
+    if (!part) part = B.scan_part;                       // (sized for n = the reads of a batch)
     const unsigned nb = (n + kScanTile - 1) / kScanTile;
-    TGSF_LAUNCH_COOP(k_scan_tiles, nb, 256, st, a, n, B.scan_part);
-    TGSF_LAUNCH_COOP(k_scan_top, 1, 64, st, B.scan_part, (uint32_t)nb, a + n);
-    TGSF_LAUNCH_COOP(k_scan_add, nb, 256, st, a, n, (const uint32_t*)B.scan_part);
+    TGSF_LAUNCH_COOP(k_scan_tiles, nb, 256, st, a, n, part);
+    TGSF_LAUNCH_COOP(k_scan_top, 1, 64, st, part, (uint32_t)nb, a + n);
+    TGSF_LAUNCH_COOP(k_scan_add, nb, 256, st, a, n, (const uint32_t*)part);
 }
 
 // redo = false: the whole pipeline of one batch, enqueued without a host round trip.
@@ -560,6 +572,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
         c->batches_since_wait++;
     }
     const bool profile = c->profile && !redo;
+    (void)profile;
     DevBatch B = c->B;
     const DevParams& P = c->P;
     B.seq = in->seq; B.qual = in->qual; B.off = in->offsets; B.len_in = in->lengths;
@@ -612,7 +625,8 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
 #if !defined(TGSF_EMUL)
     if (c->hp) { (void)hipEventRecord(c->ev_hp[0], st); (void)hipStreamWaitEvent(ss, c->ev_hp[0], 0); }
 #endif
-    TGSF_LAUNCH(k_stats<false>, gstats, 64 * kStatsWaves, ss, P, B);
+    if (c->stats_nt) TGSF_LAUNCH((k_stats<false, true>), gstats, 64 * kStatsWaves, ss, P, B);
+    else TGSF_LAUNCH((k_stats<false, false>), gstats, 64 * kStatsWaves, ss, P, B);
 #if !defined(TGSF_EMUL)
     if (c->hp) { (void)hipEventRecord(c->ev_hp[1], ss); (void)hipStreamWaitEvent(st, c->ev_hp[1], 0); }
 #endif
@@ -677,40 +691,74 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
         };
         if (!redo) launch_scans(0);
         else {
-            // The first scan left every (read, adapter)'s minimum in mid_best.  Count the columns AT those minima (what
-            // edlib reports, include/edlib.cpp:660-672), make room for exactly them, hand them over.
-            TGSF_LAUNCH(k_mid_reset, gsmall, T, ms, B);
-            rt_memset(B.pool_n, 0, 4, ms);
-            launch_scans(1);
-            uint32_t need = 0;
-            int he = rt_d2h(&need, B.pool_n, 4, ms);
-            if (!he) he = rt_sync(ms);
-            if (he) return fail(c, TGSF_E_HIP, "middle scan (counting pass) failed: %s", rt_errstr(he));
-            if (need > B.pool_cap) {
-                const uint64_t want = (uint64_t)need + need / 16 + 1024;
-                if (want > 0x7FFFFFF0ull) return fail(c, TGSF_E_CAPACITY, "middle-adapter candidates: %u columns tie their reads' minima, more than one batch can list", need);
-                void* np = nullptr;
-                if (rt_malloc(&np, (size_t)want * sizeof(MidCand) + 64))
-                    return fail(c, TGSF_E_CAPACITY, "middle-adapter candidates: no device memory for %llu slots (%.1f GB)", (unsigned long long)want, (double)want * sizeof(MidCand) * 1e-9);
-                for (void*& q : c->allocs) if (q == (void*)c->B.pool) q = np;
-                rt_free(c->B.pool);
-                c->B.pool = (MidCand*)np; c->B.pool_cap = (uint32_t)want;
-                B.pool = c->B.pool; B.pool_cap = c->B.pool_cap;
-                c->pool_regrown++;
+            // The first scan left every (read, adapter)'s minimum in mid_best.  Now every lane counts the columns AT those
+            // minima (what edlib reports, include/edlib.cpp:660-672) per adapter; a prefix sum turns the counts into slots;
+            // the pool is grown to the total; the lanes write their columns at their own slots: every read's candidates
+            // end up as one array in ascending order of position.
+            const uint64_t cells = max_segs * (uint64_t)A + 1;
+            if (cells > 0xFFFFFFF0ull) return fail(c, TGSF_E_CAPACITY, "middle scan: too many (segment, adapter) cells for the position-ordered pass");
+            uint32_t *seg_n = nullptr, *part = nullptr;
+            if (rt_malloc((void**)&seg_n, (size_t)(cells + 1) * 4 + 64) || rt_malloc((void**)&part, (size_t)(cells / kScanTile + 4) * 4 + 64)) {
+                if (seg_n) rt_free(seg_n);
+                return fail(c, TGSF_E_CAPACITY, "middle scan: no device memory for the position-ordered pass (%.1f GB)", (double)cells * 4e-9);
             }
-            if (getenv("TGSF_TRACE_POOL"))
-                fprintf(stderr, "tgsf: candidate pool overflow: %u columns at their reads' minima, pool of %u slots%s; scanning again\n", need, B.pool_cap,
-                        c->pool_regrown ? " (grown)" : "");
-            rt_memset(B.pool_n, 0, 4, ms);
-            rt_memset(B.status + 2, 0, 4, ms);
-            launch_scans(2);
+            B.seg_n = seg_n;
+            int rc = TGSF_OK;
+            do {
+                rt_memset(seg_n, 0, (size_t)(cells + 1) * 4, ms);
+                TGSF_LAUNCH(k_mid_reset, gsmall, T, ms, B, A);
+                launch_scans(1);
+                // prefix sums over the cells the batch really has (its segment count is on the device: sum the upper bound;
+                // cells beyond the last segment hold zeros and seg_n[used] == seg_n[any later cell] == total)
+                scan_u32(B, seg_n, (uint32_t)cells, ms, part);
+                uint32_t need = 0;
+                int he = rt_d2h(&need, seg_n + cells, 4, ms);
+                if (!he) he = rt_sync(ms);
+                if (he) { rc = fail(c, TGSF_E_HIP, "middle scan (counting pass) failed: %s", rt_errstr(he)); break; }
+                if (need > B.pool_cap) {
+                    const uint64_t want = (uint64_t)need + 1024;
+                    if (want > 0x7FFFFFF0ull) { rc = fail(c, TGSF_E_CAPACITY, "middle-adapter candidates: %u columns tie their reads' minima, more than one batch can list", need); break; }
+                    void* np = nullptr;
+                    if (rt_malloc(&np, (size_t)want * sizeof(MidCand) + 64)) {
+                        rc = fail(c, TGSF_E_CAPACITY, "middle-adapter candidates: no device memory for %llu slots (%.1f GB)", (unsigned long long)want, (double)want * sizeof(MidCand) * 1e-9);
+                        break;
+                    }
+                    for (void*& q : c->allocs) if (q == (void*)c->B.pool) q = np;
+                    rt_free(c->B.pool);
+                    c->B.pool = (MidCand*)np; c->B.pool_cap = (uint32_t)want;
+                    B.pool = c->B.pool; B.pool_cap = c->B.pool_cap;
+                    c->pool_regrown++;
+                }
+                if (getenv("TGSF_TRACE_POOL"))
+                    fprintf(stderr, "tgsf: candidate pool overflow (or a read with a long candidate list): %u columns at their reads' minima, pool of %u slots%s; scanning again in position order\n", need, B.pool_cap,
+                            c->pool_regrown ? " (grown)" : "");
+                rt_memset(B.status + 2, 0, 4, ms);
+                launch_scans(2);
+                TGSF_LAUNCH(k_mid_link, gsmall, T, ms, B, A);
+                DevBatch Bm = B;
+                Bm.mid_mode = 2;
+                // first locations and gates per (read, adapter), then every location on a lane of its own
+                if (P.max_nw > 2) TGSF_LAUNCH(k_mid_resolve<4>, blocks_for((uint64_t)n * A, 64), 64, ms, P, Bm);
+                else TGSF_LAUNCH(k_mid_resolve<2>, blocks_for((uint64_t)n * A, 64), 64, ms, P, Bm);
+                const unsigned geach = grid_cap(std::min(blocks_for(need, 64), 65536u));
+                if (need) {
+                    if (P.max_nw > 2) TGSF_LAUNCH(k_mid_resolve_each<4>, geach, 64, ms, P, Bm);
+                    else TGSF_LAUNCH(k_mid_resolve_each<2>, geach, 64, ms, P, Bm);
+                }
+                he = rt_sync(ms);                         // seg_n is released below
+                if (he) rc = fail(c, TGSF_E_HIP, "middle scan (position-ordered pass) failed: %s", rt_errstr(he));
+            } while (0);
+            rt_free(seg_n);
+            rt_free(part);
+            B.seg_n = nullptr;
+            if (rc) return rc;
         }
 #if !defined(TGSF_EMUL)
         if (c->hp && c->side_mid) { (void)hipEventRecord(c->ev_hp[1], ms); (void)hipStreamWaitEvent(st, c->ev_hp[1], 0); }
 #endif
     }
     STAGE_MARK();
-    if (P.filter && A > 0) {
+    if (P.filter && A > 0 && !redo) {
         if (P.max_nw > 2) TGSF_LAUNCH(k_mid_resolve<4>, blocks_for((uint64_t)n * A, 64), 64, st, P, B);
         else TGSF_LAUNCH(k_mid_resolve<2>, blocks_for((uint64_t)n * A, 64), 64, st, P, B);
     }
@@ -742,7 +790,8 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
 #if !defined(TGSF_EMUL)
     if (c->hp) { (void)hipEventRecord(c->ev_hp[0], st); (void)hipStreamWaitEvent(ss, c->ev_hp[0], 0); }
 #endif
-    TGSF_LAUNCH(k_stats<true>, gstats, 64 * kStatsWaves, ss, P, B);
+    if (c->stats_nt) TGSF_LAUNCH((k_stats<true, true>), gstats, 64 * kStatsWaves, ss, P, B);
+    else TGSF_LAUNCH((k_stats<true, false>), gstats, 64 * kStatsWaves, ss, P, B);
 #if !defined(TGSF_EMUL)
     if (c->hp) { (void)hipEventRecord(c->ev_hp[1], ss); (void)hipStreamWaitEvent(st, c->ev_hp[1], 0); }
 #endif

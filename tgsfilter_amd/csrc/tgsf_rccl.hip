@@ -52,6 +52,16 @@ extern "C" int tgsf_rccl_allreduce_counters(tgsf_ctx* ctx, void* nccl_comm, int 
     void* d_ctr = nullptr;
     uint64_t n = 0;
     if ((e = tgsf_counters_device(ctx, &d_ctr, &n))) return fail(e, "%s", tgsf_last_error(ctx));
+    // the vector lives on the context's device: work there whatever the caller's current device is (and put that back)
+    int prev_dev = -1, ctx_dev = -1;
+    (void)hipGetDevice(&prev_dev);
+    {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, d_ctr) != hipSuccess) return fail(TGSF_E_HIP, "cannot tell the device of the tally vector");
+        ctx_dev = at.device;
+    }
+    if (ctx_dev != prev_dev && hipSetDevice(ctx_dev) != hipSuccess) return fail(TGSF_E_HIP, "hipSetDevice(%d) failed", ctx_dev);
+    struct Restore { int from, to; ~Restore() { if (from != to && to >= 0) (void)hipSetDevice(to); } } restore{ctx_dev, prev_dev};
     ncclComm_t comm = (ncclComm_t)nccl_comm;
     hipStream_t st = (hipStream_t)hip_stream;
     hipStream_t own = nullptr;

@@ -262,7 +262,11 @@ void RecordIndex::produce(const char* data, size_t size, bool fastq, int threads
         size_t n = 0, published = 0;
         uint32_t longest = 0;
         while (rd.next(r)) {
-            if (n / kChunk >= chunks_.size()) break;
+            if (n / kChunk >= chunks_.size()) {   // 4.3e9 records: never silently a shorter input
+                std::cerr << "Error: more than " << chunks_.size() * kChunk << " records in the input: beyond what this build indexes" << std::endl;
+                fflush(nullptr);
+                _exit(255);
+            }
             if (n % kChunk == 0) chunks_[n / kChunk].reset(new Rec[kChunk]);
             Rec& x = chunks_[n / kChunk][n % kChunk];
             x.name = r.name.data(); x.name_len = (uint32_t)r.name.size();

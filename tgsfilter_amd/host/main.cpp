@@ -30,6 +30,7 @@ static int g_done_fd = -1;
 {
     fflush(nullptr);
     if (g_done_fd >= 0) {
+        prctl(PR_SET_PDEATHSIG, 0);                   // the parent is about to leave in the ordinary way: no signal for that
         if (write(g_done_fd, &code, sizeof code) != (ssize_t)sizeof code) { /* the parent is gone: nothing to tell */ }
         close(0); close(1); close(2);                 // the caller's pipes see end-of-file now, not when the teardown is over
     }
@@ -221,8 +222,10 @@ int main(int argc, char** argv)
         const bool may_map = !o.only_qc && !o.out_gz && !o.downsample && run_filter_pass && !o.out_file.empty() &&
                              !(w && !strcmp(w, "writev"));
         // address space for the output mapping: what the input could turn into (a streamed input's text size is unknown)
+        // (address space only: pages exist where records are laid out.  A record's header is repeated in front of each of
+        // its fragments, so an output can outgrow its input -- by a factor only headers of kilobytes reach.)
         if (may_map) sink.open(o.out_file, streaming ? std::max<uint64_t>(64ull << 30, 64ull * in.size())
-                                                     : (uint64_t)in.size() + in.size() / 4 + (16u << 20));
+                                                     : 4 * (uint64_t)in.size() + (1ull << 30));
         if (!o.only_qc && !sink.is_open() && !out.open(o)) leave(1);
     }
     const Api& L = lib();                                              // joins the loader thread
@@ -479,7 +482,7 @@ int main(int argc, char** argv)
             }
             in_seen += b->span;
             if (fill && at) {
-                if (sink.planned() + at > sink.capacity()) die("output larger than the space mapped for it");
+                if (sink.planned() + at > sink.capacity()) die("output more than four times the size of the input: larger than the space mapped for it (TGSF_WRITER=writev writes such a file)");
                 {
                     // How far the file will go: what is left of the input times the share of it that was written so far
                     // (plus a little).  (A streamed input's text size is estimated from the share of the file decoded so far.)

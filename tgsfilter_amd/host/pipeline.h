@@ -141,10 +141,13 @@ inline double now_s()
 
 // Fatal errors can come from any thread while others are inside HIP calls or blocked on queues: no static
 // destructors, no runtime teardown -- flush what was said and leave with the reference's exit status (-1).
+// (an output file that was extended ahead of the records is cut back to what was planned for it: no NUL-padded tail stays behind)
+inline std::atomic<void (*)()>& on_die() { static std::atomic<void (*)()> f{nullptr}; return f; }
 [[noreturn]] inline void die(const std::string& msg)
 {
     std::cerr << "Error: " << msg << std::endl;
     fflush(nullptr);
+    if (void (*f)() = on_die().exchange(nullptr)) f();
     _exit(255);
 }
 
@@ -323,8 +326,12 @@ public:
             ok = map_ != MAP_FAILED;
         }
         if (!ok) { ::close(fd_); fd_ = -1; return false; }
+        live() = this;
+        on_die().store([] { if (MappedSink* s = live()) s->cut_back(); });
         return true;
     }
+    // a fatal path: leave the records laid out so far, not the pages reserved ahead of them
+    void cut_back() { if (fd_ >= 0 && reserved_ > size_ && ftruncate(fd_, (off_t)size_) != 0) { /* nothing more to do */ } }
     uint64_t reserved() const { return reserved_; }
     uint64_t planned() const { return size_; }
     uint64_t capacity() const { return cap_; }
@@ -362,10 +369,12 @@ public:
         if (reserved_ != size_ && ftruncate(fd_, (off_t)size_) != 0) die("cannot set the size of the output file");
         ::close(fd_);
         fd_ = -1;
+        if (live() == this) { live() = nullptr; on_die().store(nullptr); }
     }
     bool is_open() const { return fd_ >= 0; }
     double t_falloc = 0;
 private:
+    static MappedSink*& live() { static MappedSink* s = nullptr; return s; }
     int fd_ = -1;
     char* map_ = nullptr;
     uint64_t size_ = 0, reserved_ = 0, cap_ = 0;

@@ -30,6 +30,7 @@ def load():
         _rccl.ncclGetUniqueId.argtypes = [C.POINTER(_UniqueId)]
         _rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
         _rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        _rccl.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         _rccl.ncclGetErrorString.restype = C.c_char_p
         _lib = C.CDLL(os.path.join(_HERE, "libtgsf_rccl.so"))
         _lib.tgsf_rccl_allreduce_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -55,6 +56,16 @@ def comm_init_rank(uid: bytes, rank: int, world: int):
     if rc != 0:
         raise RcclError("ncclCommInitRank: " + _rccl.ncclGetErrorString(rc).decode())
     return comm
+
+
+def comm_count(comm) -> int:
+    """Ranks RCCL itself sees in the communicator (ncclCommCount): evidence that the job's collective spans the job."""
+    load()
+    n = C.c_int(0)
+    rc = _rccl.ncclCommCount(comm, C.byref(n))
+    if rc != 0:
+        raise RcclError("ncclCommCount: " + _rccl.ncclGetErrorString(rc).decode())
+    return int(n.value)
 
 
 def comm_destroy(comm):
