@@ -92,6 +92,18 @@ def cli_processes():
             stat = open("/proc/%s/stat" % d).read()
             name, state = stat[stat.index("(") + 1:stat.rindex(")")], stat[stat.rindex(")") + 2]
             if state in "ZX":
+                # a zombie thread-group LEADER whose other threads are still on their way out: the last of them is the
+                # one that takes the address space down
+                alive = False
+                for t in os.listdir("/proc/%s/task" % d):
+                    ts = open("/proc/%s/task/%s/stat" % (d, t)).read()
+                    if ts[ts.rindex(")") + 2] not in "ZX":
+                        alive = True
+                        break
+                if not alive:
+                    continue
+                if name == comm:
+                    out.append(int(d))
                 continue
             try:
                 if os.path.realpath(os.readlink("/proc/%s/exe" % d)) == real:
@@ -497,6 +509,11 @@ def kernel_leg(args, torch, dist, world, rank, local_rank, device, xdev, host_gr
     max_len = max(int(b["h_lens"].max()) for b in batches)
     p_kwargs = dict(adapters=wl_adapters, min_len=1000, min_q=20.0 if hifi else 10.0, head_trim=0, tail_trim=0,
                     min_repeat=args.min_repeat, kmer=args.kmer)
+    if args.short_adapters:
+        # for information: a ligation-kit adapter pair of 28 bp (src/TGSFilter.cpp:2974-2975) with -M 15 -- adapters of at
+        # most 32 bp take the one-dword column in the middle scan (the default -M 35 never searches the middle for them)
+        p_kwargs.update(adapters=[b"AATGTACTTCGTTCAGTTACGTATTGCT", b"AGCAATACGTAACTGAACGAAGTACATT"], mid_match_len=15)
+        flags += " -a ligation28.fa -M 15"
     p = abi.make_params(args.workload, max_batch_bases=max_bases + 64, max_batch_reads=args.reads, max_read_len=max_len, **p_kwargs)
     NS = max(1, args.streams)
     ctxs = [capi.Context(p, local_rank) for _ in range(NS)]
@@ -677,7 +694,7 @@ def kernel_leg(args, torch, dist, world, rank, local_rank, device, xdev, host_gr
         "value": bases_all / dt / 1e9, "unit": "Gbases/s", "steps": K, "warmup": W, "ms_per_step": dt / max(len(my_steps), 1) * 1e3,
         "scaling": "strong (fixed job of %d batches dealt over %d ranks)" % (K, world) if world > 1 else "single GPU",
         "workload": ("C3 shape: synthetic HiFi reads N(%.0f,/6) bp, %s" % (mean_len, flags)) if hifi else
-                    ("C2: synthetic ONT reads, lognormal mean %.0f bp, %s, adapters ONT rapid + reverse complement" % (mean_len, flags)),
+                    ("C2: synthetic ONT reads, lognormal mean %.0f bp, %s, adapters %s" % (mean_len, flags, "ONT ligation 28 bp + reverse complement" if args.short_adapters else "ONT rapid + reverse complement")),
         "reads_per_step": args.reads, "gbases_per_step": bases / steps_mine / 1e9, "batches_in_flight_per_gpu": NS,
         "oracle_check": oracle_note,
         "tally_exchange": ("one SUM all-reduce of the tally vector over RCCL (libtgsf_rccl), inside the timed region" if comm is not None else
@@ -714,6 +731,7 @@ def main():
     ap.add_argument("--reads", type=int, default=131072, help="reads per kernel-path step")
     ap.add_argument("--mean-len", type=float, default=None)
     ap.add_argument("--min-repeat", type=int, default=0, help="-p of config C5, for information")
+    ap.add_argument("--short-adapters", action="store_true", help="kernel path with a 28-bp adapter pair and -M 15 (the one-dword scan column), for information")
     ap.add_argument("--kmer", type=int, default=11)
     ap.add_argument("--workload", choices=["ont", "hifi"], default="ont")
     ap.add_argument("--max-len", type=int, default=2_000_000)

@@ -208,6 +208,14 @@ int tgsf_abi_version(void);
 int tgsf_prepare_device(int device);
 
 /*
+ * Where a device sits in the host (nothing in the reference: it has no device): its PCI bus id ("0000:c1:00.0", NUL
+ * terminated, into bus_id[0..len)) and the NUMA node of that PCI function (-1 where the platform does not say).
+ * A multi-GPU caller binds each device's feeder threads -- and so the pinned staging buffers tgsf_create allocates from
+ * them -- to the GPU's own node.  Does not initialise the device.
+ */
+int tgsf_device_location(int device, char* bus_id, int len, int* numa_node);
+
+/*
  * Create a context on HIP device `device`.  Replaces the construction of
  * TGSFilterTask (:1757-1790: the accumulator rows) for one "worker" = one GPU.
  */

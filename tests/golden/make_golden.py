@@ -96,6 +96,11 @@ CASES.update({
     "hifi_phred64_auto": (dict(seed=33, n=900, kind="hifi", mean_len=1400, p5=0.5, p3=0.4), None, "-x hifi -l 1000 -b 8", "fq", "phred64"),
 })
 
+CASES.update({
+    # -e beyond the 512 positions one launch of the end-table kernel tallies (round 3: one launch per slab of 512)
+    "ont_e1300": (dict(seed=37, n=80, kind="ont", mean_len=3500, zoo=True, pmid=0.05), [synth.ONT_RAPID], "-x ont -l 1000 -q 10 -5 0 -3 0 -e 1300"),
+})
+
 IN_EXT = {"fq": "in.fq", "bam": "in.bam", "sam": "in.sam", "fa": "in.fa"}
 
 

@@ -26,7 +26,7 @@ def test_emul_edlib_vectors(emul, golden_dir):
     parity.edlib_vectors(emul, golden_dir)
 
 
-@pytest.mark.parametrize("name", ["ont_zoo", "ont_trim", "ont_discard", "hifi_zoo", "long_adapter", "qc_only", "ont_m1", "huge_adapter", "ont_phred64"])
+@pytest.mark.parametrize("name", ["ont_zoo", "ont_trim", "ont_discard", "hifi_zoo", "long_adapter", "qc_only", "ont_m1", "huge_adapter", "ont_phred64", "ont_e1300"])
 def test_emul_golden(emul, golden_dir, name):
     parity.golden_case(emul, golden_dir, name)
 
@@ -201,3 +201,24 @@ def test_emul_golden_with_lanes_in_reverse_order(emul, golden_dir, name, monkeyp
     """The candidate lists of the one-pass scan are in whatever order the lanes append: results must not depend on it."""
     monkeypatch.setenv("TGSF_EMUL_ORDER", "reverse")
     parity.golden_case(emul, golden_dir, name)
+
+
+ONT_LIGATION_28 = b"AATGTACTTCGTTCAGTTACGTATTGCT"      # src/TGSFilter.cpp:2974-2977 (library entries 4..7)
+ONT_LIGATION_28_RC = b"AGCAATACGTAACTGAACGAAGTACATT"
+ONT_LIGATION_22 = b"GCAATACGTAACTGAACGAAGT"
+ONT_LIGATION_22_RC = b"ACTTCGTTCAGTTACGTATTGC"
+
+
+@pytest.mark.parametrize("ads", [[ONT_LIGATION_28, ONT_LIGATION_28_RC], [ONT_LIGATION_22, ONT_LIGATION_22_RC, ONT_LIGATION_28, ONT_LIGATION_28_RC],
+                                 [ONT_LIGATION_22, ONT_LIGATION_22_RC, synth.ONT_RAPID, synth.ONT_RAPID_RC], [b"ACGTTGCA" * 4, ONT_LIGATION_22]])
+@pytest.mark.parametrize("no32", ["0", "1"])
+def test_emul_short_adapters_dword_column(emul, ads, no32, monkeypatch):
+    """Adapters of at most 32 bp run the middle scan with the one-dword column (Hot32): same locations as the 64-bit column
+    (TGSF_NO_HOT32=1) and as the oracle; mixed sets take one pass per word class."""
+    monkeypatch.setenv("TGSF_NO_HOT32", no32)
+    reads = synth.make_reads(31, 30, "ont", mean_len=5000, zoo=True, pmid=0.8, adapter=ads[0], err=0.06)
+    p = parity.sized(abi.make_params("ont", adapters=ads, min_q=7.0, mid_match_len=14, end_match_len=4), reads)
+    ctx = capi.Context(p, 0, emul)
+    r, f, _ = parity.compare_batch(ctx, p, reads)
+    assert (r["flags"] & abi.RF_ADMID).any()              # the planted copies were found in the middle
+    ctx.close()

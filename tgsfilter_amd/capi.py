@@ -19,7 +19,7 @@ DEFAULT_LIB = os.path.join(_HERE, "libtgsf.so")
 _LIBS = {}
 
 SYMBOLS = [
-    "tgsf_abi_version", "tgsf_prepare_device", "tgsf_create", "tgsf_destroy", "tgsf_submit", "tgsf_submit_async", "tgsf_submit_device",
+    "tgsf_abi_version", "tgsf_prepare_device", "tgsf_device_location", "tgsf_create", "tgsf_destroy", "tgsf_submit", "tgsf_submit_async", "tgsf_submit_device",
     "tgsf_wait",
     "tgsf_counters_len", "tgsf_counters", "tgsf_counters_used", "tgsf_counters_merge", "tgsf_counters_device", "tgsf_reset_counters", "tgsf_profile",
     "tgsf_stage_times", "tgsf_stage_name", "tgsf_align_windows", "tgsf_last_error",
@@ -43,6 +43,7 @@ def load(path: str | None = None):
     vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
     L.tgsf_abi_version.restype = C.c_int
     L.tgsf_prepare_device.argtypes = [C.c_int]
+    L.tgsf_device_location.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int)]
     L.tgsf_create.argtypes = [C.POINTER(abi.Params), C.c_int, C.POINTER(vp)]
     L.tgsf_destroy.argtypes = [vp]
     L.tgsf_destroy.restype = None

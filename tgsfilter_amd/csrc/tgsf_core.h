@@ -203,6 +203,44 @@ TGSF_HD int popc64_acc(uint64_t x, int acc) {
 #endif
 }
 TGSF_HD int hot_score(const Hot& s) { return (int)popc64(s.p) - (int)popc64(s.m); }
+// bottom-row value <= lim  <=>  popcount(Pv) <= popcount(Mv) + lim
+TGSF_HD bool hot_within(const Hot& s, int lim) { return popc64_acc(s.p, 0) <= popc64_acc(s.m, lim); }
+TGSF_HD uint64_t hot_eq(const Hot&, uint64_t top) { return top; }
+
+// The same column for adapters of at most 32 bp (8 of the reference's 22 library adapters, src/TGSFilter.cpp:2974-2989:
+// the ligation and barcoding kits): the adapter in the top Q bits of ONE 32-bit word -- 10 instructions instead of 17
+// (1 and, 1 add, 2 shifts, 6 three-input ops), a dword of LDS per symbol instead of two.
+struct Hot32 {
+    uint32_t p, m;
+};
+TGSF_HD void hot_init(Hot32& s, int Q) {
+    s.p = (Q >= 32) ? ~0u : (~0u << (32 - Q));
+    s.m = 0u;
+}
+TGSF_HD void hot_step(Hot32& s, uint32_t Eq) {
+    const uint32_t Pv = s.p, Mv = s.m;
+    const uint32_t t = Eq & Pv;                          // v_and
+    const uint32_t sum = t + Pv;                         // v_add_u32
+    const uint32_t u = sum | Pv | Eq;                    // v_or3             (= Xh | Pv)
+    uint32_t Ph = Mv | ~u;                               // v_bfi / v_bitop3
+    uint32_t Mh = (sum & t) | (~sum & Pv);               // v_bfi             (= Pv & Xh)
+    Ph <<= 1; Mh <<= 1;                                  // 2 v_lshlrev_b32
+    const uint32_t x = Eq | Mv | Ph;                     // v_or3             (= Xv | Ph')
+    s.p = Mh | ~x;                                       // v_bitop3
+    s.m = bitop3<0xE0>(Ph, Eq, Mv);                      // v_bitop3          (= Ph' & (Eq | Mv))
+}
+TGSF_HD int hot_score(const Hot32& s) { return (int)popc32(s.p) - (int)popc32(s.m); }
+TGSF_HD bool hot_within(const Hot32& s, int lim) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(s.m), "v"(lim));
+    return (int)popc32(s.p) <= r;
+#else
+    return (int)popc32(s.p) <= (int)popc32(s.m) + lim;
+#endif
+}
+// the 32-bit Eq row from the 64-bit top-aligned one: its high half (bits below the adapter are wildcards in both)
+TGSF_HD uint32_t hot_eq(const Hot32&, uint64_t top) { return (uint32_t)(top >> 32); }
 
 // ---------------------------------------------------------------------------
 // QC columns for 4 bases at a time (SWAR).  s: 4 sequence bytes, q: 4 quality

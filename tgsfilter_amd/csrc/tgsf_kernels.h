@@ -756,13 +756,14 @@ TGSF_KERNEL k_scan_add(uint32_t* a, uint32_t n, const uint32_t* part)
 // per wave, not per read.
 // ---------------------------------------------------------------------------
 constexpr int kEndWaves = 8;       // waves of a block share one 40 KB set of LDS tallies (LDS atomics)
-constexpr int kMaxBcLen = 512;
+constexpr int kMaxBcLen = 512;     // positions one launch tallies in LDS; a larger -e takes one launch per slab of 512 positions
+constexpr int kMaxBcLenTotal = 1 << 20;
 TGSF_D int base_col(uint32_t b) {
     b &= 0xDFu;
     return b == 'A' ? 0 : b == 'T' ? 1 : b == 'G' ? 2 : b == 'C' ? 3 : 4;
 }
 template <bool CLEAN>
-TGSF_KERNEL k_end_tables(DevParams P, DevBatch B)
+TGSF_KERNEL k_end_tables(DevParams P, DevBatch B, uint32_t slab)
 {
     if (CLEAN && pool_overflowed(B)) return;
     // [end][slot][10][lane]: 5 counts, 5 quality sums; position = slot*64 + lane
@@ -771,7 +772,9 @@ TGSF_KERNEL k_end_tables(DevParams P, DevBatch B)
     const uint32_t gw = blockIdx.x * kEndWaves + wave, nw = gridDim.x * kEndWaves;
     const uint32_t n = CLEAN ? stored_frags(B) : B.n;
     const uint32_t bc = (uint32_t)P.bc_len;
-    const uint32_t slots = (bc + 63u) / 64u;
+    const uint32_t p0 = slab * (uint32_t)kMaxBcLen;                      // first position of this launch's slab
+    const uint32_t span = bc - p0 < (uint32_t)kMaxBcLen ? bc - p0 : (uint32_t)kMaxBcLen;
+    const uint32_t slots = (span + 63u) / 64u;
     uint32_t* flat = &acc[0][0][0][0];
     for (uint32_t i = TGSF_COOP_BEGIN; i < 2u * (kMaxBcLen / 64) * 10u * 64u; i += TGSF_COOP_STRIDE) flat[i] = 0;
     TGSF_BLOCK_SYNC();
@@ -793,7 +796,7 @@ TGSF_KERNEL k_end_tables(DevParams P, DevBatch B)
             }
         }
         for (uint32_t s = 0; s < slots; s++) {
-            const uint32_t p = s * 64u + lane;
+            const uint32_t p = p0 + s * 64u + lane;
             uint32_t b5[2], q5[2], b3[2], q3[2];
             bool on[2];
 #pragma unroll
@@ -815,7 +818,7 @@ TGSF_KERNEL k_end_tables(DevParams P, DevBatch B)
     const int64_t qt = P.qtype;
     for (uint32_t k = TGSF_COOP_BEGIN; k < 2u * slots * 5u * 64u; k += TGSF_COOP_STRIDE) {
         const uint32_t ln = k & 63u, c = (k >> 6) % 5u, s = ((k >> 6) / 5u) % slots, e = (k >> 6) / (5u * slots);
-        const uint32_t p = s * 64u + ln;
+        const uint32_t p = p0 + s * 64u + ln;
         if (p >= bc) continue;
         const uint32_t cn = acc[e][s][c][ln];
         if (!cn) continue;
@@ -1178,15 +1181,17 @@ TGSF_KERNEL k_mid_link(DevBatch B, int A)
     }
 }
 
-template <int AT>
+// HT = Hot: adapters of 33..64 bp (one 64-bit word per column); HT = Hot32: adapters of at most 32 bp (one dword).
+template <int AT, class HT = Hot>
 TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
 {
-    TGSF_SHARED uint64_t eqt[256][AT];
+    typedef decltype(hot_eq(HT(), 0ull)) eq_t;
+    TGSF_SHARED eq_t eqt[256][AT];
     // per lane and adapter: up to 4 columns that tie the lane's best value so far (slow path only)
     TGSF_SHARED int32_t tie_col[256][AT][4];
     for (uint32_t i = TGSF_COOP_BEGIN; i < 256u * AT; i += TGSF_COOP_STRIDE) {
         uint32_t sym = i / AT, j = i % AT;
-        eqt[sym][j] = (int)j < na ? P.peq_top[(size_t)(a0 + j) * 256 + sym] : 0ull;
+        eqt[sym][j] = (int)j < na ? hot_eq(HT(), P.peq_top[(size_t)(a0 + j) * 256 + sym]) : (eq_t)0;
     }
     TGSF_BLOCK_SYNC();
     const uint32_t total = B.seg_cnt[B.n];
@@ -1207,7 +1212,7 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
     int c1 = (int)((blk + 1) * S - amid);
     if (c1 > ML) c1 = ML;
 
-    Hot st[AT];
+    HT st[AT];
     uint32_t slot[AT];        // mode 1: columns counted so far; mode 2: the next slot of this (lane, adapter)
     int lim[AT];              // best bottom-row value seen so far in the owned columns (k+1: none yet)
     int lim3[AT];             // the every-4th-column test: lim + 2 while nothing is recorded yet (only a value
@@ -1284,7 +1289,7 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
         const uint32_t d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            Hot h1[AT], h2[AT], h3[AT];
+            HT h1[AT], h2[AT], h3[AT];
             step_all(d[k] & 0xFFu);
 #pragma unroll
             for (int j = 0; j < AT; j++) h1[j] = st[j];
@@ -1298,7 +1303,7 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
             // value <= lim + 3  <=>  popcount(Pv) <= popcount(Mv) + (lim + 3): two accumulating v_bcnt per side
             bool any = false;
 #pragma unroll
-            for (int j = 0; j < AT; j++) any |= (popc64_acc(st[j].p, 0) <= popc64_acc(st[j].m, lim3[j]));
+            for (int j = 0; j < AT; j++) any |= hot_within(st[j], lim3[j]);
             if (__builtin_expect(any && own, 0)) {          // a few % of the tests: keep this code out of the hot loop
 #pragma unroll
                 for (int j = 0; j < AT; j++) {

@@ -48,6 +48,7 @@ struct tgsf_ctx {
     uint32_t cap_reads, max_read_len, n_bins;
     unsigned endtab_grid = 512;             // k_end_tables: LDS-atomic bound, 40 KB of LDS per block: two blocks per CU (128: 0.36 ms, 512: 0.19 ms)
     unsigned stats_grid = 768, mid_grid = 0;   // tuning knobs (TGSF_STATS_GRID, TGSF_MID_GRID; 0 = one lane per segment)
+    bool no_hot32 = false;                    // TGSF_NO_HOT32=1: adapters <= 32 bp take the 64-bit column too (A/B, tests)
     bool stats_nt = true;                     // k_stats fetches the text with non-temporal loads (2.24 -> 2.06 ms raw, 5.4 -> 5.8 TB/s; TGSF_STATS_NT=0: plain loads)
     uint64_t ctr_words;
     int scratch_cols;
@@ -278,6 +279,32 @@ extern "C" int tgsf_prepare_device(int device)
     return TGSF_OK;
 }
 
+extern "C" int tgsf_device_location(int device, char* bus_id, int len, int* numa_node)
+{
+    if (numa_node) *numa_node = -1;
+    if (bus_id && len > 0) bus_id[0] = 0;
+#if !defined(TGSF_EMUL)
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return TGSF_E_NO_DEVICE;
+    char id[64] = {0};
+    if (hipDeviceGetPCIBusId(id, (int)sizeof id, device) != hipSuccess) return TGSF_E_HIP;
+    for (char* p = id; *p; p++) if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');       // sysfs spells it in lower case
+    if (bus_id && len > 0) { strncpy(bus_id, id, (size_t)len - 1); bus_id[len - 1] = 0; }
+    if (numa_node) {
+        const std::string path = std::string("/sys/bus/pci/devices/") + id + "/numa_node";
+        if (FILE* f = fopen(path.c_str(), "r")) {
+            int v = -1;
+            if (fscanf(f, "%d", &v) == 1) *numa_node = v;
+            fclose(f);
+        }
+    }
+    return TGSF_OK;
+#else
+    (void)device;
+    return TGSF_OK;
+#endif
+}
+
 extern "C" const char* tgsf_last_error(tgsf_ctx* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
 
 extern "C" void tgsf_destroy(tgsf_ctx* c)
@@ -317,7 +344,7 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     if (p->min_repeat > 0 && (p->kmer < 1 || p->kmer > 32))
         return fail(nullptr, TGSF_E_UNSUPPORTED, "-k %d: the repeat gate supports k-mer sizes 1..32 (the reference's k-mers are 64 bits)", p->kmer);
     if (p->qtype != 33 && p->qtype != 64) return fail(nullptr, TGSF_E_INVALID, "qtype must be 33 or 64");
-    if (p->bc_len < 0 || p->bc_len > kMaxBcLen) return fail(nullptr, TGSF_E_INVALID, "bc_len (-e) outside [0,%d]", kMaxBcLen);
+    if (p->bc_len < 0 || p->bc_len > kMaxBcLenTotal) return fail(nullptr, TGSF_E_INVALID, "bc_len (-e) outside [0,%d]", kMaxBcLenTotal);
     if (p->filter && p->n_adapters > 0) {
         if (!(p->end_sim > 0.f) || !(p->mid_sim > 0.f)) return fail(nullptr, TGSF_E_INVALID, "similarities must be > 0");
         if (p->end_len < 0 || p->extra_len < 0) return fail(nullptr, TGSF_E_INVALID, "end_len / extra_len must be >= 0");
@@ -422,6 +449,7 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     P.seg_cols = kSegCols;
     if (const char* e = getenv("TGSF_STATS_GRID")) { int v = atoi(e); if (v >= 1 && v <= 65536) c->stats_grid = (unsigned)v; }
     if (const char* e = getenv("TGSF_STATS_NT")) c->stats_nt = atoi(e) > 0;
+    if (const char* e = getenv("TGSF_NO_HOT32")) c->no_hot32 = atoi(e) > 0;
     if (const char* e = getenv("TGSF_ENDTAB_GRID")) { int v = atoi(e); if (v >= 1 && v <= 4096) c->endtab_grid = (unsigned)v; }
     if (const char* e = getenv("TGSF_MID_GRID")) { int v = atoi(e); if (v >= 1) c->mid_grid = (unsigned)v; }
     if (const char* e = getenv("TGSF_SEG_COLS")) { int v = atoi(e); if (v >= 256 && v <= 65536) P.seg_cols = v & ~15; }   // tuning knob
@@ -641,7 +669,8 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     (void)hipStreamWaitEvent(ax, c->ev_fork, 0);
     if (profile) (void)hipEventRecord(evx[0], ax);
 #endif
-    if (P.bc_len > 0) TGSF_LAUNCH(k_end_tables<false>, grid_cap(c->endtab_grid), 64 * kEndWaves, ax, P, B);
+    for (uint32_t slab = 0; slab * (uint32_t)kMaxBcLen < (uint32_t)P.bc_len; slab++)
+        TGSF_LAUNCH(k_end_tables<false>, grid_cap(c->endtab_grid), 64 * kEndWaves, ax, P, B, slab);
 #if !defined(TGSF_EMUL)
     if (profile) (void)hipEventRecord(evx[1], ax);
 #endif
@@ -678,13 +707,21 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
                 if (P.Q[a] > 192) { TGSF_LAUNCH(k_mid_scanw<4>, gseg, T, ms, P, Bm, a); a++; continue; }
                 if (P.Q[a] > 128) { TGSF_LAUNCH(k_mid_scanw<3>, gseg, T, ms, P, Bm, a); a++; continue; }
                 if (P.Q[a] > 64) { TGSF_LAUNCH(k_mid_scanw<2>, gseg, T, ms, P, Bm, a); a++; continue; }
+                // up to four adapters of one word class per pass: <= 32 bp (one dword per column) or 33..64 bp (one qword)
+                const bool narrow = P.Q[a] <= 32 && !c->no_hot32;
                 int na = 0;
-                while (a + na < A && na < 4 && P.Q[a + na] <= 64) na++;
-                switch (na) {
-                case 1: TGSF_LAUNCH(k_mid_scan1<1>, gmid, T, ms, P, Bm, a, na); break;
-                case 2: TGSF_LAUNCH(k_mid_scan1<2>, gmid, T, ms, P, Bm, a, na); break;
-                case 3: TGSF_LAUNCH(k_mid_scan1<3>, gmid, T, ms, P, Bm, a, na); break;
-                default: TGSF_LAUNCH(k_mid_scan1<4>, gmid, T, ms, P, Bm, a, na); break;
+                while (a + na < A && na < 4 && P.Q[a + na] <= 64 && ((P.Q[a + na] <= 32 && !c->no_hot32) == narrow)) na++;
+                if (narrow) switch (na) {
+                case 1: TGSF_LAUNCH((k_mid_scan1<1, Hot32>), gmid, T, ms, P, Bm, a, na); break;
+                case 2: TGSF_LAUNCH((k_mid_scan1<2, Hot32>), gmid, T, ms, P, Bm, a, na); break;
+                case 3: TGSF_LAUNCH((k_mid_scan1<3, Hot32>), gmid, T, ms, P, Bm, a, na); break;
+                default: TGSF_LAUNCH((k_mid_scan1<4, Hot32>), gmid, T, ms, P, Bm, a, na); break;
+                }
+                else switch (na) {
+                case 1: TGSF_LAUNCH((k_mid_scan1<1, Hot>), gmid, T, ms, P, Bm, a, na); break;
+                case 2: TGSF_LAUNCH((k_mid_scan1<2, Hot>), gmid, T, ms, P, Bm, a, na); break;
+                case 3: TGSF_LAUNCH((k_mid_scan1<3, Hot>), gmid, T, ms, P, Bm, a, na); break;
+                default: TGSF_LAUNCH((k_mid_scan1<4, Hot>), gmid, T, ms, P, Bm, a, na); break;
                 }
                 a += na;
             }
@@ -797,7 +834,8 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
 #endif
     STAGE_MARK();
     TGSF_LAUNCH(k_gate_frags, gfr, T, st, P, B);
-    if (P.bc_len > 0) TGSF_LAUNCH(k_end_tables<true>, grid_cap(c->endtab_grid), 64 * kEndWaves, st, P, B);
+    for (uint32_t slab = 0; slab * (uint32_t)kMaxBcLen < (uint32_t)P.bc_len; slab++)
+        TGSF_LAUNCH(k_end_tables<true>, grid_cap(c->endtab_grid), 64 * kEndWaves, st, P, B, slab);
     STAGE_MARK();
     TGSF_LAUNCH(k_finalize, gsmall, T, st, B, d_reads, d_frags, out_fcap, d_nfrags);
     STAGE_MARK();

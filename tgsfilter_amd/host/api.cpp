@@ -59,6 +59,7 @@ void load(std::vector<int> devices)
     BIND(profile, "tgsf_profile")
     BIND(stage_times, "tgsf_stage_times")
     BIND(stage_name, "tgsf_stage_name")
+    BIND(device_location, "tgsf_device_location")
 #undef BIND
     if (g_api.abi_version() != TGSF_ABI_VERSION) { g_error = path + ": ABI version mismatch"; return; }
     g_load_s = now_s() - t0;

@@ -25,6 +25,7 @@ struct Api {
     decltype(&tgsf_profile) profile;              // stage timing (TGSF_TIMING only)
     decltype(&tgsf_stage_times) stage_times;
     decltype(&tgsf_stage_name) stage_name;
+    decltype(&tgsf_device_location) device_location;
 };
 
 // Starts the helper thread: dlopen + tgsf_prepare_device on each device.  Call once, early.

@@ -11,6 +11,7 @@
 #include "prepass.h"
 #include "report.h"
 
+#include <sched.h>
 #include <signal.h>
 #include <sys/prctl.h>
 #include <sys/wait.h>
@@ -25,6 +26,26 @@ using namespace host;
 // waiting parent, which returns to the caller at once, and the child's address space is taken down in the background --
 // the caller then shares the machine with that teardown for a moment (and schedulers see a short-lived orphan).
 static int g_done_fd = -1;
+
+// CPUs' worth of time this process may use: the hardware's threads, or less where a control group caps it (cgroup v2
+// cpu.max, as container runtimes set it).  -t keeps the reference's meaning and clamp (:488-499: hardware threads); the
+// pipeline's own pools are sized from this -- 32 threads indexing the input at once on a box capped at 16 CPUs are
+// throttled together with everything else of the run (measured, 135-GB input: 7.2 s with 32 indexing threads, 6.2 s with 8).
+static int cpu_budget()
+{
+    int hw = (int)std::thread::hardware_concurrency();
+    if (hw <= 0) hw = 1;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64] = {0};
+        long long per = 0;
+        if (fscanf(f, "%63s %lld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) {
+            const long long quota = atoll(q);
+            if (quota > 0) hw = (int)std::min<long long>(hw, std::max<long long>(1, (quota + per - 1) / per));
+        }
+        fclose(f);
+    }
+    return hw;
+}
 
 [[noreturn]] static void leave(int code)
 {
@@ -123,7 +144,9 @@ int main(int argc, char** argv)
         return std::unique_ptr<ChunkReader>(new ChunkReader(std::move(src), !fasta_in, chunk_bytes, 20));   // <= 20 x 64 MB of text alive
     };
     // mapped / decoded input: the records are indexed once, in the background, for the pre-pass and for the filter pass
-    const int scan_threads = std::max(1, std::min(o.n_thread, 32));
+    const int budget = cpu_budget();
+    // indexing runs ahead of everything else and is memory-bound from a few threads on: half the CPU budget at most
+    const int scan_threads = std::max(1, std::min({o.n_thread, 32, std::max(2, budget / 2)}));
     std::unique_ptr<RecordIndex> records_p;
     if (!streaming) records_p.reset(new RecordIndex(in.data(), in.size(), !fasta_in, scan_threads));
 
@@ -342,7 +365,38 @@ int main(int argc, char** argv)
     });
 
     std::mutex gpu_time_m;
+    // Several GPUs: a device's feeders -- and the pinned staging buffers tgsf_create allocates from them -- stay
+    // on the CPUs of the GPU's own NUMA node, so that no feeder pushes its copies across the socket link.  With one GPU
+    // binding was measured within noise and is left off; TGSF_NUMA=1 / 0 forces it on / off.
+    bool numa_bind = o.devices.size() > 1;
+    if (const char* e = getenv("TGSF_NUMA")) numa_bind = atoi(e) > 0;
+    std::vector<int> dev_node(ctx_dev.size(), -1);
+    std::vector<double> dev_submit_s(ctx_dev.size(), 0.0);
+    std::vector<uint64_t> dev_bytes(ctx_dev.size(), 0), dev_batches(ctx_dev.size(), 0);
     auto feed = [&](size_t k) {                                        // filter_sequence, :1919-2064, one batch per call
+        if (numa_bind) {
+            int node = -1;
+            char bus[64];
+            if (L.device_location(ctx_dev[k], bus, (int)sizeof bus, &node) == TGSF_OK && node >= 0) {
+                std::ifstream f("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist");
+                std::string list;
+                cpu_set_t set;
+                CPU_ZERO(&set);
+                int n_set = 0;
+                if (f && std::getline(f, list)) {                      // "0-63,128-191"
+                    size_t i = 0;
+                    while (i < list.size()) {
+                        const int a = atoi(list.c_str() + i);
+                        int b = a;
+                        size_t j = list.find_first_of(",-", i);
+                        if (j != std::string::npos && list[j] == '-') { b = atoi(list.c_str() + j + 1); j = list.find(',', j); }
+                        for (int c2 = a; c2 <= b && c2 < CPU_SETSIZE; c2++) { CPU_SET(c2, &set); n_set++; }
+                        i = j == std::string::npos ? list.size() : j + 1;
+                    }
+                }
+                if (n_set > 0 && sched_setaffinity(0, sizeof set, &set) == 0) dev_node[k] = node;
+            }
+        }
         if (L.create(&p, ctx_dev[k], &ctxs[k]) != TGSF_OK) die(L.last_error(nullptr));
         tgsf_ctx* fctx = ctxs[k];
         if (timing) (void)L.profile(fctx, 1);                          // HIP events around the stages of every batch (GPU: line)
@@ -362,6 +416,7 @@ int main(int argc, char** argv)
             tgsf_batch_out bo{b->res.data(), b->frags.data(), (uint32_t)b->frags.size(), 0};
             if (L.submit(fctx, &bi, &bo) != TGSF_OK) die(L.last_error(fctx));
             { std::lock_guard<std::mutex> l(gpu_time_m); t_gpu += now_s() - g0; if (t_first == 0) t_first = now_s() - t_p0; }
+            dev_submit_s[k] += now_s() - g0; dev_bytes[k] += b->span; dev_batches[k]++;
             b->n_frags = bo.n_frags;
             to_writer.put(std::move(b));
         }
@@ -401,14 +456,20 @@ int main(int argc, char** argv)
     // page of the output otherwise wait at exit) or where the resident size matters (a streamed input: the mapped part
     // of the output counts as resident).
     const bool sync_exit = g_done_fd < 0;                              // one process (the default): the teardown is on the clock
-    const bool release_input = sync_exit && !streaming && in.mapped() && !o.downsample;
-    const bool release_output = sync_exit || streaming;
+    bool release_input = sync_exit && !streaming && in.mapped() && !o.downsample;
+    bool release_output = sync_exit || streaming;
+    if (const char* e = getenv("TGSF_RELEASE")) {                      // experiment knob: none | in | out | both
+        release_input = release_input && (!strcmp(e, "in") || !strcmp(e, "both"));
+        release_output = (release_output && (!strcmp(e, "out") || !strcmp(e, "both"))) || streaming;
+    }
+    uint64_t release_piece = 16u << 20;
+    if (const char* e = getenv("TGSF_RELEASE_PIECE")) { const long long v = atoll(e); if (v >= 4096) release_piece = (uint64_t)v; }   // experiment knob
     Channel<std::pair<const char*, uint64_t>> to_release(1 << 16);
     std::thread releaser([&] {
         for (;;) {
             const std::pair<const char*, uint64_t> r = to_release.get();
             if (!r.first) break;
-            for (uint64_t o2 = 0; o2 < r.second; o2 += (16u << 20)) MappedSink::release(r.first + o2, std::min<uint64_t>(16u << 20, r.second - o2));
+            for (uint64_t o2 = 0; o2 < r.second; o2 += release_piece) MappedSink::release(r.first + o2, std::min<uint64_t>(release_piece, r.second - o2));
         }
     });
     using Emit = Batch::Emit;
@@ -875,6 +936,18 @@ int main(int argc, char** argv)
                 sum * 1e-3 / std::max(1e-9, now_s() - t_start));
         for (int i = 0; i < TGSF_N_STAGES; i++) if (tot[i] > 0) fprintf(stderr, " %s %.1f ms", L.stage_name(i), tot[i]);
         fprintf(stderr, "\n");
+    }
+    if (timing) {
+        // per device: what its feeders moved (text in, records out: H2D + kernels + D2H inside tgsf_submit)
+        for (size_t di = 0; di < o.devices.size(); di++) {
+            if (std::find(o.devices.begin(), o.devices.begin() + (long)di, o.devices[di]) != o.devices.begin() + (long)di) continue;   // (listed twice)
+            double sub = 0; uint64_t by = 0, nb2 = 0; int nf2 = 0, node = -1;
+            for (size_t k = 0; k < ctx_dev.size(); k++)
+                if (ctx_dev[k] == o.devices[di]) { sub += dev_submit_s[k]; by += dev_bytes[k]; nb2 += dev_batches[k]; nf2++; node = std::max(node, dev_node[k]); }
+            fprintf(stderr, "DEVICE %d: %llu batches, %.2f GB of text through %d feeders, tgsf_submit %.3f s summed = %.1f GB/s per feeder, %.1f GB/s for the device over the pipeline's %.3f s%s\n",
+                    o.devices[di], (unsigned long long)nb2, by * 1e-9, nf2, sub, sub > 0 ? by * 1e-9 / sub : 0.0, t_pipe > 0 ? by * 1e-9 / t_pipe : 0.0, t_pipe,
+                    node >= 0 ? (" (feeders bound to NUMA node " + std::to_string(node) + ")").c_str() : "");
+        }
     }
     if (timing && o.downsample)
         fprintf(stderr, "DOWN: selection %.3f | QC pass over the kept reads (%s, %.2f GB of them in %.2f GB of text): context %.3f, batches + submits %.3f (its own thread; %d submits %.3f, the first %.3f) | writing them %.3f (%s) | closing the output %.3f\n",

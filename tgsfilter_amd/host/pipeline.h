@@ -324,6 +324,14 @@ public:
             cap_ = (virt_bytes + 4095) & ~uint64_t(4095);
             map_ = (char*)mmap(nullptr, cap_, PROT_READ | PROT_WRITE, MAP_SHARED, fd_, 0);      // beyond the end of the file for now
             ok = map_ != MAP_FAILED;
+            // Every page of this mapping is written once and never looked at again: say so.  Without the advice, dropping
+            // the mappings (MADV_DONTNEED behind the fill jobs, or the exit) marks each page accessed -- 20 M pages moved
+            // between the LRU lists under the lock the fallocate beside it needs for every page it adds.
+            if (ok) {
+                const char* adv = getenv("TGSF_SINK_ADVICE");                                      // experiment knob: seq | random | none
+                if (!adv || !strcmp(adv, "seq")) madvise(map_, cap_, MADV_SEQUENTIAL);
+                else if (!strcmp(adv, "random")) madvise(map_, cap_, MADV_RANDOM);
+            }
         }
         if (!ok) { ::close(fd_); fd_ = -1; return false; }
         live() = this;
