@@ -510,10 +510,11 @@ def kernel_leg(args, torch, dist, world, rank, local_rank, device, xdev, host_gr
     p_kwargs = dict(adapters=wl_adapters, min_len=1000, min_q=20.0 if hifi else 10.0, head_trim=0, tail_trim=0,
                     min_repeat=args.min_repeat, kmer=args.kmer)
     if args.short_adapters:
-        # for information: a ligation-kit adapter pair of 28 bp (src/TGSFilter.cpp:2974-2975) with -M 15 -- adapters of at
-        # most 32 bp take the one-dword column in the middle scan (the default -M 35 never searches the middle for them)
-        p_kwargs.update(adapters=[b"AATGTACTTCGTTCAGTTACGTATTGCT", b"AGCAATACGTAACTGAACGAAGTACATT"], mid_match_len=15)
-        flags += " -a ligation28.fa -M 15"
+        # for information: a ligation-kit adapter pair of 28 bp (src/TGSFilter.cpp:2974-2975) with -M 24 -- adapters of at
+        # most 32 bp take the one-dword column in the middle scan (the default -M 35 never searches the middle for them;
+        # -M 24 allows 5 differences, about the error share of the default thresholds for the 50-bp adapters)
+        p_kwargs.update(adapters=[b"AATGTACTTCGTTCAGTTACGTATTGCT", b"AGCAATACGTAACTGAACGAAGTACATT"], mid_match_len=24)
+        flags += " -a ligation28.fa -M 24"
     p = abi.make_params(args.workload, max_batch_bases=max_bases + 64, max_batch_reads=args.reads, max_read_len=max_len, **p_kwargs)
     NS = max(1, args.streams)
     ctxs = [capi.Context(p, local_rank) for _ in range(NS)]
@@ -731,7 +732,7 @@ def main():
     ap.add_argument("--reads", type=int, default=131072, help="reads per kernel-path step")
     ap.add_argument("--mean-len", type=float, default=None)
     ap.add_argument("--min-repeat", type=int, default=0, help="-p of config C5, for information")
-    ap.add_argument("--short-adapters", action="store_true", help="kernel path with a 28-bp adapter pair and -M 15 (the one-dword scan column), for information")
+    ap.add_argument("--short-adapters", action="store_true", help="kernel path with a 28-bp adapter pair and -M 24 (the one-dword scan column), for information")
     ap.add_argument("--kmer", type=int, default=11)
     ap.add_argument("--workload", choices=["ont", "hifi"], default="ont")
     ap.add_argument("--max-len", type=int, default=2_000_000)

@@ -222,3 +222,29 @@ def test_emul_short_adapters_dword_column(emul, ads, no32, monkeypatch):
     r, f, _ = parity.compare_batch(ctx, p, reads)
     assert (r["flags"] & abi.RF_ADMID).any()              # the planted copies were found in the middle
     ctx.close()
+
+
+def _shared_prefix_read(k=31, units=9000, seed=5):
+    """Thousands of distinct duplicated k-mers that share their first 16 bases: no number of leading bases
+    separates them into passes whose table holds them."""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    pre = acgt[rng.integers(0, 4, 16)].tobytes()
+    block = b"".join(pre + acgt[rng.integers(0, 4, k - 16)].tobytes() for _ in range(units))
+    s = block + block                                   # every k-mer of the block occurs twice
+    q = bytes((rng.integers(15, 35, len(s)) + 33).astype(np.uint8))
+    return (b"shared_prefix", s, q)
+
+
+def test_emul_repeat_gate_shared_prefix_fragment(emul):
+    """k = 31: the passes of the keys kernel give up on leading bases and own the k-mers by a hash of the whole key; the count
+    (checked with numpy on both sides of the gate) stays exact."""
+    read = _shared_prefix_read()
+    c = parity._kmer_repeat_np(read[1], 31)
+    assert c > 250_000
+    for pval, kept in ((c, True), (c + 1, False)):
+        p = parity.sized(abi.make_params("ont", adapters=[synth.ONT_RAPID], min_q=7.0, min_repeat=pval, kmer=31), [read])
+        ctx = capi.Context(p, 0, emul)
+        r, f = ctx.submit(*[x if i != 2 else x[:-1].copy() for i, x in enumerate(synth.pack([read]))])
+        assert len(f) == 1 and bool(f["flags"][0] & abi.FF_PASS) == kept and bool(f["flags"][0] & abi.FF_REPEAT) == (not kept)
+        ctx.close()

@@ -299,3 +299,27 @@ def test_gpu_short_adapters_dword_column(ads_key, no32, monkeypatch):
     r, f, _ = parity.compare_batch(ctx, p, reads)
     assert (r["flags"] & abi.RF_ADMID).any()
     ctx.close()
+
+
+@pytest.mark.parametrize("k", [31, 15])
+def test_gpu_repeat_gate_shared_prefix_fragment(k):
+    """Thousands of distinct duplicated k-mers sharing their first 16 (k = 15: 8) bases: the keys kernel's passes fall back
+    from leading bases to a hash of the whole key; the count stays exact (numpy, both sides of the gate)."""
+    from tests.test_emul_parity import _shared_prefix_read
+    rng = np.random.default_rng(9)
+    if k == 31:
+        read = _shared_prefix_read()
+    else:
+        acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+        pre = acgt[rng.integers(0, 4, 8)].tobytes()
+        block = b"".join(pre + acgt[rng.integers(0, 4, 7)].tobytes() for _ in range(14000))
+        s = block + block
+        read = (b"shared_prefix15", s, bytes((rng.integers(15, 35, len(s)) + 33).astype(np.uint8)))
+    c = parity._kmer_repeat_np(read[1], k)
+    for pval, kept in ((c, True), (c + 1, False)):
+        p = parity.sized(abi.make_params("ont", adapters=[synth.ONT_RAPID], min_q=7.0, min_repeat=pval, kmer=k), [read])
+        ctx = capi.Context(p, 0)
+        seq, qual, off, ln = synth.pack([read])
+        r, f = ctx.submit(seq, qual, off[:-1].copy(), ln)
+        assert len(f) == 1 and bool(f["flags"][0] & abi.FF_PASS) == kept and bool(f["flags"][0] & abi.FF_REPEAT) == (not kept)
+        ctx.close()

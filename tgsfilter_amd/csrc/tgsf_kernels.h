@@ -1921,11 +1921,13 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
                 mine = (total > 1 && first != 0ull) ? 2u : 1u;
             }
         } else if (total > 0) {
-            int PB = 0;
+            int PB = 0, PB0 = -1;
+            uint32_t hparts = 0;                                       // > 0: passes own the k-mers by a hash of the whole key
             for (;;) {
-                while (PB < k - 1 && ((uint32_t)total >> (2 * PB)) > kRepShare) PB++;
+                while (!hparts && PB < k - 1 && ((uint32_t)total >> (2 * PB)) > kRepShare) PB++;
+                if (PB0 < 0) PB0 = PB;
                 const int kb = 2 * (k - PB);                           // bits of a key: the k-mer less the pass's leading bases
-                const uint32_t passes = 1u << (2 * PB);
+                const uint32_t passes = hparts ? hparts : 1u << (2 * PB);
                 mine = 0;
                 for (uint32_t pass = 0; pass < passes; pass++) {
                     // one scan of the fragment: PHASE 0 marks A and B, PHASE 1 inserts the keys whose hash value is in B.
@@ -1946,7 +1948,7 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
                                 const int first = a - 16 * (wb + g);
                                 const int v = a + total - 16 * (wb + g);
                                 uint32_t m = 0x55555555u;              // bit 30-2j: base j of the chunk starts a k-mer to handle below
-                                if (PB == 0 && first <= 0 && v >= 16) {
+                                if (PB == 0 && !hparts && first <= 0 && v >= 16) {
                                     // a whole chunk of a single-pass fragment: sixteen keys at constant shifts, their LDS
                                     // operations issued back to back; what is left for the loop below is rare
                                     uint32_t hbv[16], oldv[16];
@@ -2002,6 +2004,7 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
                                         key = (key_t)lo32;
                                         h = lo32 * 0x9E3779B1u;
                                     }
+                                    if (hparts && ((((h ^ (h >> 15)) * 0x2C1B3C6Du) >> 12) & (hparts - 1u)) != pass) continue;   // another pass's k-mer
                                     const uint32_t hb = h >> 13;       // 19 bits
                                     const uint32_t bit = 1u << (hb & 31u);
                                     if (PHASE == 0) {
@@ -2043,11 +2046,16 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
                 if (!over_s) break;
                 TGSF_BLOCK_SYNC();
                 if (tid == 0) over_s = 0;
-                // the chunk words a lane holds (w0..w3) serve keys that start up to 16 bases behind a pass's leading bases
-                if (PB >= k - 1 || PB >= 16) { set_status(B, DS_REPEAT_TABLE, B.frag_read[f]); mine = 0; TGSF_BLOCK_SYNC(); break; }
-                PB++;
+                // A pass's table could not take the pass's duplicated k-mers.  Two more leading bases at most (each quadruples
+                // the passes; thousands of distinct duplicated k-mers may well share a long prefix -- then no number of
+                // leading bases separates them): from there on the passes own the k-mers by a hash of the whole key, as
+                // many passes as leave a pass about an eighth of the table, doubled while one still overflows.
+                if (!hparts && PB < PB0 + 2 && PB < k - 1 && PB < 15) PB++;
+                else if (!hparts) { PB = 0; hparts = 1u; while (hparts < (1u << 20) && ((uint32_t)total / hparts) > (1u << (TLOG - 3))) hparts <<= 1; }
+                else if (hparts < (1u << 20)) hparts <<= 1;
+                else { set_status(B, DS_REPEAT_TABLE, B.frag_read[f]); mine = 0; TGSF_BLOCK_SYNC(); break; }
 #if defined(TGSF_EMUL) && defined(TGSF_REP_TRACE)
-                fprintf(stderr, "k_repeat_keys: fragment %u (%d k-mers) starts over with %d leading bases\n", f, total, PB);
+                fprintf(stderr, "k_repeat_keys: fragment %u (%d k-mers) starts over with %d leading bases / %u hash parts\n", f, total, PB, hparts);
 #endif
                 TGSF_BLOCK_SYNC();
             }
