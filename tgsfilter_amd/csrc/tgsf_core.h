@@ -221,13 +221,24 @@ TGSF_HD void hot_step(Hot32& s, uint32_t Eq) {
     const uint32_t Pv = s.p, Mv = s.m;
     const uint32_t t = Eq & Pv;                          // v_and
     const uint32_t sum = t + Pv;                         // v_add_u32
-    const uint32_t u = sum | Pv | Eq;                    // v_or3             (= Xh | Pv)
-    uint32_t Ph = Mv | ~u;                               // v_bfi / v_bitop3
-    uint32_t Mh = (sum & t) | (~sum & Pv);               // v_bfi             (= Pv & Xh)
+#if defined(__HIP_DEVICE_COMPILE__)
+    // every three-input function spelled out (the compiler forms v_or3 / v_bfi from 64-bit expressions, not from these)
+    const uint32_t u = bitop3<0xFE>(sum, Pv, Eq);        // sum | Pv | Eq                 (= Xh | Pv)
+    uint32_t Ph = bitop3<0xF3>(Mv, u, u);                // Mv | ~u
+    uint32_t Mh = bitop3<0xD0>(Pv, Eq, sum);             // Pv & (Eq | ~sum)              (= Pv & Xh)
     Ph <<= 1; Mh <<= 1;                                  // 2 v_lshlrev_b32
-    const uint32_t x = Eq | Mv | Ph;                     // v_or3             (= Xv | Ph')
-    s.p = Mh | ~x;                                       // v_bitop3
-    s.m = bitop3<0xE0>(Ph, Eq, Mv);                      // v_bitop3          (= Ph' & (Eq | Mv))
+    const uint32_t x = bitop3<0xFE>(Eq, Mv, Ph);         // Eq | Mv | Ph'                 (= Xv | Ph')
+    s.p = bitop3<0xF3>(Mh, x, x);                        // Mh' | ~x
+    s.m = bitop3<0xE0>(Ph, Eq, Mv);                      // Ph' & (Eq | Mv)
+#else
+    const uint32_t u = sum | Pv | Eq;
+    uint32_t Ph = Mv | ~u;
+    uint32_t Mh = Pv & (Eq | ~sum);
+    Ph <<= 1; Mh <<= 1;
+    const uint32_t x = Eq | Mv | Ph;
+    s.p = Mh | ~x;
+    s.m = Ph & (Eq | Mv);
+#endif
 }
 TGSF_HD int hot_score(const Hot32& s) { return (int)popc32(s.p) - (int)popc32(s.m); }
 TGSF_HD bool hot_within(const Hot32& s, int lim) {

@@ -73,16 +73,22 @@ with open(O + "/%s_pmc_valu.csv" % tag, "w") as o:
     for k, d in sorted(sq.items(), key=lambda kv: -kv[1].get("SQ_INSTS_VALU", 0)):
         o.write(k + "," + ",".join("%.0f" % d.get(c, 0) for c in cols) + "\n")
 b = json.load(open(O + "/kt_single.json"))
+def named(d, prefix):
+    """the dispatch-name entry that starts with `prefix` (template arguments vary: k_mid_scan1<2, tgsf::Hot>)"""
+    for k in d:
+        if k.startswith(prefix):
+            return d[k]
+    return {}
 def hbm(k):
-    return tcc.get(k, {}).get("TCC_EA0_RDREQ_sum", 0) * 128 + write.get(k, {}).get("WRITE_SIZE", 0) * 1024
+    return named(tcc, k).get("TCC_EA0_RDREQ_sum", 0) * 128 + named(write, k).get("WRITE_SIZE", 0) * 1024
 import hashlib
 h = hashlib.sha256()
 for fn in ("tgsf_core.h", "tgsf_dev.h", "tgsf_kernels.h", "tgsf_lib.hip"):      # = bench.py kernel_source_hash()
     h.update(open(os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.getcwd()), "tgsfilter_amd", "csrc", fn), "rb").read())
 json.dump({"reads_per_step": b["kernel_path"]["reads_per_step"], "kernel_source_hash": h.hexdigest()[:16],
-           "mid_scan_hbm_bytes_per_launch": hbm("tgsf::k_mid_scan1<2>"),
-           "stats_raw_hbm_bytes_per_launch": hbm("tgsf::k_stats<false>"),
-           "mid_scan_valu_insts_per_launch": sq.get("tgsf::k_mid_scan1<2>", {}).get("SQ_INSTS_VALU"),
+           "mid_scan_hbm_bytes_per_launch": hbm("tgsf::k_mid_scan1<2"),
+           "stats_raw_hbm_bytes_per_launch": hbm("tgsf::k_stats<false"),
+           "mid_scan_valu_insts_per_launch": named(sq, "tgsf::k_mid_scan1<2").get("SQ_INSTS_VALU"),
            "valu_insts_per_batch_all_kernels": sum(d.get("SQ_INSTS_VALU", 0) for d in sq.values()),
            "source": "profiles/%s_pmc_hbm_traffic.csv (TCC_EA0_RDREQ_sum*128 + WRITE_SIZE*1024) and %s_pmc_valu.csv" % (tag, tag)},
           open(O + "/traffic.json", "w"), indent=1)
