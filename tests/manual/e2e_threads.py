@@ -19,7 +19,9 @@ DEFAULT_CLI = bench.CLI
 td = tempfile.mkdtemp(prefix="thr_", dir="/dev/shm")
 try:
     fq = os.path.join(td, "in.fq")
-    bases, nbytes = synth.write_ont_fastq(fq, n, seed=2, procs=32)
+    bases, nbytes = synth.write_ont_fastq(fq, n, seed=2, procs=32, mean_len=float(os.environ.get("MEAN_LEN", "45000")))
+    base_args = os.environ.get("BASE_ARGS", "-x ont -l 1000 -q 10").split()
+    show = os.environ.get("SHOW", "")            # e.g. SHOW=DOWN,TIMING prints those lines of the last run
     for setting in (sys.argv[3:] or [""]):
         env = dict(os.environ, TGSF_TIMING="1")
         bench.CLI = DEFAULT_CLI
@@ -39,7 +41,7 @@ try:
         for rep in range(runs):
             if os.path.isfile(out) and not os.path.islink(out):
                 os.remove(out)
-            dt, err = bench.run_cmd([bench.CLI, "-i", fq, "-o", out, "-t", "32", "-x", "ont", "-l", "1000", "-q", "10"] + extra, env)
+            dt, err = bench.run_cmd([bench.CLI, "-i", fq, "-o", out, "-t", "32"] + base_args + extra, env)
             walls.append(dt)
             cpus.append(bench.LAST_RUN_CPU.get("cpu_s", 0))
             thr.append(bench.LAST_RUN_CPU.get("throttled_periods", 0))
@@ -47,5 +49,8 @@ try:
         print("[%-70s] wall min %.3f mean %.3f s (%.2f Gbases/s) | cpu %.1f s | throttled periods %s | fallocate %.2f populate %.2f index+prepass %.2f pipeline %.2f" % (
             setting, min(walls), sum(walls) / len(walls), bases / (sum(walls) / len(walls)) / 1e9, sum(cpus) / len(cpus), thr,
             tim.get("fallocate_s", 0), tim.get("populate_s", 0), tim.get("index_prepass_s", 0), tim.get("pipeline_s", 0)), flush=True)
+        for l in err.splitlines():
+            if show and l.split(":")[0] in show.split(","):
+                print("    " + l[:1800], flush=True)
 finally:
     shutil.rmtree(td, ignore_errors=True)
