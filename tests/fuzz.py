@@ -18,11 +18,19 @@ LIB_ADAPTERS = [synth.ONT_RAPID, synth.ONT_RAPID_RC, synth.PACBIO_BLUNT, synth.P
                 bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[np.random.default_rng(241).integers(0, 4, 241)])]
 
 
+# round 3's additions to the domain (TGSF_FUZZ_WIDE=1; the seeds of earlier campaigns keep their meaning without it): 22-bp
+# adapters (the one-dword scan column, also mixed with longer ones), -e beyond one slab of the end-table kernel, and now and
+# then a candidate pool of a few slots, so that the count-and-rescan path of tgsf_wait runs on ordinary inputs too
+WIDE_ADAPTERS = [b"GCAATACGTAACTGAACGAAGT", b"ACTTCGTTCAGTTACGTATTGC", b"ACGTAACTGAACGAAGTACAGG", b"TTTTTTTTCCTGTACTTCGTTCAGTTACGT"]
+
+
 def random_case(seed: int, n_reads: int):
     rng = np.random.default_rng(seed)
+    wide = os.environ.get("TGSF_FUZZ_WIDE") == "1"
     kind = "ont" if rng.random() < 0.6 else "hifi"
     na = int(rng.choice([1, 2, 2, 3, 4]))
-    ads = [LIB_ADAPTERS[i] for i in rng.choice(len(LIB_ADAPTERS), na, replace=False)]
+    pool = LIB_ADAPTERS + (WIDE_ADAPTERS if wide else [])
+    ads = [pool[i] for i in rng.choice(len(pool), na, replace=False)]
     planted = ads[0] if rng.random() < 0.8 else None
     mean_len = float(rng.choice([800, 2500, 6000]))
     if os.environ.get("TGSF_FUZZ_MEAN_LEN"):                          # (a campaign can ask for long reads: windows of the repeat gate, many scan blocks)
@@ -54,13 +62,25 @@ def random_case(seed: int, n_reads: int):
         kw.update(min_repeat=int(rng.choice([50, 400, 1, 5])), kmer=int(rng.choice([7, 11, 12, 14, 20, 32, 9, 13, 15, 16, 17, 31])))
     if rng.random() < 0.15:
         kw.update(no_qual=True)
+    if wide:
+        if rng.random() < 0.3:
+            kw.update(bc_len=int(rng.choice([513, 700, 1300])))
+        if rng.random() < 0.5:
+            kw.update(mid_match_len=int(rng.choice([12, 16, 18, 22])))       # within reach of the short adapters
+        kw["_pool_cap"] = int(rng.choice([0, 0, 0, 3, 40]))                   # 0: the context's own sizing
     return kind, reads, kw
 
 
 def run_case(lib_path, seed: int, n_reads: int):
     kind, reads, kw = random_case(seed, n_reads)
+    pool_cap = kw.pop("_pool_cap", 0)
     p = parity.sized(abi.make_params(kind, **kw), reads)
-    ctx = capi.Context(p, 0, lib_path)
+    if pool_cap:
+        os.environ["TGSF_POOL_CAP"] = str(pool_cap)
+    try:
+        ctx = capi.Context(p, 0, lib_path)
+    finally:
+        os.environ.pop("TGSF_POOL_CAP", None)
     try:
         parity.compare_batch(ctx, p, reads, align=int(np.random.default_rng(seed).choice([1, 16])),
                              explicit_lengths=True)

@@ -96,9 +96,14 @@ CASES.update({
     "hifi_phred64_auto": (dict(seed=33, n=900, kind="hifi", mean_len=1400, p5=0.5, p3=0.4), None, "-x hifi -l 1000 -b 8", "fq", "phred64"),
 })
 
+WIDE_A = bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[np.random.default_rng(3001).integers(0, 4, 300)])
+WIDE_B = bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[np.random.default_rng(7001).integers(0, 4, 700)])
 CASES.update({
     # -e beyond the 512 positions one launch of the end-table kernel tallies (round 3: one launch per slab of 512)
     "ont_e1300": (dict(seed=37, n=80, kind="ont", mean_len=3500, zoo=True, pmid=0.05), [synth.ONT_RAPID], "-x ont -l 1000 -q 10 -5 0 -3 0 -e 1300"),
+    # adapters beyond 256 bp (-a accepts any length; the reference's edlib is multi-block): 300 and 700 bp, five and eleven words
+    "wide_adapter": (dict(seed=38, n=60, kind="ont", mean_len=4500, zoo=True, adapter=WIDE_A, pmid=0.3, err=0.05),
+                     [WIDE_A, WIDE_B], "-x ont -l 800 -q 9 -5 0 -3 2 -M 120"),
 })
 
 IN_EXT = {"fq": "in.fq", "bam": "in.bam", "sam": "in.sam", "fa": "in.fa"}

@@ -9,7 +9,7 @@ from tests import cli_check
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 THREADED = {"TGSF_BATCH_BYTES": "30000", "TGSF_CTX_PER_DEVICE": "3", "TGSF_FILL_MIN_BYTES": "1", "TGSF_SCAN_BLOCK": "5000",
-            "TGSF_STRIDE_BYTES": "70000", "TGSF_SCAN_THREADS": "3", "TGSF_DOWN_MAP_MIN": "1"}
+            "TGSF_STRIDE_BYTES": "70000", "TGSF_SCAN_THREADS": "3", "TGSF_DOWN_MAP_MIN": "1", "TGSF_DOWN_EARLY_MIN": "1"}
 STREAMED = {"TGSF_STREAM_MIN_BYTES": "1", "TGSF_CHUNK_BYTES": "20000", "TGSF_FILL_MIN_BYTES": "1", "TGSF_STRIDE_BYTES": "50000",
             "TGSF_CTX_PER_DEVICE": "3"}
 CASES = [("ont_zoo", None), ("hifi_zoo", None), ("hifi_bam", None), ("ont_sam", None), ("ont_zoo", "gzip"), ("ont_fasta", "bgzf"),

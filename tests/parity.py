@@ -295,7 +295,7 @@ def async_two_contexts(lib_path):
         c.close()
 
 
-def align_windows_random(lib_path, n, seed=9, golden_dir=None):
+def align_windows_random(lib_path, n, seed=9, golden_dir=None, lengths=None, max_window=400):
     """tgsf_align_windows against edlib itself where oracle/_ref/libedlib_ref.so exists (compiled from the
     reference's include/edlib.cpp), else against the oracle's DP restatement: random adapters of 20..256 bp,
     windows of 5..400 bp with planted mutated copies, homopolymers and Ns, assorted k."""
@@ -304,15 +304,18 @@ def align_windows_random(lib_path, n, seed=9, golden_dir=None):
     rng = np.random.default_rng(seed)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
     adapters = [synth.ONT_RAPID, synth.PACBIO_BLUNT, b"AATGTACTTCGTTCAGTTACGTATTGCT", b"GCAATACGTAACTGAACGAAGT"]
-    adapters += [bytes(acgt[rng.integers(0, 4, int(L))]) for L in (20, 33, 64, 65, 90, 127, 128, 129, 150, 192, 193, 230, 256)]
-    p = abi.make_params("ont", adapters=adapters, max_batch_bases=1 << 22, max_batch_reads=4096, max_read_len=4096)
+    adapters += [bytes(acgt[rng.integers(0, 4, int(L))]) for L in (lengths or (20, 33, 64, 65, 90, 127, 128, 129, 150, 192, 193, 230, 256))]
+    if lengths:                                   # (adapters beyond 256 bp: the wide path; a few short ones ride along)
+        adapters = adapters[4:] + adapters[:2]
+    p = abi.make_params("ont", adapters=adapters, max_batch_bases=1 << 22, max_batch_reads=4096 if not lengths else 256, max_read_len=4096,
+                        **({"mid_match_len": 1, "end_match_len": 1} if lengths else {}))
     ctx = capi.Context(p, 0, lib_path)
     buf, off, ln, aid, ks, trip = bytearray(), [], [], [], [], []
     for i in range(n):
         a = int(rng.integers(0, len(adapters)))
         q = adapters[a]
         Q = len(q)
-        T = int(rng.integers(5, 40)) if i % 9 == 0 else int(rng.integers(40, 400))
+        T = int(rng.integers(5, 40)) if i % 9 == 0 else int(rng.integers(40, max_window))
         t = bytearray(acgt[rng.integers(0, 4, T)].tobytes())
         if i % 11 == 5:
             t = bytearray(b"T" * T)
@@ -324,7 +327,7 @@ def align_windows_random(lib_path, n, seed=9, golden_dir=None):
             t[pos:pos + len(m)] = m
         if i % 13 == 7:
             t[int(rng.integers(0, len(t)))] = ord("N")
-        t = bytes(t[:400])
+        t = bytes(t[:max_window])
         k = max(1, int(rng.choice([Q - 3, Q - 14, Q - 34, Q // 3, Q // 8 + 1])))
         k = min(k, Q - 1)
         off.append(len(buf)); ln.append(len(t)); aid.append(a); ks.append(k); trip.append((q, t, k))

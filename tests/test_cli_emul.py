@@ -33,6 +33,18 @@ def test_cli_downsampling_qc_pass_both_ways(binary, golden_dir, name, how, monke
     cli_check.run_case(binary, golden_dir, name, extra_args=["-t", "5"])
 
 
+@pytest.mark.parametrize("name", ["down_gd", "down_r", "down_R", "down_F", "fasta_down"])
+def test_cli_downsampling_output_reserved_early(binary, golden_dir, name, monkeypatch):
+    """The downsampling output is instantiated while the filter pass still runs (forced here on the small goldens: tiny strides,
+    speculation beyond what the selection keeps -- the surplus is cut off) and filled stride by stride."""
+    monkeypatch.setenv("TGSF_DOWN_EARLY_MIN", "1")
+    monkeypatch.setenv("TGSF_STRIDE_BYTES", "40000")
+    monkeypatch.setenv("TGSF_DOWN_FEEDERS", "2")          # ... and the QC pass over the kept reads from two feeders (small slices: several batches)
+    monkeypatch.setenv("TGSF_DOWN_QC", "text")
+    monkeypatch.setenv("TGSF_DOWN_BATCH_BYTES", "1200000")          # (a slice ends 1 MB short of it: 150 KB of text each)
+    cli_check.run_case(binary, golden_dir, name, extra_args=["-t", "5"])
+
+
 def test_cli_gz_output_and_fasta(binary, golden_dir, tmp_path):
     """-o *.fq.gz (per-record gzip members) inflates to the reference's output; -o *.fa keeps the bases."""
     import gzip

@@ -26,7 +26,7 @@ def test_emul_edlib_vectors(emul, golden_dir):
     parity.edlib_vectors(emul, golden_dir)
 
 
-@pytest.mark.parametrize("name", ["ont_zoo", "ont_trim", "ont_discard", "hifi_zoo", "long_adapter", "qc_only", "ont_m1", "huge_adapter", "ont_phred64", "ont_e1300"])
+@pytest.mark.parametrize("name", ["ont_zoo", "ont_trim", "ont_discard", "hifi_zoo", "long_adapter", "qc_only", "ont_m1", "huge_adapter", "ont_phred64", "ont_e1300", "wide_adapter"])
 def test_emul_golden(emul, golden_dir, name):
     parity.golden_case(emul, golden_dir, name)
 
@@ -247,4 +247,25 @@ def test_emul_repeat_gate_shared_prefix_fragment(emul):
         ctx = capi.Context(p, 0, emul)
         r, f = ctx.submit(*[x if i != 2 else x[:-1].copy() for i, x in enumerate(synth.pack([read]))])
         assert len(f) == 1 and bool(f["flags"][0] & abi.FF_PASS) == kept and bool(f["flags"][0] & abi.FF_REPEAT) == (not kept)
+        ctx.close()
+
+
+def test_emul_align_windows_beyond_256_bp(emul):
+    """Adapters of 257..2048 bp (only reachable with -a; the reference's edlib is multi-block, include/edlib.cpp:182-185) through
+    the wide column: edit distance, locations, start and path length as the reference's own edlib reports them."""
+    parity.align_windows_random(emul, 300, seed=19, lengths=(257, 300, 511, 640, 1000, 2048), max_window=2600)
+
+
+def test_emul_batch_with_adapters_beyond_256_bp(emul):
+    """Whole batches with a 300-bp and a 700-bp adapter (planted in the middle and at the ends) against the oracle."""
+    rng = np.random.default_rng(3)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    a300, a700 = bytes(acgt[rng.integers(0, 4, 300)]), bytes(acgt[rng.integers(0, 4, 700)])
+    reads = synth.make_reads(41, 24, "ont", mean_len=6000, zoo=True, pmid=0.6, adapter=a300, err=0.05)
+    reads += synth.make_reads(42, 12, "ont", mean_len=9000, zoo=False, pmid=0.8, p5=0.5, adapter=a700, err=0.08)
+    for mm in (35, 200):
+        p = parity.sized(abi.make_params("ont", adapters=[a300, synth.revcomp(a300), a700, synth.ONT_RAPID], min_q=7.0, mid_match_len=mm, end_match_len=8), reads)
+        ctx = capi.Context(p, 0, emul)
+        r, f, _ = parity.compare_batch(ctx, p, reads)
+        assert (r["flags"] & abi.RF_ADMID).any()
         ctx.close()

@@ -323,3 +323,13 @@ def test_gpu_repeat_gate_shared_prefix_fragment(k):
         r, f = ctx.submit(seq, qual, off[:-1].copy(), ln)
         assert len(f) == 1 and bool(f["flags"][0] & abi.FF_PASS) == kept and bool(f["flags"][0] & abi.FF_REPEAT) == (not kept)
         ctx.close()
+
+
+def test_gpu_align_windows_beyond_256_bp():
+    """Adapters of 257..2048 bp through the wide column against the reference's own edlib (where oracle/_ref is present)."""
+    parity.align_windows_random(None, 600, seed=19, lengths=(257, 300, 511, 640, 1000, 2048), max_window=2600)
+
+
+def test_gpu_batch_with_adapters_beyond_256_bp():
+    from tests.test_emul_parity import test_emul_batch_with_adapters_beyond_256_bp as same
+    same(None)

@@ -27,8 +27,10 @@
 namespace tgsf {
 
 constexpr int kMaxAdapters = 32;
-constexpr int kMaxQ = 256;         // four 64-row words
-constexpr int kPeqW = 4;           // words per symbol in the standard-layout Peq tables
+constexpr int kMaxQ = 2048;        // adapters up to 256 bp run in registers (1..4 words); longer ones (-a accepts any length, the
+                                   // reference's edlib is multi-block, include/edlib.cpp:182-185) in kWideNW-word arrays
+constexpr int kPeqW = 4;           // words per symbol in the standard-layout Peq tables (adapters <= 256 bp)
+constexpr int kWideNW = kMaxQ / 64;   // words per symbol in the wide tables (built only when an adapter needs them)
 constexpr int kBin = 100;          // CalcAvgQuality bin width
 constexpr int kTileBins = 64;      // one bin per lane
 constexpr int kTileBases = kBin * kTileBins;   // 6400 bases per stats tile

@@ -15,7 +15,7 @@ struct DevParams {
     int no_qual;               // records without qualities (FASTA): count-only tallies, no quality gate
     int min_repeat, kmer;             // -p / -k: repeat gate (GetKmerCount), 0 = off
     int n_adapters;
-    int max_nw;                       // 1 if every adapter is <= 64 bp, else 2
+    int max_nw;                       // words of the longest adapter's column: 1, 2, 4, or kWideNW (an adapter beyond 256 bp)
     int Q[kMaxAdapters];
     int k_mid[kMaxAdapters];          // min(Q, Q - MidMatchLen + 1)   src/TGSFilter.cpp:1233, edlib.cpp:565
     int k_end[kMaxAdapters];          // min(Q, Q - EndMatchLen + 1)   :1271
@@ -29,12 +29,14 @@ struct DevParams {
     const uint64_t* peq_fwd;          // [kMaxAdapters][256][2]  standard layout
     const uint64_t* peq_rev;          // [kMaxAdapters][256][2]  reversed adapter
     const uint64_t* peq_top;          // [kMaxAdapters][256]     top-aligned single word (Q <= 64)
+    const uint64_t* peq_fwd_w;        // [n_adapters][256][kWideNW]  standard layout, every adapter (nullptr unless max_nw == kWideNW)
+    const uint64_t* peq_rev_w;        // ... reversed adapter
 };
 
 // Candidate column of the middle scan / resolved drop region (same 16-byte slot).
 struct MidCand {
     int32_t pos;      // scan: end column in window coordinates;  resolved: region start (read coords)
-    int32_t aux;      // scan: score | adapter << 8;              resolved: region end
+    int32_t aux;      // scan: score | adapter << 16;             resolved: region end
     int32_t next;     // next slot of the same read, -1 = end of list
     int32_t state;    // 0 = candidate, 1 = resolved region, 2 = rejected
 };

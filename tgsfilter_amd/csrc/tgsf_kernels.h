@@ -1026,6 +1026,120 @@ TGSF_D int min_start_all(const DevParams& P, int a, const uint8_t* t, int T, int
     return mn;
 }
 
+// ---------------------------------------------------------------------------
+// Adapters beyond 256 bp (only reachable with -a): the same searches with the column in kWideNW-word arrays walked by
+// run-time loops (they live in scratch memory: correct for any length up to kMaxQ, not fast -- such adapters are a
+// corner of the domain, the reference's multi-block edlib accepts them, include/edlib.cpp:182-185).
+// ---------------------------------------------------------------------------
+struct BvW {
+    uint64_t p[kWideNW], m[kWideNW];
+    int score;
+};
+TGSF_D void bvw_init(BvW& s, int Q, int nw) {
+    for (int w = 0; w < nw; w++) { s.p[w] = ~0ull; s.m[w] = 0ull; }
+    s.score = Q;
+}
+// one text column; hin_top 0 (infix) or +1 (prefix / global); ph_out (optional): the horizontal +1 words
+TGSF_D void bvw_step(BvW& s, const uint64_t* eq, int hin_top, int Q, int nw, uint64_t* ph_out) {
+    int hin = hin_top;
+    for (int w = 0; w < nw; w++) {
+        uint64_t Eq = eq[w], Pv = s.p[w], Mv = s.m[w];
+        uint64_t Xv = Eq | Mv;
+        if (hin < 0) Eq |= 1ull;
+        uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+        uint64_t Ph = Mv | ~(Xh | Pv);
+        uint64_t Mh = Pv & Xh;
+        if (ph_out) ph_out[w] = Ph;
+        const int bit = (w == nw - 1) ? ((Q - 1) & 63) : 63;
+        int hout = (int)((Ph >> bit) & 1ull) - (int)((Mh >> bit) & 1ull);
+        Ph <<= 1; Mh <<= 1;
+        if (hin < 0) Mh |= 1ull;
+        if (hin > 0) Ph |= 1ull;
+        s.p[w] = Mh | ~(Xv | Ph);
+        s.m[w] = Ph & Xv;
+        hin = hout;
+    }
+    s.score += hin;
+}
+TGSF_D int start_of_w(const DevParams& P, int a, const uint8_t* t, int end, int best)
+{
+    const int Q = P.Q[a], nw = (Q + 63) >> 6;
+    const uint64_t* pr = P.peq_rev_w + (size_t)a * 256 * kWideNW;
+    BvW b;
+    bvw_init(b, Q, nw);
+    int maxl = end + 1;
+    if (maxl > Q + best) maxl = Q + best;
+    int best_l = 1;
+    for (int l = 1; l <= maxl; l++) {
+        bvw_step(b, pr + (size_t)t[end - (l - 1)] * kWideNW, 1, Q, nw, nullptr);
+        if (b.score == best) best_l = l;
+    }
+    return end - best_l + 1;
+}
+TGSF_D int first_mlen_w(const DevParams& P, int a, const uint8_t* t, int start0, int end0, int best, int need, LaneScratch sc, bool exact)
+{
+    const int Q = P.Q[a], nw = (Q + 63) >> 6;
+    const int T = end0 - start0 + 1;
+    if (!exact) {
+        const int lo = T - best + (Q > T ? Q - T : 0);
+        const int slack = best - (T - Q);
+        const int hi = T - best + (slack > 0 ? slack / 2 : 0);
+        if (lo >= need) return lo;
+        if (hi < need) return -1;
+    }
+    const uint64_t* pf = P.peq_fwd_w + (size_t)a * 256 * kWideNW;
+    const uint8_t* tt = t + start0;
+    BvW s;
+    bvw_init(s, Q, nw);
+    uint64_t ph[kWideNW];
+    for (int j = 1; j <= T; j++) {
+        bvw_step(s, pf + (size_t)tt[j - 1] * kWideNW, 1, Q, nw, ph);
+        for (int w = 0; w < nw; w++) { sc.at(j, w, 2 * nw) = s.p[w]; sc.at(j, nw + w, 2 * nw) = ph[w]; }
+    }
+    int i = Q, j = T, len = 0;
+    while (i > 0 && j > 0) {                              // up > left > diagonal (edlib.cpp:1023/1057/1088)
+        const int r = i - 1;
+        if ((sc.at(j, r >> 6, 2 * nw) >> (r & 63)) & 1ull) { i--; }
+        else if ((sc.at(j, nw + (r >> 6), 2 * nw) >> (r & 63)) & 1ull) j--;
+        else { i--; j--; }
+        len++;
+    }
+    return len + i + j - best;
+}
+TGSF_D WinAln align_window_w(const DevParams& P, int a, const uint8_t* t, int T, int kk, int need, LaneScratch sc, bool exact)
+{
+    const int Q = P.Q[a], nw = (Q + 63) >> 6;
+    const uint64_t* pf = P.peq_fwd_w + (size_t)a * 256 * kWideNW;
+    WinAln r;
+    r.best = -1; r.n = 0; r.first_end = r.last_end = -1; r.start0 = 0; r.mlen = 0;
+    BvW s;
+    bvw_init(s, Q, nw);
+    int cur = kk + 1;
+    for (int j = 0; j < T; j++) {
+        bvw_step(s, pf + (size_t)t[j] * kWideNW, 0, Q, nw, nullptr);
+        if (s.score < cur) { cur = s.score; r.first_end = j; r.n = 0; }
+        if (s.score == cur && cur <= kk) { r.last_end = j; r.n++; }
+    }
+    if (cur > kk) return r;
+    r.best = cur;
+    r.start0 = start_of_w(P, a, t, r.first_end, cur);
+    r.mlen = first_mlen_w(P, a, t, r.start0, r.first_end, cur, need, sc, exact);
+    return r;
+}
+TGSF_D int min_start_all_w(const DevParams& P, int a, const uint8_t* t, int T, int best)
+{
+    const int Q = P.Q[a], nw = (Q + 63) >> 6;
+    const uint64_t* pf = P.peq_fwd_w + (size_t)a * 256 * kWideNW;
+    BvW s;
+    bvw_init(s, Q, nw);
+    int mn = T;
+    for (int j = 0; j < T; j++) {
+        bvw_step(s, pf + (size_t)t[j] * kWideNW, 0, Q, nw, nullptr);
+        if (s.score == best) { const int st = start_of_w(P, a, t, j, best); mn = st < mn ? st : mn; }
+    }
+    return mn;
+}
+
 TGSF_D LaneScratch lane_scratch(const DevBatch& B, size_t first_wave)
 {
     // one region per wave of the launch: [column][word][lane].  k_end_windows and k_mid_resolve may
@@ -1043,6 +1157,7 @@ template <int MAXNW>
 TGSF_D WinAln align_window_any(const DevParams& P, int a, const uint8_t* t, int T, int k, int need, const LaneScratch& sc, bool exact) {
     const int Q = P.Q[a];
     if (Q <= 64) return align_window<1>(P, a, t, T, k, need, sc, exact);
+    if constexpr (MAXNW > 4) { if (Q > 256) return align_window_w(P, a, t, T, k, need, sc, exact); }
     if constexpr (MAXNW > 2) { if (Q > 192) return align_window<4>(P, a, t, T, k, need, sc, exact); if (Q > 128) return align_window<3>(P, a, t, T, k, need, sc, exact); }
     return align_window<2>(P, a, t, T, k, need, sc, exact);
 }
@@ -1050,6 +1165,7 @@ template <int MAXNW>
 TGSF_D int min_start_all_any(const DevParams& P, int a, const uint8_t* t, int T, int best) {
     const int Q = P.Q[a];
     if (Q <= 64) return min_start_all<1>(P, a, t, T, best);
+    if constexpr (MAXNW > 4) { if (Q > 256) return min_start_all_w(P, a, t, T, best); }
     if constexpr (MAXNW > 2) { if (Q > 192) return min_start_all<4>(P, a, t, T, best); if (Q > 128) return min_start_all<3>(P, a, t, T, best); }
     return min_start_all<2>(P, a, t, T, best);
 }
@@ -1057,6 +1173,7 @@ template <int MAXNW>
 TGSF_D int start_of_any(const DevParams& P, int a, const uint8_t* t, int end, int best) {
     const int Q = P.Q[a];
     if (Q <= 64) return start_of<1>(P, a, t, end, best);
+    if constexpr (MAXNW > 4) { if (Q > 256) return start_of_w(P, a, t, end, best); }
     if constexpr (MAXNW > 2) { if (Q > 192) return start_of<4>(P, a, t, end, best); if (Q > 128) return start_of<3>(P, a, t, end, best); }
     return start_of<2>(P, a, t, end, best);
 }
@@ -1064,6 +1181,7 @@ template <int MAXNW>
 TGSF_D int first_mlen_any(const DevParams& P, int a, const uint8_t* t, int s0, int e0, int best, int need, const LaneScratch& sc, bool exact) {
     const int Q = P.Q[a];
     if (Q <= 64) return first_mlen<1>(P, a, t, s0, e0, best, need, sc, exact);
+    if constexpr (MAXNW > 4) { if (Q > 256) return first_mlen_w(P, a, t, s0, e0, best, need, sc, exact); }
     if constexpr (MAXNW > 2) { if (Q > 192) return first_mlen<4>(P, a, t, s0, e0, best, need, sc, exact); if (Q > 128) return first_mlen<3>(P, a, t, s0, e0, best, need, sc, exact); }
     return first_mlen<2>(P, a, t, s0, e0, best, need, sc, exact);
 }
@@ -1145,7 +1263,7 @@ TGSF_D void push_candidate(const DevBatch& B, uint32_t r, int pos, int score, in
     if (atomicAdd(&B.mid_cnt[r], 1u) == (uint32_t)kMidListMax) B.status[2] = 1u;
     MidCand c;
     c.pos = pos;
-    c.aux = score | (a << 8);
+    c.aux = score | (a << 16);
     c.state = 0;
     c.next = atomicExch(&B.mid_head[r], (int32_t)idx);
     B.pool[idx] = c;
@@ -1165,7 +1283,7 @@ TGSF_D void place_candidate(const DevBatch& B, uint32_t idx, int pos, int score,
     if (idx >= B.pool_cap) { B.status[2] = 1u; return; }              // (cannot happen: the pool was sized from the counts)
     MidCand c;
     c.pos = pos;
-    c.aux = score | (a << 8);
+    c.aux = score | (a << 16);
     c.state = 0;
     c.next = (int32_t)idx + 1;                                        // k_mid_link ends every read's list
     B.pool[idx] = c;
@@ -1411,6 +1529,59 @@ TGSF_KERNEL k_mid_scanw(DevParams P, DevBatch B, int a)
     if (B.mid_mode == 1u && slot) B.seg_n[(size_t)g * P.n_adapters + a] = slot;
 }
 
+// adapters beyond 256 bp: the wide column (see BvW), one adapter per pass, Eq rows read from the wide table in memory
+TGSF_KERNEL k_mid_scan_wide(DevParams P, DevBatch B, int a)
+{
+    TGSF_SHARED int32_t tie_col[256][4];
+    const uint32_t total = B.seg_cnt[B.n];
+    const uint32_t g = gtid();
+    if (g >= total) return;
+    const uint32_t r = find_owner(B.seg_cnt, B.n, g);
+    const uint32_t seg = g - B.seg_cnt[r];
+    const int L = (int)B.len[r];
+    const int E = P.end_len;
+    const int ML = L - 2 * E;
+    const int Q = P.Q[a], nw = (Q + 63) >> 6;
+    if (ML < Q || P.k_mid[a] < 0) return;
+    const uint64_t* pf = P.peq_fwd_w + (size_t)a * 256 * kWideNW;
+    const uint8_t* mid = B.seq + B.off[r] + E;
+    const uint64_t S = (uint64_t)P.seg_cols;
+    const uint64_t amid = (uint64_t)(uintptr_t)mid;
+    const uint64_t blk = amid / S + seg;
+    const int c0 = blk * S > amid ? (int)(blk * S - amid) : 0;
+    int c1 = (int)((blk + 1) * S - amid);
+    if (c1 > ML) c1 = ML;
+    BvW s;
+    bvw_init(s, Q, nw);
+    int32_t* ties = tie_col[threadIdx.x];
+    int ntie = 0;
+    int lim = P.k_mid[a] + 1;
+    if (B.mid_mode) {                                                  // after a pool overflow: see k_mid_scan1
+        const int gmin = B.mid_best[(size_t)r * P.n_adapters + a];
+        if (gmin > P.k_mid[a]) return;
+        lim = gmin + 1;
+    }
+    uint32_t slot = B.mid_mode == 2u ? B.seg_n[(size_t)g * P.n_adapters + a] : 0u;
+    auto hand_over = [&](int n) {
+        if (B.mid_mode == 1u) slot += (uint32_t)n;
+        else if (B.mid_mode == 2u) for (int i = 0; i < n; i++) place_candidate(B, slot++, ties[i], lim, a);
+        else if (worth_handing_over(B, r, a, P.n_adapters, lim)) for (int i = 0; i < n; i++) push_candidate(B, r, ties[i], lim, a);
+    };
+    int c = c0 - (Q + P.k_mid[a]);
+    if (c < 0) c = 0;
+    for (; c < c1; c++) {
+        bvw_step(s, pf + (size_t)mid[c] * kWideNW, 0, Q, nw, nullptr);
+        if (c < c0) continue;                                           // warm-up columns
+        if (s.score < lim) { lim = s.score; ntie = 0; }
+        if (s.score == lim && lim <= P.k_mid[a]) {
+            if (ntie == 4) { hand_over(4); ntie = 0; }
+            ties[ntie++] = c;
+        }
+    }
+    if (ntie > 0) hand_over(ntie);
+    if (B.mid_mode == 1u && slot) B.seg_n[(size_t)g * P.n_adapters + a] = slot;
+}
+
 // ---------------------------------------------------------------------------
 // k_mid_resolve: one lane per (read, adapter).  Among the read's candidates for
 // this adapter the minimum value is edlib's editDistance and the columns that
@@ -1430,8 +1601,8 @@ TGSF_KERNEL k_mid_resolve(DevParams P, DevBatch B)
     int best = 1 << 30, e0 = 1 << 30;
     for (int32_t i = head; i >= 0; i = B.pool[i].next) {
         const int aux = B.pool[i].aux;
-        if ((aux >> 8) != a) continue;
-        const int sc = aux & 0xFF, pos = B.pool[i].pos;
+        if ((aux >> 16) != a) continue;
+        const int sc = aux & 0xFFFF, pos = B.pool[i].pos;
         if (sc < best || (sc == best && pos < e0)) { best = sc; e0 = pos; }
         if (B.mid_mode) break;       // position-ordered arrays of columns AT the minimum: the first one is the first location
     }
@@ -1447,7 +1618,7 @@ TGSF_KERNEL k_mid_resolve(DevParams P, DevBatch B)
     if (B.mid_mode) { B.mid_gate[idx] = 1u; return; }                  // the locations themselves: k_mid_resolve_each, a lane each
     for (int32_t i = head; i >= 0; i = B.pool[i].next) {
         const int aux = B.pool[i].aux;
-        if ((aux >> 8) != a || (aux & 0xFF) != best) continue;
+        if ((aux >> 16) != a || (aux & 0xFFFF) != best) continue;
         const int pos = B.pool[i].pos;
         const int st = (pos == e0) ? s0 : start_of_any<MAXNW>(P, a, win, pos, best);
         int ts = st + E - P.extra_len, te = pos + E + 1 + P.extra_len;   // :1248-1256
@@ -1470,7 +1641,7 @@ TGSF_KERNEL k_mid_resolve_each(DevParams P, DevBatch B)
         uint32_t lo = 0, hi = B.n;                                     // largest r with cand_begin(r) <= i
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cand_begin(B, mid, A) <= i) lo = mid; else hi = mid; }
         const uint32_t r = lo;
-        const int aux = B.pool[i].aux, a = aux >> 8, best = aux & 0xFF, pos = B.pool[i].pos;
+        const int aux = B.pool[i].aux, a = aux >> 16, best = aux & 0xFFFF, pos = B.pool[i].pos;
         if (!B.mid_gate[(size_t)r * A + a]) continue;
         const int L = (int)B.len[r], E = P.end_len;
         const uint8_t* win = B.seq + B.off[r] + E;

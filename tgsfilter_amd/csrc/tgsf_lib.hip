@@ -181,7 +181,8 @@ static int build_tables(tgsf_ctx* c)
         const int Q = (int)s.size();
         P.Q[a] = Q;
         if (Q > 64 && P.max_nw < 2) P.max_nw = 2;
-        if (Q > 128) P.max_nw = 4;
+        if (Q > 128 && P.max_nw < 4) P.max_nw = 4;
+        if (Q > 256) P.max_nw = kWideNW;
         if (Q < P.min_Q) P.min_Q = Q;
         int km = Q - p.mid_match_len + 1;                 // src/TGSFilter.cpp:1233
         int ke = Q - p.end_match_len + 1;                 // :1271
@@ -199,7 +200,7 @@ static int build_tables(tgsf_ctx* c)
             if (m >= p.mid_match_len && (float)m / (float)Q >= p.mid_sim) P.need_mid[a] = m;
         }
         memcpy(&ad[(size_t)a * kMaxQ], s.data(), (size_t)Q);
-        for (int r = 0; r < Q; r++) {
+        for (int r = 0; r < Q && r < 64 * kPeqW; r++) {       // (adapters beyond 256 bp only use the wide tables below)
             uint8_t cf = (uint8_t)s[r], cr = (uint8_t)s[Q - 1 - r];
             fwd[(size_t)a * per_ad + (size_t)cf * kPeqW + (r >> 6)] |= 1ull << (r & 63);
             rev[(size_t)a * per_ad + (size_t)cr * kPeqW + (r >> 6)] |= 1ull << (r & 63);
@@ -224,6 +225,27 @@ static int build_tables(tgsf_ctx* c)
     rt_h2d(d_t, top.data(), top.size() * 8, c->stream);
     rt_sync(c->stream);
     P.adapter = d_ad; P.peq_fwd = d_f; P.peq_rev = d_r; P.peq_top = d_t;
+    P.peq_fwd_w = P.peq_rev_w = nullptr;
+    if (P.max_nw > 4) {                                   // an adapter beyond 256 bp: kWideNW-word tables for every adapter
+        const size_t per_w = (size_t)256 * kWideNW;
+        std::vector<uint64_t> fw((size_t)A * per_w, 0), rw((size_t)A * per_w, 0);
+        for (int a = 0; a < A; a++) {
+            const std::string& s = c->adapters[a];
+            const int Q = (int)s.size();
+            for (int r = 0; r < Q; r++) {
+                const uint8_t cf = (uint8_t)s[r], cr = (uint8_t)s[Q - 1 - r];
+                fw[(size_t)a * per_w + (size_t)cf * kWideNW + (r >> 6)] |= 1ull << (r & 63);
+                rw[(size_t)a * per_w + (size_t)cr * kWideNW + (r >> 6)] |= 1ull << (r & 63);
+            }
+        }
+        uint64_t *d_fw, *d_rw;
+        if ((e = dev_alloc(c, &d_fw, fw.size()))) return e;
+        if ((e = dev_alloc(c, &d_rw, rw.size()))) return e;
+        rt_h2d(d_fw, fw.data(), fw.size() * 8, c->stream);
+        rt_h2d(d_rw, rw.data(), rw.size() * 8, c->stream);
+        rt_sync(c->stream);
+        P.peq_fwd_w = d_fw; P.peq_rev_w = d_rw;
+    }
     return 0;
 }
 
@@ -676,7 +698,8 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
 #endif
     if (P.filter && A > 0) {
         const uint64_t nw = (uint64_t)n * A * 2;
-        if (P.max_nw > 2) TGSF_LAUNCH(k_end_windows<4>, blocks_for(nw, 64), 64, ax, P, B);
+        if (P.max_nw > 4) TGSF_LAUNCH(k_end_windows<kWideNW>, blocks_for(nw, 64), 64, ax, P, B);
+        else if (P.max_nw > 2) TGSF_LAUNCH(k_end_windows<4>, blocks_for(nw, 64), 64, ax, P, B);
         else TGSF_LAUNCH(k_end_windows<2>, blocks_for(nw, 64), 64, ax, P, B);
     }
 #if !defined(TGSF_EMUL)
@@ -704,6 +727,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
             Bm.mid_mode = mode;
             int a = 0;
             while (a < A) {
+                if (P.Q[a] > 256) { TGSF_LAUNCH(k_mid_scan_wide, gseg, T, ms, P, Bm, a); a++; continue; }
                 if (P.Q[a] > 192) { TGSF_LAUNCH(k_mid_scanw<4>, gseg, T, ms, P, Bm, a); a++; continue; }
                 if (P.Q[a] > 128) { TGSF_LAUNCH(k_mid_scanw<3>, gseg, T, ms, P, Bm, a); a++; continue; }
                 if (P.Q[a] > 64) { TGSF_LAUNCH(k_mid_scanw<2>, gseg, T, ms, P, Bm, a); a++; continue; }
@@ -775,11 +799,13 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
                 DevBatch Bm = B;
                 Bm.mid_mode = 2;
                 // first locations and gates per (read, adapter), then every location on a lane of its own
-                if (P.max_nw > 2) TGSF_LAUNCH(k_mid_resolve<4>, blocks_for((uint64_t)n * A, 64), 64, ms, P, Bm);
+                if (P.max_nw > 4) TGSF_LAUNCH(k_mid_resolve<kWideNW>, blocks_for((uint64_t)n * A, 64), 64, ms, P, Bm);
+                else if (P.max_nw > 2) TGSF_LAUNCH(k_mid_resolve<4>, blocks_for((uint64_t)n * A, 64), 64, ms, P, Bm);
                 else TGSF_LAUNCH(k_mid_resolve<2>, blocks_for((uint64_t)n * A, 64), 64, ms, P, Bm);
                 const unsigned geach = grid_cap(std::min(blocks_for(need, 64), 65536u));
                 if (need) {
-                    if (P.max_nw > 2) TGSF_LAUNCH(k_mid_resolve_each<4>, geach, 64, ms, P, Bm);
+                    if (P.max_nw > 4) TGSF_LAUNCH(k_mid_resolve_each<kWideNW>, geach, 64, ms, P, Bm);
+                    else if (P.max_nw > 2) TGSF_LAUNCH(k_mid_resolve_each<4>, geach, 64, ms, P, Bm);
                     else TGSF_LAUNCH(k_mid_resolve_each<2>, geach, 64, ms, P, Bm);
                 }
                 he = rt_sync(ms);                         // seg_n is released below
@@ -796,7 +822,8 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     }
     STAGE_MARK();
     if (P.filter && A > 0 && !redo) {
-        if (P.max_nw > 2) TGSF_LAUNCH(k_mid_resolve<4>, blocks_for((uint64_t)n * A, 64), 64, st, P, B);
+        if (P.max_nw > 4) TGSF_LAUNCH(k_mid_resolve<kWideNW>, blocks_for((uint64_t)n * A, 64), 64, st, P, B);
+        else if (P.max_nw > 2) TGSF_LAUNCH(k_mid_resolve<4>, blocks_for((uint64_t)n * A, 64), 64, st, P, B);
         else TGSF_LAUNCH(k_mid_resolve<2>, blocks_for((uint64_t)n * A, 64), 64, st, P, B);
     }
     STAGE_MARK();
@@ -1167,7 +1194,10 @@ extern "C" int tgsf_align_windows(tgsf_ctx* c, const uint8_t* seq, uint64_t n_by
         e |= rt_h2d(d_k, k, (size_t)n * 4, st);
     }
     if (!e) {
-        if (c->P.max_nw > 2)
+        if (c->P.max_nw > 4)
+            TGSF_LAUNCH(k_align_windows<kWideNW>, blocks_for(n, 64), 64, st, c->P, c->B, (const uint8_t*)d_seq, (const uint64_t*)d_off,
+                        (const uint32_t*)d_len, (const uint8_t*)d_aid, (const int32_t*)d_k, n, d_res, d_ends);
+        else if (c->P.max_nw > 2)
             TGSF_LAUNCH(k_align_windows<4>, blocks_for(n, 64), 64, st, c->P, c->B, (const uint8_t*)d_seq, (const uint64_t*)d_off,
                         (const uint32_t*)d_len, (const uint8_t*)d_aid, (const int32_t*)d_k, n, d_res, d_ends);
         else

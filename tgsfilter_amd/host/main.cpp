@@ -449,6 +449,33 @@ int main(int argc, char** argv)
     Reserver reserver(sink, populate, stride_bytes, populate_beside > 0);
     if (sink.is_open())
         reserver.start((!streaming && in.size() > (256u << 20) && !getenv("TGSF_NO_EARLY_RESERVE")) ? (uint64_t)in.size() / 4 : 0);
+    // A downsampling run writes its output only after the whole filter pass (the selection needs every fragment's length,
+    // :2297-2344) -- but the file can be instantiated meanwhile: while the filter pass is busy with the link to the device,
+    // pages for what the selection may keep are reserved and mapped (a quarter of the input at most, and no more than twice
+    // the bases asked for with -g/-d; a surplus is cut off at the end).  Large plain outputs only.
+    std::unique_ptr<MappedSink> dsink;
+    std::unique_ptr<Pool> dpop;
+    std::unique_ptr<Reserver> dres;
+    auto open_dsink = [&](uint64_t capacity, uint64_t speculative) {
+        const char* w = getenv("TGSF_WRITER");
+        if (o.out_gz || o.out_file.empty() || (w && !strcmp(w, "writev"))) return false;
+        std::unique_ptr<MappedSink> d(new MappedSink);
+        if (!d->open(o.out_file, capacity)) return false;
+        dsink = std::move(d);
+        dpop.reset(new Pool(populate_threads));
+        dres.reset(new Reserver(*dsink, *dpop, stride_bytes, false));
+        dres->start(speculative);
+        return true;
+    };
+    {
+        uint64_t early_min = 1ull << 30;
+        if (const char* e = getenv("TGSF_DOWN_EARLY_MIN")) early_min = strtoull(e, nullptr, 10);          // tests: small inputs too
+        if (o.downsample && !streaming && in.mapped() && (uint64_t)in.size() >= early_min && !getenv("TGSF_NO_EARLY_RESERVE")) {
+            uint64_t spec = (uint64_t)in.size() / 4;
+            if (o.genome_size > 0 && o.desired_depth > 0) spec = std::min<uint64_t>(spec, 2 * o.genome_size * (uint64_t)o.desired_depth + (uint64_t)in.size() / 64);
+            open_dsink(4 * (uint64_t)in.size() + (1ull << 30), spec);
+        }
+    }
     // Mappings of written batches (input text, output file).  By default nothing is dropped during the run: the program
     // works in a child process and its address space is taken down in the background after the caller has its status
     // (see work_in_a_child).  They are dropped piece by piece -- by ONE background thread: several only get in each
@@ -667,7 +694,8 @@ int main(int argc, char** argv)
         const bool down_no_qual = fasta_in || (run_filter_pass && !fastq_out);
         qp.no_qual = down_no_qual ? 1 : 0;
         qp.max_batch_bases = (1ull << 30); qp.max_batch_reads = 1u << 16;
-        tgsf_ctx* qctx = nullptr;
+        if (const char* e = getenv("TGSF_DOWN_BATCH_BYTES")) { const long long v = atoll(e); if (v > (1 << 20) + 65536) qp.max_batch_bases = (uint64_t)v; }   // test knob: several slices of a small input
+        tgsf_ctx *qctx = nullptr, *qctx2 = nullptr;
         std::vector<uint8_t> bs, bq; std::vector<uint64_t> boff; std::vector<uint32_t> blen;
         std::vector<tgsf_read_result> bres; std::vector<tgsf_fragment> bfr(16);
         auto run = [&] {
@@ -709,34 +737,59 @@ int main(int argc, char** argv)
             if (L.create(&qp, o.devices[0], &qctx) != TGSF_OK) die(L.last_error(nullptr));
             t_dcreate = now_s() - q0;
             if (in_place) {
-                std::vector<uint64_t> bqoff;
-                const char* base = nullptr;
-                uint64_t span = 0;
-                auto run_text = [&] {
-                    if (blen.empty()) return;
-                    bres.resize(blen.size());
-                    tgsf_batch_in bi; memset(&bi, 0, sizeof bi);
-                    bi.seq = bi.qual = reinterpret_cast<const uint8_t*>(base);
-                    bi.offsets = boff.data(); bi.qual_offsets = bqoff.data(); bi.lengths = blen.data();
-                    bi.n_reads = (uint32_t)blen.size(); bi.n_bytes = span;
-                    tgsf_batch_out bo{bres.data(), bfr.data(), (uint32_t)bfr.size(), 0};
-                    const double s0 = now_s();
-                    if (L.submit(qctx, &bi, &bo) != TGSF_OK) die(L.last_error(qctx));
-                    t_dsubmit += now_s() - s0; if (!n_dsubmit++) t_dfirst = now_s() - s0;
-                    boff.clear(); bqoff.clear(); blen.clear(); base = nullptr; span = 0;
+                // Slices of the text (up to 1 GB each, the kept records indexed in place) go to the device from two feeders
+                // with a context each when there is much of it: one tgsf_submit stream moves 22-29 GB/s over the link, two
+                // together about what it carries (as in the filter pass).
+                struct TextBatch { const char* base = nullptr; uint64_t span = 0; std::vector<uint64_t> off, qoff; std::vector<uint32_t> len; };
+                int workers = kept_span >= (2ull << 30) ? 2 : 1;
+                if (const char* e = getenv("TGSF_DOWN_FEEDERS")) workers = atoi(e) >= 2 ? 2 : 1;      // tests run both on small inputs
+                Channel<std::shared_ptr<TextBatch>> todo(2);
+                std::mutex tm;
+                auto work = [&](tgsf_ctx* c) {
+                    std::vector<tgsf_read_result> res;
+                    std::vector<tgsf_fragment> fr(16);
+                    for (;;) {
+                        std::shared_ptr<TextBatch> tb = todo.get();
+                        if (!tb) break;
+                        res.resize(tb->len.size());
+                        tgsf_batch_in bi; memset(&bi, 0, sizeof bi);
+                        bi.seq = bi.qual = reinterpret_cast<const uint8_t*>(tb->base);
+                        bi.offsets = tb->off.data(); bi.qual_offsets = tb->qoff.data(); bi.lengths = tb->len.data();
+                        bi.n_reads = (uint32_t)tb->len.size(); bi.n_bytes = tb->span;
+                        tgsf_batch_out bo{res.data(), fr.data(), (uint32_t)fr.size(), 0};
+                        const double s0 = now_s();
+                        if (L.submit(c, &bi, &bo) != TGSF_OK) die(L.last_error(c));
+                        std::lock_guard<std::mutex> l(tm);
+                        t_dsubmit += now_s() - s0; if (!n_dsubmit++) t_dfirst = now_s() - s0;
+                    }
+                };
+                std::thread second;
+                if (workers == 2) second = std::thread([&] {
+                    if (L.create(&qp, o.devices[0], &qctx2) != TGSF_OK) die(L.last_error(nullptr));
+                    work(qctx2);
+                });
+                std::thread first([&] { work(qctx); });
+                std::shared_ptr<TextBatch> tb(new TextBatch);
+                auto flush_text = [&] {
+                    if (tb->len.empty()) return;
+                    todo.put(std::move(tb));
+                    tb.reset(new TextBatch);
                 };
                 for (uint32_t i : by_addr) {
                     const CleanRec& c = clean_recs[i];
                     const char* e = down_no_qual ? c.seq + c.len : c.qual + c.len;
-                    if (base && ((uint64_t)(e - base) > qp.max_batch_bases - (1u << 20) || blen.size() >= qp.max_batch_reads)) run_text();
-                    if (!base) base = c.seq;
-                    boff.push_back((uint64_t)(c.seq - base));
-                    bqoff.push_back((uint64_t)((down_no_qual ? c.seq : c.qual) - base));
-                    blen.push_back(c.len);
-                    span = std::max(span, (uint64_t)(e - base));
-                    if (span > qp.max_batch_bases) die("record larger than a batch");
+                    if (tb->base && ((uint64_t)(e - tb->base) > qp.max_batch_bases - (1u << 20) || tb->len.size() >= qp.max_batch_reads)) flush_text();
+                    if (!tb->base) tb->base = c.seq;
+                    tb->off.push_back((uint64_t)(c.seq - tb->base));
+                    tb->qoff.push_back((uint64_t)((down_no_qual ? c.seq : c.qual) - tb->base));
+                    tb->len.push_back(c.len);
+                    tb->span = std::max(tb->span, (uint64_t)(e - tb->base));
+                    if (tb->span > qp.max_batch_bases) die("record larger than a batch");
                 }
-                run_text();
+                flush_text();
+                for (int k = 0; k < workers; k++) todo.put(nullptr);
+                first.join();
+                if (second.joinable()) second.join();
             } else {
                 const size_t room = (size_t)std::min<uint64_t>(qp.max_batch_bases, kept_bytes / (down_no_qual ? 1 : 2) + 16 * by_addr.size() + 128);
                 bs.reserve(room); bq.reserve(room);
@@ -762,13 +815,13 @@ int main(int argc, char** argv)
         // 6-GB/s copy under the inode lock.
         bool down_mapped = false;
         {
-            const char* w = getenv("TGSF_WRITER");
             const char* mn = getenv("TGSF_DOWN_MAP_MIN");              // tests force the mapped way on small outputs
             const uint64_t map_min = mn ? strtoull(mn, nullptr, 10) : (256ull << 20);
             std::vector<uint32_t> kept;
             std::vector<uint64_t> at;
             uint64_t total_out = 0;
-            if (!o.out_gz && !o.out_file.empty() && !(w && !strcmp(w, "writev"))) {
+            const char* w2 = getenv("TGSF_WRITER");
+            if (!o.out_gz && !o.out_file.empty() && !(w2 && !strcmp(w2, "writev"))) {
                 for (size_t i = 0; i < clean_recs.size(); i++) {
                     if (!keep[i]) continue;
                     const CleanRec& c = clean_recs[i];
@@ -778,37 +831,58 @@ int main(int argc, char** argv)
                     total_out += 1 + nm + 1 + c.len + (fastq_out ? 3 + (uint64_t)c.len : 0) + 1;
                 }
             }
-            MappedSink dsink;
-            if (total_out >= std::max<uint64_t>(map_min, 1) && dsink.open(o.out_file, total_out)) {
-                dsink.reserve_to(total_out);
+            if (!dsink && total_out >= std::max<uint64_t>(map_min, 1)) open_dsink(total_out, 0);
+            if (dsink && !kept.empty()) {
+                // stride by stride, as the filter pass writes its own output: the reserver instantiates and maps the file
+                // ahead, the records of every piece that is ready are copied in by the pool's threads
+                dres->want(total_out, total_out);
                 const int T = std::max(1, std::min(o.n_thread, 16));
-                char* const base = dsink.place(0);
-                std::vector<std::thread> team;
-                for (int t = 0; t < T; t++) team.emplace_back([&, t] {
-                    const uint64_t lo = total_out / T * t, hi = t + 1 == T ? total_out : total_out / T * (t + 1);
-                    const size_t r0 = (size_t)(std::lower_bound(at.begin(), at.end(), lo) - at.begin());
-                    const size_t r1 = (size_t)(std::lower_bound(at.begin(), at.end(), hi) - at.begin());
-                    if (r0 >= r1) return;
-                    const uint64_t b0 = at[r0], b1 = r1 < at.size() ? at[r1] : total_out;
-                    dsink.populate(b0, b1 - b0);                       // (no fallocate runs beside these faults)
-                    std::string nm;
-                    for (size_t r = r0; r < r1; r++) {
-                        const CleanRec& c = clean_recs[kept[r]];
-                        char* p = base + at[r];
-                        *p++ = fastq_out ? '@' : '>';
-                        if (c.pass_num < 2) { memcpy(p, c.name.data(), c.name.size()); p += c.name.size(); }
-                        else { nm.clear(); append_name(nm, c.name, c.pass_num); memcpy(p, nm.data(), nm.size()); p += nm.size(); }
-                        *p++ = '\n';
-                        stream_copy(p, c.seq, c.len); p += c.len;
-                        if (fastq_out) { memcpy(p, "\n+\n", 3); p += 3; stream_copy(p, c.qual, c.len); p += c.len; }
-                        *p++ = '\n';
+                Pool dfill(T);
+                char* const base = dsink->place(0);
+                // (one process: the mappings of written pieces are dropped behind the fill jobs by one thread, as in the filter pass)
+                Channel<std::pair<const char*, uint64_t>> dropped(1 << 12);
+                std::thread dropper([&] {
+                    for (;;) {
+                        const std::pair<const char*, uint64_t> r = dropped.get();
+                        if (!r.first) break;
+                        MappedSink::release(r.first, r.second);
                     }
-                    stream_fence();
                 });
-                for (std::thread& th : team) th.join();
-                dsink.place(total_out);
-                dsink.close();
+                const uint64_t piece = std::max<uint64_t>(1, std::min<uint64_t>(64ull << 20, stride_bytes / 4 + 1));
+                size_t r0 = 0;
+                while (r0 < kept.size()) {
+                    size_t r1 = (size_t)(std::lower_bound(at.begin() + (long)r0, at.end(), at[r0] + piece) - at.begin());
+                    if (r1 <= r0) r1 = r0 + 1;
+                    const uint64_t end = r1 < at.size() ? at[r1] : total_out;
+                    dres->wait_ready(end);
+                    dfill.add([&, r0, r1] {
+                        std::string nm;
+                        for (size_t r = r0; r < r1; r++) {
+                            const CleanRec& c = clean_recs[kept[r]];
+                            char* p = base + at[r];
+                            *p++ = fastq_out ? '@' : '>';
+                            if (c.pass_num < 2) { memcpy(p, c.name.data(), c.name.size()); p += c.name.size(); }
+                            else { nm.clear(); append_name(nm, c.name, c.pass_num); memcpy(p, nm.data(), nm.size()); p += nm.size(); }
+                            *p++ = '\n';
+                            stream_copy(p, c.seq, c.len); p += c.len;
+                            if (fastq_out) { memcpy(p, "\n+\n", 3); p += 3; stream_copy(p, c.qual, c.len); p += c.len; }
+                            *p++ = '\n';
+                        }
+                        stream_fence();
+                        if (release_output) dropped.put({base + at[r0], (r1 < at.size() ? at[r1] : total_out) - at[r0]});
+                    });
+                    r0 = r1;
+                }
+                dfill.finish();
+                dropped.put({nullptr, 0});
+                dropper.join();
+                dres->finish();
+                dpop->finish();
+                dsink->place(total_out);
+                dsink->close();
                 down_mapped = true;
+            } else if (dsink) {                                        // nothing kept: an empty file
+                dres->finish(); dpop->finish(); dsink->place(0); dsink->close(); down_mapped = true;
             }
         }
         for (size_t i = 0; i < clean_recs.size() && !down_mapped; i++) {
@@ -830,6 +904,13 @@ int main(int argc, char** argv)
         down_t.resize(qnw);
         if (L.counters(qctx, down_t.data(), qnw) != TGSF_OK) die(L.last_error(qctx));
         L.destroy(qctx);
+        if (qctx2) {                                                   // the second feeder's tallies: sums, maxima for the "rows used" words
+            std::vector<uint64_t> t2(qnw);
+            if (L.counters(qctx2, t2.data(), qnw) != TGSF_OK) die(L.last_error(qctx2));
+            L.destroy(qctx2);
+            for (uint64_t i = 0; i < qnw; i++)
+                down_t[i] = (i >= TGSF_CTR_ROWS && i < TGSF_CTR_ROWS + 4) ? std::max(down_t[i], t2[i]) : down_t[i] + t2[i];
+        }
     }
     { const double c0 = now_s(); if (!o.only_qc && !mapped_out) out.close(); t_dclose = now_s() - c0; }
 
