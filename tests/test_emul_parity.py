@@ -269,3 +269,13 @@ def test_emul_batch_with_adapters_beyond_256_bp(emul):
         r, f, _ = parity.compare_batch(ctx, p, reads)
         assert (r["flags"] & abi.RF_ADMID).any()
         ctx.close()
+
+
+@pytest.mark.parametrize("seed", [301348])
+def test_emul_fuzz_findings_round3(emul, seed, monkeypatch):
+    """Seeds of the round-3 GPU fuzz campaign (TGSF_FUZZ_WIDE=1) that found something.  301348: adapters of 150 and 241 bp at -M 1
+    through the position-ordered rescan -- the multi-word scans recorded columns ONE ABOVE their (read, adapter)'s minimum."""
+    monkeypatch.setenv("TGSF_FUZZ_WIDE", "1")
+    monkeypatch.setenv("TGSF_FUZZ_GATE_P", "0.5")
+    from tests import fuzz
+    fuzz.run_case(emul, seed, 150)

@@ -1503,10 +1503,12 @@ TGSF_KERNEL k_mid_scanw(DevParams P, DevBatch B, int a)
     int32_t* ties = tie_col[threadIdx.x];
     int ntie = 0;
     int lim = P.k_mid[a] + 1;                                          // nothing at or below k yet
+    int top = P.k_mid[a];                                              // values above it are never recorded
     if (B.mid_mode) {                                                  // after a pool overflow: see k_mid_scan1
         const int gmin = B.mid_best[(size_t)r * P.n_adapters + a];
         if (gmin > P.k_mid[a]) return;
         lim = gmin + 1;
+        top = gmin;                                                    // (lim itself is NOT a value to record: only the minimum is)
     }
     uint32_t slot = B.mid_mode == 2u ? B.seg_n[(size_t)g * P.n_adapters + a] : 0u;
     auto hand_over = [&](int n) {
@@ -1520,7 +1522,7 @@ TGSF_KERNEL k_mid_scanw(DevParams P, DevBatch B, int a)
     for (; c < c1; c++) {
         bv_step<NW>(s, eqt[mid[c]], 0, Q);
         if (s.score < lim) { lim = s.score; ntie = 0; }
-        if (s.score == lim && lim <= P.k_mid[a]) {
+        if (s.score == lim && lim <= top) {
             if (ntie == 4) { hand_over(4); ntie = 0; }
             ties[ntie++] = c;
         }
@@ -1556,10 +1558,12 @@ TGSF_KERNEL k_mid_scan_wide(DevParams P, DevBatch B, int a)
     int32_t* ties = tie_col[threadIdx.x];
     int ntie = 0;
     int lim = P.k_mid[a] + 1;
-    if (B.mid_mode) {                                                  // after a pool overflow: see k_mid_scan1
+    int top = P.k_mid[a];
+    if (B.mid_mode) {                                                  // after a pool overflow: see k_mid_scan1, k_mid_scanw
         const int gmin = B.mid_best[(size_t)r * P.n_adapters + a];
         if (gmin > P.k_mid[a]) return;
         lim = gmin + 1;
+        top = gmin;
     }
     uint32_t slot = B.mid_mode == 2u ? B.seg_n[(size_t)g * P.n_adapters + a] : 0u;
     auto hand_over = [&](int n) {
@@ -1573,7 +1577,7 @@ TGSF_KERNEL k_mid_scan_wide(DevParams P, DevBatch B, int a)
         bvw_step(s, pf + (size_t)mid[c] * kWideNW, 0, Q, nw, nullptr);
         if (c < c0) continue;                                           // warm-up columns
         if (s.score < lim) { lim = s.score; ntie = 0; }
-        if (s.score == lim && lim <= P.k_mid[a]) {
+        if (s.score == lim && lim <= top) {
             if (ntie == 4) { hand_over(4); ntie = 0; }
             ties[ntie++] = c;
         }
