@@ -251,9 +251,9 @@ def test_emul_repeat_gate_shared_prefix_fragment(emul):
 
 
 def test_emul_align_windows_beyond_256_bp(emul):
-    """Adapters of 257..2048 bp (only reachable with -a; the reference's edlib is multi-block, include/edlib.cpp:182-185) through
+    """Adapters of 257..1280 bp (only reachable with -a; the reference's edlib is multi-block, include/edlib.cpp:182-185) through
     the wide column: edit distance, locations, start and path length as the reference's own edlib reports them."""
-    parity.align_windows_random(emul, 300, seed=19, lengths=(257, 300, 511, 640, 1000, 2048), max_window=2600)
+    parity.align_windows_random(emul, 600, seed=19, lengths=(257, 300, 511, 640, 1000, 1280), max_window=2600)
 
 
 def test_emul_batch_with_adapters_beyond_256_bp(emul):

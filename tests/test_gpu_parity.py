@@ -326,8 +326,8 @@ def test_gpu_repeat_gate_shared_prefix_fragment(k):
 
 
 def test_gpu_align_windows_beyond_256_bp():
-    """Adapters of 257..2048 bp through the wide column against the reference's own edlib (where oracle/_ref is present)."""
-    parity.align_windows_random(None, 600, seed=19, lengths=(257, 300, 511, 640, 1000, 2048), max_window=2600)
+    """Adapters of 257..1280 bp through the wide column against the reference's own edlib (where oracle/_ref is present)."""
+    parity.align_windows_random(None, 600, seed=19, lengths=(257, 300, 511, 640, 1000, 1280), max_window=2600)
 
 
 def test_gpu_batch_with_adapters_beyond_256_bp():
