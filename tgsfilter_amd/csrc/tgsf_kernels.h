@@ -2158,56 +2158,42 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
                                     if (first > 0) m &= 0xFFFFFFFFu >> (2 * first);
                                     if (v < 16) m &= ~(0xFFFFFFFFu >> (2 * v));
                                 }
-                                // the k-mers left for this pass in this chunk (all of a pass's share when it owns them by
-                                // leading bases: about four per chunk with one base, one with two), FOUR at a time: their keys
-                                // first, then their LDS operations back to back -- one at a time each k-mer waited for its
-                                // returning ds_or before the next was even extracted
+                                // (the k-mers left for this pass one at a time: handling them four at a time -- keys first, then
+                                // their LDS operations back to back -- was measured SLOWER, 26 against 23 ms a batch at -k 13: the
+                                // kernel is bound by the instructions it issues, and the predicated group issues more of them)
                                 while (m) {
-                                    constexpr int G = 4;
-                                    key_t key[G];
-                                    uint32_t hbv[G], lo32[G], hi32[G], got[G];
-                                    bool on[G];
-#pragma unroll
-                                    for (int u = 0; u < G; u++) {
-                                        on[u] = m != 0u;
-                                        const int b = on[u] ? __builtin_ctz(m) : 0;
-                                        m &= m - 1u;                       // (0 stays 0)
-                                        const int sh = 30 - b + 2 * PB;    // bit offset of the key in the chunk sequence w0 w1 w2 w3
-                                        const bool up = sh >= 32;
-                                        const uint32_t X = up ? w1 : w0, Y = up ? w2 : w1, Z = up ? w3 : w2;
-                                        const uint32_t sb = (uint32_t)sh & 31u;
-                                        const uint32_t x0 = sb ? alignbit(X, Y, 32u - sb) : X;
-                                        uint32_t h;
-                                        hi32[u] = 0;
-                                        if (KEY64) {
-                                            const uint32_t x1 = sb ? alignbit(Y, Z, 32u - sb) : Y;
-                                            const ull k64 = (((ull)x0 << 32) | x1) >> (64 - kb);
-                                            key[u] = (key_t)k64;
-                                            lo32[u] = (uint32_t)k64; hi32[u] = (uint32_t)(k64 >> 32);
-                                            h = (lo32[u] ^ (hi32[u] * 0x85EBCA6Bu)) * 0x9E3779B1u;
-                                        } else {
-                                            lo32[u] = x0 >> (32 - kb);
-                                            key[u] = (key_t)lo32[u];
-                                            h = lo32[u] * 0x9E3779B1u;
-                                        }
-                                        if (hparts && ((((h ^ (h >> 15)) * 0x2C1B3C6Du) >> 12) & (hparts - 1u)) != pass) on[u] = false;   // another pass's k-mer
-                                        hbv[u] = h >> 13;                  // 19 bits
+                                    const int b = __builtin_ctz(m);
+                                    m &= m - 1u;
+                                    const int sh = 30 - b + 2 * PB;    // bit offset of the key in the chunk sequence w0 w1 w2 w3
+                                    const bool up = sh >= 32;
+                                    const uint32_t X = up ? w1 : w0, Y = up ? w2 : w1, Z = up ? w3 : w2;
+                                    const uint32_t sb = (uint32_t)sh & 31u;
+                                    const uint32_t x0 = sb ? alignbit(X, Y, 32u - sb) : X;
+                                    key_t key;
+                                    uint32_t h, lo32, hi32 = 0;
+                                    if (KEY64) {
+                                        const uint32_t x1 = sb ? alignbit(Y, Z, 32u - sb) : Y;
+                                        const ull k64 = (((ull)x0 << 32) | x1) >> (64 - kb);
+                                        key = (key_t)k64;
+                                        lo32 = (uint32_t)k64; hi32 = (uint32_t)(k64 >> 32);
+                                        h = (lo32 ^ (hi32 * 0x85EBCA6Bu)) * 0x9E3779B1u;
+                                    } else {
+                                        lo32 = x0 >> (32 - kb);
+                                        key = (key_t)lo32;
+                                        h = lo32 * 0x9E3779B1u;
                                     }
-#pragma unroll
-                                    for (int u = 0; u < G; u++) {
-                                        got[u] = 0;
-                                        if (on[u]) got[u] = PHASE == 0 ? atomicOr(&Am[hbv[u] >> 5], 1u << (hbv[u] & 31u)) : Bm[hbv[u] >> 5];
-                                    }
-#pragma unroll
-                                    for (int u = 0; u < G; u++) {
-                                        const uint32_t bit = 1u << (hbv[u] & 31u);
-                                        if (!on[u] || !(got[u] & bit)) continue;
-                                        if (PHASE == 0) { atomicOr(&Bm[hbv[u] >> 5], bit); continue; }
-                                        uint32_t slot = (((lo32[u] * 0xC2B2AE35u) ^ (hi32[u] * 0x27D4EB2Fu) ^ (lo32[u] >> 15)) * 0x165667B1u) >> (32u - TLOG);
+                                    if (hparts && ((((h ^ (h >> 15)) * 0x2C1B3C6Du) >> 12) & (hparts - 1u)) != pass) continue;   // another pass's k-mer
+                                    const uint32_t hb = h >> 13;       // 19 bits
+                                    const uint32_t bit = 1u << (hb & 31u);
+                                    if (PHASE == 0) {
+                                        const uint32_t old = atomicOr(&Am[hb >> 5], bit);
+                                        if (old & bit) atomicOr(&Bm[hb >> 5], bit);
+                                    } else if (Bm[hb >> 5] & bit) {
+                                        uint32_t slot = (((lo32 * 0xC2B2AE35u) ^ (hi32 * 0x27D4EB2Fu) ^ (lo32 >> 15)) * 0x165667B1u) >> (32u - TLOG);
                                         for (int probes = 0;; probes++) {
-                                            const key_t old = atomicCAS(&tab[slot], kEmpty, key[u]);
+                                            const key_t old = atomicCAS(&tab[slot], kEmpty, key);
                                             if (old == kEmpty) { mine++; break; }
-                                            if (old == key[u]) break;
+                                            if (old == key) break;
                                             if (probes >= 64) { over_s = 1; break; }
                                             slot = (slot + 1u) & ((1u << TLOG) - 1u);
                                         }
