@@ -1,21 +1,27 @@
 #!/usr/bin/env python3
 """Config C5's flags end to end (for information; bench.py's headline is C2): the C2 file (ONT reads, lognormal mean
 45 kb) with the repeat gate and downsampling switched on, the command line against the reference on the same tmpfs file, for
--k 11 (the default: LDS bitmap kernel) and -k 15 / -k 21 (keys kernel, 32- / 64-bit).  tests/manual/e2e_c5.py [n_reads]"""
+-k 11 (the default: LDS bitmap kernel) and -k 15 / -k 21 (keys kernel, 32- / 64-bit).  tests/manual/e2e_c5.py [n_reads]
+tests/manual/e2e_c5.py <n_reads> c5: config C5 AS WRITTEN instead -- ultra-long reads (lognormal, mean 150 kb, max 2 Mb), the automatic
+pre-pass, -g 3g -d 40 -p 100 -k 11 (and -g 1g -d 10, so that the downsampling has something to cut at a size that fits the box)."""
 import os, subprocess, sys, tempfile, time, shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tgsfilter_amd import synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+as_written = len(sys.argv) > 2 and sys.argv[2] == "c5"
 td = tempfile.mkdtemp(prefix="c5_", dir="/dev/shm")
 fq = os.path.join(td, "c5.fq")
 t0 = time.time()
-bases, nbytes = synth.write_ont_fastq(fq, n, seed=5)
-print("%d ONT reads, %.2f Gbases, %.1f GB of text in %.1f s" % (n, bases / 1e9, nbytes / 1e9, time.time() - t0))
+bases, nbytes = synth.write_ont_fastq(fq, n, seed=5, **({"mean_len": 150000.0, "max_len": 2_000_000} if as_written else {}))
+print("%d ONT reads%s, %.2f Gbases, %.1f GB of text in %.1f s" % (n, " (lognormal, mean 150 kb, max 2 Mb)" if as_written else "", bases / 1e9, nbytes / 1e9, time.time() - t0))
 fa = os.path.join(td, "rapid.fa")
 open(fa, "wb").write(b">rapid\n" + synth.ONT_RAPID + b"\n")
-for extra in (["-p", "100", "-k", "11"], ["-p", "100", "-k", "11", "-r", str(n // 2)], ["-p", "5", "-k", "13"], ["-p", "1", "-k", "16"], ["-p", "1", "-k", "16", "-g", "100m", "-d", "20"]):
-    flags = ["-x", "ont", "-l", "1000", "-q", "10", "-5", "0", "-3", "0", "-a", fa, "-t", "32"] + extra
+cases = (["-p", "100", "-k", "11"], ["-p", "100", "-k", "11", "-r", str(n // 2)], ["-p", "5", "-k", "13"], ["-p", "1", "-k", "16"], ["-p", "1", "-k", "16", "-g", "100m", "-d", "20"])
+if as_written:
+    cases = (["-g", "3g", "-d", "40", "-p", "100", "-k", "11"], ["-g", "1g", "-d", "10", "-p", "100", "-k", "11"])
+for extra in cases:
+    flags = (["-x", "ont", "-l", "1000", "-q", "10", "-t", "32"] if as_written else ["-x", "ont", "-l", "1000", "-q", "10", "-5", "0", "-3", "0", "-a", fa, "-t", "32"]) + extra
     print("flags:", " ".join(extra))
     res = {}
     for tag, exe in (("ours", os.path.join(ROOT, "tgsfilter_amd", "bin", "tgsfilter")), ("reference", os.path.join(ROOT, "oracle", "_ref", "tgsfilter_ref"))):
