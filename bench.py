@@ -239,6 +239,8 @@ def e2e_leg(args, n_gpus):
         raise SystemExit("bench.py: %s is missing -- run __graft_entry__.build() (there is no fallback path)" % CLI)
     budget = Budget(float(getattr(args, "e2e_budget_s", 1500.0)))
     shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    if shm and shutil.disk_usage(shm).free < (1 << 30) and shutil.disk_usage(tempfile.gettempdir()).free > shutil.disk_usage(shm).free:
+        shm = None                                    # a token /dev/shm (container default of 64 MB): stage on the temporary directory
     cfg = E2E_CONFIGS[getattr(args, "config", "c2") or "c2"]
     n_want = n_reads = args.e2e_reads if getattr(args, "e2e_reads", None) else cfg["reads"]
     per_read = cfg["per_read"]                        # bytes of text per read (2 x mean length + header)
