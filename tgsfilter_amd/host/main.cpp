@@ -476,12 +476,13 @@ int main(int argc, char** argv)
             open_dsink(4 * (uint64_t)in.size() + (1ull << 30), spec);
         }
     }
-    // Mappings of written batches (input text, output file).  By default nothing is dropped during the run: the program
-    // works in a child process and its address space is taken down in the background after the caller has its status
-    // (see work_in_a_child).  They are dropped piece by piece -- by ONE background thread: several only get in each
-    // other's way -- where the teardown is on the clock (TGSF_SYNC_EXIT: 90 ns per page of the input, ~200 ns per dirty
-    // page of the output otherwise wait at exit) or where the resident size matters (a streamed input: the mapped part
-    // of the output counts as resident).
+    // Mappings of written batches (input text, output file).  One process (the default): the teardown is on the caller's
+    // clock -- 90 ns per page of the input, ~200 ns per dirty page of the output if it all waited for the exit -- so the
+    // mappings are dropped piece by piece during the run, by ONE background thread (several only get in each other's way).
+    // Both mappings carry MADV_SEQUENTIAL: unmapping a page of a mapping without it marks the page accessed, and 20 M pages
+    // moving between the LRU lists slow the fallocate beside them by a quarter.  TGSF_DETACH=1: nothing is
+    // dropped during the run (the child's address space goes in the background), except where the resident size matters
+    // (a streamed input: the mapped part of the output counts as resident).
     const bool sync_exit = g_done_fd < 0;                              // one process (the default): the teardown is on the clock
     bool release_input = sync_exit && !streaming && in.mapped() && !o.downsample;
     bool release_output = sync_exit || streaming;
