@@ -45,6 +45,32 @@ def test_cli_downsampling_output_reserved_early(binary, golden_dir, name, monkey
     cli_check.run_case(binary, golden_dir, name, extra_args=["-t", "5"])
 
 
+@pytest.mark.parametrize("name", ["ont_zoo", "hifi_zoo", "ont_auto", "hifi_phred64_auto", "ont_e1300"])
+def test_cli_output_created_before_the_prepass(binary, golden_dir, name, monkeypatch):
+    """A large run creates its output (when there is none yet) and starts instantiating its pages beside the pre-pass; forced here
+    on the goldens, with tiny strides: same files."""
+    monkeypatch.setenv("TGSF_EARLY_OPEN_MIN", "1")
+    monkeypatch.setenv("TGSF_STRIDE_BYTES", "50000")
+    cli_check.run_case(binary, golden_dir, name, extra_args=["-t", "4"])
+
+
+def test_cli_output_created_early_is_removed_when_the_prepass_ends_the_run(binary, golden_dir, tmp_path, monkeypatch):
+    """-q at or above the largest quality of the sample ends the run in the pre-pass (Get_qType, src/TGSFilter.cpp:1063-1068): the reference
+    has not opened its output by then.  An output this program created ahead of the pre-pass is removed again; an existing file is not touched."""
+    import gzip
+    monkeypatch.setenv("TGSF_EARLY_OPEN_MIN", "1")
+    fin = tmp_path / "in.fq"
+    fin.write_bytes(gzip.open(os.path.join(golden_dir, "ont_zoo.in.fq.gz"), "rb").read())
+    out = tmp_path / "out.fq"
+    p = subprocess.run([binary, "-i", str(fin), "-o", str(out), "-x", "ont", "-q", "90"], capture_output=True, timeout=120)
+    assert p.returncode == 255 and b"Please reset -q parameter" in p.stderr and not out.exists()
+    out.write_bytes(b"precious\n")
+    p = subprocess.run([binary, "-i", str(fin), "-o", str(out), "-x", "ont", "-q", "90"], capture_output=True, timeout=120)
+    assert p.returncode == 255 and out.read_bytes() == b"precious\n"
+    p = subprocess.run([binary, "-i", str(fin), "-o", str(out), "-x", "ont", "-q", "10"], capture_output=True, timeout=120)
+    assert p.returncode == 0 and out.read_bytes().startswith(b"@")
+
+
 def test_cli_gz_output_and_fasta(binary, golden_dir, tmp_path):
     """-o *.fq.gz (per-record gzip members) inflates to the reference's output; -o *.fa keeps the bases."""
     import gzip

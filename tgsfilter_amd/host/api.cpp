@@ -1,4 +1,5 @@
 #include "api.h"
+#include "fatal.h"
 
 #include <dlfcn.h>
 #include <unistd.h>
@@ -89,8 +90,7 @@ const Api& lib()
     if (g_thread.joinable()) g_thread.join();
     if (!g_error.empty()) {
         std::cerr << "Error: " << g_error << std::endl;
-        fflush(nullptr);
-        _exit(255);
+        quit(255);
     }
     return g_api;
 }

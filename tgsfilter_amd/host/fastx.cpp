@@ -1,5 +1,7 @@
 #include "fastx.h"
 
+#include "fatal.h"
+
 #include "bam.h"
 
 #include <fcntl.h>
@@ -264,8 +266,7 @@ void RecordIndex::produce(const char* data, size_t size, bool fastq, int threads
         while (rd.next(r)) {
             if (n / kChunk >= chunks_.size()) {   // 4.3e9 records: never silently a shorter input
                 std::cerr << "Error: more than " << chunks_.size() * kChunk << " records in the input: beyond what this build indexes" << std::endl;
-                fflush(nullptr);
-                _exit(255);
+                quit(255);
             }
             if (n % kChunk == 0) chunks_[n / kChunk].reset(new Rec[kChunk]);
             Rec& x = chunks_[n / kChunk][n % kChunk];

@@ -50,6 +50,7 @@ static int cpu_budget()
 [[noreturn]] static void leave(int code)
 {
     fflush(nullptr);
+    if (code != 0) if (void (*f)() = on_die().exchange(nullptr)) f();      // (an output created ahead of the run does not stay behind)
     if (g_done_fd >= 0) {
         prctl(PR_SET_PDEATHSIG, 0);                   // the parent is about to leave in the ordinary way: no signal for that
         if (write(g_done_fd, &code, sizeof code) != (ssize_t)sizeof code) { /* the parent is gone: nothing to tell */ }
@@ -150,6 +151,29 @@ int main(int argc, char** argv)
     std::unique_ptr<RecordIndex> records_p;
     if (!streaming) records_p.reset(new RecordIndex(in.data(), in.size(), !fasta_in, scan_threads));
 
+    // The output file's pages are the critical path of a run that writes a tmpfs file: their instantiation
+    // starts NOW, beside the pre-pass and the device bring-up -- if the file does not exist yet (an existing one is not
+    // touched before the run is certain to write it: a run that ends in its pre-pass leaves it as it was, as the reference
+    // does; a file created here is removed again on such a path).
+    MappedSink sink;
+    std::atomic<bool> early_stop{false};
+    std::thread early;
+    {
+        const char* w = getenv("TGSF_WRITER");                         // "writev": always the single-stream writer
+        uint64_t early_min = 256ull << 20;
+        if (const char* e = getenv("TGSF_EARLY_OPEN_MIN")) early_min = strtoull(e, nullptr, 10);           // tests: small inputs too
+        const bool may_map_early = !o.only_qc && !o.out_gz && !o.downsample && (o.filter || o.only_qc) && !o.out_file.empty() &&
+                                   !(w && !strcmp(w, "writev")) && !o.only_adapters && !streaming && in.mapped() &&
+                                   (uint64_t)in.size() >= early_min && !getenv("TGSF_NO_EARLY_RESERVE");
+        if (may_map_early && sink.open(o.out_file, 4 * (uint64_t)in.size() + (1ull << 30), true))
+            early = std::thread([&] {
+                const uint64_t limit = (uint64_t)in.size() / 4;        // what a run keeps is not known yet; a surplus is cut off at the end
+                while (!early_stop.load() && sink.reserved() < limit)
+                    if (!sink.reserve_to(std::min<uint64_t>(limit, sink.reserved() + (256u << 20)), false)) break;   // (a nearly full file system: not this thread's call)
+            });
+    }
+    auto end_early = [&] { if (early.joinable()) { early_stop = true; early.join(); } };
+
     // ---- pre-pass, :3058-3126 ----
     PrepassResult pp;
     if (streaming) {
@@ -239,7 +263,6 @@ int main(int argc, char** argv)
     const bool fastq_out = o.out_type == 1;
     const bool run_filter_pass = o.filter || o.only_qc;                // :3061; with -F the input goes straight to downsampling
     Output out;
-    MappedSink sink;
     {
         const char* w = getenv("TGSF_WRITER");                         // "writev": always the single-stream writer
         const bool may_map = !o.only_qc && !o.out_gz && !o.downsample && run_filter_pass && !o.out_file.empty() &&
@@ -247,8 +270,8 @@ int main(int argc, char** argv)
         // address space for the output mapping: what the input could turn into (a streamed input's text size is unknown)
         // (address space only: pages exist where records are laid out.  A record's header is repeated in front of each of
         // its fragments, so an output can outgrow its input -- by a factor only headers of kilobytes reach.)
-        if (may_map) sink.open(o.out_file, streaming ? std::max<uint64_t>(64ull << 30, 64ull * in.size())
-                                                     : 4 * (uint64_t)in.size() + (1ull << 30));
+        if (may_map && !sink.is_open()) sink.open(o.out_file, streaming ? std::max<uint64_t>(64ull << 30, 64ull * in.size())
+                                                                        : 4 * (uint64_t)in.size() + (1ull << 30));
         if (!o.only_qc && !sink.is_open() && !out.open(o)) leave(1);
     }
     const Api& L = lib();                                              // joins the loader thread
@@ -446,6 +469,7 @@ int main(int argc, char** argv)
     if (const char* e = getenv("TGSF_STRIDE_BYTES")) { const long long v = atoll(e); if (v > 0) stride_bytes = (uint64_t)v; }   // tuning / test knob
     // While the library loads and the device comes up pages of the output file are instantiated already, up to a quarter
     // of the input's size (what a run keeps is not known yet; a surplus is cut off at the end).
+    end_early();                                                       // (what it reserved is mapped by the reserver's first round)
     Reserver reserver(sink, populate, stride_bytes, populate_beside > 0);
     if (sink.is_open())
         reserver.start((!streaming && in.size() > (256u << 20) && !getenv("TGSF_NO_EARLY_RESERVE")) ? (uint64_t)in.size() / 4 : 0);

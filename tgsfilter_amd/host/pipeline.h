@@ -32,6 +32,7 @@
 #include <unordered_map>
 #include <unordered_set>
 
+#include "fatal.h"
 #include "fastx.h"
 #include "options.h"
 #include "tgsf.h"
@@ -139,17 +140,7 @@ inline double now_s()
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-// Fatal errors can come from any thread while others are inside HIP calls or blocked on queues: no static
-// destructors, no runtime teardown -- flush what was said and leave with the reference's exit status (-1).
-// (an output file that was extended ahead of the records is cut back to what was planned for it: no NUL-padded tail stays behind)
-inline std::atomic<void (*)()>& on_die() { static std::atomic<void (*)()> f{nullptr}; return f; }
-[[noreturn]] inline void die(const std::string& msg)
-{
-    std::cerr << "Error: " << msg << std::endl;
-    fflush(nullptr);
-    if (void (*f)() = on_die().exchange(nullptr)) f();
-    _exit(255);
-}
+// (fatal paths: fatal.h)
 
 // libdeflate, the compressor the reference writes its .gz records with (libdeflate_gzip_compress, src/TGSFilter.cpp:
 // 786-812), bound at run time when the system has it (no header needed: four entry points of its stable C API);
@@ -315,9 +306,14 @@ private:
 // that takes fallocate; everything else (pipes, /dev/null, gzip) goes through Output above.
 class MappedSink {
 public:
-    bool open(const std::string& path, uint64_t virt_bytes) {
-        fd_ = ::open(path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
+    // only_new: succeed only if the file does not exist yet (it is created now): a caller that reserves pages before it
+    // knows that the run will get as far as writing uses this, so that an existing file is not touched by a run that ends
+    // in its pre-pass -- and a file created here is removed again if the run ends before a record is laid out (cut_back)
+    bool open(const std::string& path, uint64_t virt_bytes, bool only_new = false) {
+        fd_ = ::open(path.c_str(), only_new ? (O_RDWR | O_CREAT | O_EXCL) : (O_RDWR | O_CREAT | O_TRUNC), 0644);
         if (fd_ < 0) return false;
+        created_ = only_new;
+        path_ = path;
         struct stat st;
         bool ok = fstat(fd_, &st) == 0 && S_ISREG(st.st_mode) && fallocate(fd_, 0, 0, 4096) == 0 && ftruncate(fd_, 0) == 0;   // not every file system has fallocate
         if (ok) {
@@ -333,13 +329,17 @@ public:
                 else if (!strcmp(adv, "random")) madvise(map_, cap_, MADV_RANDOM);
             }
         }
-        if (!ok) { ::close(fd_); fd_ = -1; return false; }
+        if (!ok) { ::close(fd_); fd_ = -1; if (created_) unlink(path_.c_str()); return false; }
         live() = this;
         on_die().store([] { if (MappedSink* s = live()) s->cut_back(); });
         return true;
     }
     // a fatal path: leave the records laid out so far, not the pages reserved ahead of them
-    void cut_back() { if (fd_ >= 0 && reserved_ > size_ && ftruncate(fd_, (off_t)size_) != 0) { /* nothing more to do */ } }
+    void cut_back() {
+        if (fd_ < 0) return;
+        if (created_ && size_ == 0) { unlink(path_.c_str()); return; }
+        if (reserved_ > size_ && ftruncate(fd_, (off_t)size_) != 0) { /* nothing more to do */ }
+    }
     uint64_t reserved() const { return reserved_; }
     uint64_t planned() const { return size_; }
     uint64_t capacity() const { return cap_; }
@@ -386,6 +386,8 @@ private:
     int fd_ = -1;
     char* map_ = nullptr;
     uint64_t size_ = 0, reserved_ = 0, cap_ = 0;
+    bool created_ = false;
+    std::string path_;
 };
 
 // Copy for the fill jobs: the bulk of a sequence / quality line goes out with non-temporal stores.  The destination pages

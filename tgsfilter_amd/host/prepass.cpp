@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "api.h"
+#include "fatal.h"
 
 namespace host {
 
@@ -118,7 +119,7 @@ static void adapter_search(const Options& o, const std::vector<std::string>& end
     p.max_batch_bases = 1 << 20; p.max_read_len = 1 << 16;
     tgsf_ctx* ctx = nullptr;
     const double c0 = pp_now();
-    if (lib().create(&p, o.devices.empty() ? o.device : o.devices[0], &ctx) != TGSF_OK) { std::cerr << "Error: " << lib().last_error(nullptr) << std::endl; fflush(nullptr); _exit(255); }
+    if (lib().create(&p, o.devices.empty() ? o.device : o.devices[0], &ctx) != TGSF_OK) { std::cerr << "Error: " << lib().last_error(nullptr) << std::endl; quit(255); }
 
     g_pp_create += pp_now() - c0;
     // totals per adapter in the reference's own container (:1150, :1171): the winner among equal totals is
@@ -140,7 +141,7 @@ static void adapter_search(const Options& o, const std::vector<std::string>& end
         res.assign((size_t)n * 4, 0); eds.assign((size_t)n * 2, 0);
         const double a0 = pp_now();
         if (lib().align_windows(ctx, buf.data(), buf.size(), off.data(), len.data(), aid.data(), kk.data(), n, res.data(), eds.data()) != TGSF_OK) {
-            std::cerr << "Error: " << lib().last_error(ctx) << std::endl; fflush(nullptr); _exit(255);
+            std::cerr << "Error: " << lib().last_error(ctx) << std::endl; quit(255);
         }
         g_pp_align += pp_now() - a0; g_pp_calls++;
         for (uint32_t i = 0; i < n; i++)
@@ -194,7 +195,7 @@ PrepassResult run_prepass(Options& o, const std::function<bool(Rec&)>& next_reco
             if (o.min_q >= maxq) {
                 std::cerr << "Warning: max base quality score was: " << maxq << std::endl;
                 std::cerr << "INFO: Please reset -q parameter." << std::endl;
-                fflush(nullptr); _exit(255);
+                quit(255);
             }
         } else {
             if (maxq > 10 && o.read_type == "clr") o.min_q = 10;
