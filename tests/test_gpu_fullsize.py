@@ -110,6 +110,17 @@ def test_full_size_conservation_and_oracle_slice(batch):
     assert n_chk == 500
 
 
+def test_full_size_through_the_position_ordered_rescan(batch, monkeypatch, capfd):
+    """A BASELINE-sized batch (5.9 Gbases, ~6 M scan segments) whose candidate pool holds 1 000 slots: tgsf_wait counts, sizes and
+    rescans (millions of (segment, adapter) cells through the prefix sum), and the records and tallies are those of the one-pass run."""
+    ref_reads, ref_frags, ref_ctr = run(batch)
+    monkeypatch.setenv("TGSF_POOL_CAP", "1000")
+    monkeypatch.setenv("TGSF_TRACE_POOL", "1")
+    reads, frags, ctr = run(batch)
+    assert "scanning again in position order" in capfd.readouterr().err
+    assert np.array_equal(reads, ref_reads) and np.array_equal(frags, ref_frags) and np.array_equal(ctr, ref_ctr)
+
+
 def test_full_size_concurrent_contexts(batch):
     """Three contexts on three streams filter the same batch at the same time, twice each (what bench.py does):
     every one must produce the single-context result; tallies double."""
