@@ -820,8 +820,9 @@ def main():
             if world > 1:
                 # what can and cannot scale with the GPUs: one tmpfs output file is instantiated by one kernel
                 # thread under the inode lock, whatever the number of GPUs; the /dev/null (pipe) sink is PCIe-bound per GPU
-                e2e["scaling_note"] = ("headline sink (one tmpfs file) is bound by the kernel's page instantiation (%s) and does not scale with "
-                                       "GPUs; the dev_null sink is the one that can" % s.get("bound", "fallocate"))
+                e2e["scaling_note"] = ("headline sink = ONE tmpfs file: its pages are instantiated by one kernel thread under the inode lock "
+                                       "whatever the number of GPUs (this run's largest share: %s), so this figure does not scale with GPUs; the "
+                                       "dev_null sink (bound by the links to the devices and the host's copies) is the one that can" % s.get("bound", "fallocate"))
             if "reference_gbases_per_s" in s:
                 out["cpu_baseline"] = {
                     "value": s["reference_gbases_per_s"], "unit": "Gbases/s", "cores": e2e["threads"], "kind": "reference",
