@@ -148,20 +148,33 @@ REPEAT_LONG = [_W - 40, _W - 17, _W - 16, _W - 15, _W - 1, _W, _W + 1, _W + 15, 
                2 * _W - 33, 2 * _W - 16, 2 * _W - 15, 2 * _W + 3, 3 * _W - 20, 250000]
 
 
-def repeat_threshold_case(lib_path, k, lens, max_runs=64, alphabet=b"ACGT"):
+_S = 114688             # k-mers of a single pass of k_repeat_keys (kRepShare)
+REPEAT_SHARE = [50000, _S - 1, _S, _S + 1, 2 * _S, 2 * _S + 1, 300000]     # + k - 1 bases each: see repeat_threshold_case(..., share=True)
+
+
+def repeat_threshold_case(lib_path, k, lens, max_runs=64, alphabet=b"ACGT", share=False, plant=0, extra_thresholds=()):
     """The gate at each read's own count: with -p c the read whose repeat count is c passes, with -p c+1 it is
     dropped -- a miscount by one k-mer in either direction shows.  Lengths sit on the kernel's seams (16-base
     chunks, the window of k_repeat, two and three windows); stray N / lower-case bytes; one low-complexity read;
     a two-letter alphabet crowds the k-mers into a few passes (k_repeat_keys then starts over with more of them);
-    the reads start at any alignment (runs alternate between the packed layout and the FASTQ text in place)."""
+    the reads start at any alignment (runs alternate between the packed layout and the FASTQ text in place).
+    share: the lengths are numbers of k-mers around the passes of k_repeat_keys (one pass, two, four), the reads random
+    but for `plant` k-mers copied from elsewhere in the read (so that the count sits near a -p that the flagged
+    occurrences of the first scan alone cannot decide); extra_thresholds: -p values besides every read's own count."""
     rng = np.random.default_rng(100 + k)
     reads, counts = [], []
     for i, L in enumerate(lens):
+        if share:
+            L += k - 1
         body = np.frombuffer(alphabet, dtype=np.uint8)[rng.integers(0, len(alphabet), L)].copy()
-        if i == 1:
+        if i == 1 and not share:
             unit = body[:int(rng.integers(3, 40))]
             body = np.tile(unit, L // unit.size + 1)[:L].copy()
-        for pos in rng.integers(0, L, max(1, L // 400)):
+        if plant and i != 0:
+            n = plant + i + k - 1
+            src, dst = int(rng.integers(0, L // 2 - n)), int(rng.integers(L // 2, L - n))
+            body[dst:dst + n] = body[src:src + n]
+        for pos in rng.integers(0, L, 0 if share else max(1, L // 400)):
             body[int(pos)] = int(np.frombuffer(b"Nacgt", dtype=np.uint8)[rng.integers(0, 5)])
         q = bytes((rng.integers(12, 30, L) + 33).astype(np.uint8))
         reads.append((b"r%d_%s" % (L, b"x" * int(rng.integers(0, 16))), body.tobytes(), q))
@@ -170,6 +183,7 @@ def repeat_threshold_case(lib_path, k, lens, max_runs=64, alphabet=b"ACGT"):
     thresholds = sorted({int(c) + d for c in counts for d in (0, 1) if int(c) + d > 0})
     if len(thresholds) > max_runs:
         thresholds = [thresholds[i] for i in sorted(rng.choice(len(thresholds), max_runs, replace=False))]
+    thresholds = sorted(set(thresholds) | set(extra_thresholds))
     for run, T in enumerate(thresholds):
         p = abi.make_params("ont", adapters=[], min_q=5.0, min_len=100, min_repeat=T, kmer=k)
         p.max_batch_reads = len(reads)

@@ -113,6 +113,14 @@ def test_emul_repeat_gate_skewed_composition(emul, k):
     parity.repeat_threshold_case(emul, k, parity.REPEAT_SKEW, max_runs=4, alphabet=b"AC")
 
 
+@pytest.mark.parametrize("k,plant", [(13, 0), (16, 0), (16, 95), (22, 140)])
+def test_emul_repeat_gate_pass_seams(emul, k, plant):
+    """k_repeat_keys around its pass sizes (131 072 k-mers a pass: one pass, two, four), on random reads whose first scan
+    flags tens to thousands of first occurrences: -p below that number needs the exact count of the second scan, -p above
+    it drops the fragment without one; with k-mers copied within the read the count sits on either side of -p."""
+    parity.repeat_threshold_case(emul, k, parity.REPEAT_SHARE, max_runs=6, share=True, plant=plant, extra_thresholds=(40, 100, 2500))
+
+
 @pytest.mark.parametrize("mode", ["direct", "difference"])
 def test_emul_clean_table_strategy(emul, golden_dir, mode):
     parity.clean_table_strategy(emul, mode, golden_dir)
@@ -225,8 +233,8 @@ def test_emul_short_adapters_dword_column(emul, ads, no32, monkeypatch):
 
 
 def _shared_prefix_read(k=31, units=9000, seed=5):
-    """Thousands of distinct duplicated k-mers that share their first 16 bases: no number of leading bases
-    separates them into passes whose table holds them."""
+    """Thousands of distinct duplicated k-mers that share their first 16 bases (no number of leading bases
+    separates them into passes whose table holds them -- the passes of k_repeat_keys own the keys by a hash of the whole key)."""
     rng = np.random.default_rng(seed)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
     pre = acgt[rng.integers(0, 4, 16)].tobytes()
@@ -237,8 +245,8 @@ def _shared_prefix_read(k=31, units=9000, seed=5):
 
 
 def test_emul_repeat_gate_shared_prefix_fragment(emul):
-    """k = 31: the passes of the keys kernel give up on leading bases and own the k-mers by a hash of the whole key; the count
-    (checked with numpy on both sides of the gate) stays exact."""
+    """k = 31, 279 000 distinct duplicated k-mers in one fragment: the keys kernel starts over with as many passes as its table
+    needs (8 -> 128); the count (checked with numpy on both sides of the gate) stays exact."""
     read = _shared_prefix_read()
     c = parity._kmer_repeat_np(read[1], 31)
     assert c > 250_000

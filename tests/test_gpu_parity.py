@@ -170,9 +170,23 @@ def test_gpu_repeat_gate_skewed_composition(k, alphabet):
     parity.repeat_threshold_case(None, k, parity.REPEAT_SKEW, max_runs=6, alphabet=alphabet)
 
 
+@pytest.mark.parametrize("k,plant", [(13, 0), (15, 90), (16, 0), (16, 95), (22, 140), (31, 60)])
+def test_gpu_repeat_gate_pass_seams(k, plant):
+    """k_repeat_keys around its pass sizes (one pass, two, four), -p on either side of what the first scan flags and of
+    the exact count (see test_emul_repeat_gate_pass_seams)."""
+    parity.repeat_threshold_case(None, k, parity.REPEAT_SHARE, max_runs=8, share=True, plant=plant, extra_thresholds=(40, 100, 2500))
+
+
 @pytest.mark.parametrize("mode", ["direct", "difference"])
 def test_gpu_clean_table_strategy(golden_dir, mode):
     parity.clean_table_strategy(None, mode, golden_dir)
+
+
+@pytest.mark.parametrize("k,plant", [(13, 0), (15, 90), (16, 0), (16, 95), (22, 140), (31, 60)])
+def test_gpu_repeat_gate_pass_seams(k, plant):
+    """k_repeat_keys around its pass sizes (one pass, two, four), -p on either side of what the first scan flags and of
+    the exact count (see test_emul_repeat_gate_pass_seams)."""
+    parity.repeat_threshold_case(None, k, parity.REPEAT_SHARE, max_runs=8, share=True, plant=plant, extra_thresholds=(40, 100, 2500))
 
 
 @pytest.mark.parametrize("mode", ["direct", "difference"])
@@ -303,8 +317,8 @@ def test_gpu_short_adapters_dword_column(ads_key, no32, monkeypatch):
 
 @pytest.mark.parametrize("k", [31, 15])
 def test_gpu_repeat_gate_shared_prefix_fragment(k):
-    """Thousands of distinct duplicated k-mers sharing their first 16 (k = 15: 8) bases: the keys kernel's passes fall back
-    from leading bases to a hash of the whole key; the count stays exact (numpy, both sides of the gate)."""
+    """Thousands of distinct duplicated k-mers sharing their first 16 (k = 15: 8) bases: the keys kernel starts over with as
+    many passes (by a hash of the whole key) as its table needs; the count stays exact (numpy, both sides of the gate)."""
     from tests.test_emul_parity import _shared_prefix_read
     rng = np.random.default_rng(9)
     if k == 31:

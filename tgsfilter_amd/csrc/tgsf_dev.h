@@ -76,7 +76,9 @@ struct DevBatch {
     uint32_t* nfr;             // [n+1] fragments per read, scanned in place to frag_begin
     uint32_t* scan_part;       // [n / kScanTile + 2] per-tile totals of the prefix scans
     uint32_t* trimmed;         // [n]
-    uint32_t* rep_next;        // [1] k_repeat: next fragment to hand out
+    uint32_t* rep_next;        // [2 + rep_long_cap] k_repeat*: [0] next work item to hand out, [1] number of long fragments
+                               // (k_repeat_keys takes those that need several passes first: k_repeat_long lists them), [2..] the list
+    uint32_t  rep_long_cap;
 
     // stats work lists (raw: items are reads; clean: items are fragments [0,fcap) and, in the
     // "difference" strategy, whole reads to take back out, numbered fcap + read)

@@ -12,7 +12,7 @@
 //   k_mid_scan*      GetEditDistance middle: Myers infix scan, 1 lane = 1024 columns  [VALU-bound, dominant]
 //   k_mid_resolve    start locations + path of the first location + similarity gates
 //   k_regions<count|emit>   adapterMap: merge drop regions, keep regions, DropInfo
-//   k_repeat / k_repeat_keys   GetKmerCount gate (-p/-k), only when asked for: LDS bitmap (k <= 12) / hashed maps + keys (13..32)
+//   k_repeat / k_repeat_keys   GetKmerCount gate (-p/-k), only when asked for: LDS bitmap (k <= 11) / hashed map + keys (12..32)
 //   k_clean_plan     reads kept whole; which way the clean tables are cheaper to tally
 //   k_frag_prepare + sort + k_stats<clean> + k_gate_frags + k_end_tables<clean>
 //   k_finalize       tgsf_read_result / tgsf_fragment records
@@ -1809,8 +1809,8 @@ TGSF_KERNEL k_regions(DevParams P, DevBatch B)
 }
 
 // ---------------------------------------------------------------------------
-// k_repeat: the repeat gate, GetKmerCount (src/TGSFilter.cpp:1703-1753, :1982-1989), for k <= 13 (launched for k <= 12:
-// from 13 on k_repeat_keys is faster).
+// k_repeat: the repeat gate, GetKmerCount (src/TGSFilter.cpp:1703-1753, :1982-1989), for k <= 13 (launched for k <= 11:
+// from 12 on k_repeat_keys is faster).
 // repeat = (#k-mers) - (#distinct k-mers) of a fragment; fragments below -p are dropped before any
 // clean statistics.  k-mers are 2-bit codes (A0 C1 G2 T3, every other byte 0), first base in the top bits.
 //
@@ -1998,21 +1998,43 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat(DevParams P, DevBatch B)
 }
 
 // ---------------------------------------------------------------------------
-// k_repeat_keys: the same gate where the 4^k-bit set is too large to sweep as LDS bitmaps (k = 13..31; 32-bit keys up to
-// k = 15, 64-bit above).  Exact, in two phases per pass, all in LDS:
-//   1. every k-mer the pass owns marks bit h(k-mer) of a 2^19-bit map A (ds_or returning the old word) and, if that bit
-//      was already set, the same bit of a second map B.  A hash value marked once stands for exactly one k-mer
-//      occurrence, so popcount(A & ~B) of them are distinct k-mers, whatever the hash does.
-//   2. the occurrences whose hash value is in B -- a few percent of a random fragment, nearly all of a repetitive one --
-//      are the only ones that can hide duplicates: the fragment is scanned again and those keys (compared in full) go into
-//      an open-addressing table that takes A's place; new insertions are counted.
-//   distinct = popcount(A & ~B) + insertions.  A pass owns the k-mers that start with its PB leading bases (the match
-//   mask of k_repeat); PB is the smallest for which a pass's share of the k-mers is at most kRepShare, and one more
-//   whenever a probe sequence of the table grows long (skewed composition, or a long fragment of many distinct repeats):
-//   the fragment then starts over.  Windows, chunk layout, prefetch and work counter as in k_repeat.
+// k_repeat_keys: the same gate where the 4^k-bit set is too large to sweep as LDS bitmaps (k = 12..31; 32-bit keys up to
+// k = 15, 64-bit above).  What the gate needs is exact only around -p (:1984: repeat < MinRepeat drops the fragment), and
+// repeat = sum over the keys of (occurrences - 1) = the occurrences that are not the first of their key.  Per pass, in LDS:
+//   0. every k-mer ORs a mask of three bits, chosen by its hash, into ONE word of a 96-KB map A (a Bloom filter whose block
+//      is the word: one returning ds_or per k-mer, so the occurrences of a key are ordered by that one atomic and every
+//      one but the first finds its three bits set).  An occurrence that finds them set is "flagged": every repeat is, and
+//      so are a few first occurrences (1e-3 of them at 131 072 k-mers).  Flagged occurrences mark their hash value in a
+//      32-KB map B.  flagged = 0 -> the pass holds no repeat;  flagged < -p on a fragment's last pass -> the fragment is
+//      dropped, whatever the exact number is: no second scan (random fragments up to ~50 000 k-mers end here).
+//   1. otherwise the fragment is scanned again: the occurrences whose hash value is in B -- all occurrences of a key or
+//      none, and every repeated key's -- are counted (M) and their keys, compared in full, go into an open-addressing table
+//      that takes A's place (I insertions).  The pass's repeat = M - I, exactly, whatever the hashes do.
+//   A fragment of more than kRepShare k-mers takes 2, 4, ... passes, a pass owning the keys by a hash of the whole key (the
+//   others OR a zero: every pass runs the same straight-line code over whole chunks, sixteen keys at constant shifts with
+//   their LDS operations back to back); the passes double, the fragment starting over, when a pass's table fills up
+//   (long fragments of many distinct repeats).  A fragment is accepted as soon as the passes so far hold -p repeats.
+//   Windows, chunk layout, prefetch and work counter as in k_repeat.
 //   k = 32 follows the reference's machine there (:1748, see the oracle): the first k-mer as built, every later one 0.
 // ---------------------------------------------------------------------------
-constexpr uint32_t kRepShare = 65536;                 // k-mers of a pass for which the table behind the maps stays sparse
+constexpr uint32_t kRepShare = 114688;                // k-mers of a pass for which the flagged few stay few (~2 300 of them, ~3 300 keys for the table)
+// fragments of more than one pass (TGSF_KERNEL k_repeat_long lists them; k_repeat_keys hands them out first: a 1-Mb fragment
+// is 16 passes on ONE workgroup, milliseconds that must not begin when the others are about to finish)
+TGSF_D bool rep_long(const DevParams& P, const DevBatch& B, uint32_t f) { return (int)B.frag_len[f] - P.kmer + 1 > (int)kRepShare; }
+TGSF_KERNEL k_repeat_long(DevParams P, DevBatch B)
+{
+    if (pool_overflowed(B)) return;
+    const uint32_t nf = stored_frags(B);
+    for (uint32_t f = blockIdx.x * blockDim.x + threadIdx.x; f < nf; f += gsize()) {
+        if (!rep_long(P, B, f)) continue;
+        const uint32_t i = atomicAdd(&B.rep_next[1], 1u);
+        if (i < B.rep_long_cap) B.rep_next[2 + i] = f;                 // (always: the long fragments are disjoint pieces of the batch's bases)
+        else set_status(B, DS_FRAG_CAP, B.frag_read[f]);
+    }
+}
+constexpr uint32_t kRepAQ = 6144;                     // map A: 96 KB = 24 576 words
+constexpr uint32_t kRepBQ = 2048;                     // map B: 32 KB = 2^18 bits
+constexpr uint32_t kRepTabQ = 4096;                   // the table: the first 64 KB of A
 template <bool KEY64>
 TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
 {
@@ -2020,15 +2042,17 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
     constexpr int OV = KEY64 ? 2 : 1;                                  // chunks shared by consecutive windows (a key spans up to 3 / 2)
     constexpr uint32_t TLOG = KEY64 ? 13u : 14u;                       // slots of the table (64 KB), log2
     typedef typename std::conditional<KEY64, ull, uint32_t>::type key_t;
-    TGSF_SHARED uint4 A4[4096];                       // 64 KB: map A, then the table of full keys
-    TGSF_SHARED uint4 B4[4096];                       // 64 KB: map B
+    TGSF_SHARED uint4 A4[kRepAQ];                     // map A, then the table of full keys
+    TGSF_SHARED uint4 B4[kRepBQ];                     // map B
     TGSF_SHARED uint32_t codes[W + 8];
-    TGSF_SHARED uint32_t distinct_s, next_s, over_s;
+    TGSF_SHARED uint32_t acc_s[3], next_s, over_s;
     uint32_t* Am = reinterpret_cast<uint32_t*>(A4);
     uint32_t* Bm = reinterpret_cast<uint32_t*>(B4);
     key_t* tab = reinterpret_cast<key_t*>(A4);
     const key_t kEmpty = ~(key_t)0;                                    // no key has all its bits set (k < 16 / < 32)
     const int k = P.kmer;
+    const int kb = 2 * k;                                              // bits of a key
+    const uint32_t tail_mask = KEY64 ? ~(0xFFFFFFFFu >> ((uint32_t)(kb - 32) & 31u)) : 0u;   // 64-bit keys: their bits in the second word
     const uint32_t nf = stored_frags(B);
     uint64_t drop_n = 0, drop_b = 0;
     if (pool_overflowed(B)) return;
@@ -2041,7 +2065,11 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
     uint4 zero4, ones4;
     zero4.x = zero4.y = zero4.z = zero4.w = 0;
     ones4.x = ones4.y = ones4.z = ones4.w = ~0u;
-    for (uint32_t w = (uint32_t)tid; w < 4096u; w += (uint32_t)NT) { A4[w] = zero4; B4[w] = zero4; }
+    auto clear_maps = [&](bool b_too) TGSF_INLINE_LAMBDA {
+        for (uint32_t w = (uint32_t)tid; w < kRepAQ; w += (uint32_t)NT) A4[w] = zero4;
+        if (b_too) for (uint32_t w = (uint32_t)tid; w < kRepBQ; w += (uint32_t)NT) B4[w] = zero4;
+    };
+    clear_maps(true);
 
     auto chunks_of = [&](uint32_t f, const uint4*& base, int& a, int& L) TGSF_INLINE_LAMBDA {
         const uint8_t* s = B.seq + B.frag_off[f];
@@ -2053,6 +2081,13 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
     auto load_window = [&](const uint4* base, int words, int wb) TGSF_INLINE_LAMBDA {
         for (int g = tid; g < W + 4 && wb + g < words + 4; g += NT) codes[g] = wb + g < words ? base_codes16(base[wb + g]) : 0u;
     };
+    // the sum of a per-lane count over the workgroup (every lane gets it); slot = one of acc_s, zeroed by the caller
+    auto block_sum = [&](uint32_t v, int slot) TGSF_INLINE_LAMBDA -> uint32_t {
+        v = (uint32_t)wave_sum((uint64_t)v);
+        if (wave_leader() && v) atomicAdd(&acc_s[slot], v);
+        TGSF_BLOCK_SYNC();
+        return acc_s[slot];
+    };
 #if !defined(TGSF_EMUL)
     uint4 raw[kRepSlots];
     auto prefetch = [&](uint32_t f) TGSF_INLINE_LAMBDA {
@@ -2063,9 +2098,24 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
 #pragma unroll
         for (int sl = 0; sl < kRepSlots; sl++) { const int g = tid + sl * NT; if (g < words) raw[sl] = base[g]; }
     };
-    prefetch(blockIdx.x);
 #endif
-    uint32_t f = blockIdx.x;
+    // work items: the long fragments in the order of their list, then every other fragment in the batch's order
+    const uint32_t n_long = B.rep_next[1] < B.rep_long_cap ? B.rep_next[1] : B.rep_long_cap;
+    auto take = [&]() TGSF_INLINE_LAMBDA -> uint32_t {                 // (one lane)
+        for (;;) {
+            const uint32_t w = atomicAdd(&B.rep_next[0], 1u);
+            if (w < n_long) return B.rep_next[2 + w];
+            const uint32_t g = w - n_long;
+            if (g >= nf) return nf;
+            if (!rep_long(P, B, g)) return g;
+        }
+    };
+    if (tid == 0) next_s = take();
+    TGSF_BLOCK_SYNC();
+    uint32_t f = next_s;
+#if !defined(TGSF_EMUL)
+    prefetch(f);
+#endif
     while (f < nf) {
         const uint4* base; int a, L;
         chunks_of(f, base, a, L);
@@ -2073,7 +2123,8 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
         const int words = (a + L + 15) / 16;
         const int kwords = total > 0 ? (a + total + 15) / 16 : 0;
         const bool one_window = words <= W;
-        if (tid == 0) { distinct_s = 0; over_s = 0; next_s = gridDim.x + atomicAdd(B.rep_next, 1u); }
+        TGSF_BLOCK_SYNC();                                             // (everyone has read next_s)
+        if (tid == 0) { over_s = 0; next_s = take(); }
         TGSF_BLOCK_SYNC();
 #if defined(TGSF_EMUL)
         load_window(base, words, 0);
@@ -2087,29 +2138,45 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
 #if !defined(TGSF_EMUL)
         prefetch(fnext);
 #endif
-        uint32_t mine = 0;
-        if (total > 0 && k >= 32) {
-            if (tid == 0) {
-                ull first = 0;
-                const uint8_t* seq = B.seq + B.frag_off[f];
-                for (int i = 0; i < k; i++) first = (first << 2) | base_code(seq[i]);
-                mine = (total > 1 && first != 0ull) ? 2u : 1u;
-            }
-        } else if (total > 0) {
-            int PB = 0, PB0 = -1;
-            uint32_t hparts = 0;                                       // > 0: passes own the k-mers by a hash of the whole key
+        bool drop = false;                                             // the gate's verdict (uniform over the workgroup)
+        if (total <= 0) {
+            drop = 0 < P.min_repeat;                                   // no k-mer: repeat = 0
+        } else if (k >= 32) {
+            ull first = 0;
+            const uint8_t* seq = B.seq + B.frag_off[f];
+            for (int i = 0; i < k; i++) first = (first << 2) | base_code(seq[i]);
+            const int distinct = (total > 1 && first != 0ull) ? 2 : 1;
+            drop = total - distinct < P.min_repeat;
+        } else {
+            uint32_t plog = 0;                                         // 2^plog passes
+            while (plog < 20u && ((uint32_t)total >> plog) > kRepShare) plog++;
             for (;;) {
-                while (!hparts && PB < k - 1 && ((uint32_t)total >> (2 * PB)) > kRepShare) PB++;
-                if (PB0 < 0) PB0 = PB;
-                const int kb = 2 * (k - PB);                           // bits of a key: the k-mer less the pass's leading bases
-                const uint32_t passes = hparts ? hparts : 1u << (2 * PB);
-                mine = 0;
-                for (uint32_t pass = 0; pass < passes; pass++) {
-                    // one scan of the fragment: PHASE 0 marks A and B, PHASE 1 inserts the keys whose hash value is in B.
-                    // (Two instances: a test of the phase between the LDS operations of a chunk makes the compiler wait
-                    // for each of them in turn.)
-                    auto scan = [&](auto phase_tag) TGSF_INLINE_LAMBDA {
+                const uint32_t passes = 1u << plog;
+                uint32_t repeat = 0;                                   // exact over the passes done so far
+                uint32_t flagged = 0;
+                bool decided = false;
+                for (uint32_t pass = 0; pass < passes && !decided; pass++) {
+                    // one scan of the fragment: PHASE 0 marks A (and B for the flagged), PHASE 1 counts and inserts the keys
+                    // whose hash value is in B; MULTI: the pass owns part of the keys.  (Separate instances: a test of the
+                    // phase between the LDS operations of a chunk makes the compiler wait for each of them in turn.)
+                    uint32_t c0 = 0, c1 = 0;                           // PHASE 0: flagged;  PHASE 1: occurrences, insertions
+                    auto scan = [&](auto phase_tag, auto multi_tag) TGSF_INLINE_LAMBDA {
                         constexpr int PHASE = decltype(phase_tag)::value;
+                        constexpr bool MULTI = decltype(multi_tag)::value;
+                        // what a key's hash selects
+                        // (64-bit keys are hashed as they lie in the chunks: x0 = the first sixteen bases, x1 = the rest from bit 31
+                        // down with the bits behind the key cleared -- no 64-bit shift, one multiplication)
+                        auto hash_of = [&](uint32_t x0, uint32_t x1) TGSF_INLINE_LAMBDA -> uint32_t {
+                            return KEY64 ? ((x1 & tail_mask) ^ alignbit(x0, x0, 19u)) * 0x9E3779B1u : x0 * 0x9E3779B1u;
+                        };
+                        auto owned = [&](uint32_t h) TGSF_INLINE_LAMBDA -> bool {
+                            return !MULTI || ((h ^ (h >> 7)) & (passes - 1u)) == pass;   // (low bits: the map's word comes from the top ones)
+                        };
+                        auto a_word = [&](uint32_t h) TGSF_INLINE_LAMBDA -> uint32_t { return ((h >> 16) * (kRepAQ * 4u)) >> 16; };
+                        auto a_mask = [&](uint32_t h) TGSF_INLINE_LAMBDA -> uint32_t {
+                            const uint32_t g = h ^ (h >> 15);
+                            return (1u << (g & 31u)) | (1u << ((g >> 5) & 31u)) | (1u << ((g >> 10) & 31u));
+                        };
                         for (int wb = 0;; wb += W - OV) {
                             if (!one_window) {
                                 TGSF_BLOCK_SYNC();
@@ -2119,80 +2186,90 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
                             const bool last = wb + W >= words;
                             const int gend = last ? kwords - wb : W - OV;
                             for (int g = tid; g < gend; g += NT) {
-                                const uint32_t w0 = codes[g], w1 = codes[g + 1], w2 = codes[g + 2], w3 = codes[g + 3];
+                                const uint32_t w0 = codes[g], w1 = codes[g + 1], w2 = codes[g + 2];
                                 const int first = a - 16 * (wb + g);
                                 const int v = a + total - 16 * (wb + g);
                                 uint32_t m = 0x55555555u;              // bit 30-2j: base j of the chunk starts a k-mer to handle below
-                                if (PB == 0 && !hparts && first <= 0 && v >= 16) {
-                                    // a whole chunk of a single-pass fragment: sixteen keys at constant shifts, their LDS
-                                    // operations issued back to back; what is left for the loop below is rare
-                                    uint32_t hbv[16], oldv[16];
-#pragma unroll
-                                    for (int j = 0; j < 16; j++) {
-                                        const uint32_t x0 = j ? alignbit(w0, w1, 32u - 2u * (uint32_t)j) : w0;
-                                        uint32_t h;
-                                        if (KEY64) {
-                                            const uint32_t x1 = j ? alignbit(w1, w2, 32u - 2u * (uint32_t)j) : w1;
-                                            const ull k64 = (((ull)x0 << 32) | x1) >> (64 - kb);
-                                            h = ((uint32_t)k64 ^ ((uint32_t)(k64 >> 32) * 0x85EBCA6Bu)) * 0x9E3779B1u;
-                                        } else {
-                                            h = (x0 >> (32 - kb)) * 0x9E3779B1u;
-                                        }
-                                        hbv[j] = h >> 13;
-                                        if (PHASE == 0) oldv[j] = atomicOr(&Am[hbv[j] >> 5], 1u << (hbv[j] & 31u));
-                                        else oldv[j] = Bm[hbv[j] >> 5];
-                                    }
+                                if (first <= 0 && v >= 16) {
+                                    // a whole chunk: sixteen keys at constant shifts, their LDS operations issued back to back;
+                                    // what is left for the loop below is rare
+                                    // (eight at a time: sixteen keys' hashes, masks and answers do not fit the registers)
                                     m = 0;
 #pragma unroll
-                                    for (int j = 0; j < 16; j++) {
-                                        const uint32_t hit = oldv[j] & (1u << (hbv[j] & 31u));
-                                        if (PHASE == 0) atomicOr(&Bm[hbv[j] >> 5], hit);          // (ORs zero where the bit was new)
-                                        else if (hit) m |= 1u << (30 - 2 * j);
+                                    for (int j0 = 0; j0 < 16; j0 += 8) {
+                                        uint32_t hv[8], oldv[8], mkv[8];
+#pragma unroll
+                                        for (int jj = 0; jj < 8; jj++) {
+                                            const int j = j0 + jj;
+                                            const uint32_t x0 = j ? alignbit(w0, w1, 32u - 2u * (uint32_t)j) : w0;
+                                            uint32_t h;
+                                            if (KEY64) {
+                                                const uint32_t x1 = j ? alignbit(w1, w2, 32u - 2u * (uint32_t)j) : w1;
+                                                h = hash_of(x0, x1);
+                                            } else {
+                                                h = hash_of(x0 >> (32 - kb), 0u);
+                                            }
+                                            hv[jj] = h;
+                                            if (PHASE == 0) {
+                                                mkv[jj] = owned(h) ? a_mask(h) : 0u;
+                                                oldv[jj] = atomicOr(&Am[a_word(h)], mkv[jj]);
+                                            } else {
+                                                oldv[jj] = Bm[h >> 19];
+                                            }
+                                        }
+                                        uint32_t hits = 0;
+#pragma unroll
+                                        for (int jj = 0; jj < 8; jj++) {
+                                            bool hit;
+                                            if (PHASE == 0) hit = (mkv[jj] & ~oldv[jj]) == 0u && (!MULTI || mkv[jj] != 0u);   // every bit of the mask was there
+                                            else hit = ((oldv[jj] >> ((hv[jj] >> 14) & 31u)) & 1u) && owned(hv[jj]);
+                                            if (hit) hits |= 1u << (30 - 2 * (j0 + jj));
+                                        }
+                                        if (PHASE == 0) {
+                                            if (hits) {                // flagged occurrences (rare): counted, their hash values into B
+                                                c0 += popc32(hits);
+#pragma unroll
+                                                for (int jj = 0; jj < 8; jj++)
+                                                    if (hits & (1u << (30 - 2 * (j0 + jj)))) atomicOr(&Bm[hv[jj] >> 19], 1u << ((hv[jj] >> 14) & 31u));
+                                            }
+                                        } else {
+                                            m |= hits;
+                                        }
                                     }
                                 } else {
-                                    for (int q = 0; q < PB; q++) {
-                                        const uint32_t c = (pass >> (2 * (PB - 1 - q))) & 3u;
-                                        const uint32_t e0 = rep_eq_mask(w0, c);
-                                        m &= q ? alignbit(e0, rep_eq_mask(w1, c), 32u - 2u * (uint32_t)q) : e0;
-                                    }
                                     if (first > 0) m &= 0xFFFFFFFFu >> (2 * first);
                                     if (v < 16) m &= ~(0xFFFFFFFFu >> (2 * v));
                                 }
-                                // (the k-mers left for this pass one at a time: handling them four at a time -- keys first, then
-                                // their LDS operations back to back -- was measured SLOWER, 26 against 23 ms a batch at -k 13: the
-                                // kernel is bound by the instructions it issues, and the predicated group issues more of them)
                                 while (m) {
                                     const int b = __builtin_ctz(m);
                                     m &= m - 1u;
-                                    const int sh = 30 - b + 2 * PB;    // bit offset of the key in the chunk sequence w0 w1 w2 w3
-                                    const bool up = sh >= 32;
-                                    const uint32_t X = up ? w1 : w0, Y = up ? w2 : w1, Z = up ? w3 : w2;
-                                    const uint32_t sb = (uint32_t)sh & 31u;
-                                    const uint32_t x0 = sb ? alignbit(X, Y, 32u - sb) : X;
+                                    const uint32_t sb = (uint32_t)(30 - b);    // bit offset of the key in the chunk sequence w0 w1 w2
+                                    const uint32_t x0 = sb ? alignbit(w0, w1, 32u - sb) : w0;
                                     key_t key;
-                                    uint32_t h, lo32, hi32 = 0;
+                                    uint32_t lo32, hi32 = 0, h;
                                     if (KEY64) {
-                                        const uint32_t x1 = sb ? alignbit(Y, Z, 32u - sb) : Y;
+                                        const uint32_t x1 = sb ? alignbit(w1, w2, 32u - sb) : w1;
                                         const ull k64 = (((ull)x0 << 32) | x1) >> (64 - kb);
                                         key = (key_t)k64;
                                         lo32 = (uint32_t)k64; hi32 = (uint32_t)(k64 >> 32);
-                                        h = (lo32 ^ (hi32 * 0x85EBCA6Bu)) * 0x9E3779B1u;
+                                        h = hash_of(x0, x1);
                                     } else {
                                         lo32 = x0 >> (32 - kb);
                                         key = (key_t)lo32;
-                                        h = lo32 * 0x9E3779B1u;
+                                        h = hash_of(lo32, 0u);
                                     }
-                                    if (hparts && ((((h ^ (h >> 15)) * 0x2C1B3C6Du) >> 12) & (hparts - 1u)) != pass) continue;   // another pass's k-mer
-                                    const uint32_t hb = h >> 13;       // 19 bits
-                                    const uint32_t bit = 1u << (hb & 31u);
+                                    if (!owned(h)) continue;           // another pass's k-mer
+                                    const uint32_t bbit = 1u << ((h >> 14) & 31u);
                                     if (PHASE == 0) {
-                                        const uint32_t old = atomicOr(&Am[hb >> 5], bit);
-                                        if (old & bit) atomicOr(&Bm[hb >> 5], bit);
-                                    } else if (Bm[hb >> 5] & bit) {
+                                        const uint32_t mk = a_mask(h);
+                                        const uint32_t old = atomicOr(&Am[a_word(h)], mk);
+                                        if ((mk & ~old) == 0u) { c0++; atomicOr(&Bm[h >> 19], bbit); }
+                                    } else if (Bm[h >> 19] & bbit) {
+                                        c0++;
                                         uint32_t slot = (((lo32 * 0xC2B2AE35u) ^ (hi32 * 0x27D4EB2Fu) ^ (lo32 >> 15)) * 0x165667B1u) >> (32u - TLOG);
                                         for (int probes = 0;; probes++) {
                                             const key_t old = atomicCAS(&tab[slot], kEmpty, key);
-                                            if (old == kEmpty) { mine++; break; }
+                                            if (old == kEmpty) { c1++; break; }
                                             if (old == key) break;
                                             if (probes >= 64) { over_s = 1; break; }
                                             slot = (slot + 1u) & ((1u << TLOG) - 1u);
@@ -2203,50 +2280,58 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
                             if (last) break;
                         }
                     };
-                    for (int phase = 0; phase < 2; phase++) {
-                        if (phase == 0) scan(std::integral_constant<int, 0>());
-                        else scan(std::integral_constant<int, 1>());
+                    if (tid == 0) acc_s[0] = acc_s[1] = acc_s[2] = 0;
+                    // (the scan's first barrier stands between this and the first use)
+                    if (plog == 0) scan(std::integral_constant<int, 0>(), std::false_type());
+                    else scan(std::integral_constant<int, 0>(), std::true_type());
+                    TGSF_BLOCK_SYNC();
+                    flagged = block_sum(c0, 0);
+                    // no occurrence flagged: no repeat in this pass.  Fewer than -p could still be missing at the end of
+                    // the last pass: dropped without counting them
+                    const bool skip = flagged == 0 || (pass + 1 == passes && repeat + flagged < (uint32_t)P.min_repeat);
+#if defined(TGSF_EMUL) && defined(TGSF_REP_TRACE)
+                    fprintf(stderr, "k_repeat_keys: fragment %u (%d k-mers) pass %u of %u: %u flagged%s\n", f, total, pass, passes, flagged, skip ? ", no second scan" : "");
+#endif
+                    if (skip) {
+                        if (flagged) repeat += flagged;                // an upper bound, on the last pass only
                         TGSF_BLOCK_SYNC();
-                        if (phase == 0) {
-                            // hash values marked once: one occurrence, one distinct k-mer each; A becomes the (empty) table
-                            for (uint32_t w = (uint32_t)tid; w < 4096u; w += (uint32_t)NT) {
-                                const uint4 x = A4[w], y = B4[w];
-                                mine += popc32(x.x & ~y.x) + popc32(x.y & ~y.y) + popc32(x.z & ~y.z) + popc32(x.w & ~y.w);
-                                A4[w] = ones4;
-                            }
-                        } else {
-                            for (uint32_t w = (uint32_t)tid; w < 4096u; w += (uint32_t)NT) { A4[w] = zero4; B4[w] = zero4; }
-                        }
+                        clear_maps(flagged != 0);
                         TGSF_BLOCK_SYNC();
+                        continue;
                     }
+                    for (uint32_t w = (uint32_t)tid; w < kRepTabQ; w += (uint32_t)NT) A4[w] = ones4;    // A becomes the (empty) table
+                    c0 = c1 = 0;
+                    if (plog == 0) scan(std::integral_constant<int, 1>(), std::false_type());
+                    else scan(std::integral_constant<int, 1>(), std::true_type());
+                    TGSF_BLOCK_SYNC();
+                    const uint32_t occ = block_sum(c0, 1), ins = block_sum(c1, 2);
+                    clear_maps(true);
+                    TGSF_BLOCK_SYNC();
                     if (over_s) break;
+                    repeat += occ - ins;
+#if defined(TGSF_EMUL) && defined(TGSF_REP_TRACE)
+                    fprintf(stderr, "k_repeat_keys:   second scan: %u occurrences of %u keys, repeat so far %u\n", occ, ins, repeat);
+#endif
+                    if (repeat >= (uint32_t)P.min_repeat) decided = true;         // accepted, whatever the other passes hold
                 }
-                if (!over_s) break;
+                if (!over_s) { drop = !decided && repeat < (uint32_t)P.min_repeat; break; }
+                // A pass's table could not take the keys the pass had to compare in full: more passes -- as many as leave a
+                // pass's flagged occurrences half the table, twice as many at least -- and the fragment starts over.
                 TGSF_BLOCK_SYNC();
                 if (tid == 0) over_s = 0;
-                // A pass's table could not take the pass's duplicated k-mers.  Two more leading bases at most (each quadruples
-                // the passes; thousands of distinct duplicated k-mers may well share a long prefix -- then no number of
-                // leading bases separates them): from there on the passes own the k-mers by a hash of the whole key, as
-                // many passes as leave a pass about an eighth of the table, doubled while one still overflows.
-                if (!hparts && PB < PB0 + 2 && PB < k - 1 && PB < 15) PB++;
-                else if (!hparts) { PB = 0; hparts = 1u; while (hparts < (1u << 20) && ((uint32_t)total / hparts) > (1u << (TLOG - 3))) hparts <<= 1; }
-                else if (hparts < (1u << 20)) hparts <<= 1;
-                else { set_status(B, DS_REPEAT_TABLE, B.frag_read[f]); mine = 0; TGSF_BLOCK_SYNC(); break; }
+                uint32_t want = plog + 1u;
+                while (want < 20u && (flagged >> (want - plog)) > (1u << (TLOG - 1u))) want++;
+                if (plog >= 20u) { set_status(B, DS_REPEAT_TABLE, B.frag_read[f]); drop = false; TGSF_BLOCK_SYNC(); break; }
+                plog = want;
 #if defined(TGSF_EMUL) && defined(TGSF_REP_TRACE)
-                fprintf(stderr, "k_repeat_keys: fragment %u (%d k-mers) starts over with %d leading bases / %u hash parts\n", f, total, PB, hparts);
+                fprintf(stderr, "k_repeat_keys: fragment %u (%d k-mers) starts over with %u passes\n", f, total, 1u << plog);
 #endif
                 TGSF_BLOCK_SYNC();
             }
         }
-        mine = (uint32_t)wave_sum((uint64_t)mine);
-        if (wave_leader() && mine) atomicAdd(&distinct_s, mine);
-        TGSF_BLOCK_SYNC();
-        if (tid == 0) {
-            const int repeat = (total > 0 ? total : 0) - (int)distinct_s;
-            if (repeat < P.min_repeat) {                               // :1984-1988
-                B.frag_flags[f] |= TGSF_FF_REPEAT;
-                drop_n++; drop_b += (uint64_t)L;
-            }
+        if (tid == 0 && drop) {                                        // :1984-1988
+            B.frag_flags[f] |= TGSF_FF_REPEAT;
+            drop_n++; drop_b += (uint64_t)L;
         }
         f = fnext;
     }

@@ -515,7 +515,8 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     if (!e) e = dev_alloc(c, &B.nfr, n + 1);
     if (!e) e = dev_alloc(c, &B.scan_part, n / kScanTile + 2);
     if (!e) e = dev_alloc(c, &B.trimmed, n);
-    if (!e) e = dev_alloc(c, &B.rep_next, 4);
+    B.rep_long_cap = (uint32_t)std::min<uint64_t>(c->cap_bases / kRepShare + 16, (uint64_t)B.fcap + 16);   // a long fragment holds more than kRepShare bases
+    if (!e) e = dev_alloc(c, &B.rep_next, 2 + (size_t)B.rep_long_cap);
     if (!e) e = dev_alloc(c, &B.tile_hist, (size_t)B.max_tiles + 2);
     if (!e) e = dev_alloc(c, &B.tile_cnt, (size_t)B.max_tiles + 2);
     if (!e) e = dev_alloc(c, &B.tile_base, (size_t)B.max_tiles + 2);
@@ -834,11 +835,17 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     scan_u32(B, B.nfr, n, st);
     TGSF_LAUNCH(k_regions<true>, gsmall, T, st, P, B);
     if (P.min_repeat > 0 && !P.only_qc) {
-        // one 1024-lane workgroup per CU (152 KB of LDS each); fragments are handed out through B.rep_next
-        rt_memset(B.rep_next, 0, sizeof(uint32_t), st);
-        if (P.kmer <= 12) TGSF_LAUNCH(k_repeat, grid_cap(256u), kRepThreads, st, P, B);
-        else if (P.kmer <= 15) TGSF_LAUNCH(k_repeat_keys<false>, grid_cap(256u), kRepThreads, st, P, B);
-        else TGSF_LAUNCH(k_repeat_keys<true>, grid_cap(256u), kRepThreads, st, P, B);
+        // one 1024-lane workgroup per CU (152 KB of LDS each); fragments are handed out through B.rep_next.  k <= 11: the
+        // 4^k-bit set swept as LDS bitmaps; above: a hashed map + the full keys of the few it cannot tell apart (k = 12
+        // would be 16 sweeps: 18 ms a batch against 5)
+        rt_memset(B.rep_next, 0, 2 * sizeof(uint32_t), st);
+        static const int keys_from = getenv("TGSF_REPEAT_KEYS_FROM") ? atoi(getenv("TGSF_REPEAT_KEYS_FROM")) : 12;   // (measurements)
+        if (P.kmer < keys_from && P.kmer <= 13) TGSF_LAUNCH(k_repeat, grid_cap(256u), kRepThreads, st, P, B);
+        else {
+            TGSF_LAUNCH(k_repeat_long, gsmall, T, st, P, B);
+            if (P.kmer <= 15) TGSF_LAUNCH(k_repeat_keys<false>, grid_cap(256u), kRepThreads, st, P, B);
+            else TGSF_LAUNCH(k_repeat_keys<true>, grid_cap(256u), kRepThreads, st, P, B);
+        }
     }
     STAGE_MARK();
     // -- clean stats over the fragments
@@ -919,7 +926,7 @@ static int check_status(tgsf_ctx* c)
     switch (code) {
     case DS_BAD_LEN: return fail(c, TGSF_E_DATA, "read %u: length 0 or above max_read_len %u", detail, c->max_read_len);
     case DS_BAD_QUAL: return fail(c, TGSF_E_DATA, "quality byte >= 128 in the batch (outside the supported domain)");
-    case DS_REPEAT_TABLE: return fail(c, TGSF_E_CAPACITY, "read %u: the repeat gate's table cannot hold the duplicated k-mers of a fragment (thousands of them sharing their first 16 bases)", detail);
+    case DS_REPEAT_TABLE: return fail(c, TGSF_E_CAPACITY, "read %u: the repeat gate's table cannot hold the duplicated k-mers of a fragment (thousands of distinct ones that no hash of the key tells apart)", detail);
     case DS_TOO_MANY_REGIONS: return fail(c, TGSF_E_CAPACITY, "read %u has more than %d disjoint drop regions", detail, kMaxRegions);
     case DS_FRAG_CAP: return fail(c, TGSF_E_CAPACITY, "fragment capacity exceeded (%u)", detail);
     case DS_BAD_MEANQ: return fail(c, TGSF_E_DATA, "read %u: mean quality outside [0,256)", detail);
