@@ -199,6 +199,40 @@ def repeat_threshold_case(lib_path, k, lens, max_runs=64, alphabet=b"ACGT", shar
         ctx.close()
 
 
+def colliding_hash_read(n_special=28000, c=0x5A17C3E8, seed=3):
+    """n_special 31-mers, one after the other, built so that tail = (c ^ rotl13(head)) & ~3 (head = the first 16 bases, random;
+    tail = the other 15): they all share one of four 32-bit hash values of k_repeat_keys' first attempt -- 7 000 distinct keys
+    to a value, more than a pass's table holds, and no number of passes by that hash separates them.  The read is the chain
+    twice over, so that every one of them is a repeated key (and has to be compared in full)."""
+    rng = np.random.default_rng(seed)
+    heads = rng.integers(0, 1 << 32, n_special, dtype=np.uint64)
+    rot = ((heads << np.uint64(13)) | (heads >> np.uint64(19))) & np.uint64(0xFFFFFFFF)
+    tails = (np.uint64(c) ^ rot) & np.uint64(0xFFFFFFFC)
+    codes = np.empty((n_special, 31), dtype=np.uint8)
+    for j in range(16):
+        codes[:, j] = (heads >> np.uint64(30 - 2 * j)) & np.uint64(3)
+    for j in range(15):
+        codes[:, 16 + j] = (tails >> np.uint64(30 - 2 * j)) & np.uint64(3)
+    s = np.frombuffer(b"ACGT", dtype=np.uint8)[codes.reshape(-1)].tobytes()
+    s = s + s
+    q = bytes((rng.integers(15, 35, len(s)) + 33).astype(np.uint8))
+    return (b"colliding", s, q)
+
+
+def colliding_hash_case(lib_path):
+    """The gate at the read's own count (numpy) and one above it, k = 31, on colliding_hash_read()."""
+    read = colliding_hash_read()
+    c = _kmer_repeat_np(read[1], 31)
+    assert c > 800_000
+    for pval, kept in ((c, True), (c + 1, False)):
+        p = sized(abi.make_params("ont", adapters=[synth.ONT_RAPID], min_q=7.0, min_repeat=pval, kmer=31), [read])
+        ctx = capi.Context(p, 0, lib_path)
+        seq, qual, off, ln = synth.pack([read])
+        r, f = ctx.submit(seq, qual, off[:-1].copy(), ln)
+        assert len(f) == 1 and bool(f["flags"][0] & abi.FF_PASS) == kept and bool(f["flags"][0] & abi.FF_REPEAT) == (not kept)
+        ctx.close()
+
+
 def clean_table_strategy(lib_path, mode, golden_dir):
     """Both ways of tallying the clean bin tables (TGSF_CLEAN_TABLES=direct|difference, see k_clean_plan)
     must give the oracle's tallies: trimmed / split / dropped / low-quality / repeat-dropped reads, -F,

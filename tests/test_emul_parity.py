@@ -258,6 +258,13 @@ def test_emul_repeat_gate_shared_prefix_fragment(emul):
         ctx.close()
 
 
+def test_emul_repeat_gate_colliding_hash_values(emul):
+    """28 000 distinct repeated 31-mers constructed to share four hash values of the keys kernel: with ONE hash function no
+    number of passes separates them (checked once by hand: 2^20 passes, then TGSF_E_CAPACITY); the kernel rotates the hash
+    with every restart, and the count is exact on both sides of the gate."""
+    parity.colliding_hash_case(emul)
+
+
 def test_emul_align_windows_beyond_256_bp(emul):
     """Adapters of 257..1280 bp (only reachable with -a; the reference's edlib is multi-block, include/edlib.cpp:182-185) through
     the wide column: edit distance, locations, start and path length as the reference's own edlib reports them."""

@@ -339,6 +339,11 @@ def test_gpu_repeat_gate_shared_prefix_fragment(k):
         ctx.close()
 
 
+def test_gpu_repeat_gate_colliding_hash_values():
+    """Distinct repeated 31-mers constructed to share their hash value (see test_emul_repeat_gate_colliding_hash_values)."""
+    parity.colliding_hash_case(None)
+
+
 def test_gpu_align_windows_beyond_256_bp():
     """Adapters of 257..1280 bp through the wide column against the reference's own edlib (where oracle/_ref is present)."""
     parity.align_windows_random(None, 600, seed=19, lengths=(257, 300, 511, 640, 1000, 1280), max_window=2600)

@@ -2149,6 +2149,7 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
             drop = total - distinct < P.min_repeat;
         } else {
             uint32_t plog = 0;                                         // 2^plog passes
+            uint32_t rot = 19u;                                        // (odd, one of sixteen: see hash_of)
             while (plog < 20u && ((uint32_t)total >> plog) > kRepShare) plog++;
             for (;;) {
                 const uint32_t passes = 1u << plog;
@@ -2165,9 +2166,11 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
                         constexpr bool MULTI = decltype(multi_tag)::value;
                         // what a key's hash selects
                         // (64-bit keys are hashed as they lie in the chunks: x0 = the first sixteen bases, x1 = the rest from bit 31
-                        // down with the bits behind the key cleared -- no 64-bit shift, one multiplication)
+                        // down with the bits behind the key cleared -- no 64-bit shift, one multiplication.  The rotation is another
+                        // with every restart: distinct keys that share a hash value under one share it under another four at a time
+                        // at most (32-bit keys hash one to one))
                         auto hash_of = [&](uint32_t x0, uint32_t x1) TGSF_INLINE_LAMBDA -> uint32_t {
-                            return KEY64 ? ((x1 & tail_mask) ^ alignbit(x0, x0, 19u)) * 0x9E3779B1u : x0 * 0x9E3779B1u;
+                            return KEY64 ? ((x1 & tail_mask) ^ alignbit(x0, x0, rot)) * 0x9E3779B1u : x0 * 0x9E3779B1u;
                         };
                         auto owned = [&](uint32_t h) TGSF_INLINE_LAMBDA -> bool {
                             return !MULTI || ((h ^ (h >> 7)) & (passes - 1u)) == pass;   // (low bits: the map's word comes from the top ones)
@@ -2323,6 +2326,7 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
                 while (want < 20u && (flagged >> (want - plog)) > (1u << (TLOG - 1u))) want++;
                 if (plog >= 20u) { set_status(B, DS_REPEAT_TABLE, B.frag_read[f]); drop = false; TGSF_BLOCK_SYNC(); break; }
                 plog = want;
+                rot = (rot + 6u) & 31u;
 #if defined(TGSF_EMUL) && defined(TGSF_REP_TRACE)
                 fprintf(stderr, "k_repeat_keys: fragment %u (%d k-mers) starts over with %u passes\n", f, total, 1u << plog);
 #endif
