@@ -73,6 +73,10 @@ struct DevBatch {
     uint32_t* mid_gate;        // [n*A] (modes 1, 2) 1 = the first location's path passes the gates: every location counts
     uint32_t* seg_n;           // [segments*A + 1] (modes 1, 2) per (lane, adapter): count, then first slot
     uint32_t* seg_cnt;         // [n+1] middle segments per read, scanned in place to bases
+    uint32_t* chk_cnt;         // [n+1] 16-column chunks of each read's middle window (counted from the window's first column),
+                               // scanned in place: the flat scan (k_mid_flat) deals stretches of this one sequence of chunks
+    uint32_t  flat_pmax, flat_pmin;   // chunks of the longest / shortest stretches, powers of two (see flat_schedule)
+    uint32_t  flat_f0;         // 256ths of the sequence dealt in the longest stretches
     uint32_t* nfr;             // [n+1] fragments per read, scanned in place to frag_begin
     uint32_t* scan_part;       // [n / kScanTile + 2] per-tile totals of the prefix scans
     uint32_t* trimmed;         // [n]
@@ -120,6 +124,40 @@ struct DevBatch {
 TGSF_HD size_t ctr_end_table(int t, int bc_len) { return (size_t)533 + (size_t)t * (size_t)bc_len * 5u; }
 TGSF_HD size_t ctr_bin_table(int b, int bc_len, uint32_t n_bins) {
     return (size_t)533 + 8u * (size_t)bc_len * 5u + (size_t)b * (size_t)n_bins * 5u;
+}
+
+
+// The stretches k_mid_flat deals (see there): the chunk sequence [0, T) is cut into phases; phase 0 covers f0 / 256 of it
+// in stretches of pmax chunks, every later phase half of what is left in stretches half as long, the last (pmin chunks)
+// all the rest -- long stretches while there is plenty (one warm-up per several thousand columns), short ones at the
+// end (the launch ends everywhere within one short stretch).  A phase is a whole number of groups of 64 equal
+// stretches: the 64 lanes of a wave always work the same number of chunks.  pmax and pmin are powers of two (shifts only:
+// every lane of the scan evaluates this).
+struct FlatSchedule {
+    uint32_t nph;
+    uint32_t sh[8];            // log2 of the stretch length of the phase
+    uint32_t c0[9];            // first chunk of the phase (c0[nph] = T)
+    uint32_t d0[9];            // first stretch of the phase (d0[nph] = number of stretches, a multiple of 64)
+};
+TGSF_HD uint32_t flat_log2(uint32_t v) { uint32_t l = 0; while ((2u << l) <= v) l++; return l; }
+TGSF_HD void flat_schedule(uint32_t T, uint32_t pmax, uint32_t pmin, uint32_t f0, FlatSchedule& s)
+{
+    uint64_t c = 0, d = 0, rest = T;
+    const uint32_t shmin = flat_log2(pmin ? pmin : 1u);
+    uint32_t sh = flat_log2(pmax ? pmax : 1u), k = 0;
+    if (sh < shmin) sh = shmin;
+    for (;;) {
+        s.sh[k] = sh; s.c0[k] = (uint32_t)c; s.d0[k] = (uint32_t)d;
+        const bool last = sh <= shmin || k == 7;
+        const uint32_t gsh = sh + 6;                                    // a group: 64 stretches
+        const uint64_t want = last ? rest : (k == 0 ? (rest * f0) >> 8 : rest >> 1);
+        const uint64_t ng = last ? (rest + (1ull << gsh) - 1) >> gsh : want >> gsh;
+        const uint64_t cover = (ng << gsh) < rest ? (ng << gsh) : rest;
+        c += cover; d += ng << 6; rest -= cover; k++;
+        if (last || rest == 0) break;
+        sh--;
+    }
+    s.nph = k; s.c0[k] = (uint32_t)c; s.d0[k] = (uint32_t)d;
 }
 
 enum DevStatus : uint32_t {

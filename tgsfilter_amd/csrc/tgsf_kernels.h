@@ -190,6 +190,7 @@ TGSF_KERNEL k_prepare(DevParams P, DevBatch B, uint32_t max_read_len)
         B.mid_cnt[r] = 0;
         B.trimmed[r] = 0;
         B.seg_cnt[r] = 0;
+        B.chk_cnt[r] = 0;
         B.nfr[r] = 0;
         for (int a = 0; a < A; a++) { B.clip5[(size_t)r * A + a] = 0; B.clip3[(size_t)r * A + a] = -1; B.mid_best[(size_t)r * A + a] = 0x7FFFFFFF; }
         if (L == 0 || L > max_read_len) { set_status(B, DS_BAD_LEN, r); B.len[r] = 0; continue; }
@@ -674,7 +675,7 @@ TGSF_KERNEL k_gate_reads(DevParams P, DevBatch B)
             if (!(mq >= 0.0 && mq < 256.0)) { set_status(B, DS_BAD_MEANQ, r); }
             else {
                 if (!P.no_qual) atomicAdd(&hq[(int)mq], (ull)L);          // :1943 (records with qualities only, :1941)
-                uint32_t segs = 0;
+                uint32_t segs = 0, chunks = 0;
                 if (P.filter) {
                     if (!P.no_qual && q_fail(mq, P.min_q, P.max_q)) {
                         B.flags[r] = TGSF_RF_LOWQ;
@@ -686,10 +687,12 @@ TGSF_KERNEL k_gate_reads(DevParams P, DevBatch B)
                             const uint64_t a0 = (uint64_t)(uintptr_t)B.seq + B.off[r] + (uint64_t)P.end_len;
                             const uint64_t S = (uint64_t)P.seg_cols;
                             segs = (uint32_t)((a0 + (uint64_t)ML - 1) / S - a0 / S + 1);
+                            chunks = ((uint32_t)ML + 15u) >> 4;           // k_mid_flat: 16 columns at a time from the window's start
                         }
                     }
                 }
                 B.seg_cnt[r] = segs;
+                B.chk_cnt[r] = chunks;
             }
         }
     }
@@ -1466,6 +1469,186 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
         flush_ties(j);
         if (B.mid_mode == 1u && j < na && slot[j]) B.seg_n[(size_t)g * P.n_adapters + a0 + j] = slot[j];
     }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_mid_flat: the same search as k_mid_scan1 (first scan of a batch, mid_mode 0), with the work dealt differently.
+//
+// k_mid_scan1 gives every lane one 1 024-column block of the address space: each lane pays Q + k warm-up columns
+// (7 %), the first and last block of a read are partial while their wave runs as long as its fullest lane, and
+// unaligned heads and tails are stepped one column at a time in front of 63 waiting lanes.  Here the middle windows
+// of a batch are ONE sequence of 16-column chunks (chk_cnt: chunks counted from each window's first column,
+// prefix-summed over the reads), cut into stretches by flat_schedule (tgsf_dev.h): long ones (thousands of columns:
+// one warm-up for all of them) for most of the sequence, shorter and shorter ones at its end, so that the launch ends
+// everywhere within one short stretch.  Lane i of the grid takes stretch i -- no counter, no hand-out: the order in
+// which the hardware starts the workgroups is the queue, as it is for k_mid_scan1 (a returning atomic on one word per
+// stretch was measured: it paces the whole launch at ~20 stretches per microsecond) -- and the 64 lanes of a wave
+// always hold 64 stretches of one length.  A stretch runs across read boundaries: the lane hands over what it holds for
+// the read it leaves and starts the next window from its first column (no warm-up needed there).  Chunks are counted
+// from the window's start, not from an aligned address, so the text is fetched with unaligned 16-byte loads, one chunk
+// ahead of the columns, and no column is ever stepped alone; the last chunk of a window may hold fewer than 16
+// columns: the bytes behind them (the read's 3' end window) go through the column as well -- the state is not used
+// again -- and only columns inside the window are recorded.
+//
+// The candidates handed over and the minima in mid_best obey the same rules as k_mid_scan1's (a lane hands over
+// the columns tying the best value it has seen in ITS stretch of a read, if that is no worse than the read's best so
+// far), so everything behind the scan -- and the position-ordered scans after a pool overflow, which stay with
+// k_mid_scan1 -- is unchanged.
+// ---------------------------------------------------------------------------
+#if defined(TGSF_EMUL)
+TGSF_D uint4 load16u(const uint8_t* p) { uint4 v; memcpy(&v, p, 16); return v; }
+#else
+struct __attribute__((packed, aligned(1))) U4u { uint32_t x, y, z, w; };
+TGSF_D uint4 load16u(const uint8_t* p) { const U4u* q = reinterpret_cast<const U4u*>(p); return make_uint4(q->x, q->y, q->z, q->w); }
+#endif
+// the first nvalid bytes at p (the rest zero): the last chunk of a window when fewer than 15 bytes follow it
+TGSF_D uint4 load_upto16(const uint8_t* p, int nvalid)
+{
+    uint32_t d[4] = {0u, 0u, 0u, 0u};
+    for (int i = 0; i < nvalid && i < 16; i++) d[i >> 2] |= (uint32_t)p[i] << (8 * (i & 3));
+    uint4 v; v.x = d[0]; v.y = d[1]; v.z = d[2]; v.w = d[3];
+    return v;
+}
+
+template <int AT, class HT = Hot>
+TGSF_KERNEL k_mid_flat(DevParams P, DevBatch B, int a0, int na)
+{
+    typedef decltype(hot_eq(HT(), 0ull)) eq_t;
+    TGSF_SHARED eq_t eqt[256][AT];
+    TGSF_SHARED int32_t tie_col[256][AT][4];
+    for (uint32_t i = TGSF_COOP_BEGIN; i < 256u * AT; i += TGSF_COOP_STRIDE) {
+        uint32_t sym = i / AT, j = i % AT;
+        eqt[sym][j] = (int)j < na ? hot_eq(HT(), P.peq_top[(size_t)(a0 + j) * 256 + sym]) : (eq_t)0;
+    }
+    TGSF_BLOCK_SYNC();
+    const int E = P.end_len;
+    // values <= k are exact once the Q + k - 1 columns before them have gone through the column (an alignment within k
+    // spans at most Q + k columns of text)
+    int wu = 0;
+    for (int j = 0; j < na; j++) { const int a = a0 + j; if (P.k_mid[a] >= 0) { const int w = P.Q[a] + P.k_mid[a] - 1; wu = w > wu ? w : wu; } }
+    const uint32_t wuc = (uint32_t)(wu + 15) >> 4;
+    int32_t (*ties)[4] = tie_col[threadIdx.x];
+    FlatSchedule S;
+    flat_schedule(B.chk_cnt[B.n], B.flat_pmax, B.flat_pmin, B.flat_f0, S);
+
+    // (the host launches one lane per stretch of the longest sequence the batch can have; the emulation's small grid strides)
+    for (uint32_t d = gtid(); d < S.d0[S.nph]; d += gsize()) {
+        uint32_t ph = 0;
+        while (ph + 1 < S.nph && d >= S.d0[ph + 1]) ph++;
+        const uint64_t first64 = (uint64_t)S.c0[ph] + ((uint64_t)(d - S.d0[ph]) << S.sh[ph]);
+        if (first64 >= (uint64_t)S.c0[ph + 1]) continue;                 // (the last group of a phase may not be full)
+        const uint32_t first = (uint32_t)first64;
+        uint32_t left = S.c0[ph + 1] - first;                            // owned chunks still to do
+        if (left > (1u << S.sh[ph])) left = 1u << S.sh[ph];
+        uint32_t r = find_owner(B.chk_cnt, B.n, first);
+
+        HT st[AT];
+        int lim[AT];              // best bottom-row value seen so far in the owned columns of this read (k+1: none yet)
+        int lim3[AT];             // the every-4th-column test (see k_mid_scan1)
+        int ntie[AT];             // buffered columns attaining it
+        const uint8_t* mid = nullptr;
+        int ML = 0, c = 0, own_from = 0, cend = 0, cfull = 0;
+        auto open_read = [&](uint32_t ck) TGSF_INLINE_LAMBDA {
+            ML = (int)B.len[r] - 2 * E;
+            mid = B.seq + B.off[r] + E;
+            cend = (ML + 15) & ~15;
+            // chunks below cfull are fetched whole (16 bytes that lie inside the read): all of them unless -E is below 15
+            cfull = E >= 15 ? cend : (ML + E) & ~15;
+#pragma unroll
+            for (int j = 0; j < AT; j++) {
+                const int a = a0 + j;
+                const bool on = j < na && ML >= P.Q[a] && P.k_mid[a] >= 0;            // :1237 tsmLen >= qLen
+                hot_init(st[j], j < na ? P.Q[a] : 1);
+                lim[j] = on ? P.k_mid[a] + 1 : -1000;
+                lim3[j] = lim[j] + 2;
+                ntie[j] = 0;
+            }
+            c = ck > wuc ? (int)((ck - wuc) << 4) : 0;
+            own_from = (int)(ck << 4);
+        };
+        auto flush_ties = [&](int j) TGSF_INLINE_LAMBDA {
+            if (ntie[j] > 0 && worth_handing_over(B, r, a0 + j, P.n_adapters, lim[j]))
+                for (int i = 0; i < ntie[j]; i++) push_candidate(B, r, ties[j][i], lim[j], a0 + j);
+            ntie[j] = 0;
+        };
+        auto note = [&](int j, int sc, int col) TGSF_INLINE_LAMBDA {
+            if (sc < lim[j]) { lim[j] = sc; lim3[j] = sc + 3; ntie[j] = 0; }   // strictly better: older ties are void
+            if (sc == lim[j]) {
+                if (ntie[j] == 4) flush_ties(j);
+                ties[j][ntie[j]++] = col;
+            }
+        };
+        auto step_all = [&](uint32_t byte) TGSF_INLINE_LAMBDA {
+#pragma unroll
+            for (int j = 0; j < AT; j++) hot_step(st[j], eqt[byte][j]);
+        };
+        // 16 columns starting at column cc0 of the window; `own`: the lane records candidates there (not in the warm-up)
+        auto chunk16 = [&](const uint4& v, int cc0, bool own) TGSF_INLINE_LAMBDA {
+            const uint32_t dw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                HT h1[AT], h2[AT], h3[AT];
+                step_all(dw[k] & 0xFFu);
+#pragma unroll
+                for (int j = 0; j < AT; j++) h1[j] = st[j];
+                step_all((dw[k] >> 8) & 0xFFu);
+#pragma unroll
+                for (int j = 0; j < AT; j++) h2[j] = st[j];
+                step_all((dw[k] >> 16) & 0xFFu);
+#pragma unroll
+                for (int j = 0; j < AT; j++) h3[j] = st[j];
+                step_all(dw[k] >> 24);
+                bool any = false;
+#pragma unroll
+                for (int j = 0; j < AT; j++) any |= hot_within(st[j], lim3[j]);
+                if (__builtin_expect(any && own, 0)) {          // a few % of the tests: keep this code out of the hot loop
+                    const int cc = cc0 + 4 * k;
+#pragma unroll
+                    for (int j = 0; j < AT; j++) {
+                        const int s4j = hot_score(st[j]);
+                        const int s1 = hot_score(h1[j]), s2 = hot_score(h2[j]), s3 = hot_score(h3[j]);
+                        // (columns at or beyond ML: bytes behind the window that went through the column with its last chunk)
+                        if (cc < ML && (s1 < lim[j] || (s1 == lim[j] && ntie[j] > 0))) note(j, s1, cc);
+                        if (cc + 1 < ML && (s2 < lim[j] || (s2 == lim[j] && ntie[j] > 0))) note(j, s2, cc + 1);
+                        if (cc + 2 < ML && (s3 < lim[j] || (s3 == lim[j] && ntie[j] > 0))) note(j, s3, cc + 2);
+                        if (cc + 3 < ML && (s4j < lim[j] || (s4j == lim[j] && ntie[j] > 0))) note(j, s4j, cc + 3);
+                    }
+                }
+            }
+        };
+
+        open_read(first - B.chk_cnt[r]);
+        // the text one chunk ahead: a chunk is fetched while the one before it goes through the columns
+        uint4 nxt = load16u(c < cfull ? mid + c : mid);
+        while (left > 0u) {
+            if (__builtin_expect(c >= cfull, 0)) {
+                if (c < cend) {
+                    // the window's last columns with fewer than 15 bytes of the read behind them (-E below 15): byte by
+                    // byte, never reading beyond the read
+                    const bool own = c >= own_from;
+                    chunk16(load_upto16(mid + c, ML + E - c), c, own);
+                    c += 16;
+                    left -= own ? 1u : 0u;
+                    continue;
+                }
+                // the window is done: on to the next read that has one
+#pragma unroll
+                for (int j = 0; j < AT; j++) flush_ties(j);
+                do { r++; } while (B.chk_cnt[r + 1] == B.chk_cnt[r]);
+                open_read(0u);
+                if (c < cfull) nxt = load16u(mid + c);
+                continue;
+            }
+            const uint4 cur = nxt;
+            if (c + 16 < cfull) nxt = load16u(mid + c + 16);
+            const bool own = c >= own_from;
+            chunk16(cur, c, own);
+            c += 16;
+            left -= own ? 1u : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < AT; j++) flush_ties(j);
     }
 }
 

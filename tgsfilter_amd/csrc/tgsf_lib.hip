@@ -48,6 +48,7 @@ struct tgsf_ctx {
     uint32_t cap_reads, max_read_len, n_bins;
     unsigned endtab_grid = 512;             // k_end_tables: LDS-atomic bound, 40 KB of LDS per block: two blocks per CU (128: 0.36 ms, 512: 0.19 ms)
     unsigned stats_grid = 768, mid_grid = 0;   // tuning knobs (TGSF_STATS_GRID, TGSF_MID_GRID; 0 = one lane per segment)
+    bool flat_scan = true;                    // first middle scan of a batch by k_mid_flat (TGSF_MID_FLAT=0: k_mid_scan1, as after a pool overflow)
     bool no_hot32 = false;                    // TGSF_NO_HOT32=1: adapters <= 32 bp take the 64-bit column too (A/B, tests)
     bool stats_nt = true;                     // k_stats fetches the text with non-temporal loads (2.24 -> 2.06 ms raw, 5.4 -> 5.8 TB/s; TGSF_STATS_NT=0: plain loads)
     uint64_t ctr_words;
@@ -475,10 +476,19 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     if (const char* e = getenv("TGSF_ENDTAB_GRID")) { int v = atoi(e); if (v >= 1 && v <= 4096) c->endtab_grid = (unsigned)v; }
     if (const char* e = getenv("TGSF_MID_GRID")) { int v = atoi(e); if (v >= 1) c->mid_grid = (unsigned)v; }
     if (const char* e = getenv("TGSF_SEG_COLS")) { int v = atoi(e); if (v >= 256 && v <= 65536) P.seg_cols = v & ~15; }   // tuning knob
+    if (const char* e = getenv("TGSF_MID_FLAT")) c->flat_scan = atoi(e) > 0;
 
     int e = build_tables(c);
     DevBatch& B = c->B;
     memset(&B, 0, sizeof B);
+    // k_mid_flat's schedule (flat_schedule): 15/16 of a batch's chunks in stretches of 128 (2 048 columns: the warm-up is
+    // 4 % of that), the rest in stretches halving down to 16 chunks (the launch ends everywhere within 256 columns)
+    B.flat_pmax = 128; B.flat_pmin = 16; B.flat_f0 = 240;
+    if (const char* e = getenv("TGSF_FLAT_PMIN")) { int v = atoi(e); if (v >= 1 && v <= (1 << 20)) B.flat_pmin = (uint32_t)v; }
+    if (const char* e = getenv("TGSF_FLAT_PMAX")) { int v = atoi(e); if (v >= 1 && v <= (1 << 20)) B.flat_pmax = (uint32_t)v; }
+    if (const char* e = getenv("TGSF_FLAT_F0")) { int v = atoi(e); if (v >= 0 && v <= 256) B.flat_f0 = (uint32_t)v; }
+    B.flat_pmin = 1u << flat_log2(B.flat_pmin); B.flat_pmax = 1u << flat_log2(B.flat_pmax);
+    if (B.flat_pmax < B.flat_pmin) B.flat_pmax = B.flat_pmin;
     const size_t n = c->cap_reads;
     const int A = p->n_adapters > 0 ? p->n_adapters : 1;
     // every read start may be padded to 16 bytes by the caller
@@ -512,6 +522,8 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     if (!e) e = dev_alloc(c, &B.pool, (size_t)B.pool_cap);
     if (!e) e = dev_alloc(c, &B.pool_n, 4);
     if (!e) e = dev_alloc(c, &B.seg_cnt, n + 1);
+    if (!e) e = dev_alloc(c, &B.chk_cnt, n + 1);
+    if (c->cap_bases / 16u + n >= 0xFFFFFFF0ull) c->flat_scan = false;   // (chunk numbers are 32 bits: such a context keeps k_mid_scan1)
     if (!e) e = dev_alloc(c, &B.nfr, n + 1);
     if (!e) e = dev_alloc(c, &B.scan_part, n / kScanTile + 2);
     if (!e) e = dev_alloc(c, &B.trimmed, n);
@@ -713,7 +725,20 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     STAGE_MARK();
     STAGE_MARK();
     if (P.filter && A > 0) {
-        if (!redo) scan_u32(B, B.seg_cnt, n, st);       // (in place: a redo finds the prefix sums of the first run)
+        // the first scan of a batch by the flat kernel (adapters of at most 64 bp); one lane per stretch of the schedule:
+        // the number of stretches is known on the device only, so the grid covers the longest sequence the batch can have
+        const bool flat = c->flat_scan && !redo;
+        unsigned gflat = 1;
+        if (!redo) {
+            scan_u32(B, B.seg_cnt, n, st);              // (in place: a redo finds the prefix sums of the first run)
+            if (flat) {
+                scan_u32(B, B.chk_cnt, n, st);
+                FlatSchedule S;
+                const uint64_t tb = std::min<uint64_t>(in->n_bytes / 16u + (uint64_t)n, c->cap_bases / 16u + c->cap_reads);
+                flat_schedule((uint32_t)tb, B.flat_pmax, B.flat_pmin, B.flat_f0, S);
+                gflat = grid_cap(blocks_for((uint64_t)S.d0[S.nph] + 64u * 8u, T));   // (phase ends round up to whole groups)
+            }
+        }
         // upper bound of the segment count, known on the host: no device round trip
         const uint64_t max_segs = in->n_bytes / (uint64_t)P.seg_cols + 2ull * n + 1;
         const unsigned gseg = blocks_for(max_segs, T);
@@ -736,6 +761,22 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
                 const bool narrow = P.Q[a] <= 32 && !c->no_hot32;
                 int na = 0;
                 while (a + na < A && na < 4 && P.Q[a + na] <= 64 && ((P.Q[a + na] <= 32 && !c->no_hot32) == narrow)) na++;
+                if (flat && mode == 0) {
+                    if (narrow) switch (na) {
+                    case 1: TGSF_LAUNCH((k_mid_flat<1, Hot32>), gflat, T, ms, P, Bm, a, na); break;
+                    case 2: TGSF_LAUNCH((k_mid_flat<2, Hot32>), gflat, T, ms, P, Bm, a, na); break;
+                    case 3: TGSF_LAUNCH((k_mid_flat<3, Hot32>), gflat, T, ms, P, Bm, a, na); break;
+                    default: TGSF_LAUNCH((k_mid_flat<4, Hot32>), gflat, T, ms, P, Bm, a, na); break;
+                    }
+                    else switch (na) {
+                    case 1: TGSF_LAUNCH((k_mid_flat<1, Hot>), gflat, T, ms, P, Bm, a, na); break;
+                    case 2: TGSF_LAUNCH((k_mid_flat<2, Hot>), gflat, T, ms, P, Bm, a, na); break;
+                    case 3: TGSF_LAUNCH((k_mid_flat<3, Hot>), gflat, T, ms, P, Bm, a, na); break;
+                    default: TGSF_LAUNCH((k_mid_flat<4, Hot>), gflat, T, ms, P, Bm, a, na); break;
+                    }
+                    a += na;
+                    continue;
+                }
                 if (narrow) switch (na) {
                 case 1: TGSF_LAUNCH((k_mid_scan1<1, Hot32>), gmid, T, ms, P, Bm, a, na); break;
                 case 2: TGSF_LAUNCH((k_mid_scan1<2, Hot32>), gmid, T, ms, P, Bm, a, na); break;
