@@ -233,6 +233,50 @@ def colliding_hash_case(lib_path):
         ctx.close()
 
 
+def mid_scan_variants(lib_path, golden_dir, env):
+    """The first middle scan of a batch under `env`: TGSF_MID_FLAT=0 (k_mid_scan1, one 1 024-column block per lane) or
+    k_mid_flat with the given stretch schedule (TGSF_FLAT_PMIN / _PMAX / _F0: stretches down to ONE chunk, so that every
+    read is cut into many stretches with their warm-ups, stretches run across read boundaries and phases end in partial
+    groups).  Goldens with middle hits and splits, random batches with planted middle adapters, unpadded CSR (windows
+    at every alignment), -E below 15 (the last chunk of a window fetched byte by byte), 1 to 4 adapters per pass and
+    the one-dword column."""
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        for name in ("ont_zoo", "hifi_zoo", "ont_discard"):
+            golden_case(lib_path, golden_dir, name)
+        ads = [synth.ONT_RAPID, synth.ONT_RAPID_RC]
+        reads = synth.make_reads(801, 70, "ont", mean_len=5000, zoo=True, pmid=0.3)
+        p = sized(abi.make_params("ont", adapters=ads, min_q=8.0), reads)
+        ctx = capi.Context(p, 0, lib_path)
+        compare_batch(ctx, p, reads)
+        ctx.close()
+        ctx = capi.Context(p, 0, lib_path)
+        compare_batch(ctx, p, reads, align=1, explicit_lengths=False)       # unpadded CSR: windows at every alignment
+        ctx.close()
+        for e_len in (0, 3, 14, 15, 16, 40):                                 # -E: bytes of the read behind the window
+            reads = synth.make_reads(802 + e_len, 40, "ont", mean_len=1500, zoo=True, pmid=0.4)
+            p = sized(abi.make_params("ont", adapters=ads, min_q=8.0, end_len=e_len, min_len=100), reads)
+            ctx = capi.Context(p, 0, lib_path)
+            compare_batch(ctx, p, reads, align=1, explicit_lengths=False)
+            ctx.close()
+        # three and four adapters in one pass (33..64 bp), and a pair of at most 32 bp (the one-dword column)
+        for k, adset in enumerate(([synth.ONT_RAPID, synth.ONT_RAPID_RC, synth.PACBIO_BLUNT],
+                                   [synth.ONT_RAPID, synth.ONT_RAPID_RC, synth.PACBIO_BLUNT, synth.PACBIO_BLUNT_RC],
+                                   [synth.ONT_RAPID[:28], synth.ONT_RAPID_RC[-28:]])):
+            reads = synth.make_reads(820 + k, 40, "ont", mean_len=3000, zoo=True, pmid=0.3)
+            p = sized(abi.make_params("ont", adapters=adset, min_q=8.0, mid_match_len=24 if k == 2 else 35), reads)
+            ctx = capi.Context(p, 0, lib_path)
+            compare_batch(ctx, p, reads)
+            ctx.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def clean_table_strategy(lib_path, mode, golden_dir):
     """Both ways of tallying the clean bin tables (TGSF_CLEAN_TABLES=direct|difference, see k_clean_plan)
     must give the oracle's tallies: trimmed / split / dropped / low-quality / repeat-dropped reads, -F,

@@ -177,16 +177,23 @@ def test_gpu_repeat_gate_pass_seams(k, plant):
     parity.repeat_threshold_case(None, k, parity.REPEAT_SHARE, max_runs=8, share=True, plant=plant, extra_thresholds=(40, 100, 2500))
 
 
+# The first middle scan of a batch: k_mid_scan1 (TGSF_MID_FLAT=0) and k_mid_flat under stretch schedules from one chunk
+# per stretch (every read cut into hundreds of stretches, each with its warm-up) to the default
+MID_SCAN_ENVS = [{"TGSF_MID_FLAT": "0"},
+                 {"TGSF_FLAT_PMIN": "1", "TGSF_FLAT_PMAX": "1", "TGSF_FLAT_F0": "128"},
+                 {"TGSF_FLAT_PMIN": "1", "TGSF_FLAT_PMAX": "8", "TGSF_FLAT_F0": "100"},
+                 {"TGSF_FLAT_PMIN": "4", "TGSF_FLAT_PMAX": "64", "TGSF_FLAT_F0": "250"},
+                 {"TGSF_FLAT_PMIN": "16", "TGSF_FLAT_PMAX": "256", "TGSF_FLAT_F0": "224"}]
+
+
+@pytest.mark.parametrize("env", MID_SCAN_ENVS, ids=lambda e: "-".join(f"{k[5:].lower()}{v}" for k, v in e.items()))
+def test_gpu_mid_scan_variants(golden_dir, env):
+    parity.mid_scan_variants(None, golden_dir, env)
+
+
 @pytest.mark.parametrize("mode", ["direct", "difference"])
 def test_gpu_clean_table_strategy(golden_dir, mode):
     parity.clean_table_strategy(None, mode, golden_dir)
-
-
-@pytest.mark.parametrize("k,plant", [(13, 0), (15, 90), (16, 0), (16, 95), (22, 140), (31, 60)])
-def test_gpu_repeat_gate_pass_seams(k, plant):
-    """k_repeat_keys around its pass sizes (one pass, two, four), -p on either side of what the first scan flags and of
-    the exact count (see test_emul_repeat_gate_pass_seams)."""
-    parity.repeat_threshold_case(None, k, parity.REPEAT_SHARE, max_runs=8, share=True, plant=plant, extra_thresholds=(40, 100, 2500))
 
 
 @pytest.mark.parametrize("mode", ["direct", "difference"])

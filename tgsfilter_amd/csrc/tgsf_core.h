@@ -210,7 +210,18 @@ TGSF_HD int popc64_acc(uint64_t x, int acc) {
 }
 TGSF_HD int hot_score(const Hot& s) { return (int)popc64(s.p) - (int)popc64(s.m); }
 // bottom-row value <= lim  <=>  popcount(Pv) <= popcount(Mv) + lim
-TGSF_HD bool hot_within(const Hot& s, int lim) { return popc64_acc(s.p, 0) <= popc64_acc(s.m, lim); }
+TGSF_HD bool hot_within(const Hot& s, int lim) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // two accumulating v_bcnt_u32_b32 per side (the builtin: inline assembly makes the compiler pad the chain with s_nop)
+    const uint32_t p = (uint32_t)__builtin_popcount((uint32_t)(s.p >> 32)) + (uint32_t)__builtin_popcount((uint32_t)s.p);
+    uint32_t m = (uint32_t)__builtin_popcount((uint32_t)s.m) + (uint32_t)lim;
+    asm volatile("" : "+v"(m));                          // (keeps the sum from being regrouped into two plain counts and a three-input add)
+    m = (uint32_t)__builtin_popcount((uint32_t)(s.m >> 32)) + m;
+    return (int)p <= (int)m;
+#else
+    return popc64_acc(s.p, 0) <= popc64_acc(s.m, lim);
+#endif
+}
 TGSF_HD uint64_t hot_eq(const Hot&, uint64_t top) { return top; }
 
 // The same column for adapters of at most 32 bp (8 of the reference's 22 library adapters, src/TGSFilter.cpp:2974-2989:

@@ -1511,11 +1511,20 @@ TGSF_D uint4 load_upto16(const uint8_t* p, int nvalid)
     return v;
 }
 
+TGSF_D bool wave_any(bool b)
+{
+#if defined(TGSF_EMUL)
+    return b;
+#else
+    return __builtin_amdgcn_ballot_w64(b) != 0ull;
+#endif
+}
+
 template <int AT, class HT = Hot>
 TGSF_KERNEL k_mid_flat(DevParams P, DevBatch B, int a0, int na)
 {
     typedef decltype(hot_eq(HT(), 0ull)) eq_t;
-    TGSF_SHARED eq_t eqt[256][AT];
+    TGSF_SHARED eq_t eqt[256][AT] __attribute__((aligned(16)));
     TGSF_SHARED int32_t tie_col[256][AT][4];
     for (uint32_t i = TGSF_COOP_BEGIN; i < 256u * AT; i += TGSF_COOP_STRIDE) {
         uint32_t sym = i / AT, j = i % AT;
@@ -1619,36 +1628,58 @@ TGSF_KERNEL k_mid_flat(DevParams P, DevBatch B, int a0, int na)
         };
 
         open_read(first - B.chk_cnt[r]);
-        // the text one chunk ahead: a chunk is fetched while the one before it goes through the columns
-        uint4 nxt = load16u(c < cfull ? mid + c : mid);
-        while (left > 0u) {
-            if (__builtin_expect(c >= cfull, 0)) {
-                if (c < cend) {
+        // The loop below keeps every lane of the wave in one instruction stream without masks: the rare events of a lane
+        // (its window has no further whole chunk; its stretch is done) are looked for once per chunk with a wave-wide
+        // test and handled outside the hot body, and a lane that is done "parks": it keeps stepping over the same 16
+        // readable bytes, recording nothing, until its wave is done.  The text is fetched one chunk ahead of the
+        // columns (the chunk after the window's last whole one: that one again, never used).
+        const uint8_t* const safe = reinterpret_cast<const uint8_t*>(P.peq_top);     // 16 readable bytes for parked lanes
+        int dc = 16;
+        bool parked = false;
+        uint4 nxt = load16u(c < cfull ? mid + c : safe);
+        for (;;) {
+            // the hot loop: nothing but chunks, until some lane of the wave has an event (two chunks per trip: the
+            // copies the compiler makes of the loop-carried registers at the top of a trip are paid half as often)
+            auto chunk = [&]() TGSF_INLINE_LAMBDA {
+                const uint4 cur = nxt;
+                int pf = c + dc;
+                pf = pf < cfull - 16 ? pf : cfull - 16;
+                nxt = load16u(mid + pf);
+                const bool own = c >= own_from;
+                chunk16(cur, c, own);
+                c += dc;
+                left -= own ? 1u : 0u;
+            };
+            for (;;) {
+                if (wave_any(!parked && (left == 0u || c >= cfull))) break;
+                chunk();
+                if (wave_any(!parked && (left == 0u || c >= cfull))) break;
+                chunk();
+            }
+            if (!parked && (left == 0u || c >= cfull)) {
+                if (left == 0u) {                                         // the stretch is done
+#pragma unroll
+                    for (int j = 0; j < AT; j++) flush_ties(j);
+                    parked = true; dc = 0; c = 0; own_from = 0x7FFFFFFF; cfull = 0x7FFFFFFF; cend = 0x7FFFFFFF; ML = 0;
+                    mid = safe;
+                    nxt = load16u(safe);
+                } else if (c < cend) {
                     // the window's last columns with fewer than 15 bytes of the read behind them (-E below 15): byte by
                     // byte, never reading beyond the read
                     const bool own = c >= own_from;
                     chunk16(load_upto16(mid + c, ML + E - c), c, own);
                     c += 16;
                     left -= own ? 1u : 0u;
-                    continue;
+                } else {                                                  // the window is done: on to the next read that has one
+#pragma unroll
+                    for (int j = 0; j < AT; j++) flush_ties(j);
+                    do { r++; } while (B.chk_cnt[r + 1] == B.chk_cnt[r]);
+                    open_read(0u);
+                    nxt = load16u(c < cfull ? mid + c : safe);
                 }
-                // the window is done: on to the next read that has one
-#pragma unroll
-                for (int j = 0; j < AT; j++) flush_ties(j);
-                do { r++; } while (B.chk_cnt[r + 1] == B.chk_cnt[r]);
-                open_read(0u);
-                if (c < cfull) nxt = load16u(mid + c);
-                continue;
             }
-            const uint4 cur = nxt;
-            if (c + 16 < cfull) nxt = load16u(mid + c + 16);
-            const bool own = c >= own_from;
-            chunk16(cur, c, own);
-            c += 16;
-            left -= own ? 1u : 0u;
+            if (!wave_any(!parked)) break;
         }
-#pragma unroll
-        for (int j = 0; j < AT; j++) flush_ties(j);
     }
 }
 

@@ -481,9 +481,9 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     int e = build_tables(c);
     DevBatch& B = c->B;
     memset(&B, 0, sizeof B);
-    // k_mid_flat's schedule (flat_schedule): 15/16 of a batch's chunks in stretches of 128 (2 048 columns: the warm-up is
-    // 4 % of that), the rest in stretches halving down to 16 chunks (the launch ends everywhere within 256 columns)
-    B.flat_pmax = 128; B.flat_pmin = 16; B.flat_f0 = 240;
+    // k_mid_flat's schedule (flat_schedule): 7/8 of a batch's chunks in stretches of 256 (4 096 columns: the warm-up is
+    // 2 % of that), the rest in stretches halving down to 16 chunks (the launch ends everywhere within 256 columns)
+    B.flat_pmax = 256; B.flat_pmin = 16; B.flat_f0 = 224;
     if (const char* e = getenv("TGSF_FLAT_PMIN")) { int v = atoi(e); if (v >= 1 && v <= (1 << 20)) B.flat_pmin = (uint32_t)v; }
     if (const char* e = getenv("TGSF_FLAT_PMAX")) { int v = atoi(e); if (v >= 1 && v <= (1 << 20)) B.flat_pmax = (uint32_t)v; }
     if (const char* e = getenv("TGSF_FLAT_F0")) { int v = atoi(e); if (v >= 0 && v <= 256) B.flat_f0 = (uint32_t)v; }
