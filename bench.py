@@ -56,7 +56,7 @@ def kernel_source_hash():
     """Identifies the kernel sources a profile was taken with (profiles/traffic.json is stamped with it)."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "tgsfilter_amd", "csrc")
-    for fn in ("tgsf_core.h", "tgsf_dev.h", "tgsf_kernels.h", "tgsf_lib.hip"):
+    for fn in ("tgsf_hip.h", "tgsf_core.h", "tgsf_dev.h", "tgsf_kernels.h", "tgsf_lib.hip"):
         h.update(open(os.path.join(d, fn), "rb").read())
     return h.hexdigest()[:16]
 

@@ -17,92 +17,18 @@
 //   k_frag_prepare + sort + k_stats<clean> + k_gate_frags + k_end_tables<clean>
 //   k_finalize       tgsf_read_result / tgsf_fragment records
 //
-// Reference lines are cited at each kernel.  The file compiles for the device
-// (hipcc) and, with -DTGSF_EMUL, as plain C++ for tests/emul (serial emulation).
+// Reference lines are cited at each kernel.  Device code on the primitives of tgsf_hip.h; tests/emul compiles
+// the same file on tgsf_emul.h (serial emulation, test infrastructure).
 #pragma once
 #include <type_traits>
 #include "tgsf_dev.h"
 #include "../../include/tgsf.h"
 static_assert(TGSF_CTR_END_TABLES == 533, "tally layout");
 
-// ---------------------------------------------------------------------------
-// execution-model shims
-// ---------------------------------------------------------------------------
-#if defined(TGSF_EMUL)
-namespace tgsf_emul {
-struct Dim3 { unsigned x, y, z; };
-extern thread_local Dim3 threadIdx, blockIdx, blockDim, gridDim;
-}
-using tgsf_emul::threadIdx; using tgsf_emul::blockIdx; using tgsf_emul::blockDim; using tgsf_emul::gridDim;
-#define TGSF_KERNEL static void
-#define TGSF_INLINE_LAMBDA
-#define TGSF_BOUNDS(threads, waves_per_simd)
-#define TGSF_SHARED static thread_local      /* contexts may run on several host threads at once */
-#define TGSF_BLOCK_SYNC() ((void)0)
-#define TGSF_WAVE_SYNC() ((void)0)
-// cooperative loops: every emulated thread performs all iterations (idempotent fills)
-#define TGSF_COOP_BEGIN 0u
-#define TGSF_COOP_STRIDE 1u
-#define TGSF_WCOOP_BEGIN(lane) 0u
-#define TGSF_WCOOP_STRIDE 1u
-template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
-template <class T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
-template <class T> static inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
-template <class T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
-template <class T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
-template <class T> static inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
-#else
-#define TGSF_KERNEL __global__ void
-#define TGSF_INLINE_LAMBDA __attribute__((always_inline))
-#define TGSF_BOUNDS(threads, waves_per_simd) __launch_bounds__(threads, waves_per_simd)
-#define TGSF_SHARED __shared__
-#define TGSF_BLOCK_SYNC() __syncthreads()
-#define TGSF_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
-#define TGSF_COOP_BEGIN threadIdx.x
-#define TGSF_COOP_STRIDE blockDim.x
-#define TGSF_WCOOP_BEGIN(lane) (lane)
-#define TGSF_WCOOP_STRIDE 64u
-#endif
-
 namespace tgsf {
 
 typedef unsigned long long ull;
 
-// ---- wave-level reductions (emulation: one lane at a time, every lane is a leader) ----
-TGSF_D uint64_t wave_sum(uint64_t v) {
-#if defined(TGSF_EMUL)
-    return v;
-#else
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-#endif
-}
-TGSF_D uint32_t wave_max(uint32_t v) {
-#if defined(TGSF_EMUL)
-    return v;
-#else
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { uint32_t u = __shfl_xor(v, o, 64); v = u > v ? u : v; }
-    return v;
-#endif
-}
-TGSF_D uint32_t wave_or(uint32_t v) {
-#if defined(TGSF_EMUL)
-    return v;
-#else
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
-    return v;
-#endif
-}
-TGSF_D bool wave_leader() {
-#if defined(TGSF_EMUL)
-    return true;
-#else
-    return (threadIdx.x & 63u) == 0u;
-#endif
-}
 // add a per-lane contribution to one global u64 word: one atomic per wave.
 // Must be reached by all lanes of the wave (pass 0 for lanes with nothing to add).
 TGSF_D void wave_add_u64(uint64_t* dst, uint64_t v) {
@@ -405,31 +331,6 @@ TGSF_KERNEL k_build_work(DevBatch B)
         B.work[2 * (size_t)w] = e;
         B.work[2 * (size_t)w + 1] = q;
     }
-}
-
-TGSF_D uint32_t wave_bcast(uint32_t v, uint32_t src_lane) {
-#if defined(TGSF_EMUL)
-    (void)src_lane; return v;
-#else
-    return (uint32_t)__shfl((int)v, (int)src_lane, 64);
-#endif
-}
-// lane src_lane's value as a wave-uniform (scalar) value; src_lane must be wave-uniform
-TGSF_D uint32_t wave_pick(uint32_t v, uint32_t src_lane) {
-#if defined(TGSF_EMUL)
-    (void)src_lane; return v;
-#else
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src_lane);
-#endif
-}
-TGSF_D int32_t wave_sum_i32(int32_t v) {
-#if defined(TGSF_EMUL)
-    return v;
-#else
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-#endif
 }
 
 // 51 KB of LDS per block already limits a CU to 3 blocks (3 waves per SIMD): take that register budget
@@ -1496,12 +1397,6 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
 // far), so everything behind the scan -- and the position-ordered scans after a pool overflow, which stay with
 // k_mid_scan1 -- is unchanged.
 // ---------------------------------------------------------------------------
-#if defined(TGSF_EMUL)
-TGSF_D uint4 load16u(const uint8_t* p) { uint4 v; memcpy(&v, p, 16); return v; }
-#else
-struct __attribute__((packed, aligned(1))) U4u { uint32_t x, y, z, w; };
-TGSF_D uint4 load16u(const uint8_t* p) { const U4u* q = reinterpret_cast<const U4u*>(p); return make_uint4(q->x, q->y, q->z, q->w); }
-#endif
 // the first nvalid bytes at p (the rest zero): the last chunk of a window when fewer than 15 bytes follow it
 TGSF_D uint4 load_upto16(const uint8_t* p, int nvalid)
 {
@@ -1509,15 +1404,6 @@ TGSF_D uint4 load_upto16(const uint8_t* p, int nvalid)
     for (int i = 0; i < nvalid && i < 16; i++) d[i >> 2] |= (uint32_t)p[i] << (8 * (i & 3));
     uint4 v; v.x = d[0]; v.y = d[1]; v.z = d[2]; v.w = d[3];
     return v;
-}
-
-TGSF_D bool wave_any(bool b)
-{
-#if defined(TGSF_EMUL)
-    return b;
-#else
-    return __builtin_amdgcn_ballot_w64(b) != 0ull;
-#endif
 }
 
 template <int AT, class HT = Hot>
@@ -2088,12 +1974,8 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat(DevParams P, DevBatch B)
     const uint32_t nf = stored_frags(B);
     uint64_t drop_n = 0, drop_b = 0;
     if (pool_overflowed(B)) return;
-#if defined(TGSF_EMUL)
-    const int NT = 1, tid = 0;                                         // emulation: one lane does the whole fragment
-    if (threadIdx.x != 0) return;
-#else
-    const int NT = kRepThreads, tid = (int)threadIdx.x;
-#endif
+    const int NT = kTgsfEmul ? 1 : kRepThreads, tid = kTgsfEmul ? 0 : (int)threadIdx.x;   // (emulation: one lane does the whole fragment)
+    if (kTgsfEmul && threadIdx.x != 0) return;
     uint4 zero4;
     zero4.x = zero4.y = zero4.z = zero4.w = 0;
     for (uint32_t w = (uint32_t)tid; w < 8192u; w += (uint32_t)NT) bm4[w] = zero4;
@@ -2109,10 +1991,10 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat(DevParams P, DevBatch B)
     auto load_window = [&](const uint4* base, int words, int wb) TGSF_INLINE_LAMBDA {
         for (int g = tid; g < W && wb + g < words; g += NT) codes[g] = base_codes16(base[wb + g]);
     };
-#if !defined(TGSF_EMUL)
+    // the next fragment's text on its way into registers while this one is counted (the serial emulation reads windows)
     uint4 raw[kRepSlots];
     auto prefetch = [&](uint32_t f) TGSF_INLINE_LAMBDA {
-        if (f >= nf) return;
+        if (kTgsfEmul || f >= nf) return;
         const uint4* base; int a, L;
         chunks_of(f, base, a, L);
         const int words = (a + L + 15) / 16;
@@ -2120,7 +2002,6 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat(DevParams P, DevBatch B)
         for (int sl = 0; sl < kRepSlots; sl++) { const int g = tid + sl * NT; if (g < words) raw[sl] = base[g]; }
     };
     prefetch(blockIdx.x);
-#endif
     uint32_t f = blockIdx.x;
     while (f < nf) {
         const uint4* base; int a, L;
@@ -2131,17 +2012,14 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat(DevParams P, DevBatch B)
         const bool one_window = words <= W;
         if (tid == 0) { distinct_s = 0; next_s = gridDim.x + atomicAdd(B.rep_next, 1u); }
         TGSF_BLOCK_SYNC();                                             // the previous fragment's readers of codes[] are done
-#if defined(TGSF_EMUL)
-        load_window(base, words, 0);
-#else
+        if (kTgsfEmul) load_window(base, words, 0);
+        else {
 #pragma unroll
-        for (int sl = 0; sl < kRepSlots; sl++) { const int g = tid + sl * NT; if (g < words) codes[g] = base_codes16(raw[sl]); }
-#endif
+            for (int sl = 0; sl < kRepSlots; sl++) { const int g = tid + sl * NT; if (g < words) codes[g] = base_codes16(raw[sl]); }
+        }
         TGSF_BLOCK_SYNC();
         const uint32_t fnext = next_s;
-#if !defined(TGSF_EMUL)
         prefetch(fnext);
-#endif
         uint32_t mine = 0;
         for (uint32_t pass = 0; pass < passes && kwords > 0; pass++) {
             // windows of W chunks; a k-mer starting in chunk g reads chunk g+1 too, so consecutive windows share one chunk
@@ -2270,12 +2148,8 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
     const uint32_t nf = stored_frags(B);
     uint64_t drop_n = 0, drop_b = 0;
     if (pool_overflowed(B)) return;
-#if defined(TGSF_EMUL)
-    const int NT = 1, tid = 0;
-    if (threadIdx.x != 0) return;
-#else
-    const int NT = kRepThreads, tid = (int)threadIdx.x;
-#endif
+    const int NT = kTgsfEmul ? 1 : kRepThreads, tid = kTgsfEmul ? 0 : (int)threadIdx.x;   // (emulation: one lane does the whole fragment)
+    if (kTgsfEmul && threadIdx.x != 0) return;
     uint4 zero4, ones4;
     zero4.x = zero4.y = zero4.z = zero4.w = 0;
     ones4.x = ones4.y = ones4.z = ones4.w = ~0u;
@@ -2302,17 +2176,16 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
         TGSF_BLOCK_SYNC();
         return acc_s[slot];
     };
-#if !defined(TGSF_EMUL)
+    // the next fragment's text on its way into registers while this one is counted (the serial emulation reads windows)
     uint4 raw[kRepSlots];
     auto prefetch = [&](uint32_t f) TGSF_INLINE_LAMBDA {
-        if (f >= nf) return;
+        if (kTgsfEmul || f >= nf) return;
         const uint4* base; int a, L;
         chunks_of(f, base, a, L);
         const int words = (a + L + 15) / 16;
 #pragma unroll
         for (int sl = 0; sl < kRepSlots; sl++) { const int g = tid + sl * NT; if (g < words) raw[sl] = base[g]; }
     };
-#endif
     // work items: the long fragments in the order of their list, then every other fragment in the batch's order
     const uint32_t n_long = B.rep_next[1] < B.rep_long_cap ? B.rep_next[1] : B.rep_long_cap;
     auto take = [&]() TGSF_INLINE_LAMBDA -> uint32_t {                 // (one lane)
@@ -2327,9 +2200,7 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
     if (tid == 0) next_s = take();
     TGSF_BLOCK_SYNC();
     uint32_t f = next_s;
-#if !defined(TGSF_EMUL)
     prefetch(f);
-#endif
     while (f < nf) {
         const uint4* base; int a, L;
         chunks_of(f, base, a, L);
@@ -2340,18 +2211,15 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
         TGSF_BLOCK_SYNC();                                             // (everyone has read next_s)
         if (tid == 0) { over_s = 0; next_s = take(); }
         TGSF_BLOCK_SYNC();
-#if defined(TGSF_EMUL)
-        load_window(base, words, 0);
-#else
+        if (kTgsfEmul) load_window(base, words, 0);
+        else {
 #pragma unroll
-        for (int sl = 0; sl < kRepSlots; sl++) { const int g = tid + sl * NT; if (g < words) codes[g] = base_codes16(raw[sl]); }
-        if (tid < 8) codes[(words < W ? words : W) + tid] = 0;
-#endif
+            for (int sl = 0; sl < kRepSlots; sl++) { const int g = tid + sl * NT; if (g < words) codes[g] = base_codes16(raw[sl]); }
+            if (tid < 8) codes[(words < W ? words : W) + tid] = 0;
+        }
         TGSF_BLOCK_SYNC();
         const uint32_t fnext = next_s;
-#if !defined(TGSF_EMUL)
         prefetch(fnext);
-#endif
         bool drop = false;                                             // the gate's verdict (uniform over the workgroup)
         if (total <= 0) {
             drop = 0 < P.min_repeat;                                   // no k-mer: repeat = 0
@@ -2506,9 +2374,6 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
                     // no occurrence flagged: no repeat in this pass.  Fewer than -p could still be missing at the end of
                     // the last pass: dropped without counting them
                     const bool skip = flagged == 0 || (pass + 1 == passes && repeat + flagged < (uint32_t)P.min_repeat);
-#if defined(TGSF_EMUL) && defined(TGSF_REP_TRACE)
-                    fprintf(stderr, "k_repeat_keys: fragment %u (%d k-mers) pass %u of %u: %u flagged%s\n", f, total, pass, passes, flagged, skip ? ", no second scan" : "");
-#endif
                     if (skip) {
                         if (flagged) repeat += flagged;                // an upper bound, on the last pass only
                         TGSF_BLOCK_SYNC();
@@ -2526,9 +2391,6 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
                     TGSF_BLOCK_SYNC();
                     if (over_s) break;
                     repeat += occ - ins;
-#if defined(TGSF_EMUL) && defined(TGSF_REP_TRACE)
-                    fprintf(stderr, "k_repeat_keys:   second scan: %u occurrences of %u keys, repeat so far %u\n", occ, ins, repeat);
-#endif
                     if (repeat >= (uint32_t)P.min_repeat) decided = true;         // accepted, whatever the other passes hold
                 }
                 if (!over_s) { drop = !decided && repeat < (uint32_t)P.min_repeat; break; }
@@ -2541,9 +2403,6 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
                 if (plog >= 20u) { set_status(B, DS_REPEAT_TABLE, B.frag_read[f]); drop = false; TGSF_BLOCK_SYNC(); break; }
                 plog = want;
                 rot = (rot + 6u) & 31u;
-#if defined(TGSF_EMUL) && defined(TGSF_REP_TRACE)
-                fprintf(stderr, "k_repeat_keys: fragment %u (%d k-mers) starts over with %u passes\n", f, total, 1u << plog);
-#endif
                 TGSF_BLOCK_SYNC();
             }
         }

@@ -83,7 +83,7 @@ def hbm(k):
     return named(tcc, k).get("TCC_EA0_RDREQ_sum", 0) * 128 + named(write, k).get("WRITE_SIZE", 0) * 1024
 import hashlib
 h = hashlib.sha256()
-for fn in ("tgsf_core.h", "tgsf_dev.h", "tgsf_kernels.h", "tgsf_lib.hip"):      # = bench.py kernel_source_hash()
+for fn in ("tgsf_hip.h", "tgsf_core.h", "tgsf_dev.h", "tgsf_kernels.h", "tgsf_lib.hip"):      # = bench.py kernel_source_hash()
     h.update(open(os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.getcwd()), "tgsfilter_amd", "csrc", fn), "rb").read())
 json.dump({"reads_per_step": b["kernel_path"]["reads_per_step"], "kernel_source_hash": h.hexdigest()[:16],
            "mid_scan_hbm_bytes_per_launch": hbm("tgsf::k_mid_scan1<2"),
