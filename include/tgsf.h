@@ -240,16 +240,25 @@ int tgsf_submit_async(tgsf_ctx* ctx, const tgsf_batch_in* in, tgsf_batch_out* ou
 /*
  * Same, but every pointer in `in` and `out` is a DEVICE pointer already
  * resident in HBM and the work is enqueued on `hip_stream` (a hipStream_t, or
- * NULL for the context's own stream) without synchronising: the caller
- * synchronises the stream (or calls tgsf_wait) before reading results.
+ * NULL for the context's own stream) without synchronising.
  * out->n_frags is not filled; the fragment count is written to
  * *d_n_frags (device uint32) if that pointer is non-NULL.
+ *
+ * Several batches may be enqueued one after the other (up to TGSF_MAX_ENQUEUED; one more makes the call wait for
+ * the earlier ones).  A batch's results and its share of the tallies are FINAL ONLY WHEN tgsf_wait(ctx) HAS RETURNED,
+ * and every buffer `in` and `out` point to must stay valid and untouched until then: a batch whose middle-adapter
+ * candidates outgrow the context's pool (a read whose best alignment is tied column after column: every tied column is
+ * a location, include/edlib.cpp:660-672) is left alone by its first run and run again, from its inputs, inside
+ * tgsf_wait.  A caller that only synchronises its stream and finds TGSF_NFRAGS_NOT_FINAL in *d_n_frags is looking at
+ * such a batch: its records are not written yet.
  */
+#define TGSF_MAX_ENQUEUED 64
+#define TGSF_NFRAGS_NOT_FINAL 0xFFFFFFFFu
 int tgsf_submit_device(tgsf_ctx* ctx, const tgsf_batch_in* in, tgsf_batch_out* out,
                        uint32_t* d_n_frags, void* hip_stream);
 
-/* Block until everything submitted on this context has finished; complete a pending tgsf_submit_async
- * batch; report async errors. */
+/* Block until everything submitted on this context has finished; run again the batches whose candidate pool
+ * overflowed (see tgsf_submit_device); complete a pending tgsf_submit_async batch; report async errors. */
 int tgsf_wait(tgsf_ctx* ctx);
 
 /* Number of uint64 words tgsf_counters() writes, and the table geometry. */

@@ -201,7 +201,7 @@ def test_emul_golden_through_the_overflow_path(emul, golden_dir, name, order, mo
 
 def test_emul_pool_overflow_over_several_batches(emul, monkeypatch):
     """Tallies accumulate correctly when some batches of a run take the overflow path and others do not; a batch submitted
-    asynchronously is completed by tgsf_wait; two batches enqueued without a wait between them report the overflow."""
+    asynchronously is completed by tgsf_wait."""
     monkeypatch.setenv("TGSF_POOL_CAP", "3")
     plain = synth.make_reads(21, 10, "ont", mean_len=2500, zoo=False, pmid=0.0, p5=0.0)
     busy = synth.make_reads(22, 10, "ont", mean_len=2500, zoo=True, pmid=1.0)
@@ -214,6 +214,40 @@ def test_emul_pool_overflow_over_several_batches(emul, monkeypatch):
         got_r, got_f = ctx.submit(seq, qual, offsets[:-1].copy(), lengths)
         exp_r, exp_f, exp = orc.filter_batch(p, seq, qual, offsets, lengths, n_bins=ctx.n_bins, ctr=exp)
         assert np.array_equal(got_r, exp_r) and np.array_equal(got_f, exp_f)
+    assert np.array_equal(ctx.counters(), exp)
+    ctx.close()
+
+
+def test_emul_pool_overflow_in_batches_enqueued_together(emul, monkeypatch):
+    """tgsf_submit_device, several batches enqueued before one tgsf_wait (in the emulation device memory is host memory):
+    the ones whose candidate pool overflows are left alone by their first run -- the fragment count says so -- and run
+    again by tgsf_wait from their inputs, the others are untouched; records and tallies equal the oracle's (what the first
+    runs added to the raw tables is not added twice)."""
+    monkeypatch.setenv("TGSF_POOL_CAP", "3")
+    from oracle import orc
+    plain = synth.make_reads(21, 10, "ont", mean_len=2500, zoo=False, pmid=0.0, p5=0.0)
+    busy = synth.make_reads(22, 10, "ont", mean_len=2500, zoo=True, pmid=1.0)
+    p = parity.sized(abi.make_params("ont", adapters=[synth.ONT_RAPID, synth.ONT_RAPID_RC], min_q=7.0), plain + busy)
+    ctx = capi.Context(p, 0, emul)
+    exp = np.zeros(ctx.ctr_words, dtype=np.uint64)
+    keep, want = [], []
+    for reads in (busy, plain, busy, busy, plain):
+        seq, qual, offsets, lengths = synth.pack(reads)
+        off = offsets[:-1].astype(np.uint64).copy()
+        exp_r, exp_f, exp = orc.filter_batch(p, seq, qual, offsets, lengths, n_bins=ctx.n_bins, ctr=exp)
+        o_r = np.zeros(len(reads), dtype=abi.READ_RESULT_DTYPE)
+        o_f = np.zeros(len(exp_f) + 16, dtype=abi.FRAGMENT_DTYPE)
+        o_n = np.zeros(1, dtype=np.uint32)
+        ln = lengths.astype(np.uint32).copy()
+        keep.append((seq, qual, off, ln, o_r, o_f, o_n))
+        want.append((exp_r, exp_f))
+        ctx.submit_device(seq.ctypes.data, qual.ctypes.data, off.ctypes.data, ln.ctypes.data, len(reads), seq.size,
+                          o_r.ctypes.data, o_f.ctypes.data, len(o_f), o_n.ctypes.data, None)
+    flagged = [int(k[6][0]) == abi.NFRAGS_NOT_FINAL for k in keep]
+    assert flagged == [True, False, True, True, False]
+    ctx.wait()
+    for (seq, qual, off, ln, o_r, o_f, o_n), (exp_r, exp_f) in zip(keep, want):
+        assert np.array_equal(o_r, exp_r) and np.array_equal(o_f[:int(o_n[0])], exp_f)
     assert np.array_equal(ctx.counters(), exp)
     ctx.close()
 
@@ -269,6 +303,29 @@ def test_emul_repeat_gate_shared_prefix_fragment(emul):
         ctx = capi.Context(p, 0, emul)
         r, f = ctx.submit(*[x if i != 2 else x[:-1].copy() for i, x in enumerate(synth.pack([read]))])
         assert len(f) == 1 and bool(f["flags"][0] & abi.FF_PASS) == kept and bool(f["flags"][0] & abi.FF_REPEAT) == (not kept)
+        ctx.close()
+
+
+@pytest.mark.parametrize("max_plog", [0, 2])
+def test_emul_repeat_gate_counted_in_memory(emul, max_plog, monkeypatch):
+    """The repeat gate's last resort (where the LDS table gave up the reference completes, :1703-1753): a fragment
+    whose duplicated k-mers overflow a pass's table has its distinct k-mers counted in an open-addressing set in memory.
+    TGSF_REP_MAX_PLOG forces that at the first / third overflow instead of after 1 024 passes; exact on both sides of -p."""
+    monkeypatch.setenv("TGSF_REP_MAX_PLOG", str(max_plog))
+    read = _shared_prefix_read()
+    c = parity._kmer_repeat_np(read[1], 31)
+    for pval, kept in ((c, True), (c + 1, False)):
+        p = parity.sized(abi.make_params("ont", adapters=[synth.ONT_RAPID], min_q=7.0, min_repeat=pval, kmer=31), [read])
+        ctx = capi.Context(p, 0, emul)
+        r, f = ctx.submit(*[x if i != 2 else x[:-1].copy() for i, x in enumerate(synth.pack([read]))])
+        assert len(f) == 1 and bool(f["flags"][0] & abi.FF_PASS) == kept and bool(f["flags"][0] & abi.FF_REPEAT) == (not kept)
+        ctx.close()
+    # whole batches through the same path (every k of the keys kernel, 32- and 64-bit keys), against the oracle
+    for k in (12, 15, 16, 31):
+        reads = parity.repeat_reads(seed=300 + k, n=24)
+        p = parity.sized(abi.make_params("ont", adapters=[synth.ONT_RAPID, synth.ONT_RAPID_RC], min_q=8.0, min_repeat=60, kmer=k), reads)
+        ctx = capi.Context(p, 0, emul)
+        parity.compare_batch(ctx, p, reads)
         ctx.close()
 
 

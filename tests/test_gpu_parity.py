@@ -264,8 +264,8 @@ def test_gpu_golden_through_the_overflow_path(golden_dir, name, monkeypatch, cap
 
 
 def test_gpu_pool_overflow_device_batches(monkeypatch):
-    """tgsf_submit_device: one batch + tgsf_wait takes the fallback (results as without the overflow); two batches
-    enqueued without a wait between them cannot be recovered (the context's buffers hold the second one) and say so."""
+    """tgsf_submit_device: one batch + tgsf_wait takes the fallback (results as without the overflow); so do several
+    batches enqueued without a wait between them (the reference completes such inputs, include/edlib.cpp:660-672)."""
     import torch
     reads = synth.make_reads(22, 40, "ont", mean_len=2500, zoo=True, pmid=1.0)
     p = parity.sized(abi.make_params("ont", adapters=[synth.ONT_RAPID, synth.ONT_RAPID_RC], min_q=7.0), reads)
@@ -296,12 +296,28 @@ def test_gpu_pool_overflow_device_batches(monkeypatch):
     assert np.array_equal(got_r, exp_r) and np.array_equal(got_f, exp_f) and np.array_equal(ctx.counters(), exp_ctr)
     ctx.close()
     ctx = capi.Context(p, 0)          # (the first context has grown its pool by now: a new one starts from the forced 2 slots)
-    go()
-    go()
+    # Three batches enqueued without a wait between them, each into buffers of its own: every one overflows, is left alone
+    # by its first run (the fragment count says so to a caller that only synchronises its stream) and is run again by
+    # tgsf_wait from its inputs; the raw tallies of the first runs are not added twice.
+    outs = [(torch.zeros(n * 32, dtype=torch.uint8, device=dev), torch.zeros(fcap * 24, dtype=torch.uint8, device=dev),
+             torch.zeros(4, dtype=torch.int32, device=dev)) for _ in range(3)]
+    for o_r, o_f, o_n in outs:
+        ctx.submit_device(d["seq"].data_ptr(), d["qual"].data_ptr(), d["off"].data_ptr(), d["len"].data_ptr(), n, seq.size,
+                          o_r.data_ptr(), o_f.data_ptr(), fcap, o_n.data_ptr(), st.cuda_stream)
     st.synchronize()
-    with pytest.raises(capi.TgsfError) as e:
-        ctx.wait()
-    assert "without tgsf_wait between them" in str(e.value)
+    for _, _, o_n in outs:
+        assert int(o_n[0].item()) & 0xFFFFFFFF == abi.NFRAGS_NOT_FINAL
+    ctx.wait()
+    st.synchronize()
+    for o_r, o_f, o_n in outs:
+        got_r = o_r.cpu().numpy().view(abi.READ_RESULT_DTYPE)
+        got_f = o_f.cpu().numpy().view(abi.FRAGMENT_DTYPE)[:int(o_n[0].item())]
+        assert np.array_equal(got_r, exp_r) and np.array_equal(got_f, exp_f)
+    ref = capi.Context(p, 0)
+    for _ in range(3):
+        ref.submit(seq, qual, offsets[:-1].copy(), lengths)
+    assert np.array_equal(ctx.counters(), ref.counters())
+    ref.close()
     ctx.close()
 
 
@@ -344,6 +360,22 @@ def test_gpu_repeat_gate_shared_prefix_fragment(k):
         r, f = ctx.submit(seq, qual, off[:-1].copy(), ln)
         assert len(f) == 1 and bool(f["flags"][0] & abi.FF_PASS) == kept and bool(f["flags"][0] & abi.FF_REPEAT) == (not kept)
         ctx.close()
+
+
+@pytest.mark.parametrize("k", [15, 31])
+@pytest.mark.parametrize("max_plog", [0, 3])
+def test_gpu_repeat_gate_counted_in_memory(k, max_plog, monkeypatch):
+    """The repeat gate's last resort: a fragment whose duplicated k-mers overflow a pass's LDS table has its distinct
+    k-mers counted in an open-addressing set in memory (the reference's unordered_set, src/TGSFilter.cpp:1703-1753) -- forced
+    here at the first / fourth overflow instead of after 1 024 passes (TGSF_REP_MAX_PLOG); exact on both sides of -p, and in
+    whole batches (several workgroups taking turns at the one table)."""
+    monkeypatch.setenv("TGSF_REP_MAX_PLOG", str(max_plog))
+    test_gpu_repeat_gate_shared_prefix_fragment(k)
+    reads = parity.repeat_reads(seed=400 + k, n=200)
+    p = parity.sized(abi.make_params("ont", adapters=[synth.ONT_RAPID, synth.ONT_RAPID_RC], min_q=8.0, min_repeat=60, kmer=k), reads)
+    ctx = capi.Context(p, 0)
+    parity.compare_batch(ctx, p, reads)
+    ctx.close()
 
 
 def test_gpu_repeat_gate_colliding_hash_values():

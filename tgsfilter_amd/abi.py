@@ -20,6 +20,8 @@ OK, E_INVALID, E_NO_DEVICE, E_HIP, E_CAPACITY, E_UNSUPPORTED, E_DATA = 0, -1, -2
 
 RF_LOWQ, RF_AD5P, RF_AD3P, RF_ADMID, RF_DISCARDED = 0x01, 0x02, 0x04, 0x08, 0x10
 FF_PASS, FF_REPEAT = 0x01, 0x02
+MAX_ENQUEUED = 64                   # TGSF_MAX_ENQUEUED: tgsf_submit_device batches between two tgsf_wait
+NFRAGS_NOT_FINAL = 0xFFFFFFFF       # TGSF_NFRAGS_NOT_FINAL: the batch is run again by tgsf_wait (candidate pool overflow)
 
 CTR_DROPINFO, CTR_RAW_DIFFQ, CTR_CLEAN_DIFFQ, CTR_ROWS, CTR_END_TABLES = 0, 17, 273, 529, 533
 (T_RAW5P_QUAL, T_RAW5P_CNT, T_RAW3P_QUAL, T_RAW3P_CNT,

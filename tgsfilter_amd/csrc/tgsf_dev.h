@@ -64,7 +64,7 @@ struct DevBatch {
     uint32_t* pool_n;          // number of slots used
     uint32_t  mid_mode;        // middle scan: 0 = one pass, candidates go to per-read lists in the order the lanes get to them
                                // (the pool usually holds them all, and a read has a handful).  When the pool overflows or a
-                               // read collects more than kMidListMax of them (status[2]) the scan runs twice more with
+                               // read collects more than kMidListMax of them (*ovf) the scan runs twice more with
                                // mid_best known: 1 = every lane counts the columns at its (read, adapter)'s minimum into
                                // seg_n, 2 = after a prefix sum over seg_n the lanes write exactly those columns at their
                                // own offsets: the pool (grown to fit) then holds every read's candidates as one array,
@@ -83,6 +83,10 @@ struct DevBatch {
     uint32_t* rep_next;        // [2 + rep_long_cap] k_repeat*: [0] next work item to hand out, [1] number of long fragments
                                // (k_repeat_keys takes those that need several passes first: k_repeat_long lists them), [2..] the list
     uint32_t  rep_long_cap;
+    unsigned long long* rep_tab;   // [1 << rep_tab_log2] k_repeat_keys: the set of a fragment's k-mers, in full, in memory -- for the fragment whose
+    uint32_t  rep_tab_log2;        // duplicated k-mers no number of passes through the LDS table separates (one workgroup at a time:
+    uint32_t* rep_lock;            // rep_lock)
+    uint32_t  rep_max_plog;        // passes (log2) beyond which that happens (kRepMaxPlog; TGSF_REP_MAX_PLOG: tests)
 
     // stats work lists (raw: items are reads; clean: items are fragments [0,fcap) and, in the
     // "difference" strategy, whole reads to take back out, numbered fcap + read)
@@ -116,8 +120,11 @@ struct DevBatch {
     size_t    scratch_mid_wave0; // first wave region of k_mid_resolve (after those of k_end_windows)
 
     uint64_t* ctr;             // the flat tally vector (include/tgsf.h layout)
-    uint32_t* status;          // [4] device-side words: [0] error code, [1] detail, [2] the candidate pool overflowed (the
-                               // kernels behind the middle scan then leave the batch alone: tgsf_wait runs them again, see mid_mode)
+    uint32_t* status;          // [4] device-side words: [0] error code, [1] detail
+    uint32_t* ovf;             // [1] THIS batch's word: the candidate pool overflowed (the kernels behind the middle scan then
+                               // leave the batch alone: tgsf_wait runs the batch again, see mid_mode and `replay`)
+    uint32_t  replay;          // 1 = the batch is run a second time after such an overflow: what its first run added to the
+                               // tallies in front of the middle scan (raw tables, low-quality reads) is not added again
 };
 
 // include/tgsf.h layout of the tally vector, callable from device code
@@ -168,7 +175,7 @@ enum DevStatus : uint32_t {
     DS_TOO_MANY_REGIONS = 4,
     DS_FRAG_CAP = 5,
     DS_BAD_MEANQ = 6,      // mean quality outside [0,256): the reference indexes out of bounds
-    DS_REPEAT_TABLE = 7,   // repeat gate: a pass's table of full keys cannot hold the fragment's duplicated k-mers
+    DS_REPEAT_TABLE = 7,   // (no longer raised: such a fragment's k-mers are counted in memory, rep_distinct_in_memory)
 };
 
 }  // namespace tgsf

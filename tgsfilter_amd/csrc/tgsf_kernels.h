@@ -45,7 +45,7 @@ TGSF_D void set_status(const DevBatch& B, uint32_t code, uint32_t detail) {
 
 // The candidate pool of the middle scan overflowed: everything behind the scan leaves this batch alone (no tally, no
 // record is written), and tgsf_wait runs the scan and those kernels again with a pool grown to fit (mid_mode).
-TGSF_D bool pool_overflowed(const DevBatch& B) { return B.status[2] != 0u; }
+TGSF_D bool pool_overflowed(const DevBatch& B) { return *B.ovf != 0u; }
 
 // fragments actually stored (the count may exceed the capacity: DS_FRAG_CAP)
 TGSF_D uint32_t stored_frags(const DevBatch& B) { uint32_t nf = B.nfr[B.n]; return nf < B.fcap ? nf : B.fcap; }
@@ -168,8 +168,10 @@ TGSF_KERNEL k_clean_plan(DevParams P, DevBatch B)
 template <bool CLEAN>
 TGSF_KERNEL k_fold_raw(DevParams P, DevBatch B)
 {
-    if (CLEAN && pool_overflowed(B)) return;           // (the clean instance runs behind the middle scan)
-    const bool add = !CLEAN || clean_by_difference(B);
+    // (the clean instance runs behind the middle scan: a batch whose candidate pool overflowed is left alone, but the
+    // batch's table is still handed back empty -- the next batch's raw pass adds to it, and the second run of this one)
+    const bool left_alone = CLEAN && pool_overflowed(B);
+    const bool add = !left_alone && (!CLEAN || clean_by_difference(B));
     uint64_t rows = B.plan[0];
     if (rows > P.n_bins) rows = P.n_bins;
     const size_t nw = (size_t)rows * 5, stride = (size_t)P.n_bins * 5;
@@ -575,12 +577,12 @@ TGSF_KERNEL k_gate_reads(DevParams P, DevBatch B)
             const double mq = mean_q(B.sumq[r], L);
             if (!(mq >= 0.0 && mq < 256.0)) { set_status(B, DS_BAD_MEANQ, r); }
             else {
-                if (!P.no_qual) atomicAdd(&hq[(int)mq], (ull)L);          // :1943 (records with qualities only, :1941)
+                if (!P.no_qual && !B.replay) atomicAdd(&hq[(int)mq], (ull)L);   // :1943 (records with qualities only, :1941)
                 uint32_t segs = 0, chunks = 0;
                 if (P.filter) {
                     if (!P.no_qual && q_fail(mq, P.min_q, P.max_q)) {
                         B.flags[r] = TGSF_RF_LOWQ;
-                        lowq_reads++; lowq_bases += L;
+                        if (!B.replay) { lowq_reads++; lowq_bases += L; }
                     } else {
                         int ML = (int)L - 2 * P.end_len;              // :1236 tsmLen
                         if (ML >= P.min_Q) {
@@ -1159,12 +1161,12 @@ TGSF_D bool worth_handing_over(const DevBatch& B, uint32_t r, int a, int A, int 
 }
 TGSF_D void push_candidate(const DevBatch& B, uint32_t r, int pos, int score, int a)
 {
-    if (B.status[2]) return;                                          // the scan will be redone anyway
+    if (*B.ovf) return;                                               // the scan will be redone anyway
     uint32_t idx = atomicAdd(B.pool_n, 1u);
     // Not errors: tgsf_wait re-runs the scan into a pool that fits, in position order (mid_mode).  A long list in the
     // order the lanes happened to reach it would cost the region kernel a pass over the list per out-of-order region.
-    if (idx >= B.pool_cap) { B.status[2] = 1u; return; }
-    if (atomicAdd(&B.mid_cnt[r], 1u) == (uint32_t)kMidListMax) B.status[2] = 1u;
+    if (idx >= B.pool_cap) { *B.ovf = 1u; return; }
+    if (atomicAdd(&B.mid_cnt[r], 1u) == (uint32_t)kMidListMax) *B.ovf = 1u;
     MidCand c;
     c.pos = pos;
     c.aux = score | (a << 16);
@@ -1184,7 +1186,7 @@ TGSF_KERNEL k_mid_reset(DevBatch B, int A)
 // a candidate written at its own slot (mode 2): the slots of a read are consecutive, in ascending order of position
 TGSF_D void place_candidate(const DevBatch& B, uint32_t idx, int pos, int score, int a)
 {
-    if (idx >= B.pool_cap) { B.status[2] = 1u; return; }              // (cannot happen: the pool was sized from the counts)
+    if (idx >= B.pool_cap) { *B.ovf = 1u; return; }                   // (cannot happen: the pool was sized from the counts)
     MidCand c;
     c.pos = pos;
     c.aux = score | (a << 16);
@@ -2124,6 +2126,43 @@ TGSF_KERNEL k_repeat_long(DevParams P, DevBatch B)
         else set_status(B, DS_FRAG_CAP, B.frag_read[f]);
     }
 }
+constexpr uint32_t kRepMaxPlog = 10;                  // passes (log2) beyond which a fragment's k-mers are counted in memory instead
+// The number of distinct k-mers among the `total` k-mers of the text at s (GetKmerCount's set, src/TGSFilter.cpp:1703-1753;
+// k <= 31: 2-bit codes, non-ACGT and lower case = 0 as there, :1709-1724), by the whole workgroup: an open-addressing set
+// of the full keys in B.rep_tab.  Every access to the table is an agent-scope atomic or a write-through store (the
+// workgroups that use it one after the other may sit on different XCDs, whose L2s do not see each other's lines).
+// acc: a word of LDS.  Called by all lanes of the workgroup together.
+TGSF_D uint32_t rep_distinct_in_memory(const DevBatch& B, const uint8_t* s, int total, int k, int tid, int NT, uint32_t* acc)
+{
+    const ull kEmptyKey = ~0ull;                                       // no key has all its bits set (k <= 31)
+    uint32_t lg = 4;
+    while (lg < B.rep_tab_log2 && (1ull << lg) < 2ull * (ull)total) lg++;
+    const ull mask = (1ull << lg) - 1ull;
+    if (tid == 0) { while (atomicCAS(B.rep_lock, 0u, 1u) != 0u) { } *acc = 0u; }
+    TGSF_BLOCK_SYNC();
+    for (ull i = (ull)tid; i <= mask; i += (ull)NT) atomicExch(&B.rep_tab[i], kEmptyKey);
+    TGSF_BLOCK_SYNC();
+    uint32_t mine = 0;
+    for (int i = tid; i < total; i += NT) {
+        ull key = 0;
+        for (int j = 0; j < k; j++) key = (key << 2) | base_code(s[i + j]);
+        ull h = (key * 0x9E3779B97F4A7C15ull) >> (64u - lg);
+        for (;;) {
+            const ull old = atomicCAS(&B.rep_tab[h], kEmptyKey, key);
+            if (old == kEmptyKey) { mine++; break; }
+            if (old == key) break;
+            h = (h + 1ull) & mask;
+        }
+    }
+    mine = (uint32_t)wave_sum((uint64_t)mine);
+    if (wave_leader() && mine) atomicAdd(acc, mine);
+    TGSF_BLOCK_SYNC();
+    const uint32_t distinct = *acc;
+    TGSF_BLOCK_SYNC();
+    if (tid == 0) { *acc = 0u; atomicExch(B.rep_lock, 0u); }
+    TGSF_BLOCK_SYNC();
+    return distinct;
+}
 constexpr uint32_t kRepAQ = 6144;                     // map A: 96 KB = 24 576 words
 constexpr uint32_t kRepBQ = 2048;                     // map B: 32 KB = 2^18 bits
 constexpr uint32_t kRepTabQ = 4096;                   // the table: the first 64 KB of A
@@ -2399,8 +2438,16 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat_keys(DevParams P, DevBatch B)
                 TGSF_BLOCK_SYNC();
                 if (tid == 0) over_s = 0;
                 uint32_t want = plog + 1u;
-                while (want < 20u && (flagged >> (want - plog)) > (1u << (TLOG - 1u))) want++;
-                if (plog >= 20u) { set_status(B, DS_REPEAT_TABLE, B.frag_read[f]); drop = false; TGSF_BLOCK_SYNC(); break; }
+                while (want < B.rep_max_plog && (flagged >> (want - plog)) > (1u << (TLOG - 1u))) want++;
+                if (plog >= B.rep_max_plog) {
+                    // No number of passes the LDS table can afford separates this fragment's duplicated k-mers (thousands of
+                    // distinct ones whichever way the key is hashed): count its distinct k-mers the plain way, as the
+                    // reference does (:1703-1753, an unordered_set of all of them) -- every key, in full, into an
+                    // open-addressing set in memory, one workgroup at a time.  repeat = k-mers - distinct ones, exactly.
+                    const uint32_t distinct = rep_distinct_in_memory(B, B.seq + B.frag_off[f], total, k, tid, NT, &acc_s[0]);
+                    drop = (uint32_t)total - distinct < (uint32_t)P.min_repeat;
+                    break;
+                }
                 plog = want;
                 rot = (rot + 6u) & 31u;
                 TGSF_BLOCK_SYNC();
@@ -2471,7 +2518,12 @@ TGSF_KERNEL k_ctr_merge(uint64_t* dst, const uint64_t* src, uint64_t n)
 TGSF_KERNEL k_finalize(DevBatch B, tgsf_read_result* out_reads, tgsf_fragment* out_frags,
                        uint32_t out_fcap, uint32_t* out_nfrags)
 {
-    if (pool_overflowed(B)) return;
+    if (pool_overflowed(B)) {
+        // no record of this batch is final: tgsf_wait runs it again.  A caller of tgsf_submit_device that looks at its
+        // buffers before that finds TGSF_NFRAGS_NOT_FINAL in the fragment count.
+        if (gtid() == 0 && out_nfrags) *out_nfrags = TGSF_NFRAGS_NOT_FINAL;
+        return;
+    }
     const uint32_t nf = B.nfr[B.n];
     if (gtid() == 0) {
         if (out_nfrags) *out_nfrags = nf;

@@ -86,15 +86,15 @@ struct tgsf_ctx {
     uint32_t* pend_nf_p;       // fragment count of the pending batch       } into it are truly asynchronous
     // batch enqueued by tgsf_submit_async, completed by tgsf_wait
     tgsf_batch_out* pend_out = nullptr;
-    // the most recent batch as the pipeline saw it (device pointers), and how many were enqueued since the last
-    // tgsf_wait: when the candidate pool of the middle scan overflows (DevBatch::status[2]) tgsf_wait runs the scan and
-    // everything behind it again with a pool grown to fit -- possible while the batch's buffers still hold ITS data
-    tgsf_batch_in last_in;
-    tgsf_read_result* last_reads = nullptr;
-    tgsf_fragment* last_frags = nullptr;
-    uint32_t last_fcap = 0;
-    uint32_t* last_nfrags = nullptr;
-    uint32_t batches_since_wait = 0;
+    // the batches enqueued since the last tgsf_wait, as the pipeline saw them (device pointers): a batch whose candidate
+    // pool overflowed in the middle scan (its word of ovf_ring) was left alone by every kernel behind the scan, and
+    // tgsf_wait runs it again from its inputs -- which the caller keeps untouched until then -- with the raw-side
+    // tallies of its first run not added twice (DevBatch::replay) and a pool grown to fit
+    struct Pending { tgsf_batch_in in; tgsf_read_result* reads; tgsf_fragment* frags; uint32_t fcap; uint32_t* nfrags; rt_stream st; };
+    Pending pending[TGSF_MAX_ENQUEUED];
+    uint32_t n_pending = 0;
+    uint32_t* ovf_ring = nullptr;          // [TGSF_MAX_ENQUEUED] device words, one per enqueued batch
+    uint32_t h_ovf[TGSF_MAX_ENQUEUED];
     uint32_t pool_regrown = 0;            // times the pool had to grow (tests look at it through tgsf_last_error's sibling below)
 
 };
@@ -502,6 +502,16 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     if (!e) e = dev_alloc(c, &B.trimmed, n);
     B.rep_long_cap = (uint32_t)std::min<uint64_t>(c->cap_bases / kRepShare + 16, (uint64_t)B.fcap + 16);   // a long fragment holds more than kRepShare bases
     if (!e) e = dev_alloc(c, &B.rep_next, 2 + (size_t)B.rep_long_cap);
+    if (p->min_repeat > 0 && p->kmer >= 12 && p->kmer <= 31) {
+        // k_repeat_keys' last resort: room for the set of all k-mers of the longest fragment, half empty
+        B.rep_tab_log2 = 4;
+        while (B.rep_tab_log2 < 40 && (1ull << B.rep_tab_log2) < 2ull * c->max_read_len) B.rep_tab_log2++;
+        if (!e) e = dev_alloc(c, &B.rep_tab, (size_t)1 << B.rep_tab_log2);
+        if (!e) e = dev_alloc(c, &B.rep_lock, 4);
+        if (!e) rt_memset(B.rep_lock, 0, 16, c->stream);
+        B.rep_max_plog = kRepMaxPlog;
+        if (const char* ev = getenv("TGSF_REP_MAX_PLOG")) { int v = atoi(ev); if (v >= 0 && v <= 20) B.rep_max_plog = (uint32_t)v; }   // test knob
+    }
     if (!e) e = dev_alloc(c, &B.tile_hist, (size_t)B.max_tiles + 2);
     if (!e) e = dev_alloc(c, &B.tile_cnt, (size_t)B.max_tiles + 2);
     if (!e) e = dev_alloc(c, &B.tile_base, (size_t)B.max_tiles + 2);
@@ -539,6 +549,7 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     }
     if (!e) e = dev_alloc(c, &B.ctr, (size_t)c->ctr_words);
     if (!e) e = dev_alloc(c, &B.status, 4);
+    if (!e) e = dev_alloc(c, &c->ovf_ring, TGSF_MAX_ENQUEUED);
     if (!e) e = dev_alloc(c, &c->d_out_reads, n);
     if (!e) e = dev_alloc(c, &c->d_out_frags, (size_t)B.fcap);
     if (!e) e = dev_alloc(c, &c->d_out_nfrags, 4);
@@ -549,6 +560,8 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     }
     rt_memset(B.ctr, 0, c->ctr_words * 8, c->stream);
     rt_memset(B.status, 0, 16, c->stream);
+    rt_memset(c->ovf_ring, 0, TGSF_MAX_ENQUEUED * 4, c->stream);
+    B.ovf = c->ovf_ring;
     rt_memset(B.raw_tab, 0, 2 * (size_t)c->n_bins * 5 * 8, c->stream);
     rt_sync(c->stream);
     *out = c;
@@ -597,19 +610,27 @@ static void scan_u32(const DevBatch& B, uint32_t* a, uint32_t n, rt_stream st, u
     TGSF_LAUNCH_COOP(k_scan_add, nb, 256, st, a, n, (const uint32_t*)part);
 }
 
+static int drain_pending(tgsf_ctx* c);
+
 // redo = false: the whole pipeline of one batch, enqueued without a host round trip.
-// redo = true (from tgsf_wait, after a pool overflow): the middle scan again -- first counting the columns at each
-// (read, adapter)'s minimum, then, with the pool grown to that many slots, handing them over -- and everything behind it.
+// redo = true (from tgsf_wait, a batch whose candidate pool overflowed, run again from its inputs): the kernels in front
+// of the middle scan without their tallies (DevBatch::replay), the first scan for the minima, then the scan twice more
+// -- counting the columns at each (read, adapter)'s minimum, and, with the pool grown to that many slots, handing
+// them over in position order -- and everything behind it.  `slot`: the batch's word of ovf_ring.
 static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* d_reads, tgsf_fragment* d_frags,
-                        uint32_t out_fcap, uint32_t* d_nfrags, rt_stream st, bool redo = false)
+                        uint32_t out_fcap, uint32_t* d_nfrags, rt_stream st, bool redo = false, uint32_t slot = 0)
 {
     if (!redo) {
-        c->last_in = *in; c->last_reads = d_reads; c->last_frags = d_frags; c->last_fcap = out_fcap; c->last_nfrags = d_nfrags;
-        c->batches_since_wait++;
+        if (c->n_pending == TGSF_MAX_ENQUEUED) { int e = drain_pending(c); if (e) return e; }
+        slot = c->n_pending++;
+        tgsf_ctx::Pending& pd = c->pending[slot];
+        pd.in = *in; pd.reads = d_reads; pd.frags = d_frags; pd.fcap = out_fcap; pd.nfrags = d_nfrags; pd.st = st;
     }
     const bool profile = c->profile && !redo;
     (void)profile;
     DevBatch B = c->B;
+    B.ovf = c->ovf_ring + slot;
+    B.replay = redo ? 1u : 0u;
     const DevParams& P = c->P;
     B.seq = in->seq; B.qual = in->qual; B.off = in->offsets; B.len_in = in->lengths;
     B.qoff = in->qual_offsets ? in->qual_offsets : in->offsets;
@@ -646,8 +667,9 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     rt_stream ax = st;
     (void)ax;
 #endif
-    if (!redo) {
+    {
     // -- prepare + counting sort of reads by tile count
+    rt_memset(B.ovf, 0, 4, st);
     rt_memset(B.tile_hist, 0, tl, st);
     rt_memset(B.tile_fill, 0, tl, st);
     rt_memset(B.pool_n, 0, 4, st);
@@ -666,7 +688,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
 #if !defined(TGSF_EMUL)
     if (c->hp) { (void)hipEventRecord(c->ev_hp[1], ss); (void)hipStreamWaitEvent(st, c->ev_hp[1], 0); }
 #endif
-    TGSF_LAUNCH(k_fold_raw<false>, gfold, T, st, P, B);
+    if (!redo) TGSF_LAUNCH(k_fold_raw<false>, gfold, T, st, P, B);   // (a second run: the batch's raw tallies are in the tables already)
     STAGE_MARK();
     TGSF_LAUNCH(k_gate_reads, gsmall, T, st, P, B);
     STAGE_MARK();
@@ -677,7 +699,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     (void)hipStreamWaitEvent(ax, c->ev_fork, 0);
     if (profile) (void)hipEventRecord(evx[0], ax);
 #endif
-    for (uint32_t slab = 0; slab * (uint32_t)kMaxBcLen < (uint32_t)P.bc_len; slab++)
+    for (uint32_t slab = 0; !redo && slab * (uint32_t)kMaxBcLen < (uint32_t)P.bc_len; slab++)
         TGSF_LAUNCH(k_end_tables<false>, grid_cap(c->endtab_grid), 64 * kEndWaves, ax, P, B, slab);
 #if !defined(TGSF_EMUL)
     if (profile) (void)hipEventRecord(evx[1], ax);
@@ -692,18 +714,16 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     if (profile) (void)hipEventRecord(evx[2], ax);
     (void)hipEventRecord(c->ev_join, ax);
 #endif
-    } else {
-        stage = 4;                                      // (the stage events of a redo are not recorded)
     }
     STAGE_MARK();
     STAGE_MARK();
     if (P.filter && A > 0) {
         // the first scan of a batch by the flat kernel (adapters of at most 64 bp); one lane per stretch of the schedule:
         // the number of stretches is known on the device only, so the grid covers the longest sequence the batch can have
-        const bool flat = c->flat_scan && !redo;
+        const bool flat = c->flat_scan;
         unsigned gflat = 1;
-        if (!redo) {
-            scan_u32(B, B.seg_cnt, n, st);              // (in place: a redo finds the prefix sums of the first run)
+        {
+            scan_u32(B, B.seg_cnt, n, st);
             if (flat) {
                 scan_u32(B, B.chk_cnt, n, st);
                 FlatSchedule S;
@@ -765,8 +785,8 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
                 a += na;
             }
         };
-        if (!redo) launch_scans(0);
-        else {
+        launch_scans(0);
+        if (redo) {
             // The first scan left every (read, adapter)'s minimum in mid_best.  Now every lane counts the columns AT those
             // minima (what edlib reports, include/edlib.cpp:660-672) per adapter; a prefix sum turns the counts into slots;
             // the pool is grown to the total; the lanes write their columns at their own slots: every read's candidates
@@ -808,7 +828,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
                 if (getenv("TGSF_TRACE_POOL"))
                     fprintf(stderr, "tgsf: candidate pool overflow (or a read with a long candidate list): %u columns at their reads' minima, pool of %u slots%s; scanning again in position order\n", need, B.pool_cap,
                             c->pool_regrown ? " (grown)" : "");
-                rt_memset(B.status + 2, 0, 4, ms);
+                rt_memset(B.ovf, 0, 4, ms);
                 launch_scans(2);
                 TGSF_LAUNCH(k_mid_link, gsmall, T, ms, B, A);
                 DevBatch Bm = B;
@@ -940,7 +960,6 @@ static int check_status(tgsf_ctx* c)
     switch (code) {
     case DS_BAD_LEN: return fail(c, TGSF_E_DATA, "read %u: length 0 or above max_read_len %u", detail, c->max_read_len);
     case DS_BAD_QUAL: return fail(c, TGSF_E_DATA, "quality byte >= 128 in the batch (outside the supported domain)");
-    case DS_REPEAT_TABLE: return fail(c, TGSF_E_CAPACITY, "read %u: the repeat gate's table cannot hold the duplicated k-mers of a fragment (thousands of distinct ones that no hash of the key tells apart)", detail);
     case DS_TOO_MANY_REGIONS: return fail(c, TGSF_E_CAPACITY, "read %u has more than %d disjoint drop regions", detail, kMaxRegions);
     case DS_FRAG_CAP: return fail(c, TGSF_E_CAPACITY, "fragment capacity exceeded (%u)", detail);
     case DS_BAD_MEANQ: return fail(c, TGSF_E_DATA, "read %u: mean quality outside [0,256)", detail);
@@ -965,51 +984,62 @@ static int finish_pending(tgsf_ctx* c)
     return TGSF_OK;
 }
 
-extern "C" int tgsf_wait(tgsf_ctx* c)
+// Everything enqueued on the context completes: the streams are drained, the device's status words looked at, and
+// every batch whose candidate pool overflowed (a read whose minimum is tied column after column, e.g. a homopolymer
+// against a homopolymer adapter: nothing behind its middle scan has touched it) is run again from its inputs.
+static int drain_pending(tgsf_ctx* c)
 {
-    if (!c) return TGSF_E_INVALID;
     int e = 0;
+    const uint32_t np = c->n_pending;
 #if !defined(TGSF_EMUL)
-    // a batch enqueued with tgsf_submit_device runs on the caller's stream (and the auxiliary one): both must be
-    // idle before the status words mean anything
+    // batches enqueued with tgsf_submit_device run on the caller's streams (and the auxiliary one): all must be idle
+    // before the status words mean anything
     (void)hipSetDevice(c->device);
-    if (c->last_stream != c->stream) e = (int)hipStreamSynchronize(c->last_stream);
+    for (uint32_t i = 0; i < np && !e; i++) {
+        bool seen = c->pending[i].st == c->stream;
+        for (uint32_t j = 0; j < i && !seen; j++) seen = c->pending[j].st == c->pending[i].st;
+        if (!seen) e = (int)hipStreamSynchronize(c->pending[i].st);
+    }
     if (!e) e = (int)hipStreamSynchronize(c->aux);
 #endif
     if (!e) e = rt_d2h(c->h_status, c->B.status, 16, c->stream);
+    if (!e && np) e = rt_d2h(c->h_ovf, c->ovf_ring, (size_t)np * 4, c->stream);
     if (!e) e = rt_sync(c->stream);
-    const uint32_t enqueued = c->batches_since_wait;
-    c->batches_since_wait = 0;
+    c->n_pending = 0;
     if (e) { c->pend_out = nullptr; return fail(c, TGSF_E_HIP, "stream synchronize failed: %s", rt_errstr(e)); }
     e = check_status(c);
     if (e) { c->pend_out = nullptr; return e; }
-    if (c->h_status[2]) {
-        // The candidate pool of the middle scan overflowed (a read whose minimum is tied column after column, e.g. a
-        // homopolymer against a homopolymer adapter): nothing behind the scan has touched the batch.  Its buffers still
-        // hold it if it was the only batch enqueued since the last wait -- then the scan runs again, sized to fit.
-        if (enqueued != 1) {
-            rt_memset(c->B.status, 0, 16, c->stream);
-            rt_sync(c->stream);
-            c->pend_out = nullptr;
-            return fail(c, TGSF_E_CAPACITY, "middle-adapter candidate pool overflow in one of %u batches enqueued without tgsf_wait between them "
-                                            "(call tgsf_wait after each batch and the library re-runs the scan with a pool that fits)", enqueued);
-        }
-        rt_stream st = c->last_stream;
-        e = run_pipeline(c, &c->last_in, c->last_reads, c->last_frags, c->last_fcap, c->last_nfrags, st, true);
-        if (!e && c->pend_out) {
-            int he = rt_d2h(c->pend_nf_p, c->d_out_nfrags, 4, st);
-            he |= rt_d2h(c->pend_out->reads, c->d_out_reads, (size_t)c->last_in.n_reads * sizeof(tgsf_read_result), st);
+    for (uint32_t i = 0; i < np; i++) {
+        if (!c->h_ovf[i]) continue;
+        const tgsf_ctx::Pending pd = c->pending[i];
+        e = run_pipeline(c, &pd.in, pd.reads, pd.frags, pd.fcap, pd.nfrags, pd.st, true, i);
+        if (!e && c->pend_out && pd.reads == c->d_out_reads) {       // the batch of tgsf_submit_async: its copies again
+            int he = rt_d2h(c->pend_nf_p, c->d_out_nfrags, 4, pd.st);
+            he |= rt_d2h(c->pend_out->reads, c->d_out_reads, (size_t)pd.in.n_reads * sizeof(tgsf_read_result), pd.st);
             if (he) e = fail(c, TGSF_E_HIP, "device to host copy failed");
         }
+        uint32_t again = 0;
         if (!e) {
-            int he = rt_d2h(c->h_status, c->B.status, 16, st);
-            if (!he) he = rt_sync(st);
+            int he = rt_d2h(c->h_status, c->B.status, 16, pd.st);
+            if (!he) he = rt_d2h(&again, c->ovf_ring + i, 4, pd.st);
+            if (!he) he = rt_sync(pd.st);
+#if !defined(TGSF_EMUL)
+            if (!he) he = (int)hipStreamSynchronize(c->aux);
+#endif
             if (he) e = fail(c, TGSF_E_HIP, "stream synchronize failed: %s", rt_errstr(he));
         }
         if (!e) e = check_status(c);
-        if (!e && c->h_status[2]) e = fail(c, TGSF_E_HIP, "middle-adapter candidate pool overflowed again after it was sized to fit");
+        if (!e && again) e = fail(c, TGSF_E_HIP, "middle-adapter candidate pool overflowed again after it was sized to fit");
         if (e) { c->pend_out = nullptr; return e; }
     }
+    return TGSF_OK;
+}
+
+extern "C" int tgsf_wait(tgsf_ctx* c)
+{
+    if (!c) return TGSF_E_INVALID;
+    const int e = drain_pending(c);
+    if (e) return e;
     return finish_pending(c);
 }
 
