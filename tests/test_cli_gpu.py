@@ -89,3 +89,41 @@ def test_cli_gpu_config5_shape_against_the_reference(tmp_path, n_reads, flags):
         assert outs["ours"][1] == outs["ref"][1]
         assert outs["ours"][0] == outs["ref"][0]
         assert len(outs["ref"][0]) > 1e6
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/tgsfilter_ref not built (make -C oracle ref)")
+def test_cli_gpu_three_feeder_sets_on_a_real_file(tmp_path):
+    """What a multi-GPU run does on the host, on the one device of this box: --devices 0,0,0 = three feeder sets (nine
+    contexts) pulling batches of a 24 000-read file (C2's shape at 6 kb: 0.14 Gbases, ~290 MB of text, hundreds of batches
+    at the forced batch size) in whatever order they finish, the planner putting the records back into input order, the
+    tallies of all contexts merged on the host.  Output file, INFO lines and report must equal the --devices 0 run's byte
+    for byte, and the reference binary's (-t 1: input order)."""
+    import hashlib
+    import subprocess
+    import tempfile
+    from tgsfilter_amd import synth
+    binary = os.path.join(ROOT, "tgsfilter_amd", "bin", "tgsfilter")
+    shm = "/dev/shm" if os.access("/dev/shm", os.W_OK) else None
+    with tempfile.TemporaryDirectory(dir=shm) as td:
+        fq = os.path.join(td, "in.fq")
+        bases, _ = synth.write_ont_fastq(fq, 24_000, seed=12, mean_len=6000.0, max_len=200_000, reads_per_job=512)
+        assert bases > 1e8
+        common = ["-i", fq, "-x", "ont", "-l", "1000", "-q", "10"]               # automatic pre-pass, as C2
+        env = dict(os.environ, TGSF_BATCH_BYTES="1500000", TGSF_EARLY_OPEN_MIN="1", TGSF_STRIDE_BYTES="8000000")
+
+        def run(tag, exe, extra, e=None):
+            out = os.path.join(td, tag + ".fq")
+            p = subprocess.run([exe, "-o", out] + common + extra, capture_output=True, env=e)
+            assert p.returncode == 0, p.stderr.decode()[-2000:]
+            info = [l for l in p.stderr.decode().splitlines() if l.startswith("INFO: ") and "written to" not in l]
+            html = open(os.path.join(td, tag + ".html"), "rb").read()
+            # the report names its input and carries a time stamp in its footer: compare the tables and the plotted data
+            body = b"\n".join(l for l in html.splitlines() if b"<tr>" in l or l.lstrip().startswith(b"var data"))
+            return hashlib.sha256(open(out, "rb").read()).hexdigest(), info, hashlib.sha256(body).hexdigest()
+
+        one = run("one", binary, ["-t", "16", "--devices", "0"], env)
+        three = run("three", binary, ["-t", "16", "--devices", "0,0,0"], env)
+        ref = run("ref", REF, ["-t", "1"])
+        assert three[1] == one[1] == ref[1]
+        assert three[0] == one[0] == ref[0]
+        assert three[2] == one[2] == ref[2]

@@ -573,7 +573,7 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
 // ---------------------------------------------------------------------------
 static const char* kStageNames[TGSF_N_STAGES] = {
     "prepare+sort", "stats_raw", "gate_reads", "end_tables_raw", "end_windows", "mid_scan",
-    "mid_resolve", "regions", "stats_clean", "gate_frags+end_tables_clean", "finalize", "reserved"};
+    "mid_resolve", "regions", "repeat_gate", "stats_clean", "gate_frags+end_tables_clean", "finalize"};
 
 extern "C" const char* tgsf_stage_name(int s) { return (s >= 0 && s < TGSF_N_STAGES) ? kStageNames[s] : ""; }
 
@@ -588,7 +588,7 @@ static int harvest_profile(tgsf_ctx* c, rt_stream st)
     if (he != hipSuccess) return fail(c, TGSF_E_HIP, "stream synchronize failed: %s", hipGetErrorString(he));
     (void)hipStreamSynchronize(c->aux);
     for (int k = 0; k < c->prof_pending; k++)
-        for (int i = 0; i < TGSF_N_STAGES - 1; i++) {
+        for (int i = 0; i < TGSF_N_STAGES; i++) {
             float ms = 0.f;
             // stages 3 (end_tables_raw) and 4 (end_windows) run on the auxiliary stream, beside stage 5
             hipError_t e = (i == 3 || i == 4) ? hipEventElapsedTime(&ms, c->ev_aux[k][i - 3], c->ev_aux[k][i - 2])
@@ -868,6 +868,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     TGSF_LAUNCH(k_regions<false>, gsmall, T, st, P, B);
     scan_u32(B, B.nfr, n, st);
     TGSF_LAUNCH(k_regions<true>, gsmall, T, st, P, B);
+    STAGE_MARK();
     if (P.min_repeat > 0 && !P.only_qc) {
         // one 1024-lane workgroup per CU (152 KB of LDS each); fragments are handed out through B.rep_next.  k <= 11: the
         // 4^k-bit set swept as LDS bitmaps; above: a hashed map + the full keys of the few it cannot tell apart (k = 12

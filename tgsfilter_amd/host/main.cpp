@@ -90,6 +90,15 @@ int main(int argc, char** argv)
     Options o;
     if (parse_args(argc, argv, o)) return 1;
     work_in_a_child();
+    // SIGINT / SIGTERM: as on any fatal path, an output file created ahead of its records is removed, one partly written is
+    // cut back to the records laid out (unlink / ftruncate: async-signal-safe)
+    {
+        struct sigaction sa;
+        memset(&sa, 0, sizeof sa);
+        sa.sa_handler = [](int sig) { if (void (*f)() = on_die().exchange(nullptr)) f(); _exit(128 + sig); };
+        sigaction(SIGINT, &sa, nullptr);
+        sigaction(SIGTERM, &sa, nullptr);
+    }
     // big blocks stay in the heap instead of being mapped and unmapped one by one (see BatchStore)
     mallopt(M_MMAP_THRESHOLD, 1 << 30);
     mallopt(M_TRIM_THRESHOLD, -1);
@@ -250,13 +259,16 @@ int main(int argc, char** argv)
     // match lengths ~350 KB: keep it under 4 GB per context
     uint32_t batch_reads = 1u << 16;
     {
-        uint64_t per_read = 0;
+        // (the library's rule, tgsf_lib.hip: every alignment of a batch gets the columns of the longest one, and the
+        // words of the widest column class any adapter needs -- 1 / 2 / 4 words up to 64 / 128 / 256 bp, 20 beyond)
+        uint64_t per_read = 0, cols = 0, nw = 1;
         for (const std::string& a : adapters) {
             const int Q = (int)a.size();
             const int kmax = std::max(0, std::min(Q - 1, std::max(Q - o.end_match_len + 1, Q - o.mid_match_len + 1)));
-            const uint64_t cols = (uint64_t)(Q + kmax + 2), nw = (uint64_t)((Q + 63) / 64);
-            per_read = std::max(per_read, cols * 2 * nw * 8);
+            cols = std::max<uint64_t>(cols, (uint64_t)(Q + kmax + 2));
+            nw = std::max<uint64_t>(nw, Q > 256 ? 20 : Q > 128 ? 4 : Q > 64 ? 2 : 1);
         }
+        per_read = cols * 2 * nw * 8;
         per_read *= 3 * std::max<size_t>(adapters.size(), 1);          // two end windows + one middle alignment per adapter
         if (per_read) batch_reads = (uint32_t)std::min<uint64_t>(batch_reads, std::max<uint64_t>(256, (4ull << 30) / per_read));
     }
@@ -415,6 +427,15 @@ int main(int argc, char** argv)
                         if (j != std::string::npos && list[j] == '-') { b = atoi(list.c_str() + j + 1); j = list.find(',', j); }
                         for (int c2 = a; c2 <= b && c2 < CPU_SETSIZE; c2++) { CPU_SET(c2, &set); n_set++; }
                         i = j == std::string::npos ? list.size() : j + 1;
+                    }
+                }
+                // within what the caller allows (taskset, numactl, a container's cpuset): never a wider mask than it came with
+                cpu_set_t allowed;
+                if (n_set > 0 && sched_getaffinity(0, sizeof allowed, &allowed) == 0) {
+                    n_set = 0;
+                    for (int c2 = 0; c2 < CPU_SETSIZE; c2++) {
+                        if (CPU_ISSET(c2, &set) && !CPU_ISSET(c2, &allowed)) CPU_CLR(c2, &set);
+                        if (CPU_ISSET(c2, &set)) n_set++;
                     }
                 }
                 if (n_set > 0 && sched_setaffinity(0, sizeof set, &set) == 0) dev_node[k] = node;

@@ -334,26 +334,33 @@ public:
         on_die().store([] { if (MappedSink* s = live()) s->cut_back(); });
         return true;
     }
-    // a fatal path: leave the records laid out so far, not the pages reserved ahead of them
+    // a fatal path (any thread, or the handler of SIGINT / SIGTERM: only unlink, ftruncate and atomics here): leave the
+    // records laid out so far, not the pages reserved ahead of them.  A reserve_to in flight on another thread sees dead_
+    // when its fallocate returns and cuts the file back again itself.
     void cut_back() {
         if (fd_ < 0) return;
-        if (created_ && size_ == 0) { unlink(path_.c_str()); return; }
-        if (reserved_ > size_ && ftruncate(fd_, (off_t)size_) != 0) { /* nothing more to do */ }
+        dead_.store(true);
+        const uint64_t size = size_.load();
+        if (created_ && size == 0) { unlink(path_.c_str()); return; }
+        if (reserved_.load() > size && ftruncate(fd_, (off_t)size) != 0) { /* nothing more to do */ }
     }
-    uint64_t reserved() const { return reserved_; }
-    uint64_t planned() const { return size_; }
+    uint64_t reserved() const { return reserved_.load(); }
+    uint64_t planned() const { return size_.load(); }
     uint64_t capacity() const { return cap_; }
     // instantiate the pages up to `end`.  must: a failure ends the run (the records need the space); otherwise (the
     // speculative early reserve) it just reports false
     bool reserve_to(uint64_t end, bool must = true) {
-        if (end <= reserved_) return true;
+        const uint64_t have = reserved_.load();
+        if (end <= have) return true;
+        if (dead_.load()) return false;
         const double t0 = now_s();
-        if (fallocate(fd_, 0, (off_t)reserved_, (off_t)(end - reserved_)) != 0) {
+        if (fallocate(fd_, 0, (off_t)have, (off_t)(end - have)) != 0) {
             if (must) die(std::string("cannot extend the output file: ") + strerror(errno));
             return false;
         }
         t_falloc += now_s() - t0;
-        reserved_ = end;
+        reserved_.store(end);
+        if (dead_.load()) { cut_back(); return false; }                 // the run ended meanwhile: not one page more than it left
         return true;
     }
     // map the (instantiated) pages of [at, at+n) into the address space now, so that storing into them later takes no
@@ -365,7 +372,7 @@ public:
             for (size_t o = 0; o < len; o += 4096) { volatile char* q = p + o; *q = *q; }     // older kernels: one touch per page
     }
     // the next n bytes of the file (inside what was reserved)
-    char* place(uint64_t n) { char* p = map_ + size_; size_ += n; return p; }
+    char* place(uint64_t n) { char* p = map_ + size_.load(); size_.fetch_add(n); return p; }
     // the pages wholly inside [p, p+n) are done with: drop their mappings now, from the calling (fill) thread, instead of
     // all of them at exit from one
     static void release(const char* p, size_t n) {
@@ -374,7 +381,7 @@ public:
     }
     void close() {
         if (fd_ < 0) return;
-        if (reserved_ != size_ && ftruncate(fd_, (off_t)size_) != 0) die("cannot set the size of the output file");
+        if (reserved_.load() != size_.load() && ftruncate(fd_, (off_t)size_.load()) != 0) die("cannot set the size of the output file");
         ::close(fd_);
         fd_ = -1;
         if (live() == this) { live() = nullptr; on_die().store(nullptr); }
@@ -385,7 +392,9 @@ private:
     static MappedSink*& live() { static MappedSink* s = nullptr; return s; }
     int fd_ = -1;
     char* map_ = nullptr;
-    uint64_t size_ = 0, reserved_ = 0, cap_ = 0;
+    std::atomic<uint64_t> size_{0}, reserved_{0};
+    std::atomic<bool> dead_{false};
+    uint64_t cap_ = 0;
     bool created_ = false;
     std::string path_;
 };
@@ -498,8 +507,7 @@ public:
     void want(uint64_t estimate, uint64_t need) {
         std::lock_guard<std::mutex> l(m_);
         if (need > need_) need_ = need;
-        if (estimate > goal_) goal_ = estimate;
-        if (need_ > goal_) goal_ = need_;
+        goal_ = estimate > need_ ? estimate : need_;                    // (an estimate may shrink: what is reserved beyond it is cut off at the end)
         cv_.notify_all();
     }
     void wait_ready(uint64_t upto) {
@@ -526,8 +534,9 @@ private:
             {
                 std::unique_lock<std::mutex> l(m_);
                 cv_.wait(l, [&] { return stop_ || goal_ > at; });
+                if (stop_ && at >= need_) return;                    // stopped: only what is needed for certain is still reserved
                 if (goal_ <= at) return;        // stopped with nothing left to do
-                goal = goal_; need = need_;
+                goal = stop_ ? need_ : goal_; need = need_;
             }
             uint64_t upto = std::min<uint64_t>(goal, at + stride_);
             if (upto < sink_.reserved()) upto = sink_.reserved();

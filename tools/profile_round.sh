@@ -2,13 +2,14 @@
 # All the rocprofv3 passes behind profiles/: kernel-trace stats for the default bench line and for one batch
 # in flight, and the PMC passes (one per counter set, with --kernel-trace only).  Run on the GPU box:
 #   tools/profile_round.sh <tag>     -> gpurun_out/prof_<tag>/*.csv|json  (copy what is to be judged to profiles/)
-tag=${1:-r01}
+#   tools/profile_round.sh <tag> [bench.py arguments of the kernel path: --workload hifi | --min-repeat 100 --kmer 11 ...]
+tag=${1:-r01}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof_$tag
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 # kernel-path runs only under the profiler (the end-to-end leg starts other programs; it is timed by bench.py itself)
-K="--no-e2e --no-cpu-baseline --no-oracle-check"
+K="--no-e2e --no-cpu-baseline --no-oracle-check $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_default -- python3 $R/bench.py $K > $O/kt_default.json 2> $O/kt_default.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_single -- python3 $R/bench.py $K --streams 1 > $O/kt_single.json 2> $O/kt_single.err
 B="python3 $R/bench.py $K --kernel-steps 2 --kernel-warmup 1 --streams 1"
@@ -59,7 +60,19 @@ def pmc(run):
         k = short(row["Kernel_Name"])
         agg[k][row["Counter_Name"]] += float(row["Counter_Value"]); n[k][row["Counter_Name"]] += 1
     return {k: {c: v / n[k][c] for c, v in d.items()} for k, d in agg.items()}
+def per_batch(run):
+    """per kernel name: the counters summed over a batch's dispatches of it (a batch = one k_finalize)"""
+    rows = []
+    for fn in glob.glob(O + "/" + run + "/**/*counter_collection.csv", recursive=True):
+        rows += list(csv.DictReader(open(fn)))
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); nb = collections.Counter()
+    for row in real_dispatches(rows, "Grid_Size"):
+        k = short(row["Kernel_Name"])
+        agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
+        if k == "tgsf::k_finalize": nb[row["Counter_Name"]] += 1
+    return {k: {c: v / max(nb[c], 1) for c, v in d.items()} for k, d in agg.items()}
 fetch, write, tcc, sq = pmc("pmc_fetch"), pmc("pmc_write"), pmc("pmc_tcc"), pmc("pmc_sq")
+b_write, b_tcc, b_sq = per_batch("pmc_write"), per_batch("pmc_tcc"), per_batch("pmc_sq")
 kernels = sorted(set(fetch) | set(write) | set(tcc), key=lambda k: -tcc.get(k, {}).get("TCC_EA0_RDREQ_sum", 0))
 with open(O + "/%s_pmc_hbm_traffic.csv" % tag, "w") as o:
     o.write("kernel,FETCH_SIZE_KB,WRITE_SIZE_KB,TCC_EA0_RDREQ,TCC_HIT,TCC_MISS,read_bytes_corrected,write_bytes\n")
@@ -85,12 +98,23 @@ import hashlib
 h = hashlib.sha256()
 for fn in ("tgsf_hip.h", "tgsf_core.h", "tgsf_dev.h", "tgsf_kernels.h", "tgsf_lib.hip"):      # = bench.py kernel_source_hash()
     h.update(open(os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.getcwd()), "tgsfilter_amd", "csrc", fn), "rb").read())
-json.dump({"reads_per_step": b["kernel_path"]["reads_per_step"], "kernel_source_hash": h.hexdigest()[:16],
-           "mid_scan_hbm_bytes_per_launch": hbm("tgsf::k_mid_scan1<2"),
-           "stats_raw_hbm_bytes_per_launch": hbm("tgsf::k_stats<false"),
-           "mid_scan_valu_insts_per_launch": named(sq, "tgsf::k_mid_scan1<2").get("SQ_INSTS_VALU"),
-           "valu_insts_per_batch_all_kernels": sum(d.get("SQ_INSTS_VALU", 0) for d in sq.values()),
-           "source": "profiles/%s_pmc_hbm_traffic.csv (TCC_EA0_RDREQ_sum*128 + WRITE_SIZE*1024) and %s_pmc_valu.csv" % (tag, tag)},
+STAGES = {"mid_scan": ("tgsf::k_mid_flat", "tgsf::k_mid_scan"), "stats_raw": ("tgsf::k_stats<false",), "stats_clean": ("tgsf::k_stats<true",),
+          "repeat_gate": ("tgsf::k_repeat",), "end_windows": ("tgsf::k_end_windows",)}
+def stage_sum(d, prefixes, counter, scale=1.0):
+    return sum(v.get(counter, 0.0) * scale for k, v in d.items() if k.startswith(prefixes))
+per_stage = {}
+for st, pre in STAGES.items():
+    rd, wr = stage_sum(b_tcc, pre, "TCC_EA0_RDREQ_sum", 128.0), stage_sum(b_write, pre, "WRITE_SIZE", 1024.0)
+    vi = stage_sum(b_sq, pre, "SQ_INSTS_VALU")
+    if rd or wr or vi:
+        per_stage[st] = {"hbm_bytes_per_batch": rd + wr, "hbm_read_bytes_per_batch": rd, "valu_insts_per_batch": vi}
+json.dump({"kernel_source_hash": h.hexdigest()[:16],
+           "signatures": {b["kernel_path"]["signature"]: {
+               "reads_per_step": b["kernel_path"]["reads_per_step"], "stages": per_stage,
+               "hbm_bytes_per_batch_all_kernels": sum(v.get("TCC_EA0_RDREQ_sum", 0) * 128 for v in b_tcc.values()) + sum(v.get("WRITE_SIZE", 0) * 1024 for v in b_write.values()),
+               "valu_insts_per_batch_all_kernels": sum(d.get("SQ_INSTS_VALU", 0) for d in b_sq.values()),
+               "source": "profiles/%s_pmc_hbm_traffic.csv (TCC_EA0_RDREQ_sum*128 + WRITE_SIZE*1024) and %s_pmc_valu.csv" % (tag, tag)}}},
           open(O + "/traffic.json", "w"), indent=1)
 PY
+rm -rf $O/kt_default $O/kt_single $O/pmc_fetch $O/pmc_write $O/pmc_tcc $O/pmc_sq      # (raw traces: tens of MB; gpurun_out/ travels back only below 64 MiB)
 ls $O
