@@ -786,6 +786,10 @@ def main():
         args.min_repeat = args.min_repeat or 100
         if args.reads == 131072:
             args.reads = 32768             # (4.9 Gbases a step, as C2's steps)
+    if args.config == "c3":                # the kernel path in C3's shape: HiFi reads, blunt adapter pair, -M 35 -T 50 (the defaults)
+        args.workload = "hifi"
+        if args.reads == 131072:
+            args.reads = 262144            # (4.7 Gbases a step)
     # stdout carries exactly one line, the result: whatever libraries print there meanwhile goes to stderr
     sys.stdout.flush()
     real_stdout = os.dup(1)

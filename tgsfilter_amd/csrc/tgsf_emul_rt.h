@@ -24,6 +24,7 @@ static void emul_launch(unsigned grid, unsigned block, F f)
         }
 }
 #define TGSF_LAUNCH(kernel, grid, block, stream, ...) emul_launch((grid), (block), [&] { kernel(__VA_ARGS__); })
+#define TGSF_LAUNCH_LDS(kernel, grid, block, lds, stream, ...) emul_launch((grid), (block), [&] { (void)(lds); kernel(__VA_ARGS__); })
 // block-cooperative kernels are written for any block size; emulate them with one thread
 #define TGSF_LAUNCH_COOP(kernel, grid, block, stream, ...) emul_launch((grid), 1u, [&] { kernel(__VA_ARGS__); })
 // the emulation trades speed for fidelity: small grids

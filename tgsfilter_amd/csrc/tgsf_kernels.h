@@ -1517,40 +1517,52 @@ TGSF_KERNEL k_mid_flat(DevParams P, DevBatch B, int a0, int na)
 
         open_read(first - B.chk_cnt[r]);
         // The loop below keeps every lane of the wave in one instruction stream without masks: the rare events of a lane
-        // (its window has no further whole chunk; its stretch is done) are looked for once per chunk with a wave-wide
-        // test and handled outside the hot body, and a lane that is done "parks": it keeps stepping over the same 16
-        // readable bytes, recording nothing, until its wave is done.  The text is fetched one chunk ahead of the
-        // columns (the chunk after the window's last whole one: that one again, never used).
+        // (its window has no further whole chunk; its stretch is done) are looked for with a wave-wide test before every
+        // chunk and handled outside the hot loop, and a lane that is done "parks": it keeps stepping over the same 16
+        // readable bytes, recording nothing, until its wave is done.
+        // The text comes 64 bytes per lane at a time (a lane's 128-byte line is asked for twice, not eight times: the
+        // lines of all resident lanes together outgrow the L2s, and every further touch would be another trip to the
+        // fabric), one fetch group ahead of the columns: the four chunks of a trip of the hot loop sit in g0..g3; a chunk is
+        // copied out as it is taken up, and while the last one goes through the columns the next four are on their way.
+        // (Chunks past the window's last whole one: that one again, never used.)
         const uint8_t* const safe = reinterpret_cast<const uint8_t*>(P.peq_top);     // 16 readable bytes for parked lanes
         int dc = 16;
         bool parked = false;
-        uint4 nxt = load16u(c < cfull ? mid + c : safe);
+        uint4 g0, g1, g2, g3;
+        auto fetch4 = [&](int at) TGSF_INLINE_LAMBDA {                // the chunks at columns at, at + dc, at + 2 dc, at + 3 dc
+            const int last = cfull - 16;
+            const int p0 = at < last ? at : last, p1 = at + dc < last ? at + dc : last;
+            const int p2 = at + 2 * dc < last ? at + 2 * dc : last, p3 = at + 3 * dc < last ? at + 3 * dc : last;
+            g0 = load16u(mid + p0); g1 = load16u(mid + p1); g2 = load16u(mid + p2); g3 = load16u(mid + p3);
+        };
+        auto event = [&]() TGSF_INLINE_LAMBDA -> bool { return !parked && (left == 0u || c >= cfull); };
+        auto chunk = [&](const uint4& v) TGSF_INLINE_LAMBDA {
+            const bool own = c >= own_from;
+            chunk16(v, c, own);
+            c += dc;
+            left -= own ? 1u : 0u;
+        };
         for (;;) {
-            // the hot loop: nothing but chunks, until some lane of the wave has an event (two chunks per trip: the
-            // copies the compiler makes of the loop-carried registers at the top of a trip are paid half as often)
-            auto chunk = [&]() TGSF_INLINE_LAMBDA {
-                const uint4 cur = nxt;
-                int pf = c + dc;
-                pf = pf < cfull - 16 ? pf : cfull - 16;
-                nxt = load16u(mid + pf);
-                const bool own = c >= own_from;
-                chunk16(cur, c, own);
-                c += dc;
-                left -= own ? 1u : 0u;
-            };
-            for (;;) {
-                if (wave_any(!parked && (left == 0u || c >= cfull))) break;
-                chunk();
-                if (wave_any(!parked && (left == 0u || c >= cfull))) break;
-                chunk();
+            // the hot loop: four chunks a trip, until some lane of the wave has an event
+            if (!wave_any(event())) {
+                if (c < cfull) fetch4(c); else { g0 = g1 = g2 = g3 = load16u(safe); }
+                for (;;) {
+                    { const uint4 cur = g0; chunk(cur); }
+                    if (wave_any(event())) break;
+                    { const uint4 cur = g1; chunk(cur); }
+                    if (wave_any(event())) break;
+                    { const uint4 cur = g2; chunk(cur); }
+                    if (wave_any(event())) break;
+                    { const uint4 cur = g3; fetch4(c + dc); chunk(cur); }
+                    if (wave_any(event())) break;
+                }
             }
-            if (!parked && (left == 0u || c >= cfull)) {
+            if (event()) {
                 if (left == 0u) {                                         // the stretch is done
 #pragma unroll
                     for (int j = 0; j < AT; j++) flush_ties(j);
                     parked = true; dc = 0; c = 0; own_from = 0x7FFFFFFF; cfull = 0x7FFFFFFF; cend = 0x7FFFFFFF; ML = 0;
                     mid = safe;
-                    nxt = load16u(safe);
                 } else if (c < cend) {
                     // the window's last columns with fewer than 15 bytes of the read behind them (-E below 15): byte by
                     // byte, never reading beyond the read
@@ -1563,7 +1575,6 @@ TGSF_KERNEL k_mid_flat(DevParams P, DevBatch B, int a0, int na)
                     for (int j = 0; j < AT; j++) flush_ties(j);
                     do { r++; } while (B.chk_cnt[r + 1] == B.chk_cnt[r]);
                     open_read(0u);
-                    nxt = load16u(c < cfull ? mid + c : safe);
                 }
             }
             if (!wave_any(!parked)) break;

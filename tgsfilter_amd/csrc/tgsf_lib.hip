@@ -47,6 +47,7 @@ struct tgsf_ctx {
     uint32_t cap_reads, max_read_len, n_bins;
     unsigned endtab_grid = 512;             // k_end_tables: LDS-atomic bound, 40 KB of LDS per block: two blocks per CU (128: 0.36 ms, 512: 0.19 ms)
     unsigned stats_grid = 768, mid_grid = 0;   // tuning knobs (TGSF_STATS_GRID, TGSF_MID_GRID; 0 = one lane per segment)
+    unsigned flat_lds_pad = 0;                 // TGSF_FLAT_LDS_PAD (experiment): dynamic LDS per workgroup of k_mid_flat, to leave room on every CU
     bool flat_scan = true;                    // first middle scan of a batch by k_mid_flat (TGSF_MID_FLAT=0: k_mid_scan1, as after a pool overflow)
     bool no_hot32 = false;                    // TGSF_NO_HOT32=1: adapters <= 32 bp take the 64-bit column too (A/B, tests)
     bool stats_nt = true;                     // k_stats fetches the text with non-temporal loads (2.24 -> 2.06 ms raw, 5.4 -> 5.8 TB/s; TGSF_STATS_NT=0: plain loads)
@@ -122,6 +123,8 @@ static int rt_sync(rt_stream s) { return (int)hipStreamSynchronize(s); }
 static const char* rt_errstr(int e) { return hipGetErrorString((hipError_t)e); }
 #define TGSF_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (stream), __VA_ARGS__)
 #define TGSF_LAUNCH_COOP TGSF_LAUNCH
+// with `lds` bytes of dynamic LDS on top of the kernel's own (nothing uses them: they bound the workgroups a CU holds)
+#define TGSF_LAUNCH_LDS(kernel, grid, block, lds, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (lds), (stream), __VA_ARGS__)
 static unsigned grid_cap(unsigned g) { return g; }
 #endif
 
@@ -450,6 +453,7 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     if (const char* e = getenv("TGSF_MID_GRID")) { int v = atoi(e); if (v >= 1) c->mid_grid = (unsigned)v; }
     if (const char* e = getenv("TGSF_SEG_COLS")) { int v = atoi(e); if (v >= 256 && v <= 65536) P.seg_cols = v & ~15; }   // tuning knob
     if (const char* e = getenv("TGSF_MID_FLAT")) c->flat_scan = atoi(e) > 0;
+    if (const char* e = getenv("TGSF_FLAT_LDS_PAD")) { int v = atoi(e); if (v >= 0 && v <= 140000) c->flat_lds_pad = (unsigned)v; }
 
     int e = build_tables(c);
     DevBatch& B = c->B;
@@ -755,17 +759,18 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
                 int na = 0;
                 while (a + na < A && na < 4 && P.Q[a + na] <= 64 && ((P.Q[a + na] <= 32 && !c->no_hot32) == narrow)) na++;
                 if (flat && mode == 0) {
+                    const unsigned lp = c->flat_lds_pad;
                     if (narrow) switch (na) {
-                    case 1: TGSF_LAUNCH((k_mid_flat<1, Hot32>), gflat, T, ms, P, Bm, a, na); break;
-                    case 2: TGSF_LAUNCH((k_mid_flat<2, Hot32>), gflat, T, ms, P, Bm, a, na); break;
-                    case 3: TGSF_LAUNCH((k_mid_flat<3, Hot32>), gflat, T, ms, P, Bm, a, na); break;
-                    default: TGSF_LAUNCH((k_mid_flat<4, Hot32>), gflat, T, ms, P, Bm, a, na); break;
+                    case 1: TGSF_LAUNCH_LDS((k_mid_flat<1, Hot32>), gflat, T, lp, ms, P, Bm, a, na); break;
+                    case 2: TGSF_LAUNCH_LDS((k_mid_flat<2, Hot32>), gflat, T, lp, ms, P, Bm, a, na); break;
+                    case 3: TGSF_LAUNCH_LDS((k_mid_flat<3, Hot32>), gflat, T, lp, ms, P, Bm, a, na); break;
+                    default: TGSF_LAUNCH_LDS((k_mid_flat<4, Hot32>), gflat, T, lp, ms, P, Bm, a, na); break;
                     }
                     else switch (na) {
-                    case 1: TGSF_LAUNCH((k_mid_flat<1, Hot>), gflat, T, ms, P, Bm, a, na); break;
-                    case 2: TGSF_LAUNCH((k_mid_flat<2, Hot>), gflat, T, ms, P, Bm, a, na); break;
-                    case 3: TGSF_LAUNCH((k_mid_flat<3, Hot>), gflat, T, ms, P, Bm, a, na); break;
-                    default: TGSF_LAUNCH((k_mid_flat<4, Hot>), gflat, T, ms, P, Bm, a, na); break;
+                    case 1: TGSF_LAUNCH_LDS((k_mid_flat<1, Hot>), gflat, T, lp, ms, P, Bm, a, na); break;
+                    case 2: TGSF_LAUNCH_LDS((k_mid_flat<2, Hot>), gflat, T, lp, ms, P, Bm, a, na); break;
+                    case 3: TGSF_LAUNCH_LDS((k_mid_flat<3, Hot>), gflat, T, lp, ms, P, Bm, a, na); break;
+                    default: TGSF_LAUNCH_LDS((k_mid_flat<4, Hot>), gflat, T, lp, ms, P, Bm, a, na); break;
                     }
                     a += na;
                     continue;
