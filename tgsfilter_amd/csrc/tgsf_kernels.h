@@ -1976,7 +1976,8 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat(DevParams P, DevBatch B)
     constexpr int W = kRepWords;
     TGSF_SHARED uint4 bm4[8192];                      // 128 KB: one partition of the 4^k-bit "seen" set
     TGSF_SHARED uint32_t codes[W + 4];                // a window of the fragment as 2-bit codes
-    TGSF_SHARED uint32_t distinct_s, next_s;
+    TGSF_SHARED uint32_t next_s;
+    TGSF_SHARED int rep_s;                           // repeats found in the passes done so far: their k-mers less their distinct ones
     uint32_t* bm = reinterpret_cast<uint32_t*>(bm4);
     const int k = P.kmer;
     const uint32_t space_log2 = 2u * (uint32_t)k;                      // k <= 13 -> <= 26 bits
@@ -2023,7 +2024,7 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat(DevParams P, DevBatch B)
         const int words = (a + L + 15) / 16;                           // chunks holding the fragment
         const int kwords = total > 0 ? (a + total + 15) / 16 : 0;      // chunks in which a k-mer starts
         const bool one_window = words <= W;
-        if (tid == 0) { distinct_s = 0; next_s = gridDim.x + atomicAdd(B.rep_next, 1u); }
+        if (tid == 0) { rep_s = 0; next_s = gridDim.x + atomicAdd(B.rep_next, 1u); }
         TGSF_BLOCK_SYNC();                                             // the previous fragment's readers of codes[] are done
         if (kTgsfEmul) load_window(base, words, 0);
         else {
@@ -2033,8 +2034,8 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat(DevParams P, DevBatch B)
         TGSF_BLOCK_SYNC();
         const uint32_t fnext = next_s;
         prefetch(fnext);
-        uint32_t mine = 0;
         for (uint32_t pass = 0; pass < passes && kwords > 0; pass++) {
+            uint32_t own = 0;                                          // k-mers this lane marks in this pass
             // windows of W chunks; a k-mer starting in chunk g reads chunk g+1 too, so consecutive windows share one chunk
             for (int wb = 0;; wb += W - 1) {
                 if (!one_window && !(pass == 0 && wb == 0)) {
@@ -2049,6 +2050,7 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat(DevParams P, DevBatch B)
                     const int first = a - 16 * (wb + g);               // starts before the fragment's first base (chunk 0 only)
                     const int v = a + total - 16 * (wb + g);           // starts up to the last k-mer
                     if (PB == 0 && first <= 0 && v >= 16) {
+                        own += 16u;
 #pragma unroll
                         for (int j = 0; j < 16; j++) {
                             const uint32_t t = j ? alignbit(hi, lo, 32u - 2u * (uint32_t)j) : hi;   // the k-mer from bit 31 down
@@ -2062,6 +2064,7 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat(DevParams P, DevBatch B)
                         if (PB >= 3) m &= alignbit(rep_eq_mask(hi, pass & 3u), rep_eq_mask(lo, pass & 3u), 28u);
                         if (first > 0) m &= 0xFFFFFFFFu >> (2 * first);
                         if (v < 16) m &= ~(0xFFFFFFFFu >> (2 * v));
+                        own += popc32(m);
                         const uint64_t win = ((uint64_t)hi << 32) | lo;
                         const int c0 = 30 + 2 * PB;
                         while (m) {
@@ -2077,18 +2080,22 @@ TGSF_KERNEL TGSF_BOUNDS(kRepThreads, 4) k_repeat(DevParams P, DevBatch B)
             }
             // distinct k-mers of this partition = set bits of the bitmap; leave it clear
             TGSF_BLOCK_SYNC();
+            uint32_t mine = 0;
             for (uint32_t w = (uint32_t)tid; w < part_q; w += (uint32_t)NT) {
                 const uint4 q = bm4[w];
                 mine += popc32(q.x) + popc32(q.y) + popc32(q.z) + popc32(q.w);
                 bm4[w] = zero4;
             }
+            // the repeats of this pass: its k-mers less its distinct ones (never negative over the workgroup)
+            const int part = wave_sum_i32((int)own - (int)mine);
+            if (wave_leader() && part) atomicAdd(&rep_s, part);
             TGSF_BLOCK_SYNC();
+            // What the gate asks is whether repeat reaches -p (:1984), and every pass only adds to it: a fragment is
+            // accepted as soon as the passes so far hold -p repeats (a 150-kb read: after the first of its four passes).
+            if (rep_s >= P.min_repeat) break;
         }
-        mine = (uint32_t)wave_sum((uint64_t)mine);
-        if (wave_leader() && mine) atomicAdd(&distinct_s, mine);
-        TGSF_BLOCK_SYNC();
         if (tid == 0) {
-            const int repeat = (total > 0 ? total : 0) - (int)distinct_s;
+            const int repeat = rep_s;                                  // all of them, or enough of them
             if (repeat < P.min_repeat) {                               // :1984-1988
                 B.frag_flags[f] |= TGSF_FF_REPEAT;
                 drop_n++; drop_b += (uint64_t)L;
