@@ -21,6 +21,7 @@
 #define TGSF_ON_DEVICE(...)
 #define TGSF_ON_EMUL(...) __VA_ARGS__
 constexpr bool kTgsfEmul = true;
+#define TGSF_WAVE_PRIO(p) ((void)0)
 
 struct uint4 { uint32_t x, y, z, w; };
 namespace tgsf_emul {

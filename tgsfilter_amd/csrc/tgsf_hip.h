@@ -22,6 +22,8 @@
 #define TGSF_ON_DEVICE(...) __VA_ARGS__
 #define TGSF_ON_EMUL(...)
 constexpr bool kTgsfEmul = false;
+// issue priority of the wave from here on (0..3; priority outranks age in the SIMD's arbitration)
+#define TGSF_WAVE_PRIO(p) __builtin_amdgcn_s_setprio(p)
 
 namespace tgsf {
 

@@ -397,7 +397,35 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
             c->h_pinned = pw; c->h_status = pw; c->pend_nf_p = pw + 4;
         }
     }
-    if ((he = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking)) != hipSuccess ||
+    if ((he = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking)) != hipSuccess || ndev <= 0) {
+        delete c;
+        return fail(nullptr, TGSF_E_NO_DEVICE, "no HIP device available (%s); libtgsf has no CPU fallback", hipGetErrorString(he));
+    }
+    if (device < 0 || device >= ndev) { delete c; return fail(nullptr, TGSF_E_NO_DEVICE, "device %d out of range (%d devices)", device, ndev); }
+    if ((he = hipSetDevice(device)) != hipSuccess) { delete c; return fail(nullptr, TGSF_E_HIP, "hipSetDevice: %s", hipGetErrorString(he)); }
+    if ((he = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+        delete c; return fail(nullptr, TGSF_E_HIP, "hipStreamCreate: %s", hipGetErrorString(he));
+    }
+    c->own_stream = true;
+    c->prof_pending = 0;
+    {
+        uint32_t* pw = nullptr;
+        if (hipHostMalloc((void**)&pw, 64, hipHostMallocDefault) == hipSuccess && pw) {
+            memset(pw, 0, 64);
+            c->h_pinned = pw; c->h_status = pw; c->pend_nf_p = pw + 4;
+        }
+    }
+    {
+        // the auxiliary stream's short kernels (end windows, end tables) run beside the middle scan, whose workgroups fill
+        // every CU for a millisecond each: with a priority above the scan's they get the slots that free up first
+        // (TGSF_AUX_PRIO=0: plain stream)
+        const char* ap = getenv("TGSF_AUX_PRIO");
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);               // hi = numerically lowest = greatest priority
+        he = (ap && atoi(ap) == 0) ? hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking)
+                                   : hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, hi);
+    }
+    if (he != hipSuccess ||
         (he = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess ||
         (he = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) {
         tgsf_destroy(c); return fail(nullptr, TGSF_E_HIP, "auxiliary stream: %s", hipGetErrorString(he));
