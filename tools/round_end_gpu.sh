@@ -4,7 +4,7 @@
 #   tools/round_end_gpu.sh bench           the full default bench line (as the driver runs it) + --config c5
 #   tools/round_end_gpu.sh suite           the GPU test suite
 cd $GRAFT_REPO_ROOT
-what=${1:-suite}; tag=${2:-r03}
+what=${1:-suite}; tag=${2:-r04}
 R=$GRAFT_REPO_ROOT
 brief() { python3 -c "
 import json,sys
