@@ -42,6 +42,16 @@ def test_struct_layout_matches_header():
                    abi.READ_RESULT_DTYPE.itemsize, abi.FRAGMENT_DTYPE.itemsize]
 
 
+def test_constants_match_header():
+    """The constants of the tgsf_submit_device contract as the Python binding states them."""
+    import re
+    from tgsfilter_amd import abi
+    hdr = open(os.path.join(ROOT, "include", "tgsf.h")).read()
+    assert int(re.search(r"#define TGSF_MAX_ENQUEUED (\d+)", hdr).group(1)) == abi.MAX_ENQUEUED
+    assert int(re.search(r"#define TGSF_NFRAGS_NOT_FINAL (0x[0-9A-Fa-f]+)u", hdr).group(1), 16) == abi.NFRAGS_NOT_FINAL
+    assert int(re.search(r"#define TGSF_N_STAGES (\d+)", hdr).group(1)) == abi.N_STAGES
+
+
 def test_no_device_fails_loudly(lib):
     import torch
     if torch.cuda.is_available():

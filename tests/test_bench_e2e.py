@@ -27,6 +27,9 @@ def test_e2e_leg_with_the_emulated_cli(monkeypatch):
     v = r["variants"]["pinned_prepass"]
     assert v["same_counters"] and v["same_output_multiset"] and "-5 0 -3 0 -a rapid.fa" in v["flags"]
     assert r["reads"] == 16 and r["bases"] > 0 and r["flags"] == "-x ont -l 1000 -q 10" and not r["skipped"]
+    # the reference is timed several times (mean and best both reported, the cgroup's CPU accounting of every run)
+    assert len(s["reference_wall_s_runs"]) == bench.REF_RUNS == len(s["reference_cpu_runs"])
+    assert s["reference_wall_s_min"] <= s["reference_wall_s"] and s["speedup_vs_reference_best_run"] <= s["speedup_vs_reference"] * 1.0000001
 
 
 @pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/tgsfilter_ref not built (make -C oracle ref)")
@@ -39,6 +42,19 @@ def test_e2e_leg_config_c5_with_the_emulated_cli(monkeypatch):
     r = bench.e2e_leg(args, 1)
     s = r["sinks"]["tmpfs_file"]
     assert r["flags"] == "-x ont -l 1000 -q 10 -g 3g -d 40 -p 100 -k 11" and "C5" in r["config"]
+    assert s["same_counters"] and s["same_output_multiset"] and s["output_records"] > 0 and "variants" not in r
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/tgsfilter_ref not built (make -C oracle ref)")
+def test_e2e_leg_config_c3_with_the_emulated_cli(monkeypatch):
+    """--config c3: HiFi reads, -x hifi -l 1000 -q 20 -M 35 -T 50 with the automatic pre-pass, the reference beside it."""
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tgsfilter_amd", "host"), "emul"], check=True)
+    import bench
+    monkeypatch.setattr(bench, "CLI", os.path.join(ROOT, "tests", "emul", "tgsfilter_emul"))
+    args = types.SimpleNamespace(e2e_reads=40, steps=1, warmup=0, no_cpu_baseline=False, config="c3")
+    r = bench.e2e_leg(args, 1)
+    s = r["sinks"]["tmpfs_file"]
+    assert r["flags"] == "-x hifi -l 1000 -q 20 -M 35 -T 50" and "C3" in r["config"]
     assert s["same_counters"] and s["same_output_multiset"] and s["output_records"] > 0 and "variants" not in r
 
 
