@@ -158,7 +158,7 @@ TGSF_HD void hot_step(Hot32& s, uint32_t Eq) {
     s.m = bitop3<0xE0>(Ph, Eq, Mv);                      // Ph' & (Eq | Mv)
 }
 TGSF_HD int hot_score(const Hot32& s) { return (int)popc32(s.p) - (int)popc32(s.m); }
-TGSF_HD bool hot_within(const Hot32& s, int lim) { return (int)popc32(s.p) <= popc32_acc(s.m, lim); }
+TGSF_HD bool hot_within(const Hot32& s, int lim) { return (int)popc32(s.p) <= (int)(popc32(s.m) + (uint32_t)lim); }   // (one accumulating v_bcnt per side)
 // the 32-bit Eq row from the 64-bit top-aligned one: its high half (bits below the adapter are wildcards in both)
 TGSF_HD uint32_t hot_eq(const Hot32&, uint64_t top) { return (uint32_t)(top >> 32); }
 

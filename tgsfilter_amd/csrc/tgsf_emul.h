@@ -64,8 +64,6 @@ TGSF_HD uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c) {
 }
 TGSF_HD void pin(uint64_t&) {}
 TGSF_HD void pin(uint32_t&) {}
-TGSF_HD int popc64_acc(uint64_t x, int acc) { return (int)popc64(x) + acc; }
-TGSF_HD int popc32_acc(uint32_t x, int acc) { return (int)popc32(x) + acc; }
 struct QcConsts { uint32_t k[4]; };
 TGSF_HD QcConsts qc_consts() { return QcConsts{{0x41414141u, 0x54545454u, 0x47474747u, 0x43434343u}}; }
 TGSF_HD uint32_t xad7f(uint32_t x7, uint32_t k) { return (x7 ^ k) + 0x7F7F7F7Fu; }

@@ -45,18 +45,6 @@ TGSF_D uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_am
 // keeps a value in the registers it is in (no instruction): stops the compiler from re-deriving or regrouping it
 TGSF_D void pin(uint64_t& v) { asm volatile("" : "+v"(v)); }
 TGSF_D void pin(uint32_t& v) { asm volatile("" : "+v"(v)); }
-// popcount(x) + acc as two accumulating v_bcnt_u32_b32 (the compiler adds acc separately when popcount(x) has another use)
-TGSF_D int popc64_acc(uint64_t x, int acc) {
-    int r;
-    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"((uint32_t)x), "v"(acc));
-    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(r) : "v"((uint32_t)(x >> 32)));
-    return r;
-}
-TGSF_D int popc32_acc(uint32_t x, int acc) {
-    int r;
-    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
-    return r;
-}
 // The class constants of the QC tallies held in VGPRs, so that (x7 ^ K) + 0x7F7F7F7F is one v_xad_u32
 // (a VOP3 instruction reads one scalar at most): 4 instructions per class and dword.
 struct QcConsts { uint32_t k[4]; };
