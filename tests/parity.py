@@ -233,6 +233,71 @@ def colliding_hash_case(lib_path):
         ctx.close()
 
 
+def mid_filter_cases(lib_path, env):
+    """k_mid_flat as a filter (adapters of 33..64 bp within at most kSuffixMaxK = 12 differences: the last 32 rows in the
+    dword column, marked chunks rechecked by k_mid_recheck) under `env` (TGSF_MID_FILTER: 0 off, 1 / 2 the test stride):
+    every -M from an exact match to the first value past the filter's range, the 35/36-bp library adapters with their
+    homopolymer tails against homopolymer reads (every chunk marked: k_mid_recheck's list outgrows its LDS, the candidate
+    pool overflows and the batch is run again), adapters planted across chunk and read boundaries and in a window's last,
+    partial chunk, mixed passes (filtered, unfiltered and one-dword adapters in one context)."""
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        pb = [synth.PACBIO_BLUNT, synth.PACBIO_BLUNT_RC]
+        for mml in (45, 44, 40, 35, 34, 33, 32):                             # k = 1, 2, 6, 11, 12, 13 (unfiltered), 14
+            reads = synth.make_reads(900 + mml, 48, "hifi", mean_len=2500, zoo=True, pmid=0.5, err=0.5 * (46 - mml) / 45.0)
+            p = sized(abi.make_params("hifi", adapters=pb, mid_match_len=mml, min_len=200), reads)
+            ctx = capi.Context(p, 0, lib_path)
+            compare_batch(ctx, p, reads, align=1, explicit_lengths=False)
+            ctx.close()
+        # the kit adapters with homopolymer tails, and reads that are one long homopolymer / dinucleotide repeat
+        tails = [b"AAAAAAAAAAAAAAAAAATTAACGGAGGAGGAGGA", b"TCCTCCTCCTCCGTTAATTTTTTTTTTTTTTTTTT",
+                 b"TTTTTTTTCCTGTACTTCGTTCAGTTACGTATTGCT", b"AGCAATACGTAACTGAACGAAGTACAGGAAAAAAAA"]
+        rng = np.random.default_rng(77)
+        reads = synth.make_reads(950, 24, "hifi", mean_len=3000, zoo=True, pmid=0.6, adapter=tails[1])
+        for i, (base, L) in enumerate(((b"T", 70000), (b"A", 5000), (b"TC", 9000), (b"T", 331), (b"GGA", 6000))):
+            seq = (base * (L // len(base) + 1))[:L]
+            reads.insert(3 * i + 1, (b"mono%d" % i, seq, bytes(rng.integers(60, 70, L, dtype=np.uint8))))
+        for mml in (35, 30, 24):
+            p = sized(abi.make_params("hifi", adapters=tails, mid_match_len=mml, min_len=100), reads)
+            ctx = capi.Context(p, 0, lib_path)
+            compare_batch(ctx, p, reads)
+            ctx.close()
+        # an adapter ending in each of the 16 columns of a chunk, in the first / last chunk of a window and across the
+        # boundary of two reads' windows (E = 0: the window is the read), with up to k differences
+        rng = np.random.default_rng(78)
+        reads = []
+        for i in range(64):
+            L = int(rng.integers(300, 700))
+            seq = bytearray(synth._ACGT[rng.integers(0, 4, L)].tobytes())
+            a = synth.mutate(rng, pb[i & 1], 0.02 * (i % 6))
+            at = (0, L - len(a), L - len(a) - 1 - i % 16, 16 * (i % 9) + i % 16, L // 2 + i % 16)[i % 5]
+            at = max(0, min(at, L - len(a)))
+            seq[at:at + len(a)] = a
+            reads.append((b"edge%d" % i, bytes(seq), bytes(rng.integers(60, 70, L, dtype=np.uint8))))
+        for e_len in (0, 7, 150):
+            p = sized(abi.make_params("hifi", adapters=pb, end_len=e_len, min_len=50), reads)
+            ctx = capi.Context(p, 0, lib_path)
+            compare_batch(ctx, p, reads, align=1, explicit_lengths=False)
+            ctx.close()
+        # filtered, unfiltered and one-dword adapters in one context, in an order that alternates the classes
+        mixed = [synth.PACBIO_BLUNT, synth.ONT_RAPID, synth.PACBIO_BLUNT_RC, synth.ONT_RAPID[:28], tails[2], tails[3],
+                 b"CTTGCGGGCGGCGGACTCTCCTCTGAAGATAGAGCGACAGGCAAG", b"CTTGCCTGTCGCTCTATCTTCAGAGGAGAGTCCGCCGCCCGCAAG", synth.ONT_RAPID_RC]
+        reads = synth.make_reads(960, 40, "hifi", mean_len=3000, zoo=True, pmid=0.5)
+        reads += synth.make_reads(961, 20, "ont", mean_len=3000, zoo=True, pmid=0.5)
+        reads += synth.make_reads(962, 20, "hifi", mean_len=3000, zoo=True, pmid=0.5, adapter=mixed[6])
+        p = sized(abi.make_params("hifi", adapters=mixed, min_len=200), reads)
+        ctx = capi.Context(p, 0, lib_path)
+        compare_batch(ctx, p, reads)
+        ctx.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def mid_scan_variants(lib_path, golden_dir, env):
     """The first middle scan of a batch under `env`: TGSF_MID_FLAT=0 (k_mid_scan1, one 1 024-column block per lane) or
     k_mid_flat with the given stretch schedule (TGSF_FLAT_PMIN / _PMAX / _F0: stretches down to ONE chunk, so that every

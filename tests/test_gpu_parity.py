@@ -191,6 +191,15 @@ def test_gpu_mid_scan_variants(golden_dir, env):
     parity.mid_scan_variants(None, golden_dir, env)
 
 
+MID_FILTER_ENVS = [{"TGSF_MID_FILTER": "0"}, {"TGSF_MID_FILTER": "1"}, {"TGSF_MID_FILTER": "2"},
+                   {"TGSF_MID_FILTER": "2", "TGSF_FLAT_PMIN": "1", "TGSF_FLAT_PMAX": "4", "TGSF_FLAT_F0": "128"}]
+
+
+@pytest.mark.parametrize("env", MID_FILTER_ENVS, ids=lambda e: "-".join(f"{k[5:].lower()}{v}" for k, v in e.items()))
+def test_gpu_mid_filter(env):
+    parity.mid_filter_cases(None, env)
+
+
 @pytest.mark.parametrize("mode", ["direct", "difference"])
 def test_gpu_clean_table_strategy(golden_dir, mode):
     parity.clean_table_strategy(None, mode, golden_dir)

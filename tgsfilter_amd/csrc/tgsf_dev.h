@@ -76,6 +76,8 @@ struct DevBatch {
     uint32_t* chk_cnt;         // [n+1] 16-column chunks of each read's middle window (counted from the window's first column),
                                // scanned in place: the flat scan (k_mid_flat) deals stretches of this one sequence of chunks
     uint32_t  flat_pmax, flat_pmin;   // chunks of the longest / shortest stretches, powers of two (see flat_schedule)
+    uint32_t* chk_mark;        // [chunks / 32 + 2] one bit per chunk of that sequence, per pass of the filtering flat scan: the LAST 32 rows of
+                               // one of the pass's adapters came within k of a column of the chunk: k_mid_recheck puts the whole adapter there
     uint32_t  flat_f0;         // 256ths of the sequence dealt in the longest stretches
     uint32_t* nfr;             // [n+1] fragments per read, scanned in place to frag_begin
     uint32_t* scan_part;       // [n / kScanTile + 2] per-tile totals of the prefix scans

@@ -1412,9 +1412,19 @@ TGSF_D uint4 load_upto16(const uint8_t* p, int nvalid)
     return v;
 }
 
-template <int AT, class HT = Hot>
+//
+// FS > 0 (with HT = Hot32, adapters of 33..64 bp searched within few differences: kSuffixMaxK): the scan as a FILTER.
+// If the whole adapter ends at column j within k differences, so do its last 32 rows (the rows of an alignment below
+// any row are an alignment of the adapter's tail, ending at the same column, with no more differences): only the last 32
+// rows go through the column here -- the high dword of the top-aligned Eq row, the 10-instruction dword column -- and
+// nothing is recorded but one bit per chunk (chk_mark) in which that value came within k; k_mid_recheck, launched right
+// behind, puts the whole adapter through the marked chunks and hands over the candidates.  The value is looked at every
+// FS-th column against k + FS - 1 (neighbouring bottom-row values differ by at most 1; marking more than needed costs a
+// recheck, never a candidate).  On random sequence the 45-bp PacBio adapters at k = 11 mark 2 chunks in 1 000.
+template <int AT, class HT = Hot, int FS = 0>
 TGSF_KERNEL k_mid_flat(DevParams P, DevBatch B, int a0, int na)
 {
+    static_assert(FS == 0 || (16 % FS) == 0, "the filter's test stride divides a chunk");
     typedef decltype(hot_eq(HT(), 0ull)) eq_t;
     TGSF_SHARED eq_t eqt[256][AT] __attribute__((aligned(16)));
     TGSF_SHARED int32_t tie_col[256][AT][4];
@@ -1461,7 +1471,7 @@ TGSF_KERNEL k_mid_flat(DevParams P, DevBatch B, int a0, int na)
                 const int a = a0 + j;
                 const bool on = j < na && ML >= P.Q[a] && P.k_mid[a] >= 0;            // :1237 tsmLen >= qLen
                 hot_init(st[j], j < na ? P.Q[a] : 1);
-                lim[j] = on ? P.k_mid[a] + 1 : -1000;
+                lim[j] = on ? P.k_mid[a] + (FS ? FS - 1 : 1) : -1000;             // (the filter: the bound of its test, fixed)
                 lim3[j] = lim[j] + 2;
                 ntie[j] = 0;
             }
@@ -1487,6 +1497,22 @@ TGSF_KERNEL k_mid_flat(DevParams P, DevBatch B, int a0, int na)
         // 16 columns starting at column cc0 of the window; `own`: the lane records candidates there (not in the warm-up)
         auto chunk16 = [&](const uint4& v, int cc0, bool own) TGSF_INLINE_LAMBDA {
             const uint32_t dw[4] = {v.x, v.y, v.z, v.w};
+            if (FS) {                                                 // the filter: one bit for the whole chunk
+                bool any = false;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    step_all((dw[k >> 2] >> (8 * (k & 3))) & 0xFFu);
+                    if ((k % (FS ? FS : 1)) == (FS ? FS : 1) - 1) {
+#pragma unroll
+                        for (int j = 0; j < AT; j++) any |= hot_within(st[j], lim[j]);
+                    }
+                }
+                if (__builtin_expect(any && own, 0)) {
+                    const uint32_t g = B.chk_cnt[r] + ((uint32_t)cc0 >> 4);
+                    atomicOr(&B.chk_mark[g >> 5], 1u << (g & 31u));
+                }
+                return;
+            }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 HT h1[AT], h2[AT], h3[AT];
@@ -1583,6 +1609,71 @@ TGSF_KERNEL k_mid_flat(DevParams P, DevBatch B, int a0, int na)
             }
             if (!wave_any(!parked)) break;
         }
+    }
+}
+
+// k_mid_recheck: behind a filtering pass of k_mid_flat (FS > 0, adapters a0 .. a0 + na - 1): every chunk marked in
+// chk_mark goes through the whole 64-bit column of each of the pass's adapters, from Q + k - 1 columns before it (values
+// <= k are exact from there on, as in every scan here), and what its 16 columns hold is handed over by k_mid_scan1's rules:
+// the columns tying the best value <= k seen in the chunk, if that is no worse than the read's best so far.  Marked chunks
+// are few and scattered: a workgroup collects the (chunk, adapter) pairs of kRecheckWords words of the bitmap in LDS and
+// its lanes share them out (a list that outgrows its LDS is finished by the lane that found it full).
+constexpr int kRecheckWords = 1024;      // bitmap words (32 768 chunks, half a million columns) per round of a workgroup
+constexpr int kRecheckList = 2048;
+TGSF_D void recheck_chunk(const DevParams& P, const DevBatch& B, const uint64_t (*eq)[4], int a0, uint32_t item)
+{
+    const uint32_t g = item >> 2;
+    const int j = (int)(item & 3u), a = a0 + j;
+    const uint32_t r = find_owner(B.chk_cnt, B.n, g);
+    const int E = P.end_len, Q = P.Q[a], k = P.k_mid[a];
+    const int ML = (int)B.len[r] - 2 * E;
+    if (k < 0 || ML < Q) return;                                                  // :1237 (never marked for such a pair alone)
+    const uint8_t* mid = B.seq + B.off[r] + E;
+    const int c1 = (int)((g - B.chk_cnt[r]) << 4);                                // the chunk's first column
+    const int c2 = c1 + 16 < ML ? c1 + 16 : ML;
+    int c = c1 - (Q + k - 1);
+    if (c < 0) c = 0;
+    Hot st;
+    hot_init(st, Q);
+    for (; c < c1; c++) hot_step(st, eq[mid[c]][j]);
+    int lim = k + 1;
+    uint32_t ties = 0u;                                                           // columns of the chunk at lim
+    for (; c < c2; c++) {
+        hot_step(st, eq[mid[c]][j]);
+        const int sc = hot_score(st);
+        if (sc < lim) { lim = sc; ties = 0u; }
+        if (sc == lim) ties |= 1u << (c - c1);
+    }
+    if (ties && worth_handing_over(B, r, a, P.n_adapters, lim))
+        for (; ties; ties &= ties - 1u) push_candidate(B, r, c1 + __builtin_ctz(ties), lim, a);
+}
+TGSF_KERNEL k_mid_recheck(DevParams P, DevBatch B, int a0, int na)
+{
+    TGSF_SHARED uint64_t eq[256][4];
+    TGSF_SHARED uint32_t list[kRecheckList];
+    TGSF_SHARED uint32_t list_n;
+    for (uint32_t i = TGSF_COOP_BEGIN; i < 256u * 4u; i += TGSF_COOP_STRIDE) {
+        const uint32_t sym = i >> 2, j = i & 3u;
+        eq[sym][j] = (int)j < na ? P.peq_top[(size_t)(a0 + j) * 256 + sym] : 0ull;
+    }
+    const uint32_t words = (B.chk_cnt[B.n] + 31u) >> 5;
+    for (uint32_t w0 = blockIdx.x * (uint32_t)kRecheckWords; w0 < words; w0 += gridDim.x * (uint32_t)kRecheckWords) {
+        if (TGSF_COOP_BEGIN == 0u) list_n = 0u;
+        TGSF_BLOCK_SYNC();
+        for (uint32_t i = TGSF_COOP_BEGIN; i < (uint32_t)kRecheckWords && w0 + i < words; i += TGSF_COOP_STRIDE) {
+            for (uint32_t bits = B.chk_mark[w0 + i]; bits; bits &= bits - 1u) {
+                const uint32_t g = ((w0 + i) << 5) + (uint32_t)__builtin_ctz(bits);
+                const uint32_t at = atomicAdd(&list_n, (uint32_t)na);
+                for (int j = 0; j < na; j++) {
+                    if (at + (uint32_t)j < (uint32_t)kRecheckList) list[at + (uint32_t)j] = (g << 2) | (uint32_t)j;
+                    else recheck_chunk(P, B, eq, a0, (g << 2) | (uint32_t)j);
+                }
+            }
+        }
+        TGSF_BLOCK_SYNC();
+        const uint32_t n = list_n < (uint32_t)kRecheckList ? list_n : (uint32_t)kRecheckList;
+        for (uint32_t i = TGSF_COOP_BEGIN; i < n; i += TGSF_COOP_STRIDE) recheck_chunk(P, B, eq, a0, list[i]);
+        TGSF_BLOCK_SYNC();
     }
 }
 

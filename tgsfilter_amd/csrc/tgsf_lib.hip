@@ -49,6 +49,7 @@ struct tgsf_ctx {
     unsigned stats_grid = 768, mid_grid = 0;   // tuning knobs (TGSF_STATS_GRID, TGSF_MID_GRID; 0 = one lane per segment)
     unsigned flat_lds_pad = 0;                 // TGSF_FLAT_LDS_PAD (experiment): dynamic LDS per workgroup of k_mid_flat, to leave room on every CU
     bool flat_scan = true;                    // first middle scan of a batch by k_mid_flat (TGSF_MID_FLAT=0: k_mid_scan1, as after a pool overflow)
+    int suffix_filter = 2;                    // TGSF_MID_FILTER: test stride of k_mid_flat's 32-row filter for adapters of 33..64 bp at k <= kSuffixMaxK (0: off, 1, 2)
     bool no_hot32 = false;                    // TGSF_NO_HOT32=1: adapters <= 32 bp take the 64-bit column too (A/B, tests)
     bool stats_nt = true;                     // k_stats fetches the text with non-temporal loads (2.24 -> 2.06 ms raw, 5.4 -> 5.8 TB/s; TGSF_STATS_NT=0: plain loads)
     uint64_t ctr_words;
@@ -481,6 +482,7 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     if (const char* e = getenv("TGSF_MID_GRID")) { int v = atoi(e); if (v >= 1) c->mid_grid = (unsigned)v; }
     if (const char* e = getenv("TGSF_SEG_COLS")) { int v = atoi(e); if (v >= 256 && v <= 65536) P.seg_cols = v & ~15; }   // tuning knob
     if (const char* e = getenv("TGSF_MID_FLAT")) c->flat_scan = atoi(e) > 0;
+    if (const char* e = getenv("TGSF_MID_FILTER")) { int v = atoi(e); if (v >= 0 && v <= 2) c->suffix_filter = v; }
     if (const char* e = getenv("TGSF_FLAT_LDS_PAD")) { int v = atoi(e); if (v >= 0 && v <= 140000) c->flat_lds_pad = (unsigned)v; }
 
     int e = build_tables(c);
@@ -529,6 +531,8 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     if (!e) e = dev_alloc(c, &B.seg_cnt, n + 1);
     if (!e) e = dev_alloc(c, &B.chk_cnt, n + 1);
     if (c->cap_bases / 16u + n >= 0xFFFFFFF0ull) c->flat_scan = false;   // (chunk numbers are 32 bits: such a context keeps k_mid_scan1)
+    if (c->cap_bases / 16u + n >= (1ull << 30) || !c->flat_scan) c->suffix_filter = 0;   // (k_mid_recheck's items: a chunk number and two bits)
+    if (!e && c->suffix_filter) e = dev_alloc(c, &B.chk_mark, (size_t)((c->cap_bases / 16u + n) / 32u + 2u));
     if (!e) e = dev_alloc(c, &B.nfr, n + 1);
     if (!e) e = dev_alloc(c, &B.scan_part, n / kScanTile + 2);
     if (!e) e = dev_alloc(c, &B.trimmed, n);
@@ -754,12 +758,14 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
         // the number of stretches is known on the device only, so the grid covers the longest sequence the batch can have
         const bool flat = c->flat_scan;
         unsigned gflat = 1;
+        uint64_t flat_chunks = 0;                  // upper bound of the batch's chunk count, known on the host
         {
             scan_u32(B, B.seg_cnt, n, st);
             if (flat) {
                 scan_u32(B, B.chk_cnt, n, st);
                 FlatSchedule S;
                 const uint64_t tb = std::min<uint64_t>(in->n_bytes / 16u + (uint64_t)n, c->cap_bases / 16u + c->cap_reads);
+                flat_chunks = tb;
                 flat_schedule((uint32_t)tb, B.flat_pmax, B.flat_pmin, B.flat_f0, S);
                 gflat = grid_cap(blocks_for((uint64_t)S.d0[S.nph] + 64u * 8u, T));   // (phase ends round up to whole groups)
             }
@@ -782,10 +788,36 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
                 if (P.Q[a] > 192) { TGSF_LAUNCH(k_mid_scanw<4>, gseg, T, ms, P, Bm, a); a++; continue; }
                 if (P.Q[a] > 128) { TGSF_LAUNCH(k_mid_scanw<3>, gseg, T, ms, P, Bm, a); a++; continue; }
                 if (P.Q[a] > 64) { TGSF_LAUNCH(k_mid_scanw<2>, gseg, T, ms, P, Bm, a); a++; continue; }
-                // up to four adapters of one word class per pass: <= 32 bp (one dword per column) or 33..64 bp (one qword)
-                const bool narrow = P.Q[a] <= 32 && !c->no_hot32;
+                // up to four adapters of one word class per pass: <= 32 bp (one dword per column), 33..64 bp (one qword), or --
+                // the flat scan only -- 33..64 bp within few differences (the last 32 rows as a filter, the rest rechecked)
+                auto cls = [&](int x) {
+                    if (P.Q[x] <= 32 && !c->no_hot32) return 0;
+                    if (flat && mode == 0 && c->suffix_filter && P.Q[x] > 32 && P.k_mid[x] >= 0 && P.k_mid[x] <= kSuffixMaxK) return 2;
+                    return 1;
+                };
+                const int kind = cls(a);
+                const bool narrow = kind == 0;
                 int na = 0;
-                while (a + na < A && na < 4 && P.Q[a + na] <= 64 && ((P.Q[a + na] <= 32 && !c->no_hot32) == narrow)) na++;
+                while (a + na < A && na < 4 && P.Q[a + na] <= 64 && cls(a + na) == kind) na++;
+                if (kind == 2) {
+                    const unsigned lp = c->flat_lds_pad;
+                    rt_memset(Bm.chk_mark, 0, (size_t)(flat_chunks / 32u + 2u) * 4u, ms);
+                    if (c->suffix_filter == 1) switch (na) {
+                    case 1: TGSF_LAUNCH_LDS((k_mid_flat<1, Hot32, 1>), gflat, T, lp, ms, P, Bm, a, na); break;
+                    case 2: TGSF_LAUNCH_LDS((k_mid_flat<2, Hot32, 1>), gflat, T, lp, ms, P, Bm, a, na); break;
+                    case 3: TGSF_LAUNCH_LDS((k_mid_flat<3, Hot32, 1>), gflat, T, lp, ms, P, Bm, a, na); break;
+                    default: TGSF_LAUNCH_LDS((k_mid_flat<4, Hot32, 1>), gflat, T, lp, ms, P, Bm, a, na); break;
+                    }
+                    else switch (na) {
+                    case 1: TGSF_LAUNCH_LDS((k_mid_flat<1, Hot32, 2>), gflat, T, lp, ms, P, Bm, a, na); break;
+                    case 2: TGSF_LAUNCH_LDS((k_mid_flat<2, Hot32, 2>), gflat, T, lp, ms, P, Bm, a, na); break;
+                    case 3: TGSF_LAUNCH_LDS((k_mid_flat<3, Hot32, 2>), gflat, T, lp, ms, P, Bm, a, na); break;
+                    default: TGSF_LAUNCH_LDS((k_mid_flat<4, Hot32, 2>), gflat, T, lp, ms, P, Bm, a, na); break;
+                    }
+                    TGSF_LAUNCH_COOP(k_mid_recheck, grid_cap(blocks_for(flat_chunks / 32u + 1u, (unsigned)kRecheckWords)), T, ms, P, Bm, a, na);
+                    a += na;
+                    continue;
+                }
                 if (flat && mode == 0) {
                     const unsigned lp = c->flat_lds_pad;
                     if (narrow) switch (na) {
