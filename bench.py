@@ -678,7 +678,7 @@ def kernel_leg(args, torch, dist, world, rank, local_rank, device, xdev, host_gr
     # stages of the auxiliary stream run beside the middle scan) -- the middle scan at C2 / C3, the repeat gate at C5
     aux = ("end_tables_raw", "end_windows")
     dom = max((k for k in excl_stage_ms if k not in aux), key=lambda k: excl_stage_ms[k])
-    KERNELS = {"mid_scan": ("k_mid_flat<AT, Hot|Hot32> (Myers infix scan of the read middles; k_mid_scanw / k_mid_scan_wide for adapters beyond 64 bp)", "valu"),
+    KERNELS = {"mid_scan": ("k_mid_flat<AT, Hot|Hot32[, filter]> (Myers infix scan of the read middles; + k_mid_recheck behind a filtering pass; k_mid_scanw / k_mid_scan_wide for adapters beyond 64 bp)", "valu"),
                "repeat_gate": ("k_repeat (k <= 11) / k_repeat_keys (k 12..31): GetKmerCount per kept fragment", "valu"),
                "stats_raw": ("k_stats<raw> (CalcAvgQuality on every read)", "hbm"),
                "stats_clean": ("k_stats<clean> (CalcAvgQuality on the kept fragments)", "hbm")}

@@ -192,7 +192,8 @@ def test_gpu_mid_scan_variants(golden_dir, env):
 
 
 MID_FILTER_ENVS = [{"TGSF_MID_FILTER": "0"}, {"TGSF_MID_FILTER": "1"}, {"TGSF_MID_FILTER": "2"},
-                   {"TGSF_MID_FILTER": "2", "TGSF_FLAT_PMIN": "1", "TGSF_FLAT_PMAX": "4", "TGSF_FLAT_F0": "128"}]
+                   {"TGSF_MID_FILTER": "2", "TGSF_FLAT_PMIN": "1", "TGSF_FLAT_PMAX": "4", "TGSF_FLAT_F0": "128"},
+                   {"TGSF_MID_FILTER": "1", "TGSF_RECHECK_CAP": "5"}]        # (a list of five marks: the rest rechecked where found)
 
 
 @pytest.mark.parametrize("env", MID_FILTER_ENVS, ids=lambda e: "-".join(f"{k[5:].lower()}{v}" for k, v in e.items()))

@@ -76,8 +76,12 @@ struct DevBatch {
     uint32_t* chk_cnt;         // [n+1] 16-column chunks of each read's middle window (counted from the window's first column),
                                // scanned in place: the flat scan (k_mid_flat) deals stretches of this one sequence of chunks
     uint32_t  flat_pmax, flat_pmin;   // chunks of the longest / shortest stretches, powers of two (see flat_schedule)
-    uint32_t* chk_mark;        // [chunks / 32 + 2] one bit per chunk of that sequence, per pass of the filtering flat scan: the LAST 32 rows of
-                               // one of the pass's adapters came within k of a column of the chunk: k_mid_recheck puts the whole adapter there
+    uint32_t* chk_mark;        // [4][mark_stride] one bit per chunk of that sequence and adapter of a pass of the filtering flat scan: the LAST 32
+                               // rows of the adapter came within k of a column of the chunk: k_mid_recheck puts the whole adapter there
+    uint32_t  mark_stride;     // words per adapter (this batch's chunks / 32, rounded up)
+    uint32_t* rc_list;         // [rc_cap] the marks of a pass as one list (chunk * 4 + the adapter's place in the pass): k_mid_marks -> k_mid_recheck
+    uint32_t* rc_n;            // entries asked for (beyond rc_cap: rechecked by k_mid_marks itself)
+    uint32_t  rc_cap;
     uint32_t  flat_f0;         // 256ths of the sequence dealt in the longest stretches
     uint32_t* nfr;             // [n+1] fragments per read, scanned in place to frag_begin
     uint32_t* scan_part;       // [n / kScanTile + 2] per-tile totals of the prefix scans

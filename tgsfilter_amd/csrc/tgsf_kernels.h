@@ -1417,8 +1417,8 @@ TGSF_D uint4 load_upto16(const uint8_t* p, int nvalid)
 // If the whole adapter ends at column j within k differences, so do its last 32 rows (the rows of an alignment below
 // any row are an alignment of the adapter's tail, ending at the same column, with no more differences): only the last 32
 // rows go through the column here -- the high dword of the top-aligned Eq row, the 10-instruction dword column -- and
-// nothing is recorded but one bit per chunk (chk_mark) in which that value came within k; k_mid_recheck, launched right
-// behind, puts the whole adapter through the marked chunks and hands over the candidates.  The value is looked at every
+// nothing is recorded but one bit per chunk and adapter (chk_mark) in which that value came within k; k_mid_recheck,
+// launched right behind, puts the whole adapter through the chunks marked for it and hands over the candidates.  The value is looked at every
 // FS-th column against k + FS - 1 (neighbouring bottom-row values differ by at most 1; marking more than needed costs a
 // recheck, never a candidate).  On random sequence the 45-bp PacBio adapters at k = 11 mark 2 chunks in 1 000.
 template <int AT, class HT = Hot, int FS = 0>
@@ -1460,7 +1460,9 @@ TGSF_KERNEL k_mid_flat(DevParams P, DevBatch B, int a0, int na)
         int ntie[AT];             // buffered columns attaining it
         const uint8_t* mid = nullptr;
         int ML = 0, c = 0, own_from = 0, cend = 0, cfull = 0;
+        uint32_t cbase = 0u;      // (the filter) number of the window's first chunk in the batch's sequence of chunks
         auto open_read = [&](uint32_t ck) TGSF_INLINE_LAMBDA {
+            if (FS) cbase = B.chk_cnt[r];
             ML = (int)B.len[r] - 2 * E;
             mid = B.seq + B.off[r] + E;
             cend = (ML + 15) & ~15;
@@ -1497,19 +1499,26 @@ TGSF_KERNEL k_mid_flat(DevParams P, DevBatch B, int a0, int na)
         // 16 columns starting at column cc0 of the window; `own`: the lane records candidates there (not in the warm-up)
         auto chunk16 = [&](const uint4& v, int cc0, bool own) TGSF_INLINE_LAMBDA {
             const uint32_t dw[4] = {v.x, v.y, v.z, v.w};
-            if (FS) {                                                 // the filter: one bit for the whole chunk
-                bool any = false;
+            if (FS) {                                                 // the filter: one bit per adapter for the whole chunk
+                bool hit[AT];
+#pragma unroll
+                for (int j = 0; j < AT; j++) hit[j] = false;
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
                     step_all((dw[k >> 2] >> (8 * (k & 3))) & 0xFFu);
                     if ((k % (FS ? FS : 1)) == (FS ? FS : 1) - 1) {
 #pragma unroll
-                        for (int j = 0; j < AT; j++) any |= hot_within(st[j], lim[j]);
+                        for (int j = 0; j < AT; j++) hit[j] |= hot_within(st[j], lim[j]);
                     }
                 }
+                bool any = false;
+#pragma unroll
+                for (int j = 0; j < AT; j++) any |= hit[j];
                 if (__builtin_expect(any && own, 0)) {
-                    const uint32_t g = B.chk_cnt[r] + ((uint32_t)cc0 >> 4);
-                    atomicOr(&B.chk_mark[g >> 5], 1u << (g & 31u));
+                    const uint32_t g = cbase + ((uint32_t)cc0 >> 4);
+#pragma unroll
+                    for (int j = 0; j < AT; j++)
+                        if (hit[j]) atomicOr(&B.chk_mark[(size_t)j * B.mark_stride + (g >> 5)], 1u << (g & 31u));
                 }
                 return;
             }
@@ -1612,14 +1621,19 @@ TGSF_KERNEL k_mid_flat(DevParams P, DevBatch B, int a0, int na)
     }
 }
 
-// k_mid_recheck: behind a filtering pass of k_mid_flat (FS > 0, adapters a0 .. a0 + na - 1): every chunk marked in
-// chk_mark goes through the whole 64-bit column of each of the pass's adapters, from Q + k - 1 columns before it (values
-// <= k are exact from there on, as in every scan here), and what its 16 columns hold is handed over by k_mid_scan1's rules:
-// the columns tying the best value <= k seen in the chunk, if that is no worse than the read's best so far.  Marked chunks
-// are few and scattered: a workgroup collects the (chunk, adapter) pairs of kRecheckWords words of the bitmap in LDS and
-// its lanes share them out (a list that outgrows its LDS is finished by the lane that found it full).
-constexpr int kRecheckWords = 1024;      // bitmap words (32 768 chunks, half a million columns) per round of a workgroup
-constexpr int kRecheckList = 2048;
+// k_mid_marks + k_mid_recheck: behind a filtering pass of k_mid_flat (FS > 0, adapters a0 .. a0 + na - 1): every chunk
+// marked for an adapter in chk_mark goes through that adapter's whole 64-bit column, from Q + k - 1 columns before it
+// (values <= k are exact from there on, as in every scan here), and what its 16 columns hold is handed over by
+// k_mid_scan1's rules: the columns tying the best value <= k seen in the chunk, if that is no worse than the read's best
+// so far.  Marked chunks are few and scattered (a few in a thousand), and each costs some 70 columns: k_mid_marks
+// turns the bitmaps into one list (a workgroup collects the marks of kRecheckWords words of each bitmap in LDS and
+// appends them with one atomic), k_mid_recheck gives every lane of the chip one entry at a time.  Marks beyond the list's
+// room (homopolymer reads against homopolymer adapters: every chunk) are rechecked on the spot by k_mid_marks.
+constexpr int kRecheckWords = 4096;      // bitmap words (131 072 chunks, two million columns) per round of a workgroup
+constexpr int kRecheckList = 4096;
+constexpr int kRecheckPieces = 6;        // 16-byte pieces of text per marked chunk: warm-up (at most 64 + kSuffixMaxK - 1 columns) + the chunk
+static_assert(64 + kSuffixMaxK - 1 + 16 <= 16 * kRecheckPieces, "k_mid_recheck: the warm-up and the chunk fit its pieces");
+// item: chunk number * 4 + the adapter's place in the pass
 TGSF_D void recheck_chunk(const DevParams& P, const DevBatch& B, const uint64_t (*eq)[4], int a0, uint32_t item)
 {
     const uint32_t g = item >> 2;
@@ -1627,54 +1641,94 @@ TGSF_D void recheck_chunk(const DevParams& P, const DevBatch& B, const uint64_t 
     const uint32_t r = find_owner(B.chk_cnt, B.n, g);
     const int E = P.end_len, Q = P.Q[a], k = P.k_mid[a];
     const int ML = (int)B.len[r] - 2 * E;
-    if (k < 0 || ML < Q) return;                                                  // :1237 (never marked for such a pair alone)
+    if (k < 0 || ML < Q) return;                                                  // :1237 (never marked)
     const uint8_t* mid = B.seq + B.off[r] + E;
     const int c1 = (int)((g - B.chk_cnt[r]) << 4);                                // the chunk's first column
     const int c2 = c1 + 16 < ML ? c1 + 16 : ML;
-    int c = c1 - (Q + k - 1);
-    if (c < 0) c = 0;
     Hot st;
     hot_init(st, Q);
-    for (; c < c1; c++) hot_step(st, eq[mid[c]][j]);
     int lim = k + 1;
     uint32_t ties = 0u;                                                           // columns of the chunk at lim
-    for (; c < c2; c++) {
-        hot_step(st, eq[mid[c]][j]);
-        const int sc = hot_score(st);
-        if (sc < lim) { lim = sc; ties = 0u; }
-        if (sc == lim) ties |= 1u << (c - c1);
+    int c = c1 - (Q + k - 1);
+    if (c < 0) c = 0;
+    // the text in 16-byte pieces, all asked for at once (bytes behind the window belong to the read's 3' end window;
+    // fewer than 16 of them left: byte by byte)
+    auto piece = [&](int at) TGSF_INLINE_LAMBDA -> uint4 {
+        if (at >= c2) { uint4 z; z.x = z.y = z.z = z.w = 0u; return z; }
+        return at + 16 <= ML + E ? load16u(mid + at) : load_upto16(mid + at, ML + E - at);
+    };
+    uint4 p0 = piece(c), p1 = piece(c + 16), p2 = piece(c + 32), p3 = piece(c + 48), p4 = piece(c + 64), p5 = piece(c + 80);
+    while (c < c2) {
+        const uint32_t dw[4] = {p0.x, p0.y, p0.z, p0.w};
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            if (c + i < c2) {
+                hot_step(st, eq[(dw[i >> 2] >> (8 * (i & 3))) & 0xFFu][j]);
+                if (c + i >= c1) {
+                    const int sc = hot_score(st);
+                    if (sc < lim) { lim = sc; ties = 0u; }
+                    if (sc == lim) ties |= 1u << (c + i - c1);
+                }
+            }
+        }
+        c += 16;
+        p0 = p1; p1 = p2; p2 = p3; p3 = p4; p4 = p5;
     }
     if (ties && worth_handing_over(B, r, a, P.n_adapters, lim))
         for (; ties; ties &= ties - 1u) push_candidate(B, r, c1 + __builtin_ctz(ties), lim, a);
 }
-TGSF_KERNEL k_mid_recheck(DevParams P, DevBatch B, int a0, int na)
+TGSF_D void recheck_eq_rows(const DevParams& P, uint64_t (*eq)[4], int a0, int na)
 {
-    TGSF_SHARED uint64_t eq[256][4];
-    TGSF_SHARED uint32_t list[kRecheckList];
-    TGSF_SHARED uint32_t list_n;
     for (uint32_t i = TGSF_COOP_BEGIN; i < 256u * 4u; i += TGSF_COOP_STRIDE) {
         const uint32_t sym = i >> 2, j = i & 3u;
         eq[sym][j] = (int)j < na ? P.peq_top[(size_t)(a0 + j) * 256 + sym] : 0ull;
     }
-    const uint32_t words = (B.chk_cnt[B.n] + 31u) >> 5;
+}
+TGSF_KERNEL k_mid_marks(DevParams P, DevBatch B, int a0, int na)
+{
+    TGSF_SHARED uint64_t eq[256][4];
+    TGSF_SHARED uint32_t list[kRecheckList];
+    TGSF_SHARED uint32_t list_n, list_at;
+    recheck_eq_rows(P, eq, a0, na);
+    const uint32_t total = B.chk_cnt[B.n], words = (total + 31u) >> 5;
     for (uint32_t w0 = blockIdx.x * (uint32_t)kRecheckWords; w0 < words; w0 += gridDim.x * (uint32_t)kRecheckWords) {
         if (TGSF_COOP_BEGIN == 0u) list_n = 0u;
         TGSF_BLOCK_SYNC();
-        for (uint32_t i = TGSF_COOP_BEGIN; i < (uint32_t)kRecheckWords && w0 + i < words; i += TGSF_COOP_STRIDE) {
-            for (uint32_t bits = B.chk_mark[w0 + i]; bits; bits &= bits - 1u) {
-                const uint32_t g = ((w0 + i) << 5) + (uint32_t)__builtin_ctz(bits);
-                const uint32_t at = atomicAdd(&list_n, (uint32_t)na);
-                for (int j = 0; j < na; j++) {
-                    if (at + (uint32_t)j < (uint32_t)kRecheckList) list[at + (uint32_t)j] = (g << 2) | (uint32_t)j;
-                    else recheck_chunk(P, B, eq, a0, (g << 2) | (uint32_t)j);
-                }
+        for (int j = 0; j < na; j++) {
+            // (four words a load: mark_stride is a multiple of four, words past the batch's last are zero)
+            const uint4* marks = reinterpret_cast<const uint4*>(B.chk_mark + (size_t)j * B.mark_stride + w0);
+            for (uint32_t i = TGSF_COOP_BEGIN; i < (uint32_t)kRecheckWords / 4u && w0 + 4u * i < words; i += TGSF_COOP_STRIDE) {
+                const uint4 m = marks[i];
+                const uint32_t mw[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+                for (uint32_t q = 0; q < 4u; q++)
+                    for (uint32_t bits = mw[q]; bits; bits &= bits - 1u) {
+                        const uint32_t item = ((((w0 + 4u * i + q) << 5) + (uint32_t)__builtin_ctz(bits)) << 2) | (uint32_t)j;
+                        const uint32_t at = atomicAdd(&list_n, 1u);
+                        if (at < (uint32_t)kRecheckList) list[at] = item;
+                        else recheck_chunk(P, B, eq, a0, item);
+                    }
             }
         }
         TGSF_BLOCK_SYNC();
         const uint32_t n = list_n < (uint32_t)kRecheckList ? list_n : (uint32_t)kRecheckList;
-        for (uint32_t i = TGSF_COOP_BEGIN; i < n; i += TGSF_COOP_STRIDE) recheck_chunk(P, B, eq, a0, list[i]);
+        if (TGSF_COOP_BEGIN == 0u) list_at = n ? atomicAdd(B.rc_n, n) : 0u;
+        TGSF_BLOCK_SYNC();
+        const uint32_t at = list_at;
+        for (uint32_t i = TGSF_COOP_BEGIN; i < n; i += TGSF_COOP_STRIDE) {
+            if (at + i < B.rc_cap) B.rc_list[at + i] = list[i];
+            else recheck_chunk(P, B, eq, a0, list[i]);
+        }
         TGSF_BLOCK_SYNC();
     }
+}
+TGSF_KERNEL k_mid_recheck(DevParams P, DevBatch B, int a0, int na)
+{
+    TGSF_SHARED uint64_t eq[256][4];
+    recheck_eq_rows(P, eq, a0, na);
+    TGSF_BLOCK_SYNC();
+    const uint32_t n = *B.rc_n < B.rc_cap ? *B.rc_n : B.rc_cap;
+    for (uint32_t i = gtid(); i < n; i += gsize()) recheck_chunk(P, B, eq, a0, B.rc_list[i]);
 }
 
 // adapters of 65..256 bp: NW-word standard layout (NW = ceil(Q / 64) = 2, 3 or 4), one adapter per pass

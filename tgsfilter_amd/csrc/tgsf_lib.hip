@@ -532,7 +532,14 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     if (!e) e = dev_alloc(c, &B.chk_cnt, n + 1);
     if (c->cap_bases / 16u + n >= 0xFFFFFFF0ull) c->flat_scan = false;   // (chunk numbers are 32 bits: such a context keeps k_mid_scan1)
     if (c->cap_bases / 16u + n >= (1ull << 30) || !c->flat_scan) c->suffix_filter = 0;   // (k_mid_recheck's items: a chunk number and two bits)
-    if (!e && c->suffix_filter) e = dev_alloc(c, &B.chk_mark, (size_t)((c->cap_bases / 16u + n) / 32u + 2u));
+    if (!e && c->suffix_filter) e = dev_alloc(c, &B.chk_mark, (size_t)4 * (size_t)((c->cap_bases / 16u + n) / 32u + 8u));
+    if (c->suffix_filter) {
+        // a mark in 25 chunks has room in the list (random sequence: a few in a thousand), the rest is done where it is found
+        B.rc_cap = (uint32_t)std::min<uint64_t>((c->cap_bases / 16u + n) / 25u + 4096u, 1ull << 24);
+        if (const char* e2 = getenv("TGSF_RECHECK_CAP")) { int v = atoi(e2); if (v >= 0) B.rc_cap = (uint32_t)v; }   // test knob
+        if (!e) e = dev_alloc(c, &B.rc_list, (size_t)B.rc_cap + 1);
+        if (!e) e = dev_alloc(c, &B.rc_n, 4);
+    }
     if (!e) e = dev_alloc(c, &B.nfr, n + 1);
     if (!e) e = dev_alloc(c, &B.scan_part, n / kScanTile + 2);
     if (!e) e = dev_alloc(c, &B.trimmed, n);
@@ -801,7 +808,9 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
                 while (a + na < A && na < 4 && P.Q[a + na] <= 64 && cls(a + na) == kind) na++;
                 if (kind == 2) {
                     const unsigned lp = c->flat_lds_pad;
-                    rt_memset(Bm.chk_mark, 0, (size_t)(flat_chunks / 32u + 2u) * 4u, ms);
+                    Bm.mark_stride = (uint32_t)((flat_chunks / 32u + 7u) & ~3ull);            // (k_mid_marks reads four words a load)
+                    rt_memset(Bm.chk_mark, 0, (size_t)na * Bm.mark_stride * 4u, ms);
+                    rt_memset(Bm.rc_n, 0, 4, ms);
                     if (c->suffix_filter == 1) switch (na) {
                     case 1: TGSF_LAUNCH_LDS((k_mid_flat<1, Hot32, 1>), gflat, T, lp, ms, P, Bm, a, na); break;
                     case 2: TGSF_LAUNCH_LDS((k_mid_flat<2, Hot32, 1>), gflat, T, lp, ms, P, Bm, a, na); break;
@@ -814,7 +823,9 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
                     case 3: TGSF_LAUNCH_LDS((k_mid_flat<3, Hot32, 2>), gflat, T, lp, ms, P, Bm, a, na); break;
                     default: TGSF_LAUNCH_LDS((k_mid_flat<4, Hot32, 2>), gflat, T, lp, ms, P, Bm, a, na); break;
                     }
-                    TGSF_LAUNCH_COOP(k_mid_recheck, grid_cap(blocks_for(flat_chunks / 32u + 1u, (unsigned)kRecheckWords)), T, ms, P, Bm, a, na);
+                    const unsigned grc = grid_cap(blocks_for(flat_chunks / 32u + 1u, (unsigned)kRecheckWords));
+                    TGSF_LAUNCH_COOP(k_mid_marks, grc, T, ms, P, Bm, a, na);
+                    TGSF_LAUNCH(k_mid_recheck, grid_cap(2048u), T, ms, P, Bm, a, na);
                     a += na;
                     continue;
                 }

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for v in "$@"; do export "$v"; done
 rm -rf $R/gpurun_out/r4_kt_$tag
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r4_kt_$tag -- python3 $R/bench.py --no-e2e --no-cpu-baseline --no-oracle-check --kernel-steps ${R4_STEPS:-12} --kernel-warmup 2 --streams ${R4_STREAMS:-1} > $R/gpurun_out/r4_kt_$tag.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r4_kt_$tag -- python3 $R/bench.py --no-e2e --no-cpu-baseline --no-oracle-check --kernel-steps ${R4_STEPS:-12} --kernel-warmup 2 --streams ${R4_STREAMS:-1} ${R4_ARGS} > $R/gpurun_out/r4_kt_$tag.log 2>&1
 python3 - $tag <<'PY'
 import csv, glob, os, sys, collections
 R=os.environ["GRAFT_REPO_ROOT"]; tag=sys.argv[1]

@@ -6,7 +6,7 @@
 import collections, json, re, sys
 asm = sys.argv[1] if len(sys.argv) > 1 else "/tmp/tgsf_lib.s"
 traffic = sys.argv[2] if len(sys.argv) > 2 else None
-KERNEL = "_ZN4tgsf10k_mid_flatILi2ENS_3HotEEEvNS_9DevParamsENS_8DevBatchEii"
+KERNEL = "_ZN4tgsf10k_mid_flatILi2ENS_3HotELi0EEEvNS_9DevParamsENS_8DevBatchEii"
 lines = open(asm).read().split("\n")
 start = next(i for i, l in enumerate(lines) if l.startswith(KERNEL + ":"))
 end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
