@@ -98,7 +98,7 @@ import hashlib
 h = hashlib.sha256()
 for fn in ("tgsf_hip.h", "tgsf_core.h", "tgsf_dev.h", "tgsf_kernels.h", "tgsf_lib.hip"):      # = bench.py kernel_source_hash()
     h.update(open(os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.getcwd()), "tgsfilter_amd", "csrc", fn), "rb").read())
-STAGES = {"mid_scan": ("tgsf::k_mid_flat", "tgsf::k_mid_scan", "tgsf::k_mid_recheck"), "stats_raw": ("tgsf::k_stats<false",), "stats_clean": ("tgsf::k_stats<true",),
+STAGES = {"mid_scan": ("tgsf::k_mid_flat", "tgsf::k_mid_scan", "tgsf::k_mid_recheck", "tgsf::k_mid_marks"), "stats_raw": ("tgsf::k_stats<false",), "stats_clean": ("tgsf::k_stats<true",),
           "repeat_gate": ("tgsf::k_repeat",), "end_windows": ("tgsf::k_end_windows",)}
 def stage_sum(d, prefixes, counter, scale=1.0):
     return sum(v.get(counter, 0.0) * scale for k, v in d.items() if k.startswith(prefixes))

@@ -82,3 +82,33 @@ if traffic:
             print("  (divide by the wave-columns of the launch -- bench.py's batch: the columns of the surviving reads' middle windows / 64 -- for the")
             print("   instructions per owned column pair: the loop's figure above x the warm-up columns of every stretch (80 per 4 096), the lanes")
             print("   parked or beyond the end of their wave's last stretch, the chunk that ends a window, the rare paths)")
+
+# ---- the scan as a filter: k_mid_flat<2, Hot32, FS> (the last 32 rows of two adapters of 33..64 bp in the dword column) ----
+def hot_loop(kernel):
+    st = next(i for i, l in enumerate(lines) if l.startswith(kernel + ":"))
+    en = next(i for i in range(st, len(lines)) if "s_endpgm" in lines[i])
+    b = lines[st:en + 1]
+    pick = None
+    for i, l in enumerate(b):
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if not m or "Inner Loop Header" not in "\n".join(b[i:i + 4]):
+            continue
+        back = [j for j in range(i + 1, len(b)) if re.search(r"\bs_c?branch\w*\s+" + re.escape(m.group(1)) + r"$", b[j].strip())]
+        if not back:
+            continue
+        reg = b[i:back[-1] + 1]
+        n = sum(1 for x in reg if "v_bitop3_b32" in x)
+        if pick is None or n > pick[0]:
+            pick = (n, m.group(1), reg)
+    return pick
+print()
+print("The scan as a filter (adapters of 33..64 bp within <= 12 differences): k_mid_flat<2, tgsf::Hot32, FS>, the adapter's last 32 rows in the")
+print("10-instruction dword column (6 v_bitop3, v_and, v_add, 2 v_lshlrev per adapter), looked at every FS-th column (2 v_bcnt + 1 v_cmp per adapter)")
+for fs in (1, 2):
+    n, lab2, reg = hot_loop("_ZN4tgsf10k_mid_flatILi2ENS_5Hot32ELi%dEEEvNS_9DevParamsENS_8DevBatchEii" % fs)
+    ins2 = [x.strip().split()[0] for x in reg if x.startswith("\t") and not x.strip().startswith((";", "."))]
+    ch = n / 192.0                                  # 6 v_bitop3 per adapter and column: 192 per 16-column chunk of two adapters
+    c2 = collections.Counter(ins2)
+    v2 = sum(v for k, v in c2.items() if k.startswith("v_"))
+    print("  FS = %d: inner loop %s, %d instructions a trip = %.0f chunks; VALU per column pair %.2f (the 64-bit column's loop above: %.2f): " % (fs, lab2, len(ins2), ch, v2 / ch / 16, valu / chunks / 16)
+          + ", ".join("%s %.2f" % (k, v / ch / 16) for k, v in c2.most_common(9) if k.startswith(("v_", "ds_"))))
