@@ -280,6 +280,31 @@ def mid_filter_cases(lib_path, env):
             ctx = capi.Context(p, 0, lib_path)
             compare_batch(ctx, p, reads, align=1, explicit_lengths=False)
             ctx.close()
+        # reads whose ONLY near-match has k - 1, k, k + 1, k + 2 substitutions or inserted bases (k = 11: spread over the adapter, over its
+        # first 13 rows, over its last 32): a column at k + 1 sits in a marked chunk and must not become a candidate (with inserted bases
+        # every base of the adapter still matches: such a candidate would pass the match-length gate)
+        rng = np.random.default_rng(79)
+        reads = []
+        comp = {65: 67, 67: 65, 71: 84, 84: 71}
+        for i in range(96):
+            L = int(rng.integers(400, 900))
+            seq = bytearray(synth._ACGT[rng.integers(0, 4, L)].tobytes())
+            a = bytearray(pb[i & 1])
+            nsub = 10 + (i >> 1) % 4
+            where = (np.arange(len(a)), np.arange(13), np.arange(13, len(a)))[(i >> 3) % 3]
+            if i & 4:                        # differences that keep every base of the adapter matched: bases inserted into the text
+                for x in sorted(rng.choice(where[1:], size=min(nsub, len(where) - 1), replace=False), reverse=True):
+                    a[x:x] = bytes([comp[a[x]]])
+            else:
+                for x in rng.choice(where, size=min(nsub, len(where)), replace=False):
+                    a[x] = comp[a[x]]
+            at = int(rng.integers(0, L - len(a)))
+            seq[at:at + len(a)] = a
+            reads.append((b"near%d" % i, bytes(seq), bytes(rng.integers(60, 70, L, dtype=np.uint8))))
+        p = sized(abi.make_params("hifi", adapters=pb, end_len=0, min_len=50), reads)
+        ctx = capi.Context(p, 0, lib_path)
+        compare_batch(ctx, p, reads, align=1, explicit_lengths=False)
+        ctx.close()
         # filtered, unfiltered and one-dword adapters in one context, in an order that alternates the classes
         mixed = [synth.PACBIO_BLUNT, synth.ONT_RAPID, synth.PACBIO_BLUNT_RC, synth.ONT_RAPID[:28], tails[2], tails[3],
                  b"CTTGCGGGCGGCGGACTCTCCTCTGAAGATAGAGCGACAGGCAAG", b"CTTGCCTGTCGCTCTATCTTCAGAGGAGAGTCCGCCGCCCGCAAG", synth.ONT_RAPID_RC]

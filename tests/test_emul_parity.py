@@ -375,3 +375,14 @@ def test_emul_fuzz_findings_round3(emul, seed, monkeypatch):
     monkeypatch.setenv("TGSF_FUZZ_GATE_P", "0.5")
     from tests import fuzz
     fuzz.run_case(emul, seed, 150)
+
+
+@pytest.mark.parametrize("seed", [480061])
+def test_emul_fuzz_findings_round4(emul, seed, monkeypatch):
+    """Seeds of the round-4 GPU fuzz campaign on the filtering middle scan that found something.  480061: a read whose best
+    bottom-row value for the 45-bp adapter is k + 1 = 12, in a marked chunk -- k_mid_recheck handed the columns AT k + 1 over
+    (its running best starts there) and the read was dropped for a middle adapter it does not hold."""
+    monkeypatch.setenv("TGSF_FUZZ_WIDE", "1")
+    monkeypatch.setenv("TGSF_FUZZ_GATE_P", "0.2")
+    from tests import fuzz
+    fuzz.run_case(emul, seed, 150)

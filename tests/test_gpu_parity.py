@@ -401,3 +401,12 @@ def test_gpu_align_windows_beyond_256_bp():
 def test_gpu_batch_with_adapters_beyond_256_bp():
     from tests.test_emul_parity import test_emul_batch_with_adapters_beyond_256_bp as same
     same(None)
+
+
+@pytest.mark.parametrize("seed", [480061])
+def test_gpu_fuzz_findings_round4(seed, monkeypatch):
+    """See test_emul_fuzz_findings_round4: columns at exactly k + 1 in a chunk the filter marked."""
+    monkeypatch.setenv("TGSF_FUZZ_WIDE", "1")
+    monkeypatch.setenv("TGSF_FUZZ_GATE_P", "0.2")
+    from tests import fuzz
+    fuzz.run_case(None, seed, 150)

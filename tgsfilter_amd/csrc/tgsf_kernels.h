@@ -1666,8 +1666,8 @@ TGSF_D void recheck_chunk(const DevParams& P, const DevBatch& B, const uint64_t 
                 hot_step(st, eq[(dw[i >> 2] >> (8 * (i & 3))) & 0xFFu][j]);
                 if (c + i >= c1) {
                     const int sc = hot_score(st);
-                    if (sc < lim) { lim = sc; ties = 0u; }
-                    if (sc == lim) ties |= 1u << (c + i - c1);
+                    if (sc < lim) { lim = sc; ties = 0u; }                    // (lim starts at k + 1: a column AT k + 1 is no candidate)
+                    if (sc == lim && sc <= k) ties |= 1u << (c + i - c1);
                 }
             }
         }
