@@ -75,12 +75,16 @@ def run_case(lib_path, seed: int, n_reads: int):
     kind, reads, kw = random_case(seed, n_reads)
     pool_cap = kw.pop("_pool_cap", 0)
     p = parity.sized(abi.make_params(kind, **kw), reads)
+    outer = os.environ.get("TGSF_POOL_CAP")                 # (a campaign may set one for every case: keep it)
     if pool_cap:
         os.environ["TGSF_POOL_CAP"] = str(pool_cap)
     try:
         ctx = capi.Context(p, 0, lib_path)
     finally:
-        os.environ.pop("TGSF_POOL_CAP", None)
+        if outer is None:
+            os.environ.pop("TGSF_POOL_CAP", None)
+        else:
+            os.environ["TGSF_POOL_CAP"] = outer
     try:
         parity.compare_batch(ctx, p, reads, align=int(np.random.default_rng(seed).choice([1, 16])),
                              explicit_lengths=True)
