@@ -532,6 +532,12 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     if (!e) e = dev_alloc(c, &B.chk_cnt, n + 1);
     if (c->cap_bases / 16u + n >= 0xFFFFFFF0ull) c->flat_scan = false;   // (chunk numbers are 32 bits: such a context keeps k_mid_scan1)
     if (c->cap_bases / 16u + n >= (1ull << 30) || !c->flat_scan) c->suffix_filter = 0;   // (k_mid_recheck's items: a chunk number and two bits)
+    {
+        // (no adapter the filter takes -- the ONT rapid adapters at the default -M, k = 16 --: none of its buffers either)
+        bool any = false;
+        for (int a = 0; a < p->n_adapters; a++) any |= c->P.Q[a] > 32 && c->P.Q[a] <= 64 && c->P.k_mid[a] >= 0 && c->P.k_mid[a] <= kSuffixMaxK;
+        if (!any || !p->filter) c->suffix_filter = 0;
+    }
     if (!e && c->suffix_filter) e = dev_alloc(c, &B.chk_mark, (size_t)4 * (size_t)((c->cap_bases / 16u + n) / 32u + 8u));
     if (c->suffix_filter) {
         // a mark in 25 chunks has room in the list (random sequence: a few in a thousand), the rest is done where it is found
