@@ -33,6 +33,7 @@ constexpr int kBin = 100;          // CalcAvgQuality bin width
 constexpr int kTileBins = 64;      // one bin per lane
 constexpr int kTileBases = kBin * kTileBins;   // 6400 bases per stats tile
 constexpr int kSegCols = 1024;     // columns of the read middle owned by one lane of the infix scan
+constexpr int kMidThreads = 256;   // lanes of a workgroup of the middle scans (k_mid_flat, k_mid_scan1): their launch bound
 constexpr int kMaxRegions = 64;    // disjoint drop regions per read the region kernel can hold
 constexpr int kMidListMax = 1024;  // candidates of one read beyond which the scan is redone into position-ordered arrays
 constexpr int kSuffixMaxK = 12;    // adapters of 33..64 bp searched within at most this many differences go through the middle scan's 32-row filter (k_mid_flat)

@@ -172,6 +172,31 @@ TGSF_HD void flat_schedule(uint32_t T, uint32_t pmax, uint32_t pmin, uint32_t f0
     }
     s.nph = k; s.c0[k] = (uint32_t)c; s.d0[k] = (uint32_t)d;
 }
+// The same schedule for ONE stretch, without the arrays (a lane of k_mid_flat asks for its own: arrays indexed by the
+// phase lived in scratch memory, 112 bytes a lane): the phase stretch d falls in -- its shift, first chunk and first
+// stretch, and the chunk the phase ends at.  Returns the number of stretches of the whole schedule; d beyond it leaves
+// `sh`, `c0`, `d0`, `c1` at the last phase's values (the caller tests d against the count).
+TGSF_HD uint32_t flat_stretch(uint32_t T, uint32_t pmax, uint32_t pmin, uint32_t f0, uint32_t dq,
+                              uint32_t& sh_out, uint32_t& c0_out, uint32_t& d0_out, uint32_t& c1_out)
+{
+    uint64_t c = 0, d = 0, rest = T;
+    const uint32_t shmin = flat_log2(pmin ? pmin : 1u);
+    uint32_t sh = flat_log2(pmax ? pmax : 1u), k = 0;
+    if (sh < shmin) sh = shmin;
+    sh_out = sh; c0_out = 0; d0_out = 0; c1_out = 0;
+    for (;;) {
+        const bool last = sh <= shmin || k == 7;
+        const uint32_t gsh = sh + 6;
+        const uint64_t want = last ? rest : (k == 0 ? (rest * f0) >> 8 : rest >> 1);
+        const uint64_t ng = last ? (rest + (1ull << gsh) - 1) >> gsh : want >> gsh;
+        const uint64_t cover = (ng << gsh) < rest ? (ng << gsh) : rest;
+        if (dq >= (uint32_t)d) { sh_out = sh; c0_out = (uint32_t)c; d0_out = (uint32_t)d; c1_out = (uint32_t)(c + cover); }
+        c += cover; d += ng << 6; rest -= cover; k++;
+        if (last || rest == 0) break;
+        sh--;
+    }
+    return (uint32_t)d;
+}
 
 enum DevStatus : uint32_t {
     DS_OK = 0,

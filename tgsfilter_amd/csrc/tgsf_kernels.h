@@ -1211,7 +1211,7 @@ TGSF_KERNEL k_mid_link(DevBatch B, int A)
 
 // HT = Hot: adapters of 33..64 bp (one 64-bit word per column); HT = Hot32: adapters of at most 32 bp (one dword).
 template <int AT, class HT = Hot>
-TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
+TGSF_KERNEL TGSF_BOUNDS(kMidThreads, (AT <= 2 ? 4 : 2)) k_mid_scan1(DevParams P, DevBatch B, int a0, int na)   // (see k_mid_flat)
 {
     typedef decltype(hot_eq(HT(), 0ull)) eq_t;
     TGSF_SHARED eq_t eqt[256][AT];
@@ -1404,11 +1404,20 @@ TGSF_KERNEL k_mid_scan1(DevParams P, DevBatch B, int a0, int na)
 // k_mid_scan1 -- is unchanged.
 // ---------------------------------------------------------------------------
 // the first nvalid bytes at p (the rest zero): the last chunk of a window when fewer than 15 bytes follow it
+// (sixteen predicated byte loads at constant shifts into four registers: an array indexed by the loop variable lived
+// in scratch memory -- 112 bytes per lane in every instantiation of k_mid_flat)
 TGSF_D uint4 load_upto16(const uint8_t* p, int nvalid)
 {
-    uint32_t d[4] = {0u, 0u, 0u, 0u};
-    for (int i = 0; i < nvalid && i < 16; i++) d[i >> 2] |= (uint32_t)p[i] << (8 * (i & 3));
-    uint4 v; v.x = d[0]; v.y = d[1]; v.z = d[2]; v.w = d[3];
+    uint32_t d0 = 0u, d1 = 0u, d2 = 0u, d3 = 0u;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t s = (i < nvalid ? (uint32_t)p[i] : 0u) << (8 * (i & 3));
+        if ((i >> 2) == 0) d0 |= s;
+        else if ((i >> 2) == 1) d1 |= s;
+        else if ((i >> 2) == 2) d2 |= s;
+        else d3 |= s;
+    }
+    uint4 v; v.x = d0; v.y = d1; v.z = d2; v.w = d3;
     return v;
 }
 
@@ -1421,8 +1430,12 @@ TGSF_D uint4 load_upto16(const uint8_t* p, int nvalid)
 // launched right behind, puts the whole adapter through the chunks marked for it and hands over the candidates.  The value is looked at every
 // FS-th column against k + FS - 1 (neighbouring bottom-row values differ by at most 1; marking more than needed costs a
 // recheck, never a candidate).  On random sequence the 45-bp PacBio adapters at k = 11 mark 2 chunks in 1 000.
+// Launched with 256 lanes a workgroup (kMidThreads); without a bound the compiler assumes 1 024 and caps the kernel at
+// 128 registers: three and four adapters a pass (the ligation kits' distinct 5' and 3' adapters with their reverse
+// complements, src/TGSFilter.cpp:3105-3113) then spilled up to 426 of them.  One and two adapters keep the cap they were
+// tuned under (4 waves per SIMD); three and four take up to 256 registers at 2 waves per SIMD.
 template <int AT, class HT = Hot, int FS = 0>
-TGSF_KERNEL k_mid_flat(DevParams P, DevBatch B, int a0, int na)
+TGSF_KERNEL TGSF_BOUNDS(kMidThreads, (AT <= 2 ? 4 : 2)) k_mid_flat(DevParams P, DevBatch B, int a0, int na)
 {
     static_assert(FS == 0 || (16 % FS) == 0, "the filter's test stride divides a chunk");
     typedef decltype(hot_eq(HT(), 0ull)) eq_t;
@@ -1440,18 +1453,18 @@ TGSF_KERNEL k_mid_flat(DevParams P, DevBatch B, int a0, int na)
     for (int j = 0; j < na; j++) { const int a = a0 + j; if (P.k_mid[a] >= 0) { const int w = P.Q[a] + P.k_mid[a] - 1; wu = w > wu ? w : wu; } }
     const uint32_t wuc = (uint32_t)(wu + 15) >> 4;
     int32_t (*ties)[4] = tie_col[threadIdx.x];
-    FlatSchedule S;
-    flat_schedule(B.chk_cnt[B.n], B.flat_pmax, B.flat_pmin, B.flat_f0, S);
+    const uint32_t n_chunks = B.chk_cnt[B.n];
+    uint32_t ph_sh, ph_c0, ph_d0, ph_c1;
+    const uint32_t n_stretch = flat_stretch(n_chunks, B.flat_pmax, B.flat_pmin, B.flat_f0, gtid(), ph_sh, ph_c0, ph_d0, ph_c1);
 
     // (the host launches one lane per stretch of the longest sequence the batch can have; the emulation's small grid strides)
-    for (uint32_t d = gtid(); d < S.d0[S.nph]; d += gsize()) {
-        uint32_t ph = 0;
-        while (ph + 1 < S.nph && d >= S.d0[ph + 1]) ph++;
-        const uint64_t first64 = (uint64_t)S.c0[ph] + ((uint64_t)(d - S.d0[ph]) << S.sh[ph]);
-        if (first64 >= (uint64_t)S.c0[ph + 1]) continue;                 // (the last group of a phase may not be full)
+    for (uint32_t d = gtid(); d < n_stretch; d += gsize()) {
+        if (d != gtid()) (void)flat_stretch(n_chunks, B.flat_pmax, B.flat_pmin, B.flat_f0, d, ph_sh, ph_c0, ph_d0, ph_c1);
+        const uint64_t first64 = (uint64_t)ph_c0 + ((uint64_t)(d - ph_d0) << ph_sh);
+        if (first64 >= (uint64_t)ph_c1) continue;                        // (the last group of a phase may not be full)
         const uint32_t first = (uint32_t)first64;
-        uint32_t left = S.c0[ph + 1] - first;                            // owned chunks still to do
-        if (left > (1u << S.sh[ph])) left = 1u << S.sh[ph];
+        uint32_t left = ph_c1 - first;                                   // owned chunks still to do
+        if (left > (1u << ph_sh)) left = 1u << ph_sh;
         uint32_t r = find_owner(B.chk_cnt, B.n, first);
 
         HT st[AT];

@@ -398,24 +398,6 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
             c->h_pinned = pw; c->h_status = pw; c->pend_nf_p = pw + 4;
         }
     }
-    if ((he = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking)) != hipSuccess || ndev <= 0) {
-        delete c;
-        return fail(nullptr, TGSF_E_NO_DEVICE, "no HIP device available (%s); libtgsf has no CPU fallback", hipGetErrorString(he));
-    }
-    if (device < 0 || device >= ndev) { delete c; return fail(nullptr, TGSF_E_NO_DEVICE, "device %d out of range (%d devices)", device, ndev); }
-    if ((he = hipSetDevice(device)) != hipSuccess) { delete c; return fail(nullptr, TGSF_E_HIP, "hipSetDevice: %s", hipGetErrorString(he)); }
-    if ((he = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
-        delete c; return fail(nullptr, TGSF_E_HIP, "hipStreamCreate: %s", hipGetErrorString(he));
-    }
-    c->own_stream = true;
-    c->prof_pending = 0;
-    {
-        uint32_t* pw = nullptr;
-        if (hipHostMalloc((void**)&pw, 64, hipHostMallocDefault) == hipSuccess && pw) {
-            memset(pw, 0, 64);
-            c->h_pinned = pw; c->h_status = pw; c->pend_nf_p = pw + 4;
-        }
-    }
     {
         // the auxiliary stream's short kernels (end windows, end tables) run beside the middle scan, whose workgroups fill
         // every CU for a millisecond each: with a priority above the scan's they get the slots that free up first
@@ -687,6 +669,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     const uint32_t n = B.n;
     const int A = P.n_adapters;
     const unsigned T = 256;
+    static_assert(kMidThreads == 256, "k_mid_flat / k_mid_scan1 are launched with T lanes a workgroup");
     c->last_stream = st;
     const unsigned gsmall = grid_cap(std::min(blocks_for(n, T), 2048u));
     const unsigned gstats = grid_cap(c->stats_grid);   // 3 blocks (12 waves) per CU on 256 CUs: LDS-limited
