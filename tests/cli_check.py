@@ -10,8 +10,18 @@ import subprocess
 import tempfile
 
 
-def run_case(binary: str, golden_dir: str, name: str, extra_args=(), compress=None):
-    """compress: hand the FASTA/FASTQ input over as "gzip" (two members), "bgzf" (bgzip blocks) or "sam.gz"/... -- the
+def shardable(golden_dir: str, name: str) -> bool:
+    """Golden cases a sharded job (tgsfilter --ranks / --shard) takes: plain FASTQ / FASTA text in, no downsampling."""
+    cmd = json.load(open(os.path.join(golden_dir, name + ".cmd.json")))
+    flags = cmd["flags"].split()
+    return cmd.get("in_format", "fq") in ("fq", "fa") and not any(f in flags for f in ("-g", "-d", "-r", "-R", "-A"))
+
+
+def run_case(binary: str, golden_dir: str, name: str, extra_args=(), compress=None, ranks=None, launcher="fork"):
+    """ranks: run as a sharded job of that many rank processes (launcher "fork": tgsfilter --ranks N starts them itself;
+    "external": this function starts N processes with --shard r/N --rendezvous <socket>, as torchrun or mpirun would) --
+    the parts, concatenated in rank order, must be the reference's file, stderr and report as ever.
+    compress: hand the FASTA/FASTQ input over as "gzip" (two members), "bgzf" (bgzip blocks) or "sam.gz"/... -- the
     reference reads any of them (:567-640); the golden output does not depend on it."""
     cmd = json.load(open(os.path.join(golden_dir, name + ".cmd.json")))
     ref_out = gzip.open(os.path.join(golden_dir, name + ".out.fq.gz"), "rb").read()
@@ -42,10 +52,25 @@ def run_case(binary: str, golden_dir: str, name: str, extra_args=(), compress=No
                 for i, a in enumerate(cmd["adapters"]):
                     f.write(">a%d\n%s\n" % (i, a))
             args += ["-a", fa]
-        p = subprocess.run(args, capture_output=True, cwd=td)
-        err = p.stderr.decode().replace(td + "/", "")
-        assert p.returncode == 0, err
-        out = open(os.path.join(td, "out.fa" if fmt == "fa" else "out.fq"), "rb").read() if not qc else b""
+        out_name = os.path.join(td, "out.fa" if fmt == "fa" else "out.fq")
+        if ranks and launcher == "external":
+            procs = [subprocess.Popen(args + ["--shard", "%d/%d" % (r, ranks), "--rendezvous", os.path.join(td, "rdv.sock")],
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=td) for r in range(ranks)]
+            outs = [q.communicate(timeout=600) for q in procs]
+            err = b"".join(o[1] for o in outs).decode().replace(td + "/", "")
+            assert all(q.returncode == 0 for q in procs), err
+        else:
+            if ranks:
+                args += ["--ranks", str(ranks)]
+            p = subprocess.run(args, capture_output=True, cwd=td)
+            err = p.stderr.decode().replace(td + "/", "")
+            assert p.returncode == 0, err
+        if ranks and not qc:
+            assert not os.path.exists(out_name)
+            out = b"".join(open("%s.part%d" % (out_name, r), "rb").read() for r in range(ranks))
+            err = re.sub(r"(INFO: Filtered reads were written to: \S+?)\.part0 \.\.\. .*", r"\1.", err)
+        else:
+            out = open(out_name, "rb").read() if not qc else b""
         html = open(os.path.join(td, "in.html" if qc else "out.html"), encoding="utf-8").read()
     assert out == ref_out, "output FASTQ differs from the reference's"
 

@@ -74,7 +74,8 @@ def test_rccl_library_exports():
     """libtgsf_rccl.so (include/tgsf_rccl.h, the optional tally all-reduce) loads and exports what its header declares."""
     hdr = open(os.path.join(ROOT, "include", "tgsf_rccl.h")).read()
     declared = set(re.findall(r"^\s*(?:int|void|const char\*)\s+(tgsf_rccl_\w+)\s*\(", hdr, flags=re.M))
-    assert declared == {"tgsf_rccl_allreduce_counters", "tgsf_rccl_last_error"}
+    assert declared == {"tgsf_rccl_allreduce_counters", "tgsf_rccl_last_error", "tgsf_rccl_unique_id", "tgsf_rccl_comm_init",
+                        "tgsf_rccl_comm_count", "tgsf_rccl_comm_destroy"}
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tgsfilter_amd", "csrc")], check=True)
     from tgsfilter_amd import rccl
     lib = rccl.load()

@@ -1,0 +1,232 @@
+"""One process per GPU over one input (tgsfilter --ranks N / --shard r/N, tgsfilter_amd/host/shard.h): every rank filters
+its byte range of the text and writes <out>.part<r>; the pre-pass runs on rank 0 and its constants are broadcast; the
+tallies are summed at the end (RCCL all-reduce with a GPU per rank, the ranks' sockets otherwise) and rank 0 writes the
+one report.  The parts, concatenated in rank order, must be byte for byte the reference's -t 1 output, the INFO lines and
+the report the reference's (src/TGSFilter.cpp:1808-1842 fan-out, :3208-3213 merge).
+
+CPU: the emulation build of the command line.  -m gpu: the real binary, ranks sharing device 0 (and, at the end of the
+file, a 24 000-read file against the reference binary run side by side)."""
+import gzip
+import json
+import os
+import subprocess
+
+import pytest
+
+from tests import cli_check, hostmodel
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+REF = os.path.join(ROOT, "oracle", "_ref", "tgsfilter_ref")
+GPU_BINARY = os.path.join(ROOT, "tgsfilter_amd", "bin", "tgsfilter")
+SHARDABLE = [n for n in hostmodel.GOLDEN_CASES + hostmodel.GOLDEN_CLI_ONLY if cli_check.shardable(GOLD, n)]
+
+
+@pytest.fixture(scope="module")
+def binary():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tgsfilter_amd", "host"), "emul"], check=True)
+    return os.path.join(ROOT, "tests", "emul", "tgsfilter_emul")
+
+
+def test_there_are_shardable_goldens():
+    assert len(SHARDABLE) >= 15 and "ont_auto" in SHARDABLE and "hifi_auto" in SHARDABLE
+
+
+@pytest.mark.parametrize("name", SHARDABLE)
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_cli_sharded_golden(binary, golden_dir, name, ranks):
+    cli_check.run_case(binary, golden_dir, name, ranks=ranks)
+
+
+@pytest.mark.parametrize("name", ["ont_auto", "hifi_zoo", "ont_fasta", "ont_qc"] if "ont_qc" in SHARDABLE else ["ont_auto", "hifi_zoo", "ont_fasta"])
+def test_cli_sharded_by_another_launcher(binary, golden_dir, name):
+    """--shard r/N --rendezvous <path>: the ranks are started one by one (as torchrun / mpirun would) and meet at a unix socket."""
+    cli_check.run_case(binary, golden_dir, name, ranks=3, launcher="external")
+
+
+def test_cli_one_rank_is_a_job_too(binary, golden_dir):
+    cli_check.run_case(binary, golden_dir, "ont_zoo", ranks=1)
+
+
+def test_cli_sharded_more_ranks_than_reads(binary, golden_dir, tmp_path):
+    """Ranks whose byte range holds no record start write an empty part; the job's output is still the single process's."""
+    raw = gzip.open(os.path.join(golden_dir, "ont_zoo.in.fq.gz"), "rb").read()
+    recs = raw.split(b"\n")
+    fin = tmp_path / "in.fq"
+    fin.write_bytes(b"\n".join(recs[:4 * 5]) + b"\n")                # five reads
+    common = ["-i", str(fin), "-x", "ont", "-l", "500", "-q", "7", "-5", "0", "-3", "0"]
+    p1 = subprocess.run([binary, "-o", str(tmp_path / "one.fq")] + common, capture_output=True, timeout=300)
+    p9 = subprocess.run([binary, "-o", str(tmp_path / "nine.fq"), "--ranks", "9"] + common, capture_output=True, timeout=300)
+    assert p1.returncode == 0 and p9.returncode == 0, p9.stderr.decode()[-2000:]
+    parts = b"".join((tmp_path / ("nine.fq.part%d" % r)).read_bytes() for r in range(9))
+    assert parts == (tmp_path / "one.fq").read_bytes() and len(parts) > 0
+    info = lambda e: [l for l in e.decode().splitlines() if l.startswith("INFO:") and "written to" not in l]
+    assert info(p1.stderr) == info(p9.stderr)
+
+
+def _adversarial_fastq(n=400, seed=3, crlf=False):
+    """Quality lines that begin with '@' and '+', headers that contain '+' and '@': every line start looks like a record start."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        L = int(rng.integers(600, 2500))
+        seq = bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, L)])
+        q = bytearray(rng.integers(40, 75, L).astype(np.uint8).tobytes())
+        q[0] = ord("@") if i % 2 == 0 else ord("+")
+        if L > 1:
+            q[1] = ord("@")
+        out.append(b"@read%d +@ x\n" % i + seq + b"\n+\n" + bytes(q) + b"\n")
+    text = b"".join(out)
+    return text.replace(b"\n", b"\r\n") if crlf else text
+
+
+@pytest.mark.parametrize("crlf", [False, True])
+@pytest.mark.parametrize("ranks", [2, 5, 16])
+def test_cli_sharded_cuts_on_adversarial_text(binary, tmp_path, ranks, crlf):
+    fin = tmp_path / "in.fq"
+    fin.write_bytes(_adversarial_fastq(crlf=crlf))
+    common = ["-i", str(fin), "-x", "ont", "-l", "500", "-q", "7", "-5", "3", "-3", "2", "-t", "4"]
+    p1 = subprocess.run([binary, "-o", str(tmp_path / "one.fq")] + common, capture_output=True, timeout=600)
+    pn = subprocess.run([binary, "-o", str(tmp_path / "n.fq"), "--ranks", str(ranks)] + common, capture_output=True, timeout=600)
+    assert p1.returncode == 0 and pn.returncode == 0, pn.stderr.decode()[-2000:]
+    parts = b"".join((tmp_path / ("n.fq.part%d" % r)).read_bytes() for r in range(ranks))
+    assert parts == (tmp_path / "one.fq").read_bytes() and parts.count(b"\n") >= 4 * 300
+
+
+def test_cli_sharded_refuses_a_text_it_cannot_cut_like_the_sequential_reader(binary, tmp_path):
+    """Stray lines between two records are skipped by the reference's reader within its five attempts per record
+    (src/TGSFilter.cpp:689-698): a reader that starts behind them has not seen them.  Where a cut falls next to such lines
+    the job stops with a message instead of reading the text its own way; a malformed record inside a part stops it as well."""
+    text = _adversarial_fastq(n=60)
+    recs = text.split(b"@read")
+    mid = len(recs) // 2
+    broken = b"@read".join(recs[:mid]) + b"stray line\n@read" + b"@read".join(recs[mid:])
+    fin = tmp_path / "in.fq"
+    fin.write_bytes(broken)
+    common = ["-i", str(fin), "-x", "ont", "-l", "500", "-q", "7", "-5", "0", "-3", "0"]
+    p1 = subprocess.run([binary, "-o", str(tmp_path / "one.fq")] + common, capture_output=True, timeout=300)
+    assert p1.returncode == 0                                        # (the sequential reader skips the stray line)
+    bad = 0
+    for ranks in (2, 3, 4, 6):
+        pn = subprocess.run([binary, "-o", str(tmp_path / ("n%d.fq" % ranks)), "--ranks", str(ranks)] + common, capture_output=True, timeout=300)
+        if pn.returncode != 0:
+            bad += 1
+            assert b"cannot be cut near byte" in pn.stderr
+        else:                                                        # the stray line fell inside a part: read as the sequential reader reads it
+            parts = b"".join((tmp_path / ("n%d.fq.part%d" % (ranks, r))).read_bytes() for r in range(ranks))
+            assert parts == (tmp_path / "one.fq").read_bytes()
+    # a record whose quality line is short: the sequential reader ends the stream there (:719-723); a part that holds it
+    # and is not the last cannot end where the next begins
+    lines = text.split(b"\n")
+    lines[4 * 10 + 3] = lines[4 * 10 + 3][:-5]
+    fin.write_bytes(b"\n".join(lines))
+    pn = subprocess.run([binary, "-o", str(tmp_path / "m.fq"), "--ranks", "3"] + common, capture_output=True, timeout=300)
+    assert pn.returncode != 0 and b"cannot be cut near byte" in pn.stderr
+
+
+def test_cli_sharded_refusals(binary, golden_dir, tmp_path):
+    raw = gzip.open(os.path.join(golden_dir, "ont_zoo.in.fq.gz"), "rb").read()
+    fin = tmp_path / "in.fq"
+    fin.write_bytes(raw)
+    gz = tmp_path / "in2.fq.gz"
+    gz.write_bytes(gzip.compress(raw))
+    base = [binary, "-x", "ont", "-o", str(tmp_path / "o.fq")]
+    for extra, what in ((["-i", str(fin), "--ranks", "2", "-r", "10"], b"downsampling"),
+                        (["-i", str(gz), "--ranks", "2"], b"plain FASTQ"),
+                        (["-i", str(fin), "--shard", "0/2"], b"--rendezvous"),
+                        (["-i", str(fin), "--shard", "2/2", "--rendezvous", str(tmp_path / "s")], b"no such rank"),
+                        (["-i", str(fin), "--ranks", "2", "--shard", "0/2", "--rendezvous", str(tmp_path / "s")], b"--ranks starts the ranks itself")):
+        p = subprocess.run(base + extra, capture_output=True, timeout=120)
+        assert p.returncode != 0 and what in p.stderr, (extra, p.stderr)
+    p = subprocess.run([binary, "-x", "ont", "-i", str(fin), "--ranks", "2"], capture_output=True, timeout=120)
+    assert p.returncode != 0 and b"-o is needed" in p.stderr
+
+
+def test_cli_shard_env_as_torchrun_sets_it(binary, golden_dir, tmp_path):
+    """--shard env: RANK / WORLD_SIZE (and LOCAL_RANK for the device) from the environment."""
+    raw = gzip.open(os.path.join(golden_dir, "hifi_auto.in.fq.gz"), "rb").read()
+    fin = tmp_path / "in.fq"
+    fin.write_bytes(raw)
+    cmd = json.load(open(os.path.join(golden_dir, "hifi_auto.cmd.json")))
+    assert not cmd["adapters"]
+    args = [binary, "-i", str(fin), "-o", str(tmp_path / "o.fq"), "-t", "1"] + cmd["flags"].split() + ["--shard", "env", "--rendezvous", str(tmp_path / "r.sock")]
+    procs = [subprocess.Popen(args, stderr=subprocess.PIPE, env=dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r))) for r in range(2)]
+    errs = [q.communicate(timeout=600)[1] for q in procs]
+    assert all(q.returncode == 0 for q in procs), errs
+    parts = b"".join((tmp_path / ("o.fq.part%d" % r)).read_bytes() for r in range(2))
+    assert parts == gzip.open(os.path.join(golden_dir, "hifi_auto.out.fq.gz"), "rb").read()
+    assert b"INFO:" in errs[0] and b"INFO:" not in errs[1]           # rank 0 speaks for the job
+
+
+def test_cli_sharded_job_ends_when_a_rank_fails(binary, golden_dir, tmp_path):
+    """A rank that ends with an error takes the job with it (no rank waits for ever for a peer that is gone)."""
+    raw = gzip.open(os.path.join(golden_dir, "ont_zoo.in.fq.gz"), "rb").read()
+    fin = tmp_path / "in.fq"
+    fin.write_bytes(raw)
+    # -q above the sample's qualities ends rank 0 in the pre-pass (Get_qType :1060-1065)
+    p = subprocess.run([binary, "-i", str(fin), "-o", str(tmp_path / "o.fq"), "-x", "ont", "-q", "90", "--ranks", "3"], capture_output=True, timeout=120)
+    assert p.returncode != 0 and b"Please reset -q parameter" in p.stderr
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SHARDABLE)
+def test_cli_gpu_sharded_golden(golden_dir, name):
+    """Three rank processes sharing device 0 (tallies summed over the ranks' sockets: RCCL refuses two ranks on one device)."""
+    cli_check.run_case(GPU_BINARY, golden_dir, name, ranks=3, extra_args=["--devices", "0"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ont_auto", "hifi_auto", "ont_fasta"])
+def test_cli_gpu_one_rank_all_reduces_over_rccl(golden_dir, name, monkeypatch):
+    """--ranks 1 with a GPU of its own: the communicator is set up beside the filtering and the tallies go through the RCCL
+    all-reduce (libtgsf_rccl) -- a one-rank communicator on this box; the program path of a GPU per rank."""
+    if not os.path.exists(os.path.join(ROOT, "tgsfilter_amd", "libtgsf_rccl.so")):
+        pytest.skip("libtgsf_rccl.so not built (no librccl)")
+    monkeypatch.setenv("TGSF_SHARD_EXCHANGE", "rccl")                  # (no silent fall-back to the sockets)
+    cli_check.run_case(GPU_BINARY, golden_dir, name, ranks=1)
+
+
+@pytest.mark.gpu
+def test_cli_gpu_sharded_by_another_launcher(golden_dir):
+    cli_check.run_case(GPU_BINARY, golden_dir, "ont_auto", ranks=2, launcher="external", extra_args=["--device", "0"])
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/tgsfilter_ref not built (make -C oracle ref)")
+def test_cli_gpu_three_ranks_on_a_real_file_against_the_reference(tmp_path):
+    """Config C4's program path on the one device of this box: three rank processes (three contexts each) over a
+    24 000-read file (C2's shape at 6 kb: 0.14 Gbases, ~290 MB of text) with the automatic pre-pass on rank 0.  The parts
+    concatenated in rank order, the INFO lines and the report's tables and plotted data must equal the reference binary's
+    (-t 1: input order) and the single process's."""
+    import hashlib
+    import tempfile
+    from tgsfilter_amd import synth
+    shm = "/dev/shm" if os.access("/dev/shm", os.W_OK) else None
+    with tempfile.TemporaryDirectory(dir=shm) as td:
+        fq = os.path.join(td, "in.fq")
+        bases, _ = synth.write_ont_fastq(fq, 24_000, seed=21, mean_len=6000.0, max_len=200_000, reads_per_job=512)
+        assert bases > 1e8
+        common = ["-i", fq, "-x", "ont", "-l", "1000", "-q", "10"]               # automatic pre-pass, as C2
+        env = dict(os.environ, TGSF_BATCH_BYTES="1500000", TGSF_EARLY_OPEN_MIN="1", TGSF_STRIDE_BYTES="8000000", TGSF_TIMING="1")
+
+        def run(tag, exe, extra, e=None, parts=0):
+            out = os.path.join(td, tag + ".fq")
+            p = subprocess.run([exe, "-o", out] + common + extra, capture_output=True, env=e)
+            assert p.returncode == 0, p.stderr.decode()[-2000:]
+            info = [l for l in p.stderr.decode().splitlines() if l.startswith("INFO: ") and "written to" not in l]
+            html = open(os.path.join(td, tag + ".html"), "rb").read()
+            body = b"\n".join(l for l in html.splitlines() if b"<tr>" in l or l.lstrip().startswith(b"var data"))
+            h = hashlib.sha256()
+            for f in ([out] if not parts else ["%s.part%d" % (out, r) for r in range(parts)]):
+                h.update(open(f, "rb").read())
+            return h.hexdigest(), info, hashlib.sha256(body).hexdigest(), p.stderr.decode()
+
+        one = run("one", GPU_BINARY, ["-t", "16", "--devices", "0"], env)
+        three = run("three", GPU_BINARY, ["-t", "16", "--ranks", "3", "--devices", "0"], env, parts=3)
+        ref = run("ref", REF, ["-t", "1"])
+        assert three[1] == one[1] == ref[1]
+        assert three[0] == one[0] == ref[0]
+        assert three[2] == one[2] == ref[2]
+        assert three[3].count("SHARD ") == 3 and "summed on rank 0 over the ranks' sockets" in three[3]

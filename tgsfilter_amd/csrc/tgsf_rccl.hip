@@ -4,6 +4,7 @@
 #include <rccl/rccl.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 
 #include <string>
 
@@ -23,6 +24,44 @@ static int fail(int code, const char* fmt, ...)
 }
 
 extern "C" const char* tgsf_rccl_last_error(void) { return g_err.c_str(); }
+
+static_assert(sizeof(ncclUniqueId) == TGSF_RCCL_ID_BYTES, "ncclUniqueId is 128 bytes");
+
+extern "C" int tgsf_rccl_unique_id(void* id128)
+{
+    if (!id128) return fail(TGSF_E_INVALID, "null argument");
+    ncclUniqueId id;
+    const ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) return fail(TGSF_E_HIP, "ncclGetUniqueId: %s", ncclGetErrorString(r));
+    memcpy(id128, &id, sizeof id);
+    return TGSF_OK;
+}
+
+extern "C" int tgsf_rccl_comm_init(int device, const void* id128, int rank, int world, void** nccl_comm)
+{
+    if (!id128 || !nccl_comm || world < 1 || rank < 0 || rank >= world) return fail(TGSF_E_INVALID, "bad argument");
+    *nccl_comm = nullptr;
+    if (hipSetDevice(device) != hipSuccess) return fail(TGSF_E_NO_DEVICE, "hipSetDevice(%d) failed", device);
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    ncclComm_t comm = nullptr;
+    const ncclResult_t r = ncclCommInitRank(&comm, world, id, rank);
+    if (r != ncclSuccess) return fail(TGSF_E_HIP, "ncclCommInitRank(rank %d of %d, device %d): %s", rank, world, device, ncclGetErrorString(r));
+    *nccl_comm = comm;
+    return TGSF_OK;
+}
+
+extern "C" int tgsf_rccl_comm_count(void* nccl_comm, int* n_ranks)
+{
+    if (!nccl_comm || !n_ranks) return fail(TGSF_E_INVALID, "null argument");
+    const ncclResult_t r = ncclCommCount((ncclComm_t)nccl_comm, n_ranks);
+    return r == ncclSuccess ? TGSF_OK : fail(TGSF_E_HIP, "ncclCommCount: %s", ncclGetErrorString(r));
+}
+
+extern "C" void tgsf_rccl_comm_destroy(void* nccl_comm)
+{
+    if (nccl_comm) (void)ncclCommDestroy((ncclComm_t)nccl_comm);
+}
 
 // buf = [ tallies (n words) | world slots of 4 words ]: this rank's "rows used" words move into its slot
 __global__ void k_pack_rows(unsigned long long* buf, const unsigned long long* ctr, unsigned long long n, int rank, int world)

@@ -61,6 +61,7 @@ void load(std::vector<int> devices)
     BIND(stage_times, "tgsf_stage_times")
     BIND(stage_name, "tgsf_stage_name")
     BIND(device_location, "tgsf_device_location")
+    BIND(counters_merge, "tgsf_counters_merge")
 #undef BIND
     if (g_api.abi_version() != TGSF_ABI_VERSION) { g_error = path + ": ABI version mismatch"; return; }
     g_load_s = now_s() - t0;
@@ -93,6 +94,29 @@ const Api& lib()
         quit(255);
     }
     return g_api;
+}
+
+const RcclApi* rccl_lib()
+{
+    static RcclApi api;
+    static const bool ok = [] {
+        if (getenv("TGSF_NO_RCCL")) return false;               // test knob: a box without the collective library
+        std::string path = lib_path();
+        const size_t slash = path.rfind('/');
+        path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/libtgsf_rccl.so";
+        void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!h) return false;
+#define BIND(field, sym) api.field = reinterpret_cast<decltype(api.field)>(dlsym(h, sym)); if (!api.field) return false;
+        BIND(unique_id, "tgsf_rccl_unique_id")
+        BIND(comm_init, "tgsf_rccl_comm_init")
+        BIND(comm_count, "tgsf_rccl_comm_count")
+        BIND(comm_destroy, "tgsf_rccl_comm_destroy")
+        BIND(allreduce_counters, "tgsf_rccl_allreduce_counters")
+        BIND(last_error, "tgsf_rccl_last_error")
+#undef BIND
+        return true;
+    }();
+    return ok ? &api : nullptr;
 }
 
 void lib_times(double& load_s, double& device_s) { load_s = g_load_s; device_s = g_device_s; }

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "tgsf.h"
+#include "tgsf_rccl.h"
 
 namespace host {
 
@@ -26,7 +27,21 @@ struct Api {
     decltype(&tgsf_stage_times) stage_times;
     decltype(&tgsf_stage_name) stage_name;
     decltype(&tgsf_device_location) device_location;
+    decltype(&tgsf_counters_merge) counters_merge;
 };
+
+// include/tgsf_rccl.h (libtgsf_rccl.so, beside libtgsf.so): the tally all-reduce of a job of several rank processes
+struct RcclApi {
+    decltype(&tgsf_rccl_unique_id) unique_id;
+    decltype(&tgsf_rccl_comm_init) comm_init;
+    decltype(&tgsf_rccl_comm_count) comm_count;
+    decltype(&tgsf_rccl_comm_destroy) comm_destroy;
+    decltype(&tgsf_rccl_allreduce_counters) allreduce_counters;
+    decltype(&tgsf_rccl_last_error) last_error;
+};
+// nullptr where the library is not installed or does not load (a box without RCCL): the caller then sums the tallies of
+// its ranks over their sockets.  Loads on first use (call after lib()).
+const RcclApi* rccl_lib();
 
 // Starts the helper thread: dlopen + tgsf_prepare_device on each device.  Call once, early.
 void lib_start(const std::vector<int>& devices);

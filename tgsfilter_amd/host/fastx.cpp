@@ -244,7 +244,7 @@ bool FastxReader::next_fasta(Record& r)
 }
 
 // ---------------------------------------------------------------------------
-RecordIndex::RecordIndex(const char* data, size_t size, bool fastq, int threads)
+RecordIndex::RecordIndex(const char* data, size_t size, bool fastq, int threads, size_t lead) : lead_(lead)
 {
     chunks_.resize(1u << 17);                    // x 32768 records: room for 4e9
     th_ = std::thread([=] { produce(data, size, fastq, threads); });
@@ -252,6 +252,8 @@ RecordIndex::RecordIndex(const char* data, size_t size, bool fastq, int threads)
 
 RecordIndex::~RecordIndex()
 {
+    { std::lock_guard<std::mutex> l(m_); cancel_ = true; }
+    cv_.notify_all();
     if (th_.joinable()) th_.join();
 }
 
@@ -280,6 +282,11 @@ void RecordIndex::produce(const char* data, size_t size, bool fastq, int threads
                 { std::lock_guard<std::mutex> l(m_); count_.store(n, std::memory_order_release); }
                 cv_.notify_all();
                 published = n;
+                if (lead_) {                      // a bounded lead: wait for the reader (or for the end of the index)
+                    std::unique_lock<std::mutex> l(m_);
+                    cv_.wait(l, [&] { return cancel_ || n <= wanted_ + lead_; });
+                    if (cancel_) break;
+                }
             }
         }
         longest_.store(longest);
@@ -293,6 +300,10 @@ void RecordIndex::produce(const char* data, size_t size, bool fastq, int threads
 
 bool RecordIndex::get(size_t i, Rec& r)
 {
+    if (lead_) {
+        std::lock_guard<std::mutex> l(m_);
+        if (i > wanted_) { wanted_ = i; cv_.notify_all(); }
+    }
     if (i >= count_.load(std::memory_order_acquire)) {
         std::unique_lock<std::mutex> l(m_);
         cv_.wait(l, [&] { return done_ || i < count_.load(std::memory_order_acquire); });

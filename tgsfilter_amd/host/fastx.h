@@ -105,7 +105,10 @@ struct Rec {
 };
 class RecordIndex {
 public:
-    RecordIndex(const char* data, size_t size, bool fastq, int threads);
+    // lead > 0: the indexing stays at most `lead` records ahead of the furthest get() (a pass that looks at the first
+    // reads only -- the pre-pass of a sharded job over the whole text -- does not index the rest), and ends when the
+    // index is destroyed
+    RecordIndex(const char* data, size_t size, bool fastq, int threads, size_t lead = 0);
     ~RecordIndex();
     bool get(size_t i, Rec& r);          // blocks until record i is indexed; false: the input has fewer records
     bool complete();                     // the whole input is indexed (non-blocking)
@@ -127,6 +130,8 @@ private:
     std::vector<std::unique_ptr<Rec[]>> chunks_;   // table preallocated: readers never see it move
     std::atomic<size_t> count_{0};
     std::atomic<uint32_t> longest_{0};
+    size_t lead_ = 0, wanted_ = 0;               // (lead_ > 0) the furthest record asked for so far
+    bool cancel_ = false;
     bool done_ = false;
     std::string message_;
     std::mutex m_;

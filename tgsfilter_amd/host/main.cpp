@@ -10,6 +10,7 @@
 #include "pipeline.h"
 #include "prepass.h"
 #include "report.h"
+#include "shard.h"
 
 #include <sched.h>
 #include <signal.h>
@@ -83,13 +84,68 @@ static void work_in_a_child()
 }
 
 
+// Ranks above 0 of a sharded job (shard.h) run the same code as rank 0 but leave the run's INFO lines to it: a filter in
+// front of std::cerr drops the lines that begin with "INFO:" (errors and warnings still pass).
+class InfoFilter : public std::streambuf {
+public:
+    explicit InfoFilter(std::streambuf* to) : to_(to) {}
+protected:
+    int overflow(int c) override {
+        if (c == traits_type::eof()) return sync() == 0 ? 0 : c;
+        line_.push_back((char)c);
+        if (c == '\n') flush_line();
+        return c;
+    }
+    int sync() override { flush_line(); return to_->pubsync(); }
+private:
+    void flush_line() {
+        if (!line_.empty() && line_.back() == '\n' && line_.compare(0, 5, "INFO:") == 0) { line_.clear(); return; }
+        if (!line_.empty() && line_.back() == '\n') { to_->sputn(line_.data(), (std::streamsize)line_.size()); line_.clear(); }
+    }
+    std::streambuf* to_;
+    std::string line_;
+};
+
 int main(int argc, char** argv)
 {
     double t_epoch0;
     { struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts); t_epoch0 = (double)ts.tv_sec + ts.tv_nsec * 1e-9; }
+    // (a rank above 0 started by another launcher: not even the command line's own INFO lines)
+    for (int i = 1; i + 1 < argc; i++) {
+        std::string f = argv[i];
+        f.erase(std::remove(f.begin(), f.end(), '-'), f.end());
+        if (f != "shard") continue;
+        const char* r = !strcmp(argv[i + 1], "env") ? getenv("RANK") : argv[i + 1];
+        if (r && atoi(r) > 0) std::cerr.rdbuf(new InfoFilter(std::cerr.rdbuf()));
+    }
     Options o;
     if (parse_args(argc, argv, o)) return 1;
-    work_in_a_child();
+    // ---- one process per GPU (shard.h) ----
+    RankLink link;
+    if (o.ranks >= 1 && o.shard_world > 0) { std::cerr << "Error: --ranks starts the ranks itself; --shard is for a rank started by another launcher" << std::endl; return 1; }
+    if (o.ranks >= 1 || o.shard_world >= 1) {
+        const int world = o.ranks >= 1 ? o.ranks : o.shard_world;
+        const char* why = nullptr;
+        if (o.downsample) why = "downsampling (-g/-d, -r, -R) selects among ALL reads of the input";
+        else if (o.out_file.empty() && !o.only_qc && !o.only_adapters) why = "every rank writes a part file of its own: -o is needed";
+        else if (file_type(o.in_file) == 2 || (o.in_file.size() > 3 && o.in_file.compare(o.in_file.size() - 3, 3, ".gz") == 0))
+            why = "the ranks take byte ranges of a plain FASTQ / FASTA text";
+        if (why) { std::cerr << "Error: --ranks / --shard: " << why << std::endl; return 1; }
+        if (world > 1024) { std::cerr << "Error: --ranks " << world << std::endl; return 1; }
+        if (o.ranks >= 1) {
+            fork_ranks(world, link);                                       // returns in the N children only
+            if (link.rank > 0) std::cerr.rdbuf(new InfoFilter(std::cerr.rdbuf()));
+            // rank r on device r, or on the r-th entry of --devices (cyclically: several ranks may share a GPU)
+            o.device = o.devices.empty() ? link.rank : o.devices[(size_t)link.rank % o.devices.size()];
+        } else {
+            if (o.rendezvous.empty()) { std::cerr << "Error: --shard needs --rendezvous <path>: where the ranks of the job meet (a unix socket)" << std::endl; return 1; }
+            link.rendezvous(o.shard_rank, world, o.rendezvous);
+        }
+        o.devices.assign(1, o.device);
+        o.n_thread = std::max(2, o.n_thread / world);                      // -t is the job's: every rank takes its share
+    }
+    const bool sharded = o.ranks >= 1 || o.shard_world >= 1;             // (also with one rank: the same program path, one part file)
+    if (!sharded) work_in_a_child();
     // SIGINT / SIGTERM: as on any fatal path, an output file created ahead of its records is removed, one partly written is
     // cut back to the records laid out (unlink / ftruncate: async-signal-safe)
     {
@@ -154,16 +210,34 @@ int main(int argc, char** argv)
         return std::unique_ptr<ChunkReader>(new ChunkReader(std::move(src), !fasta_in, chunk_bytes, 20));   // <= 20 x 64 MB of text alive
     };
     // mapped / decoded input: the records are indexed once, in the background, for the pre-pass and for the filter pass
-    const int budget = cpu_budget();
+    const int budget = std::max(1, cpu_budget() / link.world);         // (a sharded job: every rank takes its share)
     // indexing runs ahead of everything else and is memory-bound from a few threads on: half the CPU budget at most
     const int scan_threads = std::max(1, std::min({o.n_thread, 32, std::max(2, budget / 2)}));
+    // This rank's part of the text: all of it, or -- one process per GPU, shard.h -- the rank-th of `world` byte ranges,
+    // cut where find_record_start proposes.  The proposal is checked against the record reader's own view from both
+    // sides (the reader thread below): this rank's first record must begin exactly at the cut, and its last record must
+    // end exactly at the next rank's cut.  By induction from rank 0, which starts at byte 0, every rank then reads its
+    // records exactly as the reference's one sequential reader does (FastxReader, src/TGSFilter.cpp:521-782: its only
+    // state between two records is the position in the text); a text that cannot be cut that way -- lines that make the
+    // reader skip, a malformed record -- ends the run with a message instead of being read differently.
+    size_t text_off = 0, text_size = in.size();
+    if (sharded) {
+        if (streaming || (in.size() > 0 && !in.mapped())) die("--ranks / --shard: the input is not a plain text file");
+        const size_t lo = find_record_start(in.data(), in.size(), (size_t)((unsigned __int128)in.size() * (unsigned)link.rank / (unsigned)link.world), !fasta_in);
+        const size_t hi = link.rank + 1 == link.world ? in.size()
+                        : find_record_start(in.data(), in.size(), (size_t)((unsigned __int128)in.size() * (unsigned)(link.rank + 1) / (unsigned)link.world), !fasta_in);
+        text_off = lo; text_size = hi > lo ? hi - lo : 0;
+    }
+    const char* const text = in.data() + text_off;
     std::unique_ptr<RecordIndex> records_p;
-    if (!streaming) records_p.reset(new RecordIndex(in.data(), in.size(), !fasta_in, scan_threads));
+    if (!streaming) records_p.reset(new RecordIndex(text, text_size, !fasta_in, scan_threads));
 
     // The output file's pages are the critical path of a run that writes a tmpfs file: their instantiation
     // starts NOW, beside the pre-pass and the device bring-up -- if the file does not exist yet (an existing one is not
     // touched before the run is certain to write it: a run that ends in its pre-pass leaves it as it was, as the reference
     // does; a file created here is removed again on such a path).
+    // (a rank of a sharded job writes its own part: the parts, concatenated in rank order, are the single process's file)
+    const std::string out_path = sharded && !o.out_file.empty() ? o.out_file + ".part" + std::to_string(link.rank) : o.out_file;
     MappedSink sink;
     std::atomic<bool> early_stop{false};
     std::thread early;
@@ -173,10 +247,10 @@ int main(int argc, char** argv)
         if (const char* e = getenv("TGSF_EARLY_OPEN_MIN")) early_min = strtoull(e, nullptr, 10);           // tests: small inputs too
         const bool may_map_early = !o.only_qc && !o.out_gz && !o.downsample && (o.filter || o.only_qc) && !o.out_file.empty() &&
                                    !(w && !strcmp(w, "writev")) && !o.only_adapters && !streaming && in.mapped() &&
-                                   (uint64_t)in.size() >= early_min && !getenv("TGSF_NO_EARLY_RESERVE");
-        if (may_map_early && sink.open(o.out_file, 4 * (uint64_t)in.size() + (1ull << 30), true))
+                                   (uint64_t)text_size >= early_min && !getenv("TGSF_NO_EARLY_RESERVE");
+        if (may_map_early && sink.open(out_path, 4 * (uint64_t)text_size + (1ull << 30), true))
             early = std::thread([&] {
-                const uint64_t limit = (uint64_t)in.size() / 4;        // what a run keeps is not known yet; a surplus is cut off at the end
+                const uint64_t limit = (uint64_t)text_size / 4;        // what a run keeps is not known yet; a surplus is cut off at the end
                 while (!early_stop.load() && sink.reserved() < limit)
                     if (!sink.reserve_to(std::min<uint64_t>(limit, sink.reserved() + (256u << 20)), false)) break;   // (a nearly full file system: not this thread's call)
             });
@@ -185,7 +259,9 @@ int main(int argc, char** argv)
 
     // ---- pre-pass, :3058-3126 ----
     PrepassResult pp;
-    if (streaming) {
+    if (sharded && link.rank > 0) {
+        // (rank 0 looks at the first reads of the WHOLE input, as the reference does, and broadcasts what it found: below)
+    } else if (streaming) {
         std::unique_ptr<ChunkReader> cr = open_stream();
         std::shared_ptr<Chunk> ch;
         size_t at = 0;
@@ -202,9 +278,22 @@ int main(int argc, char** argv)
             r = ch->recs[at++];
             return true;
         });
+    } else if (sharded && link.world > 1) {
+        // the sample may reach beyond this rank's part: an index of its own over the whole text, kept a little ahead of
+        // the pre-pass and dropped when that has seen enough
+        RecordIndex whole(in.data(), in.size(), !fasta_in, scan_threads, 1u << 14);
+        RecordIndex::Cursor cur(whole);
+        pp = run_prepass(o, [&](Rec& r) { return cur.next(r); });
     } else {
         RecordIndex::Cursor cur(*records_p);
         pp = run_prepass(o, [&](Rec& r) { return cur.next(r); });
+    }
+    if (sharded) {                                                     // the pre-pass's constants, from rank 0 to every rank
+        BlobOut b;
+        if (link.rank == 0) { b.pod(pp.qtype); b.pod(pp.trim5p); b.pod(pp.trim3p); b.pod(pp.depth5p); b.pod(pp.depth3p); b.pod(o.min_q); b.str(pp.adapter5p); b.str(pp.adapter3p); }
+        link.bcast(b.s);
+        BlobIn r(b.s);
+        r.pod(pp.qtype); r.pod(pp.trim5p); r.pod(pp.trim3p); r.pod(pp.depth5p); r.pod(pp.depth3p); r.pod(o.min_q); r.str(pp.adapter5p); r.str(pp.adapter3p);
     }
     t_prepass = now_s() - t_start;
     std::vector<std::string> adapters;
@@ -252,7 +341,7 @@ int main(int argc, char** argv)
     // ---- contexts ----
     // batches are slices of the input text: sized in text bytes (about 2 bytes per base + headers)
     uint64_t batch_text = streaming ? std::min<uint64_t>(256ull << 20, chunk_bytes)
-                                    : std::min<uint64_t>(256ull << 20, std::max<uint64_t>(in.size() / 8 + 4096, 1 << 16));
+                                    : std::min<uint64_t>(256ull << 20, std::max<uint64_t>(text_size / 8 + 4096, 1 << 16));
     if (const char* e = getenv("TGSF_BATCH_BYTES")) { const long long v = atoll(e); if (v > 0) batch_text = (uint64_t)v; }   // tuning / test knob
     // reads per batch: the library keeps traceback scratch for every (read, adapter, end) of a batch -- columns x words of
     // the longest alignment each; with the library adapters that is ~12 KB per read, with 256-bp adapters and loose
@@ -282,14 +371,61 @@ int main(int argc, char** argv)
         // address space for the output mapping: what the input could turn into (a streamed input's text size is unknown)
         // (address space only: pages exist where records are laid out.  A record's header is repeated in front of each of
         // its fragments, so an output can outgrow its input -- by a factor only headers of kilobytes reach.)
-        if (may_map && !sink.is_open()) sink.open(o.out_file, streaming ? std::max<uint64_t>(64ull << 30, 64ull * in.size())
-                                                                        : 4 * (uint64_t)in.size() + (1ull << 30));
-        if (!o.only_qc && !sink.is_open() && !out.open(o)) leave(1);
+        if (may_map && !sink.is_open()) sink.open(out_path, streaming ? std::max<uint64_t>(64ull << 30, 64ull * in.size())
+                                                                      : 4 * (uint64_t)text_size + (1ull << 30));
+        Options oo = o;
+        oo.out_file = out_path;
+        if (!o.only_qc && !sink.is_open() && !out.open(oo)) leave(1);
     }
     const Api& L = lib();                                              // joins the loader thread
     double t_load = 0, t_dev = 0;
     lib_times(t_load, t_dev);
     const double t_libwait = now_s() - t_start - t_prepass;
+    // How the tallies of a sharded job will be summed at the end: on the devices, one RCCL all-reduce, when every rank has
+    // a GPU of its own -- the communicator is set up NOW, on a helper thread beside the filtering (RCCL's first
+    // initialisation takes longer than a small run) -- or over the ranks' sockets when ranks share a GPU (RCCL refuses two
+    // ranks on one device), where the collective library is missing, or with TGSF_SHARD_EXCHANGE=socket.
+    const RcclApi* R = nullptr;
+    void* rccl_comm = nullptr;
+    int rccl_rc = TGSF_OK;
+    std::string rccl_err;
+    std::thread rccl_up;
+    bool use_rccl = false;
+    if (sharded) {
+        const char* ex = getenv("TGSF_SHARD_EXCHANGE");
+        if (!(ex && !strcmp(ex, "socket"))) R = rccl_lib();
+        char bus[64] = {0};
+        int node = -1;
+        if (L.device_location(o.device, bus, (int)sizeof bus, &node) != TGSF_OK) snprintf(bus, sizeof bus, "device%d", o.device);
+        BlobOut mine;
+        mine.str(bus);
+        mine.pod<int>(R ? 1 : 0);
+        const std::vector<std::string> all = link.gather(mine.s);
+        std::string verdict(1, '0');
+        if (link.rank == 0) {
+            std::vector<std::string> seen;
+            bool ok = R != nullptr;
+            for (const std::string& a : all) {
+                BlobIn in2(a);
+                std::string b2; int have = 0;
+                in2.str(b2); in2.pod(have);
+                ok = ok && have && std::find(seen.begin(), seen.end(), b2) == seen.end();
+                seen.push_back(b2);
+            }
+            if (ok) {
+                char id[TGSF_RCCL_ID_BYTES];
+                if (R->unique_id(id) == TGSF_OK) { verdict.assign(1, '1'); verdict.append(id, sizeof id); }
+                else if (ex && !strcmp(ex, "rccl")) die(std::string("TGSF_SHARD_EXCHANGE=rccl: ") + R->last_error());
+            } else if (ex && !strcmp(ex, "rccl")) die("TGSF_SHARD_EXCHANGE=rccl: ranks share a GPU, or libtgsf_rccl.so does not load on every rank");
+        }
+        link.bcast(verdict);
+        use_rccl = verdict[0] == '1' && verdict.size() == 1 + TGSF_RCCL_ID_BYTES;
+        if (use_rccl)
+            rccl_up = std::thread([&, verdict] {
+                rccl_rc = R->comm_init(o.device, verdict.data() + 1, link.rank, link.world, &rccl_comm);
+                if (rccl_rc != TGSF_OK) rccl_err = R->last_error();     // (thread-local text: taken on this thread)
+            });
+    }
     tgsf_params p;
     memset(&p, 0, sizeof p);
     p.struct_size = sizeof p;
@@ -306,6 +442,12 @@ int main(int argc, char** argv)
     // rows of the per-100-bp tables: from the longest read when the index is complete by now (it usually is: it runs
     // at tens of GB/s beside the device bring-up), else from what the file could hold
     if (streaming) p.max_read_len = 1u << 26;
+    else if (sharded) {
+        // every rank needs the same table rows (the all-reduce sums vectors of one layout): the longest read of the whole
+        // job when the parts are indexed in a moment anyway, what the file could hold otherwise
+        if (in.size() <= (1ull << 30)) { records_p->wait_complete(); p.max_read_len = (uint32_t)std::max<uint64_t>(link.max_u64(records_p->longest()), 1024); }
+        else p.max_read_len = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(in.size() / 2, 1024), 1u << 26);
+    }
     else if (records_p->complete()) p.max_read_len = std::max<uint32_t>(records_p->longest(), 1024);
     else p.max_read_len = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(in.size() / 2, 1024), 1u << 26);
     // capacity is in buffer bytes: a text slice must fit, and so must one record of the longest read on its own
@@ -316,7 +458,7 @@ int main(int argc, char** argv)
     // or three together saturate it (~55 GB/s) and keep the kernels of one batch under the copy of another.  Batches
     // are dealt to whichever feeder is free, the planner re-sequences them, the tallies are merged at the end
     // (host side).
-    int per_dev = (streaming || in.size() > (64u << 20)) ? 3 : 1;
+    int per_dev = (streaming || text_size > (64u << 20)) ? 3 : 1;
     if (const char* e = getenv("TGSF_CTX_PER_DEVICE")) { const int v = atoi(e); if (v >= 1 && v <= 8) per_dev = v; }
     std::vector<int> ctx_dev;
     for (int d : o.devices) for (int k = 0; k < per_dev; k++) ctx_dev.push_back(d);
@@ -379,10 +521,18 @@ int main(int argc, char** argv)
             r = ch->recs[ch_at++];
             return true;
         };
+        // (a sharded job: the cuts are checked against what the reader sees, see text_off above)
+        auto bad_cut = [&](size_t at) {
+            die("--ranks / --shard: the input cannot be cut near byte " + std::to_string(at) + " the way one sequential reader would read it "
+                "(lines the reader skips, or a malformed record, near there): run it without --ranks / --shard");
+        };
+        const char* last_end = nullptr;
         while (next_record()) {
             const size_t L = r.len;
             if (L > p.max_read_len) die("read longer than the supported maximum");
             const char* rec_end = (fasta_in ? r.seq : r.qual) + L;
+            if (sharded && !last_end && link.rank > 0 && r.name != text + 1) bad_cut(text_off);
+            last_end = rec_end;
             if (!b->recs.empty() && ((uint64_t)(rec_end - b->base) > batch_text || b->recs.size() >= batch_reads)) flush();
             if (b->recs.empty()) { b->base = r.name; b->hold = ch; }
             b->off.push_back((uint64_t)(r.seq - b->base));
@@ -392,6 +542,13 @@ int main(int argc, char** argv)
             if (b->span > p.max_batch_bases) die("record larger than a batch");
             b->bases += L;
             raw_bases += L; raw_lens.push_back((int)L);
+        }
+        if (sharded && link.rank + 1 < link.world) {                   // the last record ends exactly where the next rank begins
+            const char* e = last_end ? last_end : text;
+            const char* const end = text + text_size;
+            if (e < end && *e == '\r') e++;
+            if (e < end && *e == '\n') e++;
+            if (e != end || !records_p->end_message().empty()) bad_cut(text_off + text_size);
         }
         flush();
         for (size_t d = 0; d < ctxs.size(); d++) to_gpu.put(nullptr);       // one end marker per feeder
@@ -493,7 +650,7 @@ int main(int argc, char** argv)
     end_early();                                                       // (what it reserved is mapped by the reserver's first round)
     Reserver reserver(sink, populate, stride_bytes, populate_beside > 0);
     if (sink.is_open())
-        reserver.start((!streaming && in.size() > (256u << 20) && !getenv("TGSF_NO_EARLY_RESERVE")) ? (uint64_t)in.size() / 4 : 0);
+        reserver.start((!streaming && text_size > (256u << 20) && !getenv("TGSF_NO_EARLY_RESERVE")) ? (uint64_t)text_size / 4 : 0);
     // A downsampling run writes its output only after the whole filter pass (the selection needs every fragment's length,
     // :2297-2344) -- but the file can be instantiated meanwhile: while the filter pass is busy with the link to the device,
     // pages for what the selection may keep are reserved and mapped (a quarter of the input at most, and no more than twice
@@ -622,7 +779,7 @@ int main(int argc, char** argv)
                     // (plus a little).  (A streamed input's text size is estimated from the share of the file decoded so far.)
                     const double share = in_seen ? (double)(sink.planned() + at) / (double)in_seen : 1.0;
                     const double sh = stream_share.load();
-                    const uint64_t in_total = !streaming ? (uint64_t)in.size()
+                    const uint64_t in_total = !streaming ? (uint64_t)text_size
                                             : (uint64_t)((double)stream_text.load() / (sh > 1e-6 ? sh : 1e-6));
                     uint64_t goal = sink.planned() + at + (uint64_t)(share * 1.02 * (double)(in_total - std::min<uint64_t>(in_seen, in_total)));
                     goal = std::min<uint64_t>(std::max<uint64_t>(goal, sink.planned() + at), sink.capacity());
@@ -964,7 +1121,26 @@ int main(int argc, char** argv)
     uint64_t nw = 0; int32_t bc = 0; uint32_t nbins = 0;
     L.counters_len(ctx, &nw, &bc, &nbins);
     std::vector<uint64_t> t(nw, 0), part(nw);
-    for (tgsf_ctx* c : ctxs) {                                         // sums; the four "rows used" words are maxima
+    // One process per GPU: the job's tallies = the sum over the ranks (src/TGSFilter.cpp:3208-3213 across GPUs).  With a
+    // GPU per rank: this rank's contexts folded into one vector in HBM, then ONE all-reduce of it over RCCL / xGMI
+    // (include/tgsf_rccl.h; every rank has entered tgsf_create with the same table rows, see max_read_len above).
+    const double t_x0 = now_s();
+    double t_rccl_wait = 0, t_allreduce = 0;
+    int rccl_ranks = 0;
+    std::vector<tgsf_ctx*> sum_ctxs = ctxs;
+    if (sharded && use_rccl) {
+        rccl_up.join();
+        t_rccl_wait = now_s() - t_x0;
+        if (rccl_rc != TGSF_OK) die("RCCL communicator: " + rccl_err);
+        for (size_t k = 1; k < ctxs.size(); k++)
+            if (L.counters_merge(ctxs[0], ctxs[k]) != TGSF_OK) die(L.last_error(ctxs[0]));
+        const double a0 = now_s();
+        if (R->allreduce_counters(ctxs[0], rccl_comm, link.rank, link.world, 0, nullptr) != TGSF_OK) die(std::string("tally all-reduce: ") + R->last_error());
+        t_allreduce = now_s() - a0;
+        (void)R->comm_count(rccl_comm, &rccl_ranks);
+        sum_ctxs.assign(1, ctxs[0]);                                   // (it holds the whole job's totals now, on every rank)
+    }
+    for (tgsf_ctx* c : sum_ctxs) {                                     // sums; the four "rows used" words are maxima
         uint64_t used[2] = {0, 0};                                     // of the bin tables only the rows in use travel
         if (L.counters_used(c, part.data(), nw, used) != TGSF_OK) die(L.last_error(c));
         uint64_t rows[4];
@@ -977,6 +1153,61 @@ int main(int argc, char** argv)
         }
         for (int k = 0; k < 4; k++) t[TGSF_CTR_ROWS + k] = rows[k];
     }
+    // Rank 0 of a sharded job receives every rank's read lengths (the statistics need them sorted: N50 and the like) and
+    // -- when the tallies were not summed on the devices -- its tally rows in use; it alone prints the run's statistics
+    // and writes the report.
+    const bool reports = !sharded || link.rank == 0;
+    uint64_t job_reads = raw_lens.size();
+    if (sharded) {
+        const size_t head = tgsf_ctr_bin_table(0, bc, nbins);
+        BlobOut mine;
+        mine.pod(raw_bases); mine.pod(clean_bases);
+        mine.vec(raw_lens); mine.vec(clean_lens);                      // (each sorted already, beside the pipeline)
+        std::vector<uint64_t> rows_used;
+        if (!use_rccl) {
+            rows_used.assign(t.begin(), t.begin() + (long)head);
+            for (int b = 0; b < 4; b++) {
+                const size_t at = tgsf_ctr_bin_table(b, bc, nbins), n = (size_t)std::min<uint64_t>(t[TGSF_CTR_ROWS + (b >> 1)], nbins) * 5;
+                rows_used.insert(rows_used.end(), t.begin() + (long)at, t.begin() + (long)(at + n));
+            }
+        }
+        mine.vec(rows_used);
+        const std::vector<std::string> all = link.gather(mine.s);
+        for (int k = 1; k < (int)all.size(); k++) {                    // (rank 0 only)
+            BlobIn in2(all[(size_t)k]);
+            uint64_t rb = 0, cb = 0;
+            std::vector<int> rl, cl;
+            std::vector<uint64_t> ru;
+            in2.pod(rb); in2.pod(cb); in2.vec(rl); in2.vec(cl); in2.vec(ru);
+            raw_bases += rb; clean_bases += cb;
+            const size_t r0 = raw_lens.size(), c0 = clean_lens.size();
+            raw_lens.insert(raw_lens.end(), rl.begin(), rl.end());
+            clean_lens.insert(clean_lens.end(), cl.begin(), cl.end());
+            std::inplace_merge(raw_lens.begin(), raw_lens.begin() + (long)r0, raw_lens.end());
+            std::inplace_merge(clean_lens.begin(), clean_lens.begin() + (long)c0, clean_lens.end());
+            if (!use_rccl) {
+                if (ru.size() < head) die("a rank of the job sent a tally vector of another layout");
+                uint64_t rows[4];
+                for (int q = 0; q < 4; q++) rows[q] = std::max(t[TGSF_CTR_ROWS + q], ru[TGSF_CTR_ROWS + q]);
+                for (size_t i = 0; i < head; i++) t[i] += ru[i];
+                size_t from = head;
+                for (int b = 0; b < 4; b++) {
+                    const size_t at = tgsf_ctr_bin_table(b, bc, nbins), n = (size_t)std::min<uint64_t>(ru[TGSF_CTR_ROWS + (b >> 1)], nbins) * 5;
+                    if (from + n > ru.size()) die("a rank of the job sent a tally vector of another layout");
+                    for (size_t i = 0; i < n; i++) t[at + i] += ru[from + i];
+                    from += n;
+                }
+                for (int q = 0; q < 4; q++) t[TGSF_CTR_ROWS + q] = rows[q];
+            }
+        }
+        job_reads = raw_lens.size();
+        if (timing)
+            fprintf(stderr, "SHARD %d/%d: bytes [%zu, %zu) of the text on device %d -> %s | tallies: %s (communicator ready after %.3f s of waiting, all-reduce %.4f s, %d ranks in it), exchange + gather %.3f s\n",
+                    link.rank, link.world, text_off, text_off + text_size, o.device, out_path.c_str(),
+                    use_rccl ? "RCCL all-reduce on the devices" : "summed on rank 0 over the ranks' sockets", t_rccl_wait, t_allreduce, rccl_ranks, now_s() - t_x0);
+        if (use_rccl) R->comm_destroy(rccl_comm);
+    }
+    (void)job_reads;
     auto tables = [&](const std::vector<uint64_t>& v, bool clean) {
         SideTables s;
         s.bin_qual = &v[tgsf_ctr_bin_table(clean ? TGSF_B_CLEAN_QUAL : TGSF_B_RAW_QUAL, bc, nbins)];
@@ -992,7 +1223,7 @@ int main(int argc, char** argv)
     };
     SideStats raw, clean;
     const int clean_num = (int)clean_lens.size();
-    if (run_filter_pass) {
+    if (run_filter_pass && reports) {
         if (raw_lens.empty()) die("no reads in the input");
         std::sort(raw_lens.begin(), raw_lens.end());
         side_stats(bc, raw_lens, raw_bases, tables(t, false), raw);
@@ -1019,7 +1250,11 @@ int main(int argc, char** argv)
             if (o.min_repeat > 0)
                 std::cerr << "INFO: " << d[15] << " reads were discarded with " << d[16] << " bases due to short repeat length." << std::endl;
             std::cerr << "INFO: " << clean_num << " reads with a total of " << clean_bases << " bases after filtering." << std::endl;
-            if (!o.downsample && !o.out_file.empty()) std::cerr << "INFO: Filtered reads were written to: " << o.out_file << "." << std::endl;
+            if (!o.downsample && !o.out_file.empty()) {
+                if (!sharded) std::cerr << "INFO: Filtered reads were written to: " << o.out_file << "." << std::endl;
+                else std::cerr << "INFO: Filtered reads were written to: " << o.out_file << ".part0 ... " << o.out_file << ".part" << link.world - 1
+                               << " (" << link.world << " parts; concatenated in this order they are the reads in input order)." << std::endl;
+            }
         }
     }
     if (o.downsample) {                                                // :3240-3279
@@ -1034,10 +1269,12 @@ int main(int argc, char** argv)
     }
     std::string qc = fasta_in ? "0" : "1";                             // :3286-3291
     qc += o.only_qc ? "0" : ((!o.filter && o.downsample) ? "1" : "2"); // :3293-3299
-    std::ofstream ofs(html);
-    write_report(ofs, qc, raw, clean);
-    ofs.close();
-    std::cerr << "INFO: Quality control report was written to: " << html << "." << std::endl;
+    if (reports) {
+        std::ofstream ofs(html);
+        write_report(ofs, qc, raw, clean);
+        ofs.close();
+        std::cerr << "INFO: Quality control report was written to: " << html << "." << std::endl;
+    }
     if (timing) {
         fprintf(stderr, "POOL: %zu jobs, busy %.3f, freeing job state %.3f, longest job %.3f, first job at %.3f, last job done at %.3f (pipeline start = 0, planner done at %.3f)\n",
                 pool.jobs_, t_busy, pool.destroy_, pool.longest_, pool.first_ - t_p0, pool.last_ - t_p0, t_f0 - t_p0);

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <functional>
 #include <iostream>
 #include <map>
@@ -143,6 +144,21 @@ int parse_args(int argc, char** argv, Options& o)
         {"c", [&](const char* v) { o.comp_level = atoi(v); return 0; }},
         {"t", [&](const char* v) { o.n_thread = atoi(v); return 0; }},
         {"device", [&](const char* v) { o.device = atoi(v); return 0; }},
+        {"ranks", [&](const char* v) { o.ranks = atoi(v); return 0; }},
+        {"rendezvous", [&](const char* v) { o.rendezvous = v; return 0; }},
+        {"shard", [&](const char* v) {                        // "r/N", or "env"
+             if (!strcmp(v, "env")) {
+                 const char* r = getenv("RANK"); const char* w = getenv("WORLD_SIZE"); const char* l = getenv("LOCAL_RANK");
+                 if (!r || !w) { std::cerr << "Error: --shard env needs RANK and WORLD_SIZE" << std::endl; return 1; }
+                 o.shard_rank = atoi(r); o.shard_world = atoi(w);
+                 if (l) o.device = atoi(l);
+             } else {
+                 const char* slash = strchr(v, '/');
+                 if (!slash) { std::cerr << "Error: --shard takes <rank>/<ranks>" << std::endl; return 1; }
+                 o.shard_rank = atoi(v); o.shard_world = atoi(slash + 1);
+             }
+             if (o.shard_world < 1 || o.shard_rank < 0 || o.shard_rank >= o.shard_world) { std::cerr << "Error: --shard " << v << ": no such rank" << std::endl; return 1; }
+             return 0; }},
         {"devices", [&](const char* v) {                      // not in the reference: batches are dealt to several GPUs
              o.devices.clear();
              for (const char* c = v; *c;) {

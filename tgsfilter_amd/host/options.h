@@ -44,6 +44,12 @@ struct Options {
     // this build only
     int device = 0;                   // --device <n>
     std::vector<int> devices;         // --devices a,b,...: one context + feeder thread per entry (default: {device})
+    // one process per GPU over one input (shard.h): --ranks N forks N rank processes (rank r on device r, or on the r-th
+    // entry of --devices, taken cyclically); --shard r/N is one rank of a job started by another launcher
+    // ("env": RANK / WORLD_SIZE / LOCAL_RANK as torchrun sets them), which finds the others at --rendezvous <path>
+    int ranks = 0;
+    int shard_rank = -1, shard_world = 0;
+    std::string rendezvous;
 };
 
 int print_usage();
