@@ -43,8 +43,6 @@ REF = os.path.join(ROOT, "oracle", "_ref", "tgsfilter_ref")
 # How the command line ends (host/main.cpp): by default one process, every mapping and GPU context taken down before it
 # returns ("sync"); TGSF_DETACH=1 makes it work in a child whose teardown goes on after the caller has its status.
 DEFAULT_EXIT_MODE = "sync"
-OTHER_EXIT_MODE_ENV = {"TGSF_DETACH": "1"}
-OTHER_EXIT_MODE_KEY = "detached_wall_s"
 FQ_MULTISET = os.path.join(ROOT, "tools", "fq_multiset")
 
 
@@ -217,10 +215,10 @@ class Budget:
 # mean 150 kb, max 2 Mb) through the repeat gate (-p/-k; `-k` only acts with `-p` > 0, src/TGSFilter.cpp:1982: -p 100 is
 # this bench's choice, said in SURVEY 8d) and the longest-first downsampling (-g 3g -d 40).  The reference keeps a copy of
 # the filtered reads (<inprefix>.tmp.XXXXX.fq, :3129-3137) beside its output: three files on tmpfs at once.
-REF_RUNS = 3                                  # runs of the reference per file-sink leg, budget permitting
+REF_RUNS = 2                                  # runs of the reference per thread count on the first file, budget permitting
 E2E_CONFIGS = {
     "c2": {"name": "C2 (BASELINE.json configs[1])", "reads": 4_000_000, "mean_len": 45000.0, "max_len": 2_000_000, "per_read": 90_300, "files": 2.0,
-           "flags": ["-x", "ont", "-l", "1000", "-q", "10"], "seed": 2, "what": "automatic trims and adapter identification"},
+           "flags": ["-x", "ont", "-l", "1000", "-q", "10"], "seed": 2, "what": "automatic trims and adapter identification", "split": True},
     "c3": {"name": "C3 (BASELINE.json configs[2]) at one GPU", "reads": 19_000_000, "mean_len": 18000.0, "max_len": 40_000, "per_read": 36_200, "files": 2.0,
            "flags": ["-x", "hifi", "-l", "1000", "-q", "20", "-M", "35", "-T", "50"], "seed": 3, "kind": "hifi", "reads_per_job": 1024,
            "what": "HiFi reads N(18 kb, 3 kb), PacBio blunt adapter at the README's rates, automatic pre-pass, middle-adapter split"},
@@ -230,14 +228,37 @@ E2E_CONFIGS = {
 }
 
 
+def cpu_budget():
+    """CPUs' worth of time this box's control group allows (cpu.max), or the hardware's threads."""
+    lim = cgroup_limits()
+    hw = os.cpu_count() or 2
+    return int(min(hw, max(1, round(lim["cpus"])))) if lim["cpus"] else hw
+
+
+def multiset_of(paths):
+    """The order-independent digest of the records of several files taken together (the parts of a sharded run):
+    [records, sum of record hashes mod 2^64, xor of record hashes, bytes]."""
+    tot = [0, 0, 0, 0]
+    for p in paths:
+        m = [int(x) for x in multiset(p)]
+        tot = [tot[0] + m[0], (tot[1] + m[1]) & (2**64 - 1), tot[2] ^ m[2], tot[3] + m[3]]
+    return [str(x) for x in tot]
+
+
 def e2e_leg(args, n_gpus):
-    """The command line end to end on the configuration's file (default: C2's).  Legs, in this order:
-      main     C2's own flags (-x ont -l 1000 -q 10: automatic trims, automatic adapter identification), tmpfs file sink:
-               W warm-up runs + K timed runs (the headline), 3 runs of the other exit mode, the reference up to 3 times on the
-               same file with the same flags and sink (cpu_baseline: mean and best), outputs compared as multisets, INFO lines compared;
-      dev_null the same command writing to /dev/null (the sink that can scale with the GPUs: no page instantiation);
-      pinned   the pre-pass pinned (-5 0 -3 0 -a rapid.fa) on a 400 000-read file (round 2's headline, for continuity),
-               with the reference beside it."""
+    """The command line end to end on the configuration's reads (default: C2's 4 M), staged on tmpfs as ONE file when the
+    box's memory holds input + output, as CONSECUTIVE files (same generator, seeds in a row) otherwise -- C2 as written is
+    360 GB of text + 215 GB of output, more than the box's memory control group allows at once.  A step = one pass of
+    the command line over ALL the files (one run per file; wall times summed); W warm-up passes, K timed passes.
+    Per file, in this order:
+      ours     W (first file: the others 1) warm-up runs + K timed runs into a tmpfs file (N > 1: `--ranks N`, one process
+               per GPU, a part file each);
+      theirs   the reference binary on the same file, same flags, same sink: on the first file at its own thread clamp
+               (-t min(hw-1, 32), src/TGSFilter.cpp:488-499) AND at what the box's CPU quota lets run unthrottled
+               (-t min(cpu.max - 1, 32)), REF_RUNS runs each; on the other files once, at the faster of the two.  Output
+               multisets and INFO lines compared with ours for every file;
+    then, on the first file only and budget permitting: the /dev/null sink, and (N = 1) the same run as 3 rank processes
+    sharing the GPU with a part file each (`sharded`: the program path of N GPUs on this box)."""
     from tgsfilter_amd import synth
     if not os.path.exists(CLI):
         raise SystemExit("bench.py: %s is missing -- run __graft_entry__.build() (there is no fallback path)" % CLI)
@@ -265,158 +286,246 @@ def e2e_leg(args, n_gpus):
     except (OSError, IndexError, ValueError):
         pass
     need = n_reads * per_read * cfg["files"]
+    n_files = int(getattr(args, "e2e_files", 0) or 0)
     reduced = None
-    if need > 0.85 * free:
-        n_reads = max(2000, int(n_reads * 0.85 * free / need) // 1000 * 1000 or 2000)
-        reduced = "%s holds %.0f GB: the file is %d of the configuration's %d reads (input + %s, <= %.0f x %.0f GB, kept under 85 %% of that)" % (
-            why, free / 1e9, n_reads, n_want, "one output" if cfg["files"] == 2.0 else "the reference's temporary copy and its output",
-            cfg["files"], n_reads * per_read / 1e9)
-        log("bench: " + reduced)
+    if not n_files:
+        n_files = 1
+        if need > 0.85 * free:
+            if cfg.get("split"):
+                n_files = int(-(-need // (0.80 * free)))
+            else:                                     # (a downsampling configuration selects among ALL its reads: one file, fewer reads)
+                n_reads = max(2000, int(n_reads * 0.85 * free / need) // 1000 * 1000 or 2000)
+                reduced = "%s holds %.0f GB: the file is %d of the configuration's %d reads (input + %s, <= %.0f x %.0f GB, kept under 85 %% of that)" % (
+                    why, free / 1e9, n_reads, n_want, "one output" if cfg["files"] == 2.0 else "the reference's temporary copy and its output",
+                    cfg["files"], n_reads * per_read / 1e9)
+                log("bench: " + reduced)
+    per_file = [n_reads // n_files + (1 if f < n_reads % n_files else 0) for f in range(n_files)]
+    split_note = None
+    if n_files > 1:
+        split_note = "%s holds %.0f GB, input + one output of all %d reads need %.0f GB: the reads are staged as %d consecutive files of %s reads (same generator, seeds %s)" % (
+            why, free / 1e9, n_reads, need / 1e9, n_files, "/".join(str(x) for x in sorted(set(per_file), reverse=True)),
+            ", ".join(str(cfg["seed"] + 1000 * f) for f in range(n_files)))
+        log("bench: " + split_note)
     td = tempfile.mkdtemp(prefix="tgsf_bench_", dir=shm)
-    cores = max(1, min((os.cpu_count() or 2) - 1, 32))      # the reference clamps -t to min(hw-1, 32), :488-499
+    hw_cores = max(1, min((os.cpu_count() or 2) - 1, 32))      # the reference clamps -t to min(hw-1, 32), :488-499
+    quota_cores = max(1, min(cpu_budget() - 1, 32))            # ... what the box's CPU quota lets run without throttling
     gen_procs = max(1, min((os.cpu_count() or 2) - 1, int(2 * (lim["cpus"] or 16)), 64))
     devs = ",".join(str(d) for d in range(n_gpus))
     env = dict(os.environ, TGSF_TIMING="1")
     env.pop("TGSF_SYNC_EXIT", None)
     env.pop("TGSF_DETACH", None)
-    env_other = dict(env, **OTHER_EXIT_MODE_ENV)
     have_ref = os.path.exists(REF) and not args.no_cpu_baseline
-    res = {}
+    want_ranks = int(getattr(args, "e2e_ranks", 0) or 0) or (n_gpus if n_gpus > 1 else 0)
+    rank_devs = devs if n_gpus > 1 else "0"
 
     def rm(path):
-        if os.path.isfile(path) and not os.path.islink(path):
-            os.remove(path)           # dropping a previous run's GBs of tmpfs pages is not part of a run
+        for p in [path] + ["%s.part%d" % (path, r) for r in range(64)]:
+            if os.path.isfile(p) and not os.path.islink(p):
+                os.remove(p)          # dropping a previous run's GBs of tmpfs pages is not part of a run
 
-    def ours(fq, out, flags, e=env):
+    def ours(fq, out, flags, ranks=0, rdevs=None):
         rm(out)
-        return run_cmd([CLI, "-i", fq, "-o", out, "-t", str(cores), "--devices", devs] + flags, e)
+        how = ["--ranks", str(ranks), "--devices", rdevs or rank_devs] if ranks else ["--devices", devs]
+        return run_cmd([CLI, "-i", fq, "-o", out, "-t", str(hw_cores)] + how + flags, env)
 
-    def theirs(fq, out, flags):
+    def theirs(fq, out, flags, t):
         rm(out)
-        return run_cmd([REF, "-i", fq, "-o", out, "-t", str(cores)] + flags)
+        return run_cmd([REF, "-i", fq, "-o", out, "-t", str(t)] + flags)
 
-    def timed(fq, out, flags, warm, k, e=env):
+    def timed(fq, out, flags, warm, k, ranks=0, rdevs=None):
         for _ in range(warm):
-            ours(fq, out, flags, e)
-        walls, err = [], ""
+            ours(fq, out, flags, ranks, rdevs)
+        walls, err, cpu = [], "", []
         for _ in range(k):
-            dt, err = ours(fq, out, flags, e)
+            dt, err = ours(fq, out, flags, ranks, rdevs)
             walls.append(dt)
-        return walls, err
+            cpu.append(dict(LAST_RUN_CPU))
+        return walls, err, cpu
 
-    def file_sink_leg(fq, bases, flags, warm, k, other_runs, tag, ref_runs=REF_RUNS):
-        """Ours W + K on a tmpfs file, the other exit mode, then the reference once; everything compared."""
-        out_o, out_r = os.path.join(td, tag + "_ours.fq"), os.path.join(td, tag + "_ref.fq")
-        walls, err = timed(fq, out_o, flags, warm, k)
-        s = {"runs": k, "exit_mode": DEFAULT_EXIT_MODE, "wall_s": walls, "wall_s_mean": sum(walls) / len(walls),
+    def out_files(out, ranks):
+        return ["%s.part%d" % (out, r) for r in range(ranks)] if ranks else [out]
+
+    def describe(walls, err, bases):
+        s = {"runs": len(walls), "exit_mode": DEFAULT_EXIT_MODE, "wall_s": walls, "wall_s_mean": sum(walls) / len(walls),
              "gbases_per_s": bases * len(walls) / sum(walls) / 1e9,
-             "timing_line": [l for l in err.splitlines() if l.startswith("TIMING")][-1:],
-             "timing": parse_timing(err), "cpu_last_run": dict(LAST_RUN_CPU)}
+             "timing_line": [l for l in err.splitlines() if l.startswith("TIMING")][-1:], "timing": parse_timing(err)}
         t = s["timing"]
         if t.get("total_s"):
-            parts = {"fallocate (tmpfs page instantiation, one thread, inode lock)": t.get("fallocate_s", 0.0),
+            parts = {"fallocate (tmpfs page instantiation, one thread per file, inode lock)": t.get("fallocate_s", 0.0),
                      "mapping the reserved pages": t.get("populate_s", 0.0),
                      "index + pre-pass": t.get("index_prepass_s", 0.0), "waiting for the library/device": t.get("library_wait_s", 0.0)}
             top = max(parts, key=parts.get)
             s["bound"] = "%s: %.2f s of %.2f s" % (top, parts[top], t["total_s"])
             if "gpu_kernel_s_summed" in t:
                 s["gpu_busy_frac"] = t["gpu_kernel_s_summed"] / t["total_s"]      # upper bound: contexts overlap
-        info = info_lines(err)
-        mine = multiset(out_o) if have_ref else None
-        if other_runs and budget.allows("%s: %d runs in the other exit mode" % (tag, other_runs), (other_runs + 1) * 2.0 * s["wall_s_mean"] + 5):
-            w2, err2 = timed(fq, out_o, flags, 1 if warm else 0, other_runs, env_other)
-            s[OTHER_EXIT_MODE_KEY] = w2
-            s[OTHER_EXIT_MODE_KEY + "_mean"] = sum(w2) / len(w2)
-            s[OTHER_EXIT_MODE_KEY + "_timing"] = parse_timing(err2)
-            if info_lines(err2) != info:
-                raise SystemExit("bench: INFO lines differ between the two exit modes")
-        rm(out_o)
-        if have_ref:
-            # the reference on the same file, flags and sink: up to REF_RUNS runs (the first one's output and INFO lines are
-            # compared with ours; the others are timed only), as many as the budget allows -- min and mean both reported
-            ref_walls, ref_cpu = [], []
-            for rr in range(ref_runs):
-                if rr and not budget.allows("%s: reference run %d of %d" % (tag, rr + 1, ref_runs), 1.15 * ref_walls[0] + 5):
-                    break
-                dt, rerr1 = theirs(fq, out_r, flags)
-                ref_walls.append(dt)
-                ref_cpu.append(dict(LAST_RUN_CPU))
-                if rr == 0:
-                    rerr = rerr1
-                    s["same_counters"] = info_lines(rerr) == info
-                    if not s["same_counters"]:
-                        raise SystemExit("bench: INFO lines differ from the reference's:\n%s\n---\n%s" % ("\n".join(info), "\n".join(info_lines(rerr))))
-                    theirs_ms = multiset(out_r)
-                    s["same_output_multiset"] = mine == theirs_ms
-                    s["output_records"], s["output_bytes"] = int(mine[0]), int(mine[3])
-                    if mine != theirs_ms:
-                        raise SystemExit("bench: output differs from the reference's (records sum xor bytes): %s vs %s" % (mine, theirs_ms))
-                rm(out_r)
-            dt = sum(ref_walls) / len(ref_walls)
-            s["reference_wall_s_runs"] = ref_walls
-            s["reference_wall_s"] = dt
-            s["reference_wall_s_min"] = min(ref_walls)
-            s["reference_cpu_runs"] = ref_cpu
-            s["reference_gbases_per_s"] = bases / dt / 1e9
-            s["reference_gbases_per_s_best"] = bases / min(ref_walls) / 1e9
-            s["speedup_vs_reference"] = s["gbases_per_s"] / (bases / dt / 1e9)
-            s["speedup_vs_reference_best_run"] = s["gbases_per_s"] / (bases / min(ref_walls) / 1e9)
-            s["speedup_note"] = "mean of %d runs of ours / mean of %d run%s of the reference (best run of the reference: speedup_vs_reference_best_run)" % (
-                len(walls), len(ref_walls), "" if len(ref_walls) == 1 else "s")
-            if OTHER_EXIT_MODE_KEY + "_mean" in s:
-                s["speedup_vs_reference_" + OTHER_EXIT_MODE_KEY.replace("_wall_s", "")] = dt / s[OTHER_EXIT_MODE_KEY + "_mean"]
-        s["_info"] = info
-        s["info_prepass"] = [l for l in info if any(w in l for w in ("trim 5'", "trim 3'", "5' adapter", "3' adapter", "min Phred"))]
-        log("bench: e2e %s: %s" % (tag, json.dumps({k2: v for k2, v in s.items() if k2 not in ("timing_line", "_info")})))
+        shard = [l for l in err.splitlines() if l.startswith("SHARD ")]
+        if shard:
+            s["shard_lines"] = [l[:400] for l in shard]
         return s
 
+    files, sinks, runs_by_threads = [], {}, {}
+    ref_t = None                                       # the thread count the reference is timed at on files after the first
+    est = {"gen_s": 0.0, "run_s": 0.0, "ref_s": 0.0}    # measured on the first file: what every further file will cost
+
+    def reserve(f):
+        """Seconds the files after file f still need for what is never dropped (generation, warm-up, the K timed runs,
+        the reference once with its digest): optional legs run only while that much stays in the budget."""
+        return (n_files - 1 - f) * (est["gen_s"] * 1.1 + (min(args.warmup, 1) + args.steps) * est["run_s"] * 1.1 + (est["ref_s"] * 1.2 + 30 if have_ref else 0))
     try:
-        fq = os.path.join(td, "c2.fq")
-        t0 = time.perf_counter()
-        bases, nbytes = synth.write_ont_fastq(fq, n_reads, seed=cfg["seed"], procs=gen_procs, mean_len=cfg["mean_len"], max_len=cfg["max_len"],
-                                              kind=cfg.get("kind", "ont"), reads_per_job=cfg.get("reads_per_job", 256))
-        log("bench: %d reads / %.2f Gbases / %.2f GB of FASTQ text written to %s in %.1f s by %d processes"
-            % (n_reads, bases / 1e9, nbytes / 1e9, fq, time.perf_counter() - t0, gen_procs))
         flags = list(cfg["flags"])                               # the configuration as BASELINE.json writes it
-        sinks = {}
-        sinks["tmpfs_file"] = file_sink_leg(fq, bases, flags, args.warmup, args.steps, min(3, args.steps), "c2")
-        s_file = sinks["tmpfs_file"]
-        # /dev/null through a symlink (the suffix decides the format): no page instantiation, PCIe-bound at one GPU
-        null_out = os.path.join(td, "null.fq")
-        os.symlink("/dev/null", null_out)
-        k_null = min(args.steps, 3)
-        if budget.allows("dev_null sink", (k_null + 1) * s_file["wall_s_mean"] + 5):
-            walls, err = timed(fq, null_out, flags, min(args.warmup, 1), k_null)
-            s = {"runs": k_null, "exit_mode": DEFAULT_EXIT_MODE, "wall_s": walls, "wall_s_mean": sum(walls) / len(walls),
-                 "gbases_per_s": bases * len(walls) / sum(walls) / 1e9,
-                 "timing_line": [l for l in err.splitlines() if l.startswith("TIMING")][-1:], "timing": parse_timing(err)}
-            if "reference_wall_s" in s_file:
-                s["same_counters_as_the_file_run"] = info_lines(err) == s_file["_info"]
-                if not s["same_counters_as_the_file_run"]:
-                    raise SystemExit("bench: INFO lines of the /dev/null run differ from the file run's")
-                s["speedup_vs_reference_file_run"] = s_file["reference_wall_s"] / s["wall_s_mean"]
-                s["note"] = "the reference's time is that of its tmpfs-file runs (its /dev/null run is within 5 % of that: BENCH_r02)"
-            sinks["dev_null"] = s
-            log("bench: e2e dev_null: %s" % json.dumps({k2: v for k2, v in s.items() if k2 != "timing_line"}))
+        for f in range(n_files):
+            first = f == 0
+            fq = os.path.join(td, "in%d.fq" % f)
+            t0 = time.perf_counter()
+            bases, nbytes = synth.write_ont_fastq(fq, per_file[f], seed=cfg["seed"] + 1000 * f, procs=gen_procs, mean_len=cfg["mean_len"], max_len=cfg["max_len"],
+                                                  kind=cfg.get("kind", "ont"), reads_per_job=cfg.get("reads_per_job", 256))
+            if first:
+                est["gen_s"] = time.perf_counter() - t0
+            log("bench: file %d of %d: %d reads / %.2f Gbases / %.2f GB of FASTQ text written to %s in %.1f s by %d processes"
+                % (f + 1, n_files, per_file[f], bases / 1e9, nbytes / 1e9, fq, time.perf_counter() - t0, gen_procs))
+            out_o, out_r = os.path.join(td, "ours.fq"), os.path.join(td, "ref.fq")
+            walls, err, cpu = timed(fq, out_o, flags, args.warmup if first else min(args.warmup, 1), args.steps, want_ranks)
+            s = describe(walls, err, bases)
+            if first:
+                est["run_s"] = s["wall_s_mean"]
+            s.update({"file": f, "reads": per_file[f], "bases": bases, "fastq_bytes": nbytes, "cpu_last_run": cpu[-1] if cpu else None})
+            if want_ranks:
+                s["ranks"] = want_ranks
+            info = info_lines(err)
+            mine = multiset_of(out_files(out_o, want_ranks)) if have_ref else None
+            if mine:
+                s["output_records"], s["output_bytes"] = int(mine[0]), int(mine[3])
+            rm(out_o)
+            if have_ref:
+                # the reference on the same file, flags and sink.  First file: both thread counts, REF_RUNS runs each, as
+                # the budget allows (the first run's output and INFO lines are compared with ours); later files: once.
+                plan = [hw_cores] + ([quota_cores] if quota_cores != hw_cores else []) if first else [ref_t]
+                compared = False
+                for t in plan:
+                    rw, rc = [], []
+                    for rr in range(REF_RUNS if first else 1):
+                        known = [w for v in runs_by_threads.values() for w in v["wall_s_runs"]] + rw
+                        if known and first and not budget.allows("reference -t %d run %d on file %d" % (t, rr + 1, f + 1), 1.15 * max(known) + 5 + reserve(f)):
+                            break
+                        dt, rerr = theirs(fq, out_r, flags, t)
+                        rw.append(dt)
+                        if first:
+                            est["ref_s"] = max(est["ref_s"], dt)
+                        rc.append(dict(LAST_RUN_CPU))
+                        if not compared:
+                            compared = True
+                            s["same_counters"] = info_lines(rerr) == info
+                            if not s["same_counters"]:
+                                raise SystemExit("bench: INFO lines differ from the reference's:\n%s\n---\n%s" % ("\n".join(info), "\n".join(info_lines(rerr))))
+                            theirs_ms = multiset(out_r)
+                            s["same_output_multiset"] = mine == theirs_ms
+                            if mine != theirs_ms:
+                                raise SystemExit("bench: output differs from the reference's (records sum xor bytes): %s vs %s" % (mine, theirs_ms))
+                        rm(out_r)
+                    if not rw:
+                        continue
+                    if first:
+                        runs_by_threads[str(t)] = {"threads": t, "wall_s_runs": rw, "wall_s_mean": sum(rw) / len(rw), "wall_s_min": min(rw),
+                                                   "gbases_per_s": bases / (sum(rw) / len(rw)) / 1e9, "gbases_per_s_best_run": bases / min(rw) / 1e9, "cpu_runs": rc,
+                                                   "why": "the reference's own clamp, -t min(hw-1, 32)" if t == hw_cores else
+                                                          "what the box's CPU quota (cpu.max = %s CPUs) runs without throttling" % lim["cpus"]}
+                    else:
+                        s["reference_wall_s"], s["reference_threads"], s["reference_cpu"] = rw[0], t, rc[0]
+                if first and runs_by_threads:
+                    best = max(runs_by_threads.values(), key=lambda v: v["gbases_per_s"])
+                    ref_t = best["threads"]
+                    s["reference_wall_s"], s["reference_threads"] = best["wall_s_mean"], ref_t
+            s["_info"] = info
+            s["info_prepass"] = [l for l in info if any(w in l for w in ("trim 5'", "trim 3'", "5' adapter", "3' adapter", "min Phred"))]
+            files.append(s)
+            log("bench: e2e file %d: %s" % (f + 1, json.dumps({k2: v for k2, v in s.items() if k2 not in ("timing_line", "_info", "shard_lines")})))
+            if first:
+                # /dev/null through a symlink (the suffix decides the format): no page instantiation, PCIe-bound at one GPU
+                null_out = os.path.join(td, "null.fq")
+                os.symlink("/dev/null", null_out)
+                for r in range(want_ranks):
+                    os.symlink("/dev/null", "%s.part%d" % (null_out, r))
+                k_null = min(args.steps, 3)
+                if budget.allows("dev_null sink", (k_null + 1) * s["wall_s_mean"] + 5 + reserve(f)):
+                    w2, e2, _ = timed(fq, null_out, flags, min(args.warmup, 1), k_null, want_ranks)
+                    d = describe(w2, e2, bases)
+                    d["same_counters_as_the_file_run"] = info_lines(e2) == info
+                    if not d["same_counters_as_the_file_run"]:
+                        raise SystemExit("bench: INFO lines of the /dev/null run differ from the file run's")
+                    sinks["dev_null"] = d
+                    log("bench: e2e dev_null: %s" % json.dumps({k2: v for k2, v in d.items() if k2 not in ("timing_line", "shard_lines")}))
+                # N = 1: the program path of N GPUs on this box -- rank processes sharing the GPU, a part file each (the tallies
+                # go over the ranks' sockets: RCCL refuses two ranks on one device).  Same records, same INFO lines.
+                if n_gpus == 1 and not want_ranks and not cfg["flags"].count("-g") and getattr(args, "sharded_leg", True):
+                    k_sh = min(args.steps, 3)
+                    for nr in (3,):
+                        if not budget.allows("sharded leg, %d ranks on one GPU" % nr, (k_sh + 1) * s["wall_s_mean"] + 10 + reserve(f)):
+                            break
+                        w3, e3, _ = timed(fq, out_o, flags, 1, k_sh, nr, "0")
+                        d = describe(w3, e3, bases)
+                        d["ranks"], d["devices"] = nr, "0 (shared by all ranks)"
+                        d["same_counters_as_the_file_run"] = info_lines(e3) == info
+                        if mine:
+                            d["same_output_multiset"] = multiset_of(out_files(out_o, nr)) == mine
+                        rm(out_o)
+                        if not d["same_counters_as_the_file_run"] or d.get("same_output_multiset") is False:
+                            raise SystemExit("bench: the sharded run's records or INFO lines differ from the single process's")
+                        sinks["tmpfs_part_files_%d_ranks_one_gpu" % nr] = d
+                        log("bench: e2e sharded: %s" % json.dumps({k2: v for k2, v in d.items() if k2 not in ("timing_line", "shard_lines")}))
+            os.remove(fq)
+        # ---- the whole workload: a step = one pass over all the files ----
+        K = len(files[0]["wall_s"])
+        step_walls = [sum(s["wall_s"][j] for s in files) for j in range(K)]
+        tot_bases = sum(s["bases"] for s in files)
+        agg = {"runs": K, "exit_mode": DEFAULT_EXIT_MODE, "wall_s": step_walls, "wall_s_mean": sum(step_walls) / K,
+               "gbases_per_s": tot_bases * K / sum(step_walls) / 1e9, "files": n_files,
+               "per_file": [{k2: v for k2, v in s.items() if k2 != "_info"} for s in files],
+               "timing": files[0]["timing"], "timing_line": files[0]["timing_line"], "bound": files[0].get("bound"),
+               "gpu_busy_frac": files[0].get("gpu_busy_frac"), "cpu_last_run": files[0].get("cpu_last_run"),
+               "info_prepass": files[0]["info_prepass"],
+               "output_bytes": sum(s.get("output_bytes", 0) for s in files), "output_records": sum(s.get("output_records", 0) for s in files)}
+        if want_ranks:
+            agg["ranks"] = want_ranks
+        if have_ref and all("reference_wall_s" in s for s in files):
+            ref_total = sum(s["reference_wall_s"] for s in files)
+            agg.update({"same_counters": all(s.get("same_counters") for s in files), "same_output_multiset": all(s.get("same_output_multiset") for s in files),
+                        "reference_wall_s": ref_total, "reference_threads": ref_t, "reference_gbases_per_s": tot_bases / ref_total / 1e9,
+                        "reference_runs_by_threads_first_file": runs_by_threads,
+                        "speedup_vs_reference": agg["gbases_per_s"] / (tot_bases / ref_total / 1e9),
+                        "speedup_note": "ours: mean of %d passes over %d file(s) / the reference at -t %d, the FASTER of the thread counts tried on the first file (%s), "
+                                        "every file once (the first: mean of its runs at that count)" % (K, n_files, ref_t, ", ".join("-t %s: %.3f Gbases/s" % (k2, v["gbases_per_s"]) for k2, v in runs_by_threads.items()))})
+        elif have_ref:
+            agg["reference_note"] = "the reference was not timed on every file (budget): no whole-workload baseline"
+        sinks["tmpfs_file"] = agg
+        for k2 in ("dev_null",) + tuple(k3 for k3 in sinks if k3.startswith("tmpfs_part_files")):
+            if k2 in sinks and "reference_wall_s" in files[0]:
+                sinks[k2]["speedup_vs_reference_file_run_first_file"] = files[0]["reference_wall_s"] / sinks[k2]["wall_s_mean"]
         res = {"config": cfg["name"], "config_what": cfg["what"], "box": {"cgroup_cpus": lim["cpus"], "cgroup_memory_gib": (lim["memory_bytes"] or 0) / 2**30 or None, "hw_threads": os.cpu_count()},
-               "reads": n_reads, "bases": bases, "fastq_bytes": nbytes, "flags": " ".join(flags), "threads": cores, "devices": devs,
-               "reduced": reduced,
+               "reads": n_reads, "bases": tot_bases, "fastq_bytes": sum(s["fastq_bytes"] for s in files), "files": n_files, "reads_per_file": per_file,
+               "flags": " ".join(flags), "threads": hw_cores, "devices": devs, "ranks": want_ranks or None,
+               "reduced": reduced, "split": split_note,
                "staging": "synthetic FASTQ text written to tmpfs (%s) by tgsfilter_amd/synth.write_ont_fastq before timing; "
                "read by both programs through the page cache" % (shm or "tmp"), "sinks": sinks}
-        os.remove(fq)
-        # the pinned pre-pass on round 2's file, the reference beside it
+        # the pinned pre-pass on round 2's file, the reference beside it (opt-in since round 5: --pinned-variant)
         n_pin = min(400_000, n_reads)
-        if cfg is E2E_CONFIGS["c2"] and not getattr(args, "no_pinned_variant", False) and budget.allows("pinned-pre-pass variant", 45 + n_pin * 1.1e-4):
+        if cfg is E2E_CONFIGS["c2"] and getattr(args, "pinned_variant", False) and budget.allows("pinned-pre-pass variant", 45 + n_pin * 1.1e-4):
             fq2 = os.path.join(td, "c2_400k.fq")
             bases2, nbytes2 = synth.write_ont_fastq(fq2, n_pin, seed=2, procs=gen_procs)
             fa = os.path.join(td, "rapid.fa")
             open(fa, "wb").write(b">rapid\n" + synth.ONT_RAPID + b"\n")
             pflags = ["-x", "ont", "-l", "1000", "-q", "10", "-5", "0", "-3", "0", "-a", fa]
-            v = file_sink_leg(fq2, bases2, pflags, 1, 3, 0, "pinned", ref_runs=1)      # (a side variant: the reference once)
+            out_o, out_r = os.path.join(td, "pin_ours.fq"), os.path.join(td, "pin_ref.fq")
+            w4, e4, _ = timed(fq2, out_o, pflags, 1, 3)
+            v = describe(w4, e4, bases2)
+            if have_ref:
+                m4 = multiset(out_o)
+                rm(out_o)
+                dt, rerr = theirs(fq2, out_r, pflags, ref_t or hw_cores)
+                v.update({"same_counters": info_lines(rerr) == info_lines(e4), "same_output_multiset": multiset(out_r) == m4,
+                          "reference_wall_s": dt, "speedup_vs_reference": dt / v["wall_s_mean"]})
+                rm(out_r)
             v.update({"reads": n_pin, "bases": bases2, "fastq_bytes": nbytes2, "flags": " ".join(pflags[:-1]) + " rapid.fa"})
             res["variants"] = {"pinned_prepass": v}
-        for leg in list(sinks.values()) + list(res.get("variants", {}).values()):
-            leg.pop("_info", None)
         res["skipped"] = budget.skipped
         res["seconds"] = time.perf_counter() - budget.t0
     finally:
@@ -526,13 +635,23 @@ def kernel_leg(args, torch, dist, world, rank, local_rank, device, xdev, host_gr
     from tgsfilter_amd import dist as tdist
     hifi = args.workload == "hifi"
     mean_len = args.mean_len or (18000.0 if hifi else 45000.0)
-    flags = "-x hifi -l 1000 -q 20 -5 0 -3 0" if hifi else "-x ont -l 1000 -q 10 -5 0 -3 0"
+    # the trims the end-to-end pre-pass resolves on this shape (C2's file: 5' 79, 3' 0; HiFi data: 7 / 8, the reference's
+    # README) -- with any trim no read is "kept whole", and the clean tables cost a pass of their own
+    head_trim = args.head_trim if args.head_trim is not None else (7 if hifi else 79)
+    tail_trim = args.tail_trim if args.tail_trim is not None else (8 if hifi else 0)
+    flags = ("-x hifi -l 1000 -q 20 -5 %d -3 %d" if hifi else "-x ont -l 1000 -q 10 -5 %d -3 %d") % (head_trim, tail_trim)
     wl_adapters = [synth.PACBIO_BLUNT, synth.PACBIO_BLUNT_RC] if hifi else [synth.ONT_RAPID, synth.ONT_RAPID_RC]
+    adapters_note = "PacBio blunt + reverse complement" if hifi else "ONT rapid + reverse complement"
+    if args.adapters == 4:
+        # distinct 5' and 3' adapters with their reverse complements: what the automatic identification hands over for a
+        # ligation kit (src/TGSFilter.cpp:3105-3113) -- four independent columns a pass in the middle scan
+        wl_adapters = wl_adapters + [b"GGCGTCTGCTTGGGTGTTTAACCTTTTTGTCAGAGAGGTTCCAAGTCAGAGAGGTTCCT", b"AGGAACCTCTCTGACTTGGAACCTCTCTGACAAAAAGGTTAAACACCCAAGCAGACGCC"]
+        adapters_note += " + ONT 1D^2 (59 bp) + reverse complement"
     # every rank builds the SAME two batches (same seeds): the fixed job is steps x these batches, dealt over ranks
     batches = [gen_batch(torch, device, args.reads, b + 1, mean_len, args.max_len, args.workload) for b in range(2)]
     max_bases = max(b["bases"] for b in batches)
     max_len = max(int(b["h_lens"].max()) for b in batches)
-    p_kwargs = dict(adapters=wl_adapters, min_len=1000, min_q=20.0 if hifi else 10.0, head_trim=0, tail_trim=0,
+    p_kwargs = dict(adapters=wl_adapters, min_len=1000, min_q=20.0 if hifi else 10.0, head_trim=head_trim, tail_trim=tail_trim,
                     min_repeat=args.min_repeat, kmer=args.kmer)
     if args.short_adapters:
         # for information: a ligation-kit adapter pair of 28 bp (src/TGSFilter.cpp:2974-2975) with -M 24 -- adapters of at
@@ -540,10 +659,15 @@ def kernel_leg(args, torch, dist, world, rank, local_rank, device, xdev, host_gr
         # -M 24 allows 5 differences, about the error share of the default thresholds for the 50-bp adapters)
         p_kwargs.update(adapters=[b"AATGTACTTCGTTCAGTTACGTATTGCT", b"AGCAATACGTAACTGAACGAAGTACATT"], mid_match_len=24)
         flags += " -a ligation28.fa -M 24"
+        adapters_note = "ONT ligation 28 bp + reverse complement"
+        if args.adapters == 4:                       # ... and the 22-bp pair beside it (-M 20: both are searched in the middle)
+            p_kwargs.update(adapters=p_kwargs["adapters"] + [b"GCAATACGTAACTGAACGAAGT", b"ACTTCGTTCAGTTACGTATTGC"], mid_match_len=20)
+            flags = flags.replace("-M 24", "-M 20").replace("ligation28.fa", "ligation28+22.fa")
+            adapters_note += " + ONT ligation 22 bp + reverse complement"
     p = abi.make_params(args.workload, max_batch_bases=max_bases + 64, max_batch_reads=args.reads, max_read_len=max_len, **p_kwargs)
     # what the PMC summaries of profiles/traffic.json are keyed by: the shape of a kernel-path step
-    signature = "%s:reads=%d:mean=%d:p=%d:k=%d%s" % (args.workload, args.reads, int(mean_len), args.min_repeat, args.kmer if args.min_repeat else 0,
-                                                    ":short-adapters" if args.short_adapters else "")
+    signature = "%s:reads=%d:mean=%d:p=%d:k=%d:trim=%d/%d%s%s" % (args.workload, args.reads, int(mean_len), args.min_repeat, args.kmer if args.min_repeat else 0,
+                                                                 head_trim, tail_trim, ":short-adapters" if args.short_adapters else "", ":a4" if args.adapters == 4 else "")
     NS = max(1, args.streams)
     ctxs = [capi.Context(p, local_rank) for _ in range(NS)]
     comm = None
@@ -733,8 +857,8 @@ def kernel_leg(args, torch, dist, world, rank, local_rank, device, xdev, host_gr
                 "back every step; NOT the end-to-end metric",
         "value": bases_all / dt / 1e9, "unit": "Gbases/s", "steps": K, "warmup": W, "ms_per_step": dt / max(len(my_steps), 1) * 1e3,
         "scaling": "strong (fixed job of %d batches dealt over %d ranks)" % (K, world) if world > 1 else "single GPU",
-        "workload": ("C3 shape: synthetic HiFi reads N(%.0f,/6) bp, %s" % (mean_len, flags)) if hifi else
-                    ("C2: synthetic ONT reads, lognormal mean %.0f bp, %s, adapters %s" % (mean_len, flags, "ONT ligation 28 bp + reverse complement" if args.short_adapters else "ONT rapid + reverse complement")),
+        "workload": ("C3 shape: synthetic HiFi reads N(%.0f,/6) bp, %s, adapters %s" % (mean_len, flags, adapters_note)) if hifi else
+                    ("C2: synthetic ONT reads, lognormal mean %.0f bp, %s, adapters %s" % (mean_len, flags, adapters_note)),
         "signature": signature, "reads_per_step": args.reads, "gbases_per_step": bases / steps_mine / 1e9, "batches_in_flight_per_gpu": NS,
         "oracle_check": oracle_note,
         "tally_exchange": ("one SUM all-reduce of the tally vector over RCCL (libtgsf_rccl), inside the timed region" if comm is not None else
@@ -751,6 +875,32 @@ def kernel_leg(args, torch, dist, world, rank, local_rank, device, xdev, host_gr
     return kp, roofline
 
 
+def h2d_peak(torch, device, seconds=0.6):
+    """Host-to-device rate of this GPU's link from pinned memory, three streams at once (what three feeder threads reach):
+    the roof of an end-to-end run at one GPU, whose text crosses the link once."""
+    n = 256 << 20
+    try:
+        host = [torch.empty(n, dtype=torch.uint8).pin_memory() for _ in range(3)]
+        dev = [torch.empty(n, dtype=torch.uint8, device=device) for _ in range(3)]
+        streams = [torch.cuda.Stream(device=device) for _ in range(3)]
+        for k in range(3):
+            with torch.cuda.stream(streams[k]):
+                dev[k].copy_(host[k], non_blocking=True)
+        torch.cuda.synchronize()
+        t0, moved = time.perf_counter(), 0
+        while time.perf_counter() - t0 < seconds:
+            for k in range(3):
+                with torch.cuda.stream(streams[k]):
+                    dev[k].copy_(host[k], non_blocking=True)
+            torch.cuda.synchronize()
+            moved += 3 * n
+        dt = time.perf_counter() - t0
+        return {"h2d_peak_gb_per_s": moved / dt / 1e9, "how": "three streams copying 256-MB pinned buffers to the device for %.1f s, measured in this run (after the end-to-end leg)" % dt}
+    except Exception as e:                                    # (a measurement beside the result: never the reason a run fails)
+        log("bench: link measurement failed: %r" % (e,))
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -762,7 +912,14 @@ def main():
                     "of text each); reduced -- and said so in config.workload -- to what the staging file system / the box's memory control group holds")
     ap.add_argument("--e2e-budget-s", type=float, default=1500.0, help="seconds the end-to-end leg may take: optional legs are dropped (and named in "
                     "e2e.skipped) when it runs short; the K timed steps never are")
-    ap.add_argument("--no-pinned-variant", action="store_true", help="skip the pinned-pre-pass variant (-5 0 -3 0 -a rapid.fa on 400 000 reads)")
+    ap.add_argument("--pinned-variant", action="store_true", help="also run the pinned-pre-pass variant (-5 0 -3 0 -a rapid.fa on 400 000 reads: round 2's headline)")
+    ap.add_argument("--e2e-files", type=int, default=0, help="stage the end-to-end reads as this many consecutive files (default: as few as the box's memory allows)")
+    ap.add_argument("--e2e-ranks", type=int, default=0, help="run the end-to-end command line as this many rank processes (tgsfilter --ranks; default: N for --gpus N > 1)")
+    ap.add_argument("--no-sharded-leg", dest="sharded_leg", action="store_false", help="N = 1: skip the 3-ranks-on-one-GPU leg")
+    ap.add_argument("--adapters", type=int, default=2, choices=[2, 4], help="kernel path: 2 = the configuration's adapter and its reverse complement; 4 = distinct 5' and 3' "
+                    "adapters with their reverse complements (a ligation kit, src/TGSFilter.cpp:3105-3113), for information")
+    ap.add_argument("--head-trim", type=int, default=None, help="kernel path: -5 (default: what the end-to-end pre-pass of this run resolved; 79 / 7 for the ONT / HiFi shape without one)")
+    ap.add_argument("--tail-trim", type=int, default=None, help="kernel path: -3 (default: as --head-trim; 0 / 8)")
     ap.add_argument("--no-e2e", action="store_true", help="kernel path only (profiling runs); the headline is then the kernel path")
     ap.add_argument("--no-kernel-path", action="store_true")
     ap.add_argument("--kernel-steps", type=int, default=24)
@@ -827,8 +984,24 @@ def main():
     xdev = device if args.backend == "nccl" else None
 
     kp = roofline = None
+    if e2e and args.head_trim is None and args.tail_trim is None:
+        # the kernel-path shape takes the trims the end-to-end pre-pass of this very run resolved
+        import re
+        for l in e2e["sinks"]["tmpfs_file"].get("info_prepass", []):
+            m = re.match(r"INFO: trim ([53])' end length: (\d+)", l)
+            if m:
+                setattr(args, "head_trim" if m.group(1) == "5" else "tail_trim", int(m.group(2)))
+    if world > 1:                                    # (every rank runs the same shape: rank 0's end-to-end leg decides)
+        box = [args.head_trim, args.tail_trim]
+        dist.broadcast_object_list(box, src=0, group=host_group)
+        args.head_trim, args.tail_trim = box
     if not args.no_kernel_path:
         kp, roofline = kernel_leg(args, torch, dist, world, rank, local_rank, device, xdev, host_group)
+
+    # the roof the end-to-end run sits under at one GPU: the link to the device (the text goes over it once)
+    link = None
+    if rank == 0 and e2e:
+        link = h2d_peak(torch, device)
 
     if rank == 0:
         if e2e:
@@ -837,13 +1010,16 @@ def main():
             metric = "filtered Gbases/sec (end-to-end, excl. gzip I/O)"
             cfg = E2E_CONFIGS[args.config]
             shape = "HiFi reads (N(%.0f kb, /6), Q ~ N(30, 6))" % (cfg["mean_len"] / 1e3) if cfg.get("kind") == "hifi" else "ONT reads (lognormal mean %.0f kb, max 2 Mb)" % (cfg["mean_len"] / 1e3)
-            workload = ("%s END-TO-END: %d of its %d synthetic %s; %.2f Gbases, "
-                        "%.1f GB of FASTQ text on tmpfs%s -> tgsfilter_amd/bin/tgsfilter %s -t %d (%s; "
-                        "one process, every mapping taken down before it returns) -> FASTQ file on tmpfs (%.1f GB) + report; a step = one whole "
-                        "run of the command line"
-                        % (cfg["name"], e2e["reads"], cfg["reads"], shape, e2e["bases"] / 1e9, e2e["fastq_bytes"] / 1e9,
-                           ("; REDUCED: " + e2e["reduced"]) if e2e.get("reduced") else "", e2e["flags"], e2e["threads"], cfg["what"],
-                           s.get("output_bytes", 0) / 1e9))
+            how = ("%d rank processes (tgsfilter --ranks %d, one per GPU: byte-range shards of each file, a part file per rank, pre-pass on rank 0, one "
+                   "all-reduce of the tallies, rank 0 writes the report)" % (e2e["ranks"], e2e["ranks"])) if e2e.get("ranks") else \
+                  "one process, every mapping taken down before it returns"
+            workload = ("%s END-TO-END: %d of its %d synthetic %s in %d file%s on tmpfs (%s reads each; %.2f Gbases, %.1f GB of FASTQ text%s%s) "
+                        "-> tgsfilter_amd/bin/tgsfilter %s -t %d (%s; %s) -> FASTQ on tmpfs (%.1f GB) + report; a step = one pass of the command "
+                        "line over all %d file%s (one run per file, wall times summed)"
+                        % (cfg["name"], e2e["reads"], cfg["reads"], shape, e2e["files"], "" if e2e["files"] == 1 else "s",
+                           "/".join(str(x) for x in sorted(set(e2e["reads_per_file"]), reverse=True)), e2e["bases"] / 1e9, e2e["fastq_bytes"] / 1e9,
+                           ("; REDUCED: " + e2e["reduced"]) if e2e.get("reduced") else "", ("; " + e2e["split"]) if e2e.get("split") else "",
+                           e2e["flags"], e2e["threads"], cfg["what"], how, s.get("output_bytes", 0) / 1e9, e2e["files"], "" if e2e["files"] == 1 else "s"))
         else:
             value, ms, steps, warmup = kp["value"], kp["ms_per_step"], kp["steps"], kp["warmup"]
             metric = "device-resident filter throughput (Gbases/sec, inputs in HBM; NOT end-to-end)"
@@ -854,45 +1030,56 @@ def main():
             "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": workload,
-                       "parallelism": "reads sharded over %d GPU(s) (one feeder set per GPU), one merge of the tallies" % world},
+                       "parallelism": ("%d rank processes, one per GPU: byte-range shards of the input, part files, one all-reduce of the tallies" % world) if world > 1
+                                      else "one GPU (three contexts / feeder threads); reads shard over rank processes with tgsfilter --ranks N"},
         }
         if e2e:
             out["e2e"] = e2e
             s = e2e["sinks"]["tmpfs_file"]
+            if link:
+                # how far each sink is from the roof that binds the end-to-end run: the text crosses the link once
+                e2e["link"] = link
+                for name, leg in e2e["sinks"].items():
+                    text = e2e["fastq_bytes"] if name == "tmpfs_file" else s["per_file"][0]["fastq_bytes"]
+                    leg["text_gb_per_s"] = text / leg["wall_s_mean"] / 1e9
+                    leg["link_fraction"] = leg["text_gb_per_s"] / (link["h2d_peak_gb_per_s"] * (world if leg.get("ranks") and world > 1 else 1))
             if world > 1:
-                # what can and cannot scale with the GPUs: one tmpfs output file is instantiated by one kernel
-                # thread under the inode lock, whatever the number of GPUs; the /dev/null (pipe) sink is PCIe-bound per GPU
-                e2e["scaling_note"] = ("headline sink = ONE tmpfs file: its pages are instantiated by one kernel thread under the inode lock "
-                                       "whatever the number of GPUs (this run's largest share: %s), so this figure does not scale with GPUs; the "
-                                       "dev_null sink (bound by the links to the devices and the host's copies) is the one that can" % s.get("bound", "fallocate"))
+                e2e["scaling_note"] = ("every rank instantiates the pages of its own part file (N inodes, N fallocate streams) and feeds its own GPU over its own link; "
+                                       "what the ranks share is the host: the page cache the text is read from, the memory bandwidth of the fill threads and the box's CPU "
+                                       "quota (this box: %s CPUs for %d ranks)" % (e2e["box"]["cgroup_cpus"], world))
             if "reference_gbases_per_s" in s:
+                rbt = s.get("reference_runs_by_threads_first_file") or {}
                 out["cpu_baseline"] = {
-                    "value": s["reference_gbases_per_s"], "unit": "Gbases/s", "cores": e2e["threads"], "kind": "reference",
-                    "runs": len(s["reference_wall_s_runs"]), "wall_s_runs": s["reference_wall_s_runs"], "value_best_run": s["reference_gbases_per_s_best"],
-                    "cpu_runs": s.get("reference_cpu_runs"),
-                    "sample": "the whole end-to-end file (%d reads, %.2f Gbases, %.1f GB FASTQ on tmpfs), same flags, same sink "
-                              "(tmpfs file), oracle/_ref/tgsfilter_ref -t %d, %d run(s): wall mean %.2f s, best %.2f s (value = bases / mean); "
-                              "output multiset and INFO lines (automatic trims, identified adapter, depths, counters) of the first run "
-                              "identical to ours (asserted)"
-                              % (e2e["reads"], e2e["bases"] / 1e9, e2e["fastq_bytes"] / 1e9, e2e["threads"], len(s["reference_wall_s_runs"]),
-                                 s["reference_wall_s"], s["reference_wall_s_min"])}
+                    "value": s["reference_gbases_per_s"], "unit": "Gbases/s", "cores": s["reference_threads"], "kind": "reference",
+                    "runs_by_threads": rbt,
+                    "sample": "the whole end-to-end workload (%d reads in %d file(s), %.2f Gbases, %.1f GB FASTQ on tmpfs), same flags, same sink (tmpfs file), "
+                              "oracle/_ref/tgsfilter_ref: on the first file at %s, %d run(s) each; value = all bases / the reference's wall time over all files at "
+                              "-t %d, the FASTER of them (first file: mean of its runs; other files: one run each): %.1f s; output multiset and INFO lines "
+                              "(automatic trims, identified adapter, depths, counters) identical to ours for every file (asserted)"
+                              % (e2e["reads"], e2e["files"], e2e["bases"] / 1e9, e2e["fastq_bytes"] / 1e9,
+                                 " and ".join("-t %s (%s)" % (k2, v["why"]) for k2, v in rbt.items()), max([len(v["wall_s_runs"]) for v in rbt.values()] or [1]),
+                                 s["reference_threads"], s["reference_wall_s"])}
                 out["e2e_speedup_vs_reference"] = {
                     "tmpfs_file": s.get("speedup_vs_reference"),
-                    "tmpfs_file_" + OTHER_EXIT_MODE_KEY.replace("_wall_s", ""): s.get("speedup_vs_reference_" + OTHER_EXIT_MODE_KEY.replace("_wall_s", "")),
-                    "dev_null_vs_reference_file_run": e2e["sinks"].get("dev_null", {}).get("speedup_vs_reference_file_run"),
+                    "against": "the reference at -t %d: the faster of %s on this box" % (s["reference_threads"], ", ".join("-t " + k2 for k2 in rbt) or "its clamp"),
+                    "by_reference_threads_first_file": {k2: v["wall_s_mean"] / s["per_file"][0]["wall_s_mean"] for k2, v in rbt.items()},
+                    "dev_null_vs_reference_file_run_first_file": e2e["sinks"].get("dev_null", {}).get("speedup_vs_reference_file_run_first_file"),
                     "pinned_prepass_variant": e2e.get("variants", {}).get("pinned_prepass", {}).get("speedup_vs_reference")}
         if kp:
             out["kernel_path"] = kp
             out["roofline"] = roofline
             if world > 1 and args.backend == "nccl" and kp.get("rccl_ranks") != world:
                 raise SystemExit("bench: the job's RCCL communicator has %s ranks, not %d" % (kp.get("rccl_ranks"), world))
-        # the figures a scaling curve over N is read from, side by side: the headline sink (one tmpfs file: bound by the
-        # kernel's page instantiation whatever N), the sink that can scale with the GPUs, and the device-resident kernel
-        # path (the fixed job dealt over the ranks, one tally all-reduce over RCCL)
+        # the figures a scaling curve over N is read from, side by side: the end-to-end file sink (N > 1: one rank process and
+        # one part file per GPU), the /dev/null sink, and the device-resident kernel path (the fixed job dealt over the
+        # ranks, one tally all-reduce over RCCL)
+        sharded = [v for k2, v in (e2e["sinks"].items() if e2e else []) if k2.startswith("tmpfs_part_files")]
         out["scaling_figures"] = {
             "n_gpus": world,
             "e2e_tmpfs_file_gbases_per_s": e2e["sinks"]["tmpfs_file"]["gbases_per_s"] if e2e else None,
+            "e2e_ranks": e2e.get("ranks") if e2e else None,
             "e2e_dev_null_gbases_per_s": e2e["sinks"].get("dev_null", {}).get("gbases_per_s") if e2e else None,
+            "e2e_3_ranks_sharing_one_gpu_part_files_gbases_per_s": sharded[0]["gbases_per_s"] if sharded else None,
             "kernel_path_gbases_per_s": kp["value"] if kp else None,
             "kernel_path_rccl_ranks": kp.get("rccl_ranks") if kp else None}
         sys.stdout.flush()

@@ -96,27 +96,43 @@ const Api& lib()
     return g_api;
 }
 
+namespace {
+RcclApi g_rccl;
+bool g_rccl_ok = false, g_rccl_started = false;
+std::thread g_rccl_thread;
+
+void load_rccl()
+{
+    if (getenv("TGSF_NO_RCCL")) return;                         // test knob: a box without the collective library
+    std::string path = lib_path();
+    const size_t slash = path.rfind('/');
+    path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/libtgsf_rccl.so";
+    void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);      // (brings librccl in: a few tenths of a second)
+    if (!h) return;
+#define BIND(field, sym) g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, sym)); if (!g_rccl.field) return;
+    BIND(unique_id, "tgsf_rccl_unique_id")
+    BIND(comm_init, "tgsf_rccl_comm_init")
+    BIND(comm_count, "tgsf_rccl_comm_count")
+    BIND(comm_destroy, "tgsf_rccl_comm_destroy")
+    BIND(allreduce_counters, "tgsf_rccl_allreduce_counters")
+    BIND(last_error, "tgsf_rccl_last_error")
+#undef BIND
+    g_rccl_ok = true;
+}
+}  // namespace
+
+void rccl_start()
+{
+    if (g_rccl_started) return;
+    g_rccl_started = true;
+    g_rccl_thread = std::thread(load_rccl);
+}
+
 const RcclApi* rccl_lib()
 {
-    static RcclApi api;
-    static const bool ok = [] {
-        if (getenv("TGSF_NO_RCCL")) return false;               // test knob: a box without the collective library
-        std::string path = lib_path();
-        const size_t slash = path.rfind('/');
-        path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/libtgsf_rccl.so";
-        void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
-        if (!h) return false;
-#define BIND(field, sym) api.field = reinterpret_cast<decltype(api.field)>(dlsym(h, sym)); if (!api.field) return false;
-        BIND(unique_id, "tgsf_rccl_unique_id")
-        BIND(comm_init, "tgsf_rccl_comm_init")
-        BIND(comm_count, "tgsf_rccl_comm_count")
-        BIND(comm_destroy, "tgsf_rccl_comm_destroy")
-        BIND(allreduce_counters, "tgsf_rccl_allreduce_counters")
-        BIND(last_error, "tgsf_rccl_last_error")
-#undef BIND
-        return true;
-    }();
-    return ok ? &api : nullptr;
+    rccl_start();
+    if (g_rccl_thread.joinable()) g_rccl_thread.join();
+    return g_rccl_ok ? &g_rccl : nullptr;
 }
 
 void lib_times(double& load_s, double& device_s) { load_s = g_load_s; device_s = g_device_s; }

@@ -40,7 +40,9 @@ struct RcclApi {
     decltype(&tgsf_rccl_last_error) last_error;
 };
 // nullptr where the library is not installed or does not load (a box without RCCL): the caller then sums the tallies of
-// its ranks over their sockets.  Loads on first use (call after lib()).
+// its ranks over their sockets.  rccl_start() begins loading it on a thread of its own (it brings librccl in: a few
+// tenths of a second, beside the pre-pass); rccl_lib() waits for that (and starts it if nobody has).
+void rccl_start();
 const RcclApi* rccl_lib();
 
 // Starts the helper thread: dlopen + tgsf_prepare_device on each device.  Call once, early.

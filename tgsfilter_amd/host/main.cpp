@@ -122,6 +122,7 @@ int main(int argc, char** argv)
     if (parse_args(argc, argv, o)) return 1;
     // ---- one process per GPU (shard.h) ----
     RankLink link;
+    bool shard_may_use_rccl = false;
     if (o.ranks >= 1 && o.shard_world > 0) { std::cerr << "Error: --ranks starts the ranks itself; --shard is for a rank started by another launcher" << std::endl; return 1; }
     if (o.ranks >= 1 || o.shard_world >= 1) {
         const int world = o.ranks >= 1 ? o.ranks : o.shard_world;
@@ -132,6 +133,15 @@ int main(int argc, char** argv)
             why = "the ranks take byte ranges of a plain FASTQ / FASTA text";
         if (why) { std::cerr << "Error: --ranks / --shard: " << why << std::endl; return 1; }
         if (world > 1024) { std::cerr << "Error: --ranks " << world << std::endl; return 1; }
+        // a GPU per rank? (--ranks knows before it forks; ranks started by another launcher find out when they meet)
+        {
+            std::vector<int> dv;
+            for (int r = 0; r < world && o.ranks >= 1; r++) dv.push_back(o.devices.empty() ? r : o.devices[(size_t)r % o.devices.size()]);
+            std::sort(dv.begin(), dv.end());
+            shard_may_use_rccl = o.ranks < 1 || std::adjacent_find(dv.begin(), dv.end()) == dv.end();
+            const char* ex = getenv("TGSF_SHARD_EXCHANGE");
+            if (ex && !strcmp(ex, "socket")) shard_may_use_rccl = false;
+        }
         if (o.ranks >= 1) {
             fork_ranks(world, link);                                       // returns in the N children only
             if (link.rank > 0) std::cerr.rdbuf(new InfoFilter(std::cerr.rdbuf()));
@@ -187,6 +197,7 @@ int main(int argc, char** argv)
     // the pre-pass (api.h)
     if (o.devices.empty()) o.devices.push_back(o.device);
     lib_start(o.devices);
+    if (sharded && shard_may_use_rccl) rccl_start();                   // (librccl is large: loaded beside the pre-pass, only where it can be used)
 
     // Compressed / BAM / SAM input beyond a size is STREAMED: decoded piece by piece in bounded memory, once for the
     // pre-pass (which stops after its sample of reads) and once for the filter pass, as the reference reads it twice
@@ -393,7 +404,7 @@ int main(int argc, char** argv)
     bool use_rccl = false;
     if (sharded) {
         const char* ex = getenv("TGSF_SHARD_EXCHANGE");
-        if (!(ex && !strcmp(ex, "socket"))) R = rccl_lib();
+        if (shard_may_use_rccl) R = rccl_lib();
         char bus[64] = {0};
         int node = -1;
         if (L.device_location(o.device, bus, (int)sizeof bus, &node) != TGSF_OK) snprintf(bus, sizeof bus, "device%d", o.device);
