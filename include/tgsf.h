@@ -51,7 +51,7 @@ typedef enum tgsf_status {
     TGSF_E_HIP = -3,          /* a HIP runtime call failed                              */
     TGSF_E_CAPACITY = -4,     /* caller-provided output capacity too small              */
     TGSF_E_UNSUPPORTED = -5,  /* feature named by the reference but not on this path    */
-    TGSF_E_DATA = -6          /* input bytes outside the supported domain (see below)   */
+    TGSF_E_DATA = -6          /* input the reference itself has no defined answer for (see tgsf_batch_in) */
 } tgsf_status;
 
 /*
@@ -105,9 +105,12 @@ typedef struct tgsf_params {
  * lengths differ (src/TGSFilter.cpp:719-723).  Offsets are in bytes; aligning
  * each read start to 16 bytes (leaving gaps) is allowed and is the fast layout:
  * then pass `lengths` explicitly.  With lengths == NULL, read i has length
- * offsets[i+1]-offsets[i].  Supported domain: 1 <= length <= max_read_len;
- * quality bytes < 128 (ASCII) -- a batch with a byte >= 128 fails with
- * TGSF_E_DATA (the reference would subtract qType from a negative char).
+ * offsets[i+1]-offsets[i].  Supported domain: 1 <= length <= max_read_len.
+ * Quality bytes are taken as the reference takes them: `qual[i] - qType` on a
+ * (signed) char (src/TGSFilter.cpp:1455-1457, :1508), so a byte of 128 and above
+ * stands for its value - 256.  A read whose mean of those values falls outside
+ * [0, 256) fails the batch with TGSF_E_DATA: the reference indexes
+ * rawDiffQualReadsBases[int(mean)] out of bounds there (:1943).
  */
 typedef struct tgsf_batch_in {
     const uint8_t*  seq;

@@ -106,6 +106,12 @@ CASES.update({
                      [WIDE_A, WIDE_B], "-x ont -l 800 -q 9 -5 0 -3 2 -M 120"),
 })
 
+CASES.update({
+    # quality bytes of 128 and above: the reference subtracts qType from a (signed) char (:1455-1457, :1508) -- such a byte
+    # stands for its value - 256; every read keeps a mean in [0, 256) (outside it the reference indexes out of bounds, :1943)
+    "ont_high_qual": (dict(seed=39, n=90, kind="ont", mean_len=3000, zoo=True, pmid=0.05), [synth.ONT_RAPID], "-x ont -l 1000 -q 10 -5 6 -3 3", "fq", "high_bytes"),
+})
+
 IN_EXT = {"fq": "in.fq", "bam": "in.bam", "sam": "in.sam", "fa": "in.fa"}
 
 
@@ -114,6 +120,18 @@ def tweak(reads, how):
     for i, (name, sq, q) in enumerate(reads):
         if how == "phred64":
             q = bytes(min(max(c, 33 + 16) + 31, 126) for c in q)     # every quality >= 16: min char 80 > 78 decides Phred64 (:1050)
+        elif how == "high_bytes" and i % 3 != 2 and len(sq) > 400:
+            rng = np.random.default_rng(1000 + i)
+            qa = bytearray(max(c, 33 + 30) for c in q)
+            if i % 3 == 0:
+                for pos in list(rng.integers(0, len(qa), max(1, len(qa) // 300))) + [0, len(qa) - 1, 99, 100]:
+                    qa[int(pos)] = int(rng.integers(128, 256))
+            else:
+                a = int(rng.integers(0, len(qa) - 210))
+                for j in range(a, a + 205):
+                    qa[j] = 255 if j % 3 else 128
+                qa = bytearray(c if c >= 128 else 126 for c in qa)
+            q = bytes(qa)
         elif how == "n_ends" and i % 5 == 2 and len(sq) > 900:
             sq = b"N" * 260 + sq[260:-260] + b"N" * 260
         out.append((name, sq, q))

@@ -43,6 +43,74 @@ def compare_batch(ctx: capi.Context, p: abi.Params, reads, *, align=16, explicit
     return got_r, got_f, ctr
 
 
+def high_quality_byte_reads(seed=61, n=40, kind="ont"):
+    """Reads with quality bytes of 128 and above sprinkled in: the reference subtracts qType from a (signed) char
+    (src/TGSFilter.cpp:1455-1457, :1508), so such a byte stands for its value - 256.  Every case keeps the read's
+    mean in [0, 256) (outside it the reference indexes rawDiffQualReadsBases out of bounds, :1943)."""
+    reads = synth.make_reads(seed, n, kind, mean_len=3000, zoo=True, pmid=0.05)
+    rng = np.random.default_rng(seed)
+    out = []
+    for i, (name, sq, q) in enumerate(reads):
+        q = bytearray(q)
+        L = len(q)
+        if i % 4 == 0 and L > 400:                     # a few, anywhere (tile seams, read ends, every alignment)
+            for pos in list(rng.integers(0, L, max(1, L // 300))) + [0, L - 1, 99, 100, min(L - 1, 6399), min(L - 1, 6400)]:
+                q[int(pos)] = int(rng.integers(128, 256))
+            for j in range(L):                           # ... beside high ordinary qualities: the mean stays positive
+                if q[j] < 128:
+                    q[j] = max(q[j], 33 + 35)
+        elif i % 4 == 1 and L > 400:                   # a run of them over a whole 100-base bin and across a dword
+            a = int(rng.integers(0, L - 210))
+            for j in range(a, a + 205):
+                q[j] = 255 if j % 3 else 128
+            for j in range(L):
+                if q[j] < 128:
+                    q[j] = 126
+        out.append((name, sq, bytes(q)))
+    return out
+
+
+def by_product_run(lib_path, kind, head, tail, *, monkeypatch, mode="byproduct", pool_cap=None, p5=None, n=48, batches=3):
+    """The clean tables as a by-product of the raw pass (round 5, k_stats<raw, BP>): reads expected to be kept as
+    [head_trim, L - tail_trim) are tallied into the clean tables while the raw pass holds them; the others are corrected
+    afterwards.  Several batches through ONE context (the device decides per batch whether the next one speculates), every
+    record, fragment and tally word against the oracle -- whatever the guesses were, the results may not depend on them."""
+    from oracle import orc
+    monkeypatch.setenv("TGSF_CLEAN_TABLES", mode) if mode else monkeypatch.delenv("TGSF_CLEAN_TABLES", raising=False)
+    if pool_cap:
+        monkeypatch.setenv("TGSF_POOL_CAP", str(pool_cap))
+    ad = [synth.ONT_RAPID, synth.ONT_RAPID_RC] if kind == "ont" else [synth.PACBIO_BLUNT, synth.PACBIO_BLUNT_RC]
+    sets = []
+    for b in range(batches):
+        reads = synth.make_reads(300 + 7 * b + head, n, kind, mean_len=3000 + 2500 * b, zoo=(b == 1), pmid=0.05 if b else 0.0,
+                                 p5=p5 if p5 is not None else (0.8 if kind == "ont" else 0.1))
+        if b == 2:                                     # lengths on the seams of bins, tiles and the trims themselves
+            rng = np.random.default_rng(b)
+            acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+            for L in (head + tail + 999, head + tail + 1000, head + tail + 1001, 6400, 6400 + head, 6400 + head + 1, 6399 + head + tail, 12800 + head, 6500, 1100 + head):
+                reads.append((b"seam%d" % L, bytes(acgt[rng.integers(0, 4, L)]), bytes((rng.integers(25, 40, L) + 33).astype(np.uint8))))
+        sets.append(reads)
+    p = sized(abi.make_params(kind, adapters=ad, min_q=9.0 if kind == "ont" else 20.0, head_trim=head, tail_trim=tail), [r for rs in sets for r in rs])
+    ctx = capi.Context(p, 0, lib_path)
+    exp = np.zeros(ctx.ctr_words, dtype=np.uint64)
+    try:
+        for k, reads in enumerate(sets + sets[:1]):
+            seq, qual, offsets, lengths = synth.pack(reads, align=16 if k % 2 == 0 else 1)
+            got_r, got_f = ctx.submit(seq, qual, offsets[:-1].copy() if k % 2 == 0 else offsets, lengths)
+            exp_r, exp_f, exp = orc.filter_batch(p, seq, qual, offsets, lengths, n_bins=ctx.n_bins, ctr=exp)
+            for name in ("sum_q", "flags", "n_frags", "frag_begin", "trimmed"):
+                assert np.array_equal(got_r[name], exp_r[name]), (k, name)
+            assert len(got_f) == len(exp_f)
+            for name in ("sum_q", "read", "start", "len", "flags"):
+                bad = np.nonzero(got_f[name] != exp_f[name])[0]
+                assert bad.size == 0, (k, name, bad[:8], got_f[name][bad[:8]], exp_f[name][bad[:8]])
+            ctr = ctx.counters()
+            bad = np.nonzero(ctr != exp)[0]
+            assert bad.size == 0, f"batch {k}: tally words differ at {bad[:12]}: got {ctr[bad[:12]]} exp {exp[bad[:12]]}"
+    finally:
+        ctx.close()
+
+
 def golden_case(lib_path, golden_dir, name):
     case = hostmodel.GoldenCase(golden_dir, name)
     p = sized(case.params(), case.reads)

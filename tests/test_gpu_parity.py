@@ -109,10 +109,25 @@ def test_gpu_ultra_long_reads():
     ctx.close()
 
 
-def test_gpu_bad_quality_byte_is_reported():
+@pytest.mark.parametrize("kind,align", [("ont", 16), ("ont", 1), ("hifi", 16)])
+def test_gpu_quality_bytes_of_128_and_above(kind, align):
+    """Such a byte stands for its value - 256, as in the reference's arithmetic on a signed char (round 5: no longer refused)."""
+    reads = parity.high_quality_byte_reads(kind=kind)
+    p = parity.sized(abi.make_params(kind, adapters=[synth.ONT_RAPID if kind == "ont" else synth.PACBIO_BLUNT], min_q=7.0, head_trim=13, tail_trim=4), reads)
+    ctx = capi.Context(p, 0)
+    parity.compare_batch(ctx, p, reads, align=align)
+    ctx.close()
+    p.max_batch_bases = 2 * sum(len(r[1]) for r in reads) + 64 * len(reads) + 4096      # the FASTQ text itself as the batch
+    ctx = capi.Context(p, 0)
+    parity.compare_batch_in_place(ctx, p, reads)
+    ctx.close()
+
+
+def test_gpu_mean_quality_outside_the_tables_is_reported():
+    """A read whose mean of `qual - qType` falls below 0 makes the reference index rawDiffQualReadsBases out of bounds (:1943): refused."""
     reads = synth.make_reads(43, 8, "ont", mean_len=2000)
     n, s, q = reads[3]
-    reads[3] = (n, s, q[:100] + bytes([200]) + q[101:])
+    reads[3] = (n, s, bytes([200]) * len(q))
     p = parity.sized(abi.make_params("ont", adapters=[synth.ONT_RAPID]), reads)
     ctx = capi.Context(p, 0)
     seq, qual, off, ln = synth.pack(reads)
@@ -410,3 +425,22 @@ def test_gpu_fuzz_findings_round4(seed, monkeypatch):
     monkeypatch.setenv("TGSF_FUZZ_GATE_P", "0.2")
     from tests import fuzz
     fuzz.run_case(None, seed, 150)
+
+
+@pytest.mark.parametrize("kind,head,tail", [("ont", 79, 0), ("hifi", 7, 8), ("ont", 250, 31), ("hifi", 100, 0), ("ont", 0, 5), ("ont", 99, 1)])
+@pytest.mark.parametrize("mode", ["byproduct", None])
+def test_gpu_clean_tables_as_a_by_product_of_the_raw_pass(kind, head, tail, mode, monkeypatch):
+    parity.by_product_run(None, kind, head, tail, monkeypatch=monkeypatch, mode=mode)
+
+
+@pytest.mark.parametrize("kind,head,tail", [("ont", 79, 0), ("hifi", 7, 8)])
+def test_gpu_by_product_when_most_reads_are_kept_as_expected(kind, head, tail, monkeypatch):
+    """Few adapters: nearly every read is kept as [head_trim, L - tail_trim) and nothing of it is scanned a second time."""
+    parity.by_product_run(None, kind, head, tail, monkeypatch=monkeypatch, mode=None, p5=0.02, n=120)
+
+
+@pytest.mark.parametrize("kind,head,tail", [("ont", 79, 0), ("hifi", 7, 8)])
+def test_gpu_by_product_through_a_pool_overflow(kind, head, tail, monkeypatch):
+    """A batch whose candidate pool overflows is run a second time from its inputs: what its first run tallied into the
+    clean tables as a by-product is not tallied again, and the second run takes the same decisions."""
+    parity.by_product_run(None, kind, head, tail, monkeypatch=monkeypatch, mode="byproduct", pool_cap=3)

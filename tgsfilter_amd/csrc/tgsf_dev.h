@@ -120,6 +120,17 @@ struct DevBatch {
     uint32_t* whole;           // [n] 1 = the read is kept whole (one fragment == the read, not dropped)
     uint64_t* plan;            // [4] {batch raw rows, -, bases to scan directly, bases to scan by difference}
     uint32_t  clean_force;     // 0 = choose per batch, 1 = always direct, 2 = always by difference
+    // The clean tables as a BY-PRODUCT of the raw pass (round 5; see k_stats): a read that will probably be kept as one
+    // fragment [head_trim, L - tail_trim) -- no adapter beyond the fixed trims, past both quality gates: what the raw pass
+    // can know beforehand -- has that fragment tallied into the clean tables while its bytes are in LDS for the raw ones.
+    // Afterwards only the reads that turned out otherwise are scanned again (taken back out, their real fragments put in).
+    uint32_t  bp_allowed;      // this context may speculate at all (filtering run with fixed trims, no repeat gate; TGSF_CLEAN_TABLES)
+    uint32_t* spec;            // [n] 1 = the raw pass tallies [head_trim, L - tail_trim) of this read into the clean tables
+    uint64_t* spec_sum;        // [n] clean sum of (qual - qType) over that range
+    uint32_t* bp_state;        // [2] (lives across batches) [0] speculate in the next batch: 1 = yes (set by k_clean_plan from how
+                               // this batch's speculation fared); [1] batches that speculated
+    uint32_t* bp_used;         // [1] THIS batch's word (one per enqueued batch, beside ovf): whether it speculated -- a second
+                               // run of the batch after a pool overflow must take the same decisions
 
     uint64_t* scratch;         // traceback columns, one region per wave: [column][word][lane]
     size_t    scratch_wave_words;
@@ -201,7 +212,7 @@ TGSF_HD uint32_t flat_stretch(uint32_t T, uint32_t pmax, uint32_t pmin, uint32_t
 enum DevStatus : uint32_t {
     DS_OK = 0,
     DS_BAD_LEN = 1,        // read length 0 or > max_read_len
-    DS_BAD_QUAL = 2,       // quality byte >= 128
+    DS_BAD_QUAL = 2,       // (no longer raised: a quality byte of 128 and above stands for its value - 256, as in the reference)
     DS_POOL_FULL = 3,      // candidate pool overflow
     DS_TOO_MANY_REGIONS = 4,
     DS_FRAG_CAP = 5,

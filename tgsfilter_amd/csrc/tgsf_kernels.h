@@ -58,17 +58,36 @@ TGSF_D uint32_t stored_frags(const DevBatch& B) { uint32_t nf = B.nfr[B.n]; retu
 // k_clean_plan counts the bases either way needs to scan; the cheaper one runs (difference must win by
 // a quarter: it also pays one more pass over the batch's table rows).  Valid after k_clean_plan.
 // ---------------------------------------------------------------------------
+//   by-product  (round 5) the raw pass itself tallied [head_trim, L - tail_trim) of every read it expected to be kept
+//               as exactly that (B.spec) into the clean tables: clean += - the speculated ranges of the reads that turned
+//               out otherwise + their real fragments.  `whole` then means "kept as speculated".
+// The batch speculated or it did not (B.bp_used, decided before the raw pass); when it did, that is the strategy.
+TGSF_D bool clean_by_product(const DevBatch& B) { return B.bp_allowed && *B.bp_used != 0u; }
 TGSF_D bool clean_by_difference(const DevBatch& B) {
+    if (clean_by_product(B)) return true;            // (same bookkeeping: `whole` reads are not scanned again, the others taken out)
     if (B.clean_force) return B.clean_force == 2;
     const uint64_t direct = B.plan[2], diff = B.plan[3];
     return diff + (diff >> 2) < direct;
 }
+// the range of read r the clean tables already hold when the read is `whole`: the read itself, or what the raw pass speculated on
+TGSF_D void held_range(const DevParams& P, const DevBatch& B, uint32_t r, uint32_t& s, uint32_t& e) {
+    s = 0; e = B.len[r];
+    if (clean_by_product(B)) {
+        if (B.spec[r]) { s = (uint32_t)P.head_trim; e = B.len[r] - (uint32_t)P.tail_trim; }
+        else e = 0;                                  // nothing held: nothing to take out
+    }
+}
 // Items of a stats pass.  RAW: read i.  CLEAN: fragment i (< fcap), or read i - fcap to be taken back out.
 // Length 0 = not part of the pass.
 template <bool CLEAN>
-TGSF_D uint32_t stats_item_len(const DevBatch& B, uint32_t item, bool diff) {
+TGSF_D uint32_t stats_item_len(const DevParams& P, const DevBatch& B, uint32_t item, bool diff) {
     if (!CLEAN) return B.len[item];
-    if (item >= B.fcap) return (diff && !B.whole[item - B.fcap]) ? B.len[item - B.fcap] : 0u;
+    if (item >= B.fcap) {
+        if (!diff || B.whole[item - B.fcap]) return 0u;
+        uint32_t s, e;
+        held_range(P, B, item - B.fcap, s, e);
+        return e > s ? e - s : 0u;
+    }
     if (B.frag_flags[item] & TGSF_FF_REPEAT) return 0u;          // dropped before CalcAvgQuality (:1982-1989)
     if (diff && B.whole[B.frag_read[item]]) return 0u;
     return B.frag_len[item];
@@ -107,9 +126,17 @@ TGSF_KERNEL k_prepare(DevParams P, DevBatch B, uint32_t max_read_len)
     if (use_lds) for (uint32_t i = TGSF_COOP_BEGIN; i < nbuck; i += TGSF_COOP_STRIDE) h[i] = 0;
     TGSF_BLOCK_SYNC();
     uint32_t rows = 0, erows = 0;
+    // does this batch speculate (see DevBatch::spec)?  Its first run decides from what the batch before left in bp_state
+    // and notes it in the batch's own word; a second run after a pool overflow reads that word.
+    bool speculate = false;
+    if (B.bp_allowed) {
+        speculate = B.replay ? *B.bp_used != 0u : B.bp_state[0] != 0u;
+        if (!B.replay && gtid() == 0) { *B.bp_used = speculate ? 1u : 0u; if (speculate) B.bp_state[1]++; }
+    }
     for (uint32_t r = gtid(); r < B.n; r += gsize()) {
         uint32_t L = B.len_in ? B.len_in[r] : (uint32_t)(B.off[r + 1] - B.off[r]);
         B.len[r] = L;
+        if (B.bp_allowed) { B.spec[r] = 0; B.spec_sum[r] = 0; }
         B.sumq[r] = 0;
         B.flags[r] = 0;
         B.mid_head[r] = -1;
@@ -126,6 +153,25 @@ TGSF_KERNEL k_prepare(DevParams P, DevBatch B, uint32_t max_read_len)
         rows = rw > rows ? rw : rows;
         uint32_t er = (uint32_t)P.bc_len < L ? (uint32_t)P.bc_len : L;  // :1490-1493
         erows = er > erows ? er : erows;
+        if (speculate) {
+            // kept as [head_trim, L - tail_trim) if nothing else happens to the read (adapterMap, src/TGSFilter.cpp:1334-1347,
+            // :1388-1431: one keep region of a length the filters accept) ...
+            const int64_t keep = (int64_t)L - P.head_trim - P.tail_trim;
+            bool sp = keep >= P.min_len && keep <= P.max_len;
+            // ... and if it passes the mean-quality gate (:1946-1953), which only the raw pass can tell: a guess from 64
+            // quality bytes at four places of the read.  A wrong guess costs a second look at the read, never a result.
+            if (sp && !P.no_qual) {
+                const uint8_t* q = B.qual + B.qoff[r];
+                uint32_t sum = 0, cntq = 0;
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t at = (uint32_t)(((uint64_t)(L > 16 ? L - 16 : 0) * (uint32_t)k) / 3u);
+                    for (uint32_t i = at; i < at + 16 && i < L; i++) { sum += (uint32_t)(int32_t)(int8_t)q[i] + 128u; cntq++; }
+                }
+                const double guess = ((double)sum - 128.0 * cntq) / (double)(cntq ? cntq : 1u) - (double)P.qtype;
+                sp = !q_fail(guess, P.min_q, P.max_q);
+            }
+            B.spec[r] = sp ? 1u : 0u;
+        }
     }
     wave_max_u64(&B.ctr[TGSF_CTR_ROWS + 0], rows);
     wave_max_u64(&B.plan[0], rows);
@@ -140,6 +186,7 @@ TGSF_KERNEL k_prepare(DevParams P, DevBatch B, uint32_t max_read_len)
 TGSF_KERNEL k_clean_plan(DevParams P, DevBatch B)
 {
     if (pool_overflowed(B)) return;
+    const bool bp = clean_by_product(B);
     uint64_t direct = 0, diff = 0;
     for (uint32_t r0 = blockIdx.x * blockDim.x; r0 < B.n; r0 += gsize()) {
         const uint32_t r = r0 + threadIdx.x;
@@ -149,18 +196,34 @@ TGSF_KERNEL k_clean_plan(DevParams P, DevBatch B)
         if (f1 > B.fcap) f1 = B.fcap;
         uint64_t kept = 0;
         bool whole = false;
+        uint32_t hs = 0, he = L;                       // what the clean tables hold of this read if it is `whole`
+        if (bp) held_range(P, B, r, hs, he);
         for (uint32_t f = f0; f < f1; f++) {
             if (B.frag_flags[f] & TGSF_FF_REPEAT) continue;
             kept += B.frag_len[f];
-            whole = (f1 - f0 == 1) && B.frag_len[f] == L && B.frag_start[f] == 0;
+            whole = (f1 - f0 == 1) && he > hs && B.frag_len[f] == he - hs && (uint32_t)B.frag_start[f] == hs;
         }
         if (L == 0 || P.only_qc) whole = false;
         B.whole[r] = whole ? 1u : 0u;
         direct += kept;
-        if (!whole) diff += kept + L;
+        if (!whole) diff += kept + (he > hs ? he - hs : 0u);
     }
     wave_add_u64(&B.plan[2], direct);
     wave_add_u64(&B.plan[3], diff);
+}
+
+// How the batch's speculation fared decides whether the next batch of this context speculates: the bases scanned a second
+// time (ranges taken back out + the real fragments of those reads) against what scanning every fragment would have cost.
+// (A batch that did not speculate tries again after a while: plan[1] counts them.)
+TGSF_KERNEL k_clean_plan_next(DevBatch B)
+{
+    if (gtid() != 0 || !B.bp_allowed || B.clean_force) return;
+    if (pool_overflowed(B)) return;
+    if (clean_by_product(B)) {
+        const uint64_t direct = B.plan[2], again = B.plan[3];
+        B.bp_state[0] = (2 * again <= direct) ? 1u : 0u;
+        B.bp_state[2] = 0;
+    } else if (++B.bp_state[2] >= 16u) { B.bp_state[0] = 1u; B.bp_state[2] = 0; }     // (inputs change: look again now and then)
 }
 
 // ctr tables += this batch's raw tallies (rows the batch reached only).  The CLEAN instance is the
@@ -171,7 +234,7 @@ TGSF_KERNEL k_fold_raw(DevParams P, DevBatch B)
     // (the clean instance runs behind the middle scan: a batch whose candidate pool overflowed is left alone, but the
     // batch's table is still handed back empty -- the next batch's raw pass adds to it, and the second run of this one)
     const bool left_alone = CLEAN && pool_overflowed(B);
-    const bool add = !left_alone && (!CLEAN || clean_by_difference(B));
+    const bool add = !left_alone && (!CLEAN || (clean_by_difference(B) && !clean_by_product(B)));   // (by-product: the raw pass put them there itself)
     uint64_t rows = B.plan[0];
     if (rows > P.n_bins) rows = P.n_bins;
     const size_t nw = (size_t)rows * 5, stride = (size_t)P.n_bins * 5;
@@ -203,7 +266,7 @@ TGSF_KERNEL k_frag_prepare(DevParams P, DevBatch B)
             uint32_t rw = B.frag_len[i] / kBin + 1;
             rows = rw > rows ? rw : rows;
         }
-        const uint32_t L = stats_item_len<true>(B, item, diff);
+        const uint32_t L = stats_item_len<true>(P, B, item, diff);
         if (!L) continue;
         const uint32_t v = (L + kTileBases - 1) / kTileBases;
         if (use_lds) atomicAdd(&h[v], 1u); else atomicAdd(&B.tile_hist[v], 1u);
@@ -256,7 +319,7 @@ TGSF_KERNEL k_tile_scan(DevBatch B)
 }
 
 template <bool CLEAN>
-TGSF_KERNEL k_tile_scatter(DevBatch B)
+TGSF_KERNEL k_tile_scatter(DevParams P, DevBatch B)
 {
     if (CLEAN && pool_overflowed(B)) return;
     TGSF_SHARED uint32_t h[kHistLds];
@@ -273,7 +336,7 @@ TGSF_KERNEL k_tile_scatter(DevBatch B)
         uint32_t L = 0, v = 0, local = 0, item = 0;
         if (i < n) {
             item = CLEAN ? clean_item(B, i, nf) : i;
-            L = stats_item_len<CLEAN>(B, item, diff);
+            L = stats_item_len<CLEAN>(P, B, item, diff);
             v = (L + kTileBases - 1) / kTileBases;
             if (L && use_lds) local = atomicAdd(&h[v], 1u);
         }
@@ -308,25 +371,34 @@ TGSF_KERNEL k_tile_scatter(DevBatch B)
 // ---------------------------------------------------------------------------
 constexpr int kStatsWaves = 4;
 constexpr int kTileChunks = kTileBases / 16 + 2;   // +1 misalignment, +1 zero guard
+constexpr int kTileChunksBP = (kTileBases + kBpExtra) / 16 + 2;   // a speculating batch's raw pass: kBpExtra bytes beyond the tile
 constexpr int kLaneChunks = (kTileChunks + 63) / 64;   // 16-byte chunks a lane stages per stream
+static_assert((kTileChunksBP + 63) / 64 == kLaneChunks, "the few chunks beyond a tile cost no further staging register");
 
 // work[2w] = { seq address lo, hi, bases | tile << 13, item },  work[2w+1] = { qual address lo, hi, 0, 0 }
-template <bool CLEAN>
-TGSF_KERNEL k_build_work(DevBatch B)
+// (BP: the raw pass of a speculating batch: a tile is staged with up to kBpExtra bytes of the read beyond it, which the
+// clean bins -- shifted by head_trim against the raw ones -- of the tile's last lanes reach into)
+template <bool CLEAN, bool BP = false>
+TGSF_KERNEL k_build_work(DevParams P, DevBatch B)
 {
     if (CLEAN && pool_overflowed(B)) return;
     const uint32_t mt = B.max_tiles;
     const uint32_t W = B.tile_base[mt + 1];
+    const bool diff = CLEAN && clean_by_difference(B);
+    (void)diff;
     for (uint32_t w = gtid(); w < W && w < B.work_cap; w += gsize()) {
         const uint32_t t = find_owner(B.tile_base, mt + 1, w);
         const uint32_t item = B.perm[w - B.tile_base[t]];
         const bool frag = CLEAN && item < B.fcap;
         const uint32_t rd = CLEAN ? item - B.fcap : item;
-        const uint32_t L = frag ? B.frag_len[item] : B.len[rd];
-        const uint64_t a0 = (frag ? B.frag_off[item] : B.off[rd]) + (uint64_t)t * kTileBases;
+        uint32_t hs = 0, he = frag ? 0u : B.len[rd];                   // a read taken back out: the range the tables hold of it
+        if (CLEAN && !frag) held_range(P, B, rd, hs, he);
+        const uint32_t L = frag ? B.frag_len[item] : he - hs;
+        const uint64_t a0 = (frag ? B.frag_off[item] : B.off[rd] + hs) + (uint64_t)t * kTileBases;
         uint32_t nb = L - t * kTileBases;
-        if (nb > (uint32_t)kTileBases) nb = kTileBases;
-        const uint64_t aq = (frag ? B.frag_qoff[item] : B.qoff[rd]) + (uint64_t)t * kTileBases;
+        const uint32_t most = BP ? (uint32_t)(kTileBases + kBpExtra) : (uint32_t)kTileBases;
+        if (nb > most) nb = most;
+        const uint64_t aq = (frag ? B.frag_qoff[item] : B.qoff[rd] + hs) + (uint64_t)t * kTileBases;
         uint4 e, q;
         e.x = (uint32_t)a0; e.y = (uint32_t)(a0 >> 32); e.z = nb | (t << 13); e.w = item;
         q.x = (uint32_t)aq; q.y = (uint32_t)(aq >> 32); q.z = 0; q.w = 0;
@@ -339,11 +411,16 @@ TGSF_KERNEL k_build_work(DevBatch B)
 // (the 14 staging registers per stream plus the work-list words spill at the default 128).
 // NT: the text is fetched with non-temporal loads (each byte is wanted once by this kernel; what the later kernels of the
 // batch re-read has long left the caches by then: a batch is GBs, the caches are MBs)
-template <bool CLEAN, bool NT = false>
+// BP (raw pass only): the clean tables as a by-product (DevBatch::spec).  A read the batch speculates on has, for every
+// clean bin j, the bytes [head_trim + 100 j, ...) of the read tallied into clean row j: in tile coordinates that is the
+// lane's raw bin shifted by b = head_trim mod 100 bytes (and by q = head_trim / 100 rows) -- the same 100 bytes of LDS
+// reads and the same SWAR column a second time, into a second set of ten tallies, while the tile is there anyway.
+template <bool CLEAN, bool NT = false, bool BP = false>
 TGSF_KERNEL TGSF_BOUNDS(256, 3) k_stats(DevParams P, DevBatch B)
 {
+    static_assert(!(CLEAN && BP), "the by-product belongs to the raw pass");
     if (CLEAN && pool_overflowed(B)) return;
-    TGSF_SHARED uint4 lds[kStatsWaves][2][kTileChunks];
+    TGSF_SHARED uint4 lds[kStatsWaves][2][BP ? kTileChunksBP : kTileChunks];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t gw = blockIdx.x * kStatsWaves + wave, nw = gridDim.x * kStatsWaves;
     const uint32_t mt = B.max_tiles;
@@ -363,7 +440,13 @@ TGSF_KERNEL TGSF_BOUNDS(256, 3) k_stats(DevParams P, DevBatch B)
     bool neg = false;                                  // accumulated tallies are to be taken OUT of the tables
     const QcConsts kc = qc_consts();
 
-    uint32_t cnt[4] = {0, 0, 0, 0}, qs[5] = {0, 0, 0, 0, 0}, call = 0, since = 0, qor = 0;
+    uint32_t cnt[4] = {0, 0, 0, 0}, qs[5] = {0, 0, 0, 0, 0}, call = 0, since = 0;
+    // (BP) the clean bins' tallies, rows shifted by bp_q against this lane's raw row
+    uint32_t ccnt[4] = {0, 0, 0, 0}, cqs[5] = {0, 0, 0, 0, 0}, ccall = 0;
+    const uint32_t bp_b = BP ? (uint32_t)P.head_trim % (uint32_t)kBin : 0u, bp_q = BP ? (uint32_t)P.head_trim / (uint32_t)kBin : 0u;
+    uint64_t* ctab_q = B.ctr + ctr_bin_table(TGSF_B_CLEAN_QUAL, P.bc_len, P.n_bins);
+    uint64_t* ctab_c = B.ctr + ctr_bin_table(TGSF_B_CLEAN_CNT, P.bc_len, P.n_bins);
+    (void)ccall; (void)ctab_q; (void)ctab_c; (void)bp_b; (void)bp_q;
     uint32_t t_acc = 0xFFFFFFFFu;
     uint32_t* S = reinterpret_cast<uint32_t*>(&lds[wave][0][0]);
     uint32_t* Qd = reinterpret_cast<uint32_t*>(&lds[wave][1][0]);
@@ -386,6 +469,23 @@ TGSF_KERNEL TGSF_BOUNDS(256, 3) k_stats(DevParams P, DevBatch B)
         cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0;
         qs[0] = qs[1] = qs[2] = qs[3] = qs[4] = 0;
         call = 0; since = 0;
+        if (BP) {
+            // (a second run of the batch after a pool overflow: its first run has put these there already)
+            if (ccall && !B.replay) {
+                const size_t row = ((size_t)tt * kTileBins + lane - bp_q) * 5;      // (ccall > 0: the row is not negative)
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    if (ccnt[c]) {
+                        atomicAdd((ull*)&ctab_c[row + c], (ull)ccnt[c]);
+                        atomicAdd((ull*)&ctab_q[row + c], (ull)((int64_t)(cqs[c] >> 7) - qt * (int64_t)ccnt[c]));
+                    }
+                atomicAdd((ull*)&ctab_c[row + 4], (ull)ccall);
+                atomicAdd((ull*)&ctab_q[row + 4], (ull)((int64_t)cqs[4] - qt * (int64_t)ccall));
+            }
+            ccnt[0] = ccnt[1] = ccnt[2] = ccnt[3] = 0;
+            cqs[0] = cqs[1] = cqs[2] = cqs[3] = cqs[4] = 0;
+            ccall = 0;
+        }
     };
 
     // register staging of one tile: chunk c = lane + 64*k of each stream.  The two streams may sit at
@@ -495,18 +595,17 @@ TGSF_KERNEL TGSF_BOUNDS(256, 3) k_stats(DevParams P, DevBatch B)
             const uint64_t ca0 = a0, caq = aq; const uint32_t cnb = nb, ctt = tt, citem = item;
             if (i + 1 < ng) { entry(i + 1, a0, aq, nb, tt, item); issue(a0, aq, nb); }   // in flight during the reduce
             const bool ineg = CLEAN && citem >= B.fcap;         // a read being taken back out
-            if (ctt != t_acc || ineg != neg || since >= 2048) { // qs[c] carries 128*sum: stay below 2^32
+            if (ctt != t_acc || ineg != neg || since >= 1024) { // qs[c] carries 128*sum of bytes up to 255: stay below 2^32
                 if (t_acc != 0xFFFFFFFFu) flush(t_acc);
                 t_acc = ctt;
                 neg = ineg;
             }
             ++since;
-            const int nvalid = (int)cnb - (int)lane * kBin;     // bases of this lane's bin in the tile
-            const uint32_t q4_before = qs[4];
-            int nv = 0;
-            if (nvalid > 0) {
-                nv = nvalid > kBin ? kBin : nvalid;
-                const uint32_t bos = (uint32_t)(ca0 & 15u) + lane * kBin, boq = (uint32_t)(caq & 15u) + lane * kBin;
+            // nv bytes of the tile from byte `at` on (a lane's 100-base bin, or less at an item's end) into ten tallies;
+            // returns the OR of the quality dwords
+            auto bin = [&](uint32_t at, int nv, uint32_t* cn, uint32_t* qv) TGSF_INLINE_LAMBDA -> uint32_t {
+                uint32_t qor = 0;
+                const uint32_t bos = (uint32_t)(ca0 & 15u) + at, boq = (uint32_t)(caq & 15u) + at;
                 const uint32_t ds = bos >> 2, bss = bos & 3u, dq = boq >> 2, bsq = boq & 3u;
                 const int ndw = (nv + 3) >> 2;
                 // A full bin (every tile but an item's last) runs a fixed 25 dwords, unrolled by 5: LDS reads
@@ -517,13 +616,17 @@ TGSF_KERNEL TGSF_BOUNDS(256, 3) k_stats(DevParams P, DevBatch B)
                         for (int k = 0; k < kBin / 4; k++) {
                             const uint32_t q = Qd[dq + k];
                             qor |= q;
-                            qc_accum4(kc, S[ds + k], q, cnt, qs);
+                            qc_accum4(kc, S[ds + k], q, cn, qv);
                         }
                     } else {
                         for (int k = 0; k < ndw; k++) {
-                            const uint32_t q = Qd[dq + k];
+                            uint32_t q = Qd[dq + k], sv = S[ds + k];
+                            if (BP && k == ndw - 1 && (nv & 3)) {           // (a clean bin may end inside the read: bytes follow it)
+                                const uint32_t m = (1u << (8 * (nv & 3))) - 1u;
+                                q &= m; sv &= m;
+                            }
                             qor |= q;
-                            qc_accum4(kc, S[ds + k], q, cnt, qs);
+                            qc_accum4(kc, sv, q, cn, qv);
                         }
                     }
                 } else {
@@ -535,29 +638,88 @@ TGSF_KERNEL TGSF_BOUNDS(256, 3) k_stats(DevParams P, DevBatch B)
                             const uint32_t shi = S[ds + k + 1], qhi = Qd[dq + k + 1];
                             const uint32_t q = alignbyte(qhi, qlo, bsq);
                             qor |= q;
-                            qc_accum4(kc, alignbyte(shi, slo, bss), q, cnt, qs);
+                            qc_accum4(kc, alignbyte(shi, slo, bss), q, cn, qv);
                             slo = shi; qlo = qhi;
                         }
                     } else {
                         for (int k = 0; k < ndw; k++) {
                             const uint32_t shi = S[ds + k + 1], qhi = Qd[dq + k + 1];
-                            const uint32_t q = alignbyte(qhi, qlo, bsq);
+                            uint32_t q = alignbyte(qhi, qlo, bsq), sv = alignbyte(shi, slo, bss);
+                            if (BP && k == ndw - 1 && (nv & 3)) {           // (a clean bin may end inside the read: bytes follow it)
+                                const uint32_t m = (1u << (8 * (nv & 3))) - 1u;
+                                q &= m; sv &= m;
+                            }
                             qor |= q;
-                            qc_accum4(kc, alignbyte(shi, slo, bss), q, cnt, qs);
+                            qc_accum4(kc, sv, q, cn, qv);
                             slo = shi; qlo = qhi;
                         }
                     }
                 }
+                return qor;
+            };
+            // Quality bytes of 128 and above: the reference computes `qual[i] - qType` on a (signed) char
+            // (src/TGSFilter.cpp:1455-1457), so such a byte stands for its value - 256.  The tallies took every byte as
+            // unsigned (v_dot4_u32_u8); a bin that holds such bytes -- none in real data -- is put right on the spot: 256 per
+            // high byte goes back out of the bin's row, class by class (sign: +1 where the tallies are being taken out).
+            // Returns the number of high bytes (for the item's sum).
+            auto high_bytes = [&](uint32_t at, int nv, uint64_t* tq, size_t row, bool minus) -> int32_t {
+                const uint32_t bos = (uint32_t)(ca0 & 15u) + at, boq = (uint32_t)(caq & 15u) + at;
+                const uint32_t ds = bos >> 2, bss = bos & 3u, dq = boq >> 2, bsq = boq & 3u;
+                uint32_t hc[4] = {0, 0, 0, 0}, hq[5] = {0, 0, 0, 0, 0};
+                for (int k = 0; k < ((nv + 3) >> 2); k++) {
+                    uint32_t q = alignbyte(Qd[dq + k + 1], Qd[dq + k], bsq) & 0x80808080u;
+                    if (k == ((nv + 3) >> 2) - 1 && (nv & 3)) q &= (1u << (8 * (nv & 3))) - 1u;
+                    qc_accum4(kc, alignbyte(S[ds + k + 1], S[ds + k], bss), q >> 7, hc, hq);      // (a "quality" of 1 per high byte)
+                }
+#pragma unroll
+                for (int c = 0; c < 5; c++) {
+                    const int64_t d = 256 * (int64_t)(c < 4 ? (hq[c] >> 7) : hq[4]);
+                    if (d && tq) atomicAdd((ull*)&tq[row + c], (ull)(minus ? d : -d));
+                }
+                return (int32_t)hq[4];
+            };
+            const uint32_t raw_nb = BP && cnb > (uint32_t)kTileBases ? (uint32_t)kTileBases : cnb;   // (BP: the tile is staged with bytes beyond it)
+            const int nvalid = (int)raw_nb - (int)lane * kBin;  // bases of this lane's bin in the tile
+            const uint32_t q4_before = qs[4];
+            int nv = 0;
+            uint32_t qor = 0;                                   // OR of this bin's quality dwords
+            if (nvalid > 0) {
+                nv = nvalid > kBin ? kBin : nvalid;
+                qor = bin(lane * kBin, nv, cnt, qs);
                 call += (uint32_t)nv;
             }
+            int32_t high_all = 0;
+            if (wave_or(qor & 0x80808080u) && nv > 0 && (qor & 0x80808080u))
+                high_all = high_bytes(lane * kBin, nv, tab_q, ((size_t)ctt * kTileBins + lane) * 5, ineg);
             // sumQ of the item: sum over the tile of (qual - qType), two's complement in u64 (:1457-1458)
-            const int32_t part = (int32_t)(qs[4] - q4_before) - (int32_t)qt * nv;
+            const int32_t part = (int32_t)(qs[4] - q4_before) - (int32_t)qt * nv - 256 * high_all;
             const int32_t tot = wave_sum_i32(part);
+            if (BP) {
+                // the clean bin of this lane: row j of the speculated fragment [head_trim, L - tail_trim) of the read
+                const uint32_t sp = B.spec[citem];              // (wave-uniform)
+                if (sp) {
+                    const int64_t j = (int64_t)ctt * kTileBins + lane - bp_q;
+                    const int64_t keep = (int64_t)B.len[citem] - P.head_trim - P.tail_trim;
+                    int cnv = 0;
+                    if (j >= 0 && j * kBin < keep) cnv = (int)(keep - j * kBin > kBin ? kBin : keep - j * kBin);
+                    const uint32_t c4_before = cqs[4];
+                    uint32_t cqor = 0;
+                    if (cnv > 0) {
+                        cqor = bin(lane * kBin + bp_b, cnv, ccnt, cqs);
+                        ccall += (uint32_t)cnv;
+                    }
+                    int32_t chigh = 0;
+                    if (wave_or(cqor & 0x80808080u) && cnv > 0 && (cqor & 0x80808080u))
+                        chigh = high_bytes(lane * kBin + bp_b, cnv, B.replay ? nullptr : ctab_q, (size_t)(j > 0 ? j : 0) * 5, false);
+                    const int32_t cpart = (int32_t)(cqs[4] - c4_before) - (int32_t)qt * cnv - 256 * chigh;
+                    const int32_t ctot = wave_sum_i32(cpart);
+                    if (wave_leader()) atomicAdd((ull*)&B.spec_sum[citem], (ull)(int64_t)ctot);
+                }
+            }
             if (!ineg && wave_leader()) atomicAdd((ull*)&it_sum[citem], (ull)(int64_t)tot);
         }
     }
     if (t_acc != 0xFFFFFFFFu) flush(t_acc);
-    if (wave_or(qor & 0x80808080u) && wave_leader()) set_status(B, DS_BAD_QUAL, 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -688,6 +850,7 @@ TGSF_KERNEL k_end_tables(DevParams P, DevBatch B, uint32_t slab)
         int c = base_col(b);
         // count-only variants as coded: 'g' is not a G at the 5' end (:1629), 't' is not a T at the 3' end (:1667)
         if (P.no_qual && b == (e ? (uint32_t)'t' : (uint32_t)'g')) c = 4;
+        if (q & 0x80u) q -= 256u;      // `qual[i] - qType` on a signed char (:1508): a byte of 128 and above stands for its value - 256
         if (c < 4) { atomicAdd(&acc[e][s][c][lane], 1u); atomicAdd(&acc[e][s][5 + c][lane], q); }
         atomicAdd(&acc[e][s][4][lane], 1u); atomicAdd(&acc[e][s][9][lane], q);
     };
@@ -731,7 +894,7 @@ TGSF_KERNEL k_end_tables(DevParams P, DevBatch B, uint32_t slab)
         uint64_t* tq = B.ctr + ctr_end_table((CLEAN ? 4 : 0) + (e ? 2 : 0), P.bc_len);
         uint64_t* tc = B.ctr + ctr_end_table((CLEAN ? 4 : 0) + (e ? 2 : 0) + 1, P.bc_len);
         atomicAdd((ull*)&tc[(size_t)p * 5 + c], (ull)cn);
-        atomicAdd((ull*)&tq[(size_t)p * 5 + c], (ull)((int64_t)acc[e][s][5 + c][ln] - qt * (int64_t)cn));
+        atomicAdd((ull*)&tq[(size_t)p * 5 + c], (ull)((int64_t)(int32_t)acc[e][s][5 + c][ln] - qt * (int64_t)cn));   // (a signed sum: see add)
     }
 }
 
@@ -2662,7 +2825,7 @@ TGSF_KERNEL k_gate_frags(DevParams P, DevBatch B)
         const uint32_t f = f0 + threadIdx.x;
         if (f >= nf || (B.frag_flags[f] & TGSF_FF_REPEAT)) continue;
         const uint32_t L = B.frag_len[f];
-        if (diff && B.whole[B.frag_read[f]]) B.frag_sum[f] = B.sumq[B.frag_read[f]];   // not re-scanned
+        if (diff && B.whole[B.frag_read[f]]) B.frag_sum[f] = clean_by_product(B) ? B.spec_sum[B.frag_read[f]] : B.sumq[B.frag_read[f]];   // not re-scanned
         const double cm = mean_q(B.frag_sum[f], L);
         if (!P.no_qual) {                                                 // :1992 rawQualLen > 0
             if (P.filter && q_fail(cm, P.min_q, P.max_q)) { lq_n++; lq_b += L; continue; }

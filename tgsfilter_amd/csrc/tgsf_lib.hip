@@ -96,6 +96,7 @@ struct tgsf_ctx {
     Pending pending[TGSF_MAX_ENQUEUED];
     uint32_t n_pending = 0;
     uint32_t* ovf_ring = nullptr;          // [TGSF_MAX_ENQUEUED] device words, one per enqueued batch
+    uint32_t* bp_ring = nullptr;           // [TGSF_MAX_ENQUEUED] ... and whether that batch speculated (DevBatch::bp_used)
     uint32_t h_ovf[TGSF_MAX_ENQUEUED];
     uint32_t pool_regrown = 0;            // times the pool had to grow (tests look at it through tgsf_last_error's sibling below)
 
@@ -310,6 +311,11 @@ extern "C" const char* tgsf_last_error(tgsf_ctx* ctx) { return ctx ? ctx->error.
 extern "C" void tgsf_destroy(tgsf_ctx* c)
 {
     if (!c) return;
+    if (c->B.bp_allowed && c->B.bp_state && getenv("TGSF_TRACE_BP")) {     // how often the clean tables came as a by-product
+        uint32_t w[4] = {0, 0, 0, 0};
+        if (!rt_d2h(w, c->B.bp_state, sizeof w, c->stream) && !rt_sync(c->stream))
+            fprintf(stderr, "tgsf: clean tables as a by-product of the raw pass: %u batches speculated; the next would%s\n", w[1], w[0] ? "" : " not");
+    }
 #if !defined(TGSF_EMUL)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
@@ -561,9 +567,22 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     if (!e) e = dev_alloc(c, &B.whole, n);
     if (!e) e = dev_alloc(c, &B.plan, 4);
     B.clean_force = p->only_qc ? 1u : 0u;
-    if (const char* f = getenv("TGSF_CLEAN_TABLES")) {      // test knob: "direct" | "difference"
-        if (!strcmp(f, "direct")) B.clean_force = 1;
-        else if (!strcmp(f, "difference") && !p->only_qc) B.clean_force = 2;
+    // the clean tables as a by-product of the raw pass (DevBatch::spec): a filtering run with fixed trims in front of the
+    // keep region (without trims a read kept whole is what the difference strategy handles already) and no repeat gate
+    // (its verdict comes after the raw pass); the work list words hold a staged length of 13 bits
+    B.bp_allowed = (p->filter && !p->only_qc && p->min_repeat <= 0 && (p->head_trim > 0 || p->tail_trim > 0) &&
+                    p->head_trim >= 0 && p->tail_trim >= 0) ? 1u : 0u;
+    static_assert(kTileBases + kBpExtra < (1 << 13), "staged bytes of a tile fit the work list's 13 bits");
+    if (const char* f = getenv("TGSF_CLEAN_TABLES")) {      // test knob: "direct" | "difference" | "byproduct" (always speculate)
+        if (!strcmp(f, "direct")) { B.clean_force = 1; B.bp_allowed = 0; }
+        else if (!strcmp(f, "difference") && !p->only_qc) { B.clean_force = 2; B.bp_allowed = 0; }
+        else if (!strcmp(f, "byproduct") && B.bp_allowed) B.clean_force = 3;      // (k_clean_plan_next leaves bp_state alone)
+    }
+    if (B.bp_allowed) {
+        if (!e) e = dev_alloc(c, &B.spec, n);
+        if (!e) e = dev_alloc(c, &B.spec_sum, n);
+        if (!e) e = dev_alloc(c, &B.bp_state, 4);
+        if (!e) e = dev_alloc(c, &c->bp_ring, TGSF_MAX_ENQUEUED);
     }
     {
         // traceback scratch: a window of the first location spans at most Q + k columns
@@ -593,6 +612,12 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     rt_memset(B.status, 0, 16, c->stream);
     rt_memset(c->ovf_ring, 0, TGSF_MAX_ENQUEUED * 4, c->stream);
     B.ovf = c->ovf_ring;
+    if (B.bp_allowed) {
+        const uint32_t init[4] = {1u, 0u, 0u, 0u};          // the first batch speculates
+        rt_memset(c->bp_ring, 0, TGSF_MAX_ENQUEUED * 4, c->stream);
+        (void)rt_h2d(B.bp_state, init, sizeof init, c->stream);
+        B.bp_used = c->bp_ring;
+    }
     rt_memset(B.raw_tab, 0, 2 * (size_t)c->n_bins * 5 * 8, c->stream);
     rt_sync(c->stream);
     *out = c;
@@ -661,6 +686,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     (void)profile;
     DevBatch B = c->B;
     B.ovf = c->ovf_ring + slot;
+    B.bp_used = c->bp_ring + slot;
     B.replay = redo ? 1u : 0u;
     const DevParams& P = c->P;
     B.seq = in->seq; B.qual = in->qual; B.off = in->offsets; B.len_in = in->lengths;
@@ -708,14 +734,20 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     rt_memset(B.plan, 0, 32, st);
     TGSF_LAUNCH(k_prepare, gsmall, T, st, P, B, c->max_read_len);
     TGSF_LAUNCH_COOP(k_tile_scan, 1, 64, st, B);       // a few hundred buckets: one wave
-    TGSF_LAUNCH(k_tile_scatter<false>, gsmall, T, st, B);
-    TGSF_LAUNCH(k_build_work<false>, gwork, T, st, B);
+    TGSF_LAUNCH(k_tile_scatter<false>, gsmall, T, st, P, B);
+    if (B.bp_allowed) TGSF_LAUNCH((k_build_work<false, true>), gwork, T, st, P, B);
+    else TGSF_LAUNCH((k_build_work<false, false>), gwork, T, st, P, B);
     STAGE_MARK();
     // -- raw stats
 #if !defined(TGSF_EMUL)
     if (c->hp) { (void)hipEventRecord(c->ev_hp[0], st); (void)hipStreamWaitEvent(ss, c->ev_hp[0], 0); }
 #endif
-    if (c->stats_nt) TGSF_LAUNCH((k_stats<false, true>), gstats, 64 * kStatsWaves, ss, P, B);
+    // (a context that may speculate -- DevBatch::spec -- runs the variant of the raw pass that tallies the clean bins too)
+    if (B.bp_allowed) {
+        if (c->stats_nt) TGSF_LAUNCH((k_stats<false, true, true>), gstats, 64 * kStatsWaves, ss, P, B);
+        else TGSF_LAUNCH((k_stats<false, false, true>), gstats, 64 * kStatsWaves, ss, P, B);
+    }
+    else if (c->stats_nt) TGSF_LAUNCH((k_stats<false, true>), gstats, 64 * kStatsWaves, ss, P, B);
     else TGSF_LAUNCH((k_stats<false, false>), gstats, 64 * kStatsWaves, ss, P, B);
 #if !defined(TGSF_EMUL)
     if (c->hp) { (void)hipEventRecord(c->ev_hp[1], ss); (void)hipStreamWaitEvent(st, c->ev_hp[1], 0); }
@@ -953,11 +985,12 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     rt_memset(B.tile_fill, 0, tl, st);
     const unsigned gfr = grid_cap(std::min(blocks_for((uint64_t)B.fcap + n, T), 2048u));
     TGSF_LAUNCH(k_clean_plan, gsmall, T, st, P, B);
+    if (B.bp_allowed && !redo) TGSF_LAUNCH(k_clean_plan_next, 1, 64, st, B);
     TGSF_LAUNCH(k_fold_raw<true>, gfold, T, st, P, B);
     TGSF_LAUNCH(k_frag_prepare, gfr, T, st, P, B);
     TGSF_LAUNCH_COOP(k_tile_scan, 1, 64, st, B);       // a few hundred buckets: one wave
-    TGSF_LAUNCH(k_tile_scatter<true>, gfr, T, st, B);
-    TGSF_LAUNCH(k_build_work<true>, gwork, T, st, B);
+    TGSF_LAUNCH(k_tile_scatter<true>, gfr, T, st, P, B);
+    TGSF_LAUNCH((k_build_work<true, false>), gwork, T, st, P, B);
 #if !defined(TGSF_EMUL)
     if (c->hp) { (void)hipEventRecord(c->ev_hp[0], st); (void)hipStreamWaitEvent(ss, c->ev_hp[0], 0); }
 #endif
