@@ -248,7 +248,8 @@ int tgsf_submit_async(tgsf_ctx* ctx, const tgsf_batch_in* in, tgsf_batch_out* ou
  * *d_n_frags (device uint32) if that pointer is non-NULL.
  *
  * Several batches may be enqueued one after the other (up to TGSF_MAX_ENQUEUED; one more makes the call wait for
- * the earlier ones).  A batch's results and its share of the tallies are FINAL ONLY WHEN tgsf_wait(ctx) HAS RETURNED,
+ * the whole device and close the books of the earlier ones -- which fails with TGSF_E_INVALID if one of them has to be
+ * run again, see below: only tgsf_wait does that, so call it at least every TGSF_MAX_ENQUEUED batches).  A batch's results and its share of the tallies are FINAL ONLY WHEN tgsf_wait(ctx) HAS RETURNED,
  * and every buffer `in` and `out` point to must stay valid and untouched until then: a batch whose middle-adapter
  * candidates outgrow the context's pool (a read whose best alignment is tied column after column: every tied column is
  * a location, include/edlib.cpp:660-672) is left alone by its first run and run again, from its inputs, inside

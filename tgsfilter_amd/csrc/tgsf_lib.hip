@@ -666,7 +666,7 @@ static void scan_u32(const DevBatch& B, uint32_t* a, uint32_t n, rt_stream st, u
     TGSF_LAUNCH_COOP(k_scan_add, nb, 256, st, a, n, (const uint32_t*)part);
 }
 
-static int drain_pending(tgsf_ctx* c);
+static int drain_pending(tgsf_ctx* c, bool implicit = false);
 
 // redo = false: the whole pipeline of one batch, enqueued without a host round trip.
 // redo = true (from tgsf_wait, a batch whose candidate pool overflowed, run again from its inputs): the kernels in front
@@ -677,7 +677,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
                         uint32_t out_fcap, uint32_t* d_nfrags, rt_stream st, bool redo = false, uint32_t slot = 0)
 {
     if (!redo) {
-        if (c->n_pending == TGSF_MAX_ENQUEUED) { int e = drain_pending(c); if (e) return e; }
+        if (c->n_pending == TGSF_MAX_ENQUEUED) { int e = drain_pending(c, true); if (e) return e; }
         slot = c->n_pending++;
         tgsf_ctx::Pending& pd = c->pending[slot];
         pd.in = *in; pd.reads = d_reads; pd.frags = d_frags; pd.fcap = out_fcap; pd.nfrags = d_nfrags; pd.st = st;
@@ -795,7 +795,12 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
                 const uint64_t tb = std::min<uint64_t>(in->n_bytes / 16u + (uint64_t)n, c->cap_bases / 16u + c->cap_reads);
                 flat_chunks = tb;
                 flat_schedule((uint32_t)tb, B.flat_pmax, B.flat_pmin, B.flat_f0, S);
-                gflat = grid_cap(blocks_for((uint64_t)S.d0[S.nph] + 64u * 8u, T));   // (phase ends round up to whole groups)
+                // The batch's real chunk count T' <= tb is on the device.  The number of stretches is not monotonic in it: a group
+                // of 64 long stretches that a slightly smaller T' no longer fills falls to later phases of shorter stretches
+                // (measured over all T' <= 200 000 and samples up to 30 M: at most 640 more than at tb for 256/16-chunk
+                // stretches) -- room for one group of the longest stretches dealt as the shortest, twice; a lane beyond the
+                // schedule's end exits at once, and the kernel strides by its grid should a schedule ever outgrow this.
+                gflat = grid_cap(blocks_for((uint64_t)S.d0[S.nph] + 128ull * (B.flat_pmax / B.flat_pmin) + 512u, T));
             }
         }
         // upper bound of the segment count, known on the host: no device round trip
@@ -1086,7 +1091,11 @@ static int finish_pending(tgsf_ctx* c)
 // Everything enqueued on the context completes: the streams are drained, the device's status words looked at, and
 // every batch whose candidate pool overflowed (a read whose minimum is tied column after column, e.g. a homopolymer
 // against a homopolymer adapter: nothing behind its middle scan has touched it) is run again from its inputs.
-static int drain_pending(tgsf_ctx* c)
+// implicit: not from tgsf_wait but from the submit that found TGSF_MAX_ENQUEUED batches enqueued.  The streams and buffers of
+// those batches are the caller's, and only tgsf_wait is documented as the point up to which they must stay alive: here the
+// whole device is waited for instead of the saved stream handles (a destroyed stream is no valid handle), and a batch that
+// would have to be run again from its inputs (a pool overflow) is an error -- its inputs may be gone -- that says what to do.
+static int drain_pending(tgsf_ctx* c, bool implicit)
 {
     int e = 0;
     const uint32_t np = c->n_pending;
@@ -1094,7 +1103,8 @@ static int drain_pending(tgsf_ctx* c)
     // batches enqueued with tgsf_submit_device run on the caller's streams (and the auxiliary one): all must be idle
     // before the status words mean anything
     (void)hipSetDevice(c->device);
-    for (uint32_t i = 0; i < np && !e; i++) {
+    if (implicit) e = (int)hipDeviceSynchronize();
+    for (uint32_t i = 0; i < np && !e && !implicit; i++) {
         bool seen = c->pending[i].st == c->stream;
         for (uint32_t j = 0; j < i && !seen; j++) seen = c->pending[j].st == c->pending[i].st;
         if (!seen) e = (int)hipStreamSynchronize(c->pending[i].st);
@@ -1110,6 +1120,11 @@ static int drain_pending(tgsf_ctx* c)
     if (e) { c->pend_out = nullptr; return e; }
     for (uint32_t i = 0; i < np; i++) {
         if (!c->h_ovf[i]) continue;
+        if (implicit) {
+            c->pend_out = nullptr;
+            return fail(c, TGSF_E_INVALID, "batch %u of the %u enqueued since the last tgsf_wait has to be run again from its inputs (its middle-adapter candidates "
+                                           "outgrew the pool) and only tgsf_wait may do that: call tgsf_wait at least every TGSF_MAX_ENQUEUED (%d) batches", i, np, TGSF_MAX_ENQUEUED);
+        }
         const tgsf_ctx::Pending pd = c->pending[i];
         e = run_pipeline(c, &pd.in, pd.reads, pd.frags, pd.fcap, pd.nfrags, pd.st, true, i);
         if (!e && c->pend_out && pd.reads == c->d_out_reads) {       // the batch of tgsf_submit_async: its copies again
