@@ -645,8 +645,12 @@ def kernel_leg(args, torch, dist, world, rank, local_rank, device, xdev, host_gr
     if args.adapters == 4:
         # distinct 5' and 3' adapters with their reverse complements: what the automatic identification hands over for a
         # ligation kit (src/TGSFilter.cpp:3105-3113) -- four independent columns a pass in the middle scan
-        wl_adapters = wl_adapters + [b"GGCGTCTGCTTGGGTGTTTAACCTTTTTGTCAGAGAGGTTCCAAGTCAGAGAGGTTCCT", b"AGGAACCTCTCTGACTTGGAACCTCTCTGACAAAAAGGTTAAACACCCAAGCAGACGCC"]
-        adapters_note += " + ONT 1D^2 (59 bp) + reverse complement"
+        # (the second pair: the first 50 bases of the ONT 1D^2 adapter and their reverse complement -- as long as the rapid
+        # adapter, so that all four are searched within the same 16 differences at the default -M 35 and share one pass of
+        # the middle scan; the whole 59-bp adapter at -M 35 is searched within 25 of 59: half of all random columns qualify,
+        # a shape of the candidate lists, not of the column)
+        wl_adapters = wl_adapters + [b"GGCGTCTGCTTGGGTGTTTAACCTTTTTGTCAGAGAGGTTCCAAGTCAGAG", synth.revcomp(b"GGCGTCTGCTTGGGTGTTTAACCTTTTTGTCAGAGAGGTTCCAAGTCAGAG")]
+        adapters_note += " + the first 50 bases of ONT 1D^2 + reverse complement"
     # every rank builds the SAME two batches (same seeds): the fixed job is steps x these batches, dealt over ranks
     batches = [gen_batch(torch, device, args.reads, b + 1, mean_len, args.max_len, args.workload) for b in range(2)]
     max_bases = max(b["bases"] for b in batches)
@@ -661,8 +665,8 @@ def kernel_leg(args, torch, dist, world, rank, local_rank, device, xdev, host_gr
         flags += " -a ligation28.fa -M 24"
         adapters_note = "ONT ligation 28 bp + reverse complement"
         if args.adapters == 4:                       # ... and the 22-bp pair beside it (-M 20: both are searched in the middle)
-            p_kwargs.update(adapters=p_kwargs["adapters"] + [b"GCAATACGTAACTGAACGAAGT", b"ACTTCGTTCAGTTACGTATTGC"], mid_match_len=20)
-            flags = flags.replace("-M 24", "-M 20").replace("ligation28.fa", "ligation28+22.fa")
+            p_kwargs.update(adapters=p_kwargs["adapters"] + [b"GCAATACGTAACTGAACGAAGT", b"ACTTCGTTCAGTTACGTATTGC"], mid_match_len=22)
+            flags = flags.replace("-M 24", "-M 22").replace("ligation28.fa", "ligation28+22.fa")
             adapters_note += " + ONT ligation 22 bp + reverse complement"
     p = abi.make_params(args.workload, max_batch_bases=max_bases + 64, max_batch_reads=args.reads, max_read_len=max_len, **p_kwargs)
     # what the PMC summaries of profiles/traffic.json are keyed by: the shape of a kernel-path step

@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The library's and the command line's test settings (TGSF_POOL_CAP, TGSF_BATCH_BYTES, TGSF_CLEAN_TABLES ...: they force rare
+# paths and small sizes) are read only under this switch -- a user's environment never changes the path a run takes.
+os.environ["TGSF_DEBUG_KNOBS"] = "1"
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

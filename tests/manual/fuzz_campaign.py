@@ -2,6 +2,7 @@
 """One-off campaign: many seeds of tests/fuzz.py (random parameter sets, the library against the oracle, every record and
 tally word).  tests/manual/fuzz_campaign.py <first> <last> <reads> [emul]   (TGSF_FUZZ_GATE_P=0.6: repeat gate in 60 % of the cases)"""
 import os
+os.environ.setdefault("TGSF_DEBUG_KNOBS", "1")      # the test settings used below are read only under this switch
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

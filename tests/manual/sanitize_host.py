@@ -3,6 +3,7 @@
 output) over the emulation library, on the goldens with the threaded / streamed / tiny-stride knobs forced.  CPU only
 (sanitizers are not available on the GPU pool).  tests/manual/sanitize_host.py"""
 import os, subprocess, sys
+os.environ.setdefault("TGSF_DEBUG_KNOBS", "1")      # the test settings used below are read only under this switch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tests import cli_check

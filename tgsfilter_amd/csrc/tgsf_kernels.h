@@ -212,18 +212,23 @@ TGSF_KERNEL k_clean_plan(DevParams P, DevBatch B)
     wave_add_u64(&B.plan[3], diff);
 }
 
-// How the batch's speculation fared decides whether the next batch of this context speculates: the bases scanned a second
-// time (ranges taken back out + the real fragments of those reads) against what scanning every fragment would have cost.
-// (A batch that did not speculate tries again after a while: plan[1] counts them.)
+// How the batch's speculation fared decides whether the next batch of this context speculates.  The by-product is not
+// free: the raw pass puts every speculated read's bytes through the SWAR column a second time (the clean bins are the raw
+// ones shifted by head_trim), which makes it VALU-bound -- measured on the C2 / C3 shapes (profiles/r05_clean_tables_ab.txt):
+// raw pass 2.1 -> 3.5 ms / 1.8 -> 3.5 ms, clean pass 1.47 -> 0.83 ms / 2.1 -> 0.37 ms.  It pays (a little: +1..4 % with three
+// batches in flight, 8 GB less fetched per batch) where nearly every read is kept as expected -- HiFi-shaped batches -- and
+// loses 8 % on C2's, where 40 % of the kept bases are looked at again anyway (adapters reaching beyond the 5' trim).  So:
+// go on only while the bases scanned a second time (ranges taken back out + the real fragments of those reads) stay
+// below a fifth of what scanning every fragment costs.  (A batch that did not speculate tries again after a while.)
 TGSF_KERNEL k_clean_plan_next(DevBatch B)
 {
     if (gtid() != 0 || !B.bp_allowed || B.clean_force) return;
     if (pool_overflowed(B)) return;
     if (clean_by_product(B)) {
         const uint64_t direct = B.plan[2], again = B.plan[3];
-        B.bp_state[0] = (2 * again <= direct) ? 1u : 0u;
+        B.bp_state[0] = (5 * again <= direct) ? 1u : 0u;
         B.bp_state[2] = 0;
-    } else if (++B.bp_state[2] >= 16u) { B.bp_state[0] = 1u; B.bp_state[2] = 0; }     // (inputs change: look again now and then)
+    } else if (++B.bp_state[2] >= 64u) { B.bp_state[0] = 1u; B.bp_state[2] = 0; }     // (inputs change: look again now and then)
 }
 
 // ctr tables += this batch's raw tallies (rows the batch reached only).  The CLEAN instance is the

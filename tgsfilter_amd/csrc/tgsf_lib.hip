@@ -32,6 +32,16 @@ using namespace tgsf;
 // ---------------------------------------------------------------------------
 static thread_local std::string g_create_error;
 
+// Test and diagnostic settings of the library (TGSF_POOL_CAP, TGSF_CLEAN_TABLES, TGSF_MID_FILTER, TGSF_FLAT_*, TGSF_TRACE_* ...:
+// each is explained where it is read) force rare paths and strategies in the tests.  They are read only when
+// TGSF_DEBUG_KNOBS=1 is in the environment -- the test suite sets it --: a stray variable in a user's environment never
+// changes the path a run takes.  The library has no other setting: everything else comes through tgsf_params.
+static const char* knob(const char* name)
+{
+    static const bool on = [] { const char* e = getenv("TGSF_DEBUG_KNOBS"); return e && e[0] == '1'; }();
+    return on ? getenv(name) : nullptr;
+}
+
 struct tgsf_ctx {
     tgsf_params params;
     std::vector<std::string> adapters;
@@ -45,13 +55,11 @@ struct tgsf_ctx {
     // capacities
     uint64_t cap_bases;
     uint32_t cap_reads, max_read_len, n_bins;
-    unsigned endtab_grid = 512;             // k_end_tables: LDS-atomic bound, 40 KB of LDS per block: two blocks per CU (128: 0.36 ms, 512: 0.19 ms)
-    unsigned stats_grid = 768, mid_grid = 0;   // tuning knobs (TGSF_STATS_GRID, TGSF_MID_GRID; 0 = one lane per segment)
-    unsigned flat_lds_pad = 0;                 // TGSF_FLAT_LDS_PAD (experiment): dynamic LDS per workgroup of k_mid_flat, to leave room on every CU
+    static constexpr unsigned endtab_grid = 512;   // k_end_tables: LDS-atomic bound, 40 KB of LDS per block: two blocks per CU (128: 0.36 ms, 512: 0.19 ms)
+    static constexpr unsigned stats_grid = 768;    // k_stats: 3 blocks (12 waves) per CU on 256 CUs, LDS-limited
     bool flat_scan = true;                    // first middle scan of a batch by k_mid_flat (TGSF_MID_FLAT=0: k_mid_scan1, as after a pool overflow)
     int suffix_filter = 2;                    // TGSF_MID_FILTER: test stride of k_mid_flat's 32-row filter for adapters of 33..64 bp at k <= kSuffixMaxK (0: off, 1, 2)
     bool no_hot32 = false;                    // TGSF_NO_HOT32=1: adapters <= 32 bp take the 64-bit column too (A/B, tests)
-    bool stats_nt = true;                     // k_stats fetches the text with non-temporal loads (2.24 -> 2.06 ms raw, 5.4 -> 5.8 TB/s; TGSF_STATS_NT=0: plain loads)
     uint64_t ctr_words;
     int scratch_cols;
     // internal input / output staging for tgsf_submit
@@ -75,9 +83,6 @@ struct tgsf_ctx {
     int prof_pending;
     hipStream_t aux;                      // end-window / end-table kernels overlap the middle scan here
     hipEvent_t ev_fork, ev_join;
-    hipStream_t hp;                       // optional high-priority stream for the HBM-bound stats kernels (TGSF_STATS_PRIO=1)
-    hipEvent_t ev_hp[2];
-    bool side_mid = false;                // TGSF_BIG_LOWPRIO=1: stats AND scan kernels on a lowest-priority side stream
     uint32_t* h_pinned = nullptr;
     static constexpr size_t kStageBytes = 32u << 20;
     uint8_t* stage[2] = {nullptr, nullptr};   // pinned staging for host batches in pageable memory (text_h2d)
@@ -311,7 +316,7 @@ extern "C" const char* tgsf_last_error(tgsf_ctx* ctx) { return ctx ? ctx->error.
 extern "C" void tgsf_destroy(tgsf_ctx* c)
 {
     if (!c) return;
-    if (c->B.bp_allowed && c->B.bp_state && getenv("TGSF_TRACE_BP")) {     // how often the clean tables came as a by-product
+    if (c->B.bp_allowed && c->B.bp_state && knob("TGSF_TRACE_BP")) {     // how often the clean tables came as a by-product
         uint32_t w[4] = {0, 0, 0, 0};
         if (!rt_d2h(w, c->B.bp_state, sizeof w, c->stream) && !rt_sync(c->stream))
             fprintf(stderr, "tgsf: clean tables as a by-product of the raw pass: %u batches speculated; the next would%s\n", w[1], w[0] ? "" : " not");
@@ -331,8 +336,6 @@ extern "C" void tgsf_destroy(tgsf_ctx* c)
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->aux) (void)hipStreamDestroy(c->aux);
-    if (c->hp) (void)hipStreamDestroy(c->hp);
-    for (int i = 0; i < 2; i++) if (c->ev_hp[i]) (void)hipEventDestroy(c->ev_hp[i]);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
 #endif
     for (void* p : c->allocs) rt_free(p);
@@ -383,7 +386,6 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     memset(c->ev, 0, sizeof c->ev);
     memset(c->ev_aux, 0, sizeof c->ev_aux);
     c->aux = nullptr; c->ev_fork = c->ev_join = nullptr;
-    c->hp = nullptr; c->ev_hp[0] = c->ev_hp[1] = nullptr;
     int ndev = 0;
     hipError_t he = hipGetDeviceCount(&ndev);
     if (he != hipSuccess || ndev <= 0) {
@@ -407,32 +409,14 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     {
         // the auxiliary stream's short kernels (end windows, end tables) run beside the middle scan, whose workgroups fill
         // every CU for a millisecond each: with a priority above the scan's they get the slots that free up first
-        // (TGSF_AUX_PRIO=0: plain stream)
-        const char* ap = getenv("TGSF_AUX_PRIO");
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);               // hi = numerically lowest = greatest priority
-        he = (ap && atoi(ap) == 0) ? hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking)
-                                   : hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, hi);
+        he = hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, hi);
     }
     if (he != hipSuccess ||
         (he = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess ||
         (he = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) {
         tgsf_destroy(c); return fail(nullptr, TGSF_E_HIP, "auxiliary stream: %s", hipGetErrorString(he));
-    }
-    {
-        const char* e1 = getenv("TGSF_STATS_PRIO");      // experiment knobs, see tools/sweep_overlap.sh
-        const char* e2 = getenv("TGSF_BIG_LOWPRIO");
-        const bool hi_stats = e1 && atoi(e1) > 0, low_big = e2 && atoi(e2) > 0;
-        if (hi_stats || low_big) {
-            int lo = 0, hi = 0;
-            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);       // hi = numerically lowest = greatest priority
-            c->side_mid = low_big;
-            if ((he = hipStreamCreateWithPriority(&c->hp, hipStreamNonBlocking, low_big ? lo : hi)) != hipSuccess ||
-                (he = hipEventCreateWithFlags(&c->ev_hp[0], hipEventDisableTiming)) != hipSuccess ||
-                (he = hipEventCreateWithFlags(&c->ev_hp[1], hipEventDisableTiming)) != hipSuccess) {
-                tgsf_destroy(c); return fail(nullptr, TGSF_E_HIP, "priority stream: %s", hipGetErrorString(he));
-            }
-        }
     }
 #else
     c->stream = nullptr; c->own_stream = false;
@@ -463,15 +447,10 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     P.n_bins = c->n_bins;
     c->ctr_words = tgsf_ctr_len(p->bc_len, c->n_bins);
     P.seg_cols = kSegCols;
-    if (const char* e = getenv("TGSF_STATS_GRID")) { int v = atoi(e); if (v >= 1 && v <= 65536) c->stats_grid = (unsigned)v; }
-    if (const char* e = getenv("TGSF_STATS_NT")) c->stats_nt = atoi(e) > 0;
-    if (const char* e = getenv("TGSF_NO_HOT32")) c->no_hot32 = atoi(e) > 0;
-    if (const char* e = getenv("TGSF_ENDTAB_GRID")) { int v = atoi(e); if (v >= 1 && v <= 4096) c->endtab_grid = (unsigned)v; }
-    if (const char* e = getenv("TGSF_MID_GRID")) { int v = atoi(e); if (v >= 1) c->mid_grid = (unsigned)v; }
-    if (const char* e = getenv("TGSF_SEG_COLS")) { int v = atoi(e); if (v >= 256 && v <= 65536) P.seg_cols = v & ~15; }   // tuning knob
-    if (const char* e = getenv("TGSF_MID_FLAT")) c->flat_scan = atoi(e) > 0;
-    if (const char* e = getenv("TGSF_MID_FILTER")) { int v = atoi(e); if (v >= 0 && v <= 2) c->suffix_filter = v; }
-    if (const char* e = getenv("TGSF_FLAT_LDS_PAD")) { int v = atoi(e); if (v >= 0 && v <= 140000) c->flat_lds_pad = (unsigned)v; }
+    if (const char* e = knob("TGSF_NO_HOT32")) c->no_hot32 = atoi(e) > 0;
+    if (const char* e = knob("TGSF_SEG_COLS")) { int v = atoi(e); if (v >= 256 && v <= 65536) P.seg_cols = v & ~15; }   // tuning knob
+    if (const char* e = knob("TGSF_MID_FLAT")) c->flat_scan = atoi(e) > 0;
+    if (const char* e = knob("TGSF_MID_FILTER")) { int v = atoi(e); if (v >= 0 && v <= 2) c->suffix_filter = v; }
 
     int e = build_tables(c);
     DevBatch& B = c->B;
@@ -479,9 +458,9 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     // k_mid_flat's schedule (flat_schedule): 7/8 of a batch's chunks in stretches of 256 (4 096 columns: the warm-up is
     // 2 % of that), the rest in stretches halving down to 16 chunks (the launch ends everywhere within 256 columns)
     B.flat_pmax = 256; B.flat_pmin = 16; B.flat_f0 = 224;
-    if (const char* e = getenv("TGSF_FLAT_PMIN")) { int v = atoi(e); if (v >= 1 && v <= (1 << 20)) B.flat_pmin = (uint32_t)v; }
-    if (const char* e = getenv("TGSF_FLAT_PMAX")) { int v = atoi(e); if (v >= 1 && v <= (1 << 20)) B.flat_pmax = (uint32_t)v; }
-    if (const char* e = getenv("TGSF_FLAT_F0")) { int v = atoi(e); if (v >= 0 && v <= 256) B.flat_f0 = (uint32_t)v; }
+    if (const char* e = knob("TGSF_FLAT_PMIN")) { int v = atoi(e); if (v >= 1 && v <= (1 << 20)) B.flat_pmin = (uint32_t)v; }
+    if (const char* e = knob("TGSF_FLAT_PMAX")) { int v = atoi(e); if (v >= 1 && v <= (1 << 20)) B.flat_pmax = (uint32_t)v; }
+    if (const char* e = knob("TGSF_FLAT_F0")) { int v = atoi(e); if (v >= 0 && v <= 256) B.flat_f0 = (uint32_t)v; }
     B.flat_pmin = 1u << flat_log2(B.flat_pmin); B.flat_pmax = 1u << flat_log2(B.flat_pmax);
     if (B.flat_pmax < B.flat_pmin) B.flat_pmax = B.flat_pmin;
     const size_t n = c->cap_reads;
@@ -498,7 +477,7 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     // value (4 at a time): the pool stays small for any threshold; some room per read and adapter on top
     uint64_t pool = c->cap_bases / 64 + 65536 + (uint64_t)n * 16u * (uint64_t)std::max(p->n_adapters, 1);
     B.pool_cap = (uint32_t)std::min<uint64_t>(pool, 1ull << 28);
-    if (const char* e = getenv("TGSF_POOL_CAP")) { const long long v = atoll(e); if (v >= 1 && v < (1ll << 28)) B.pool_cap = (uint32_t)v; }   // test knob: force the overflow path
+    if (const char* e = knob("TGSF_POOL_CAP")) { const long long v = atoll(e); if (v >= 1 && v < (1ll << 28)) B.pool_cap = (uint32_t)v; }   // test knob: force the overflow path
     const size_t nitems = n + (size_t)B.fcap;         // clean pass: fragments, and reads to take back out
     if (!e) e = dev_alloc(c, &c->d_seq, cap_bytes);
     if (!e) e = dev_alloc(c, &c->d_qual, cap_bytes);
@@ -530,7 +509,7 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     if (c->suffix_filter) {
         // a mark in 25 chunks has room in the list (random sequence: a few in a thousand), the rest is done where it is found
         B.rc_cap = (uint32_t)std::min<uint64_t>((c->cap_bases / 16u + n) / 25u + 4096u, 1ull << 24);
-        if (const char* e2 = getenv("TGSF_RECHECK_CAP")) { int v = atoi(e2); if (v >= 0) B.rc_cap = (uint32_t)v; }   // test knob
+        if (const char* e2 = knob("TGSF_RECHECK_CAP")) { int v = atoi(e2); if (v >= 0) B.rc_cap = (uint32_t)v; }   // test knob
         if (!e) e = dev_alloc(c, &B.rc_list, (size_t)B.rc_cap + 1);
         if (!e) e = dev_alloc(c, &B.rc_n, 4);
     }
@@ -547,7 +526,7 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
         if (!e) e = dev_alloc(c, &B.rep_lock, 4);
         if (!e) rt_memset(B.rep_lock, 0, 16, c->stream);
         B.rep_max_plog = kRepMaxPlog;
-        if (const char* ev = getenv("TGSF_REP_MAX_PLOG")) { int v = atoi(ev); if (v >= 0 && v <= 20) B.rep_max_plog = (uint32_t)v; }   // test knob
+        if (const char* ev = knob("TGSF_REP_MAX_PLOG")) { int v = atoi(ev); if (v >= 0 && v <= 20) B.rep_max_plog = (uint32_t)v; }   // test knob
     }
     if (!e) e = dev_alloc(c, &B.tile_hist, (size_t)B.max_tiles + 2);
     if (!e) e = dev_alloc(c, &B.tile_cnt, (size_t)B.max_tiles + 2);
@@ -573,7 +552,7 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     B.bp_allowed = (p->filter && !p->only_qc && p->min_repeat <= 0 && (p->head_trim > 0 || p->tail_trim > 0) &&
                     p->head_trim >= 0 && p->tail_trim >= 0) ? 1u : 0u;
     static_assert(kTileBases + kBpExtra < (1 << 13), "staged bytes of a tile fit the work list's 13 bits");
-    if (const char* f = getenv("TGSF_CLEAN_TABLES")) {      // test knob: "direct" | "difference" | "byproduct" (always speculate)
+    if (const char* f = knob("TGSF_CLEAN_TABLES")) {      // test knob: "direct" | "difference" | "byproduct" (always speculate)
         if (!strcmp(f, "direct")) { B.clean_force = 1; B.bp_allowed = 0; }
         else if (!strcmp(f, "difference") && !p->only_qc) { B.clean_force = 2; B.bp_allowed = 0; }
         else if (!strcmp(f, "byproduct") && B.bp_allowed) B.clean_force = 3;      // (k_clean_plan_next leaves bp_state alone)
@@ -717,11 +696,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
 #endif
     STAGE_MARK();
     const unsigned gwork = grid_cap(std::min(blocks_for(in->n_bytes / kTileBases + n + 1, T), 4096u));
-    rt_stream ss = st;
-    (void)ss;
-#if !defined(TGSF_EMUL)
-    if (c->hp) ss = c->hp;
-#else
+#if defined(TGSF_EMUL)
     rt_stream ax = st;
     (void)ax;
 #endif
@@ -739,19 +714,10 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     else TGSF_LAUNCH((k_build_work<false, false>), gwork, T, st, P, B);
     STAGE_MARK();
     // -- raw stats
-#if !defined(TGSF_EMUL)
-    if (c->hp) { (void)hipEventRecord(c->ev_hp[0], st); (void)hipStreamWaitEvent(ss, c->ev_hp[0], 0); }
-#endif
-    // (a context that may speculate -- DevBatch::spec -- runs the variant of the raw pass that tallies the clean bins too)
-    if (B.bp_allowed) {
-        if (c->stats_nt) TGSF_LAUNCH((k_stats<false, true, true>), gstats, 64 * kStatsWaves, ss, P, B);
-        else TGSF_LAUNCH((k_stats<false, false, true>), gstats, 64 * kStatsWaves, ss, P, B);
-    }
-    else if (c->stats_nt) TGSF_LAUNCH((k_stats<false, true>), gstats, 64 * kStatsWaves, ss, P, B);
-    else TGSF_LAUNCH((k_stats<false, false>), gstats, 64 * kStatsWaves, ss, P, B);
-#if !defined(TGSF_EMUL)
-    if (c->hp) { (void)hipEventRecord(c->ev_hp[1], ss); (void)hipStreamWaitEvent(st, c->ev_hp[1], 0); }
-#endif
+    // (a context that may speculate -- DevBatch::spec -- runs the variant of the raw pass that tallies the clean bins too;
+    // the text is fetched with non-temporal loads: 2.24 -> 2.06 ms, 5.4 -> 5.8 TB/s, round 3)
+    if (B.bp_allowed) TGSF_LAUNCH((k_stats<false, true, true>), gstats, 64 * kStatsWaves, st, P, B);
+    else TGSF_LAUNCH((k_stats<false, true>), gstats, 64 * kStatsWaves, st, P, B);
     if (!redo) TGSF_LAUNCH(k_fold_raw<false>, gfold, T, st, P, B);   // (a second run: the batch's raw tallies are in the tables already)
     STAGE_MARK();
     TGSF_LAUNCH(k_gate_reads, gsmall, T, st, P, B);
@@ -806,12 +772,9 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
         // upper bound of the segment count, known on the host: no device round trip
         const uint64_t max_segs = in->n_bytes / (uint64_t)P.seg_cols + 2ull * n + 1;
         const unsigned gseg = blocks_for(max_segs, T);
-        const unsigned gmid = c->mid_grid ? std::min(gseg, c->mid_grid) : gseg;
+        const unsigned gmid = gseg;
         rt_stream ms = st;
         (void)ms;
-#if !defined(TGSF_EMUL)
-        if (c->hp && c->side_mid) { ms = c->hp; (void)hipEventRecord(c->ev_hp[0], st); (void)hipStreamWaitEvent(ms, c->ev_hp[0], 0); }
-#endif
         auto launch_scans = [&](uint32_t mode) {
             DevBatch Bm = B;
             Bm.mid_mode = mode;
@@ -833,7 +796,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
                 int na = 0;
                 while (a + na < A && na < 4 && P.Q[a + na] <= 64 && cls(a + na) == kind) na++;
                 if (kind == 2) {
-                    const unsigned lp = c->flat_lds_pad;
+                    const unsigned lp = 0;
                     Bm.mark_stride = (uint32_t)((flat_chunks / 32u + 7u) & ~3ull);            // (k_mid_marks reads four words a load)
                     rt_memset(Bm.chk_mark, 0, (size_t)na * Bm.mark_stride * 4u, ms);
                     rt_memset(Bm.rc_n, 0, 4, ms);
@@ -856,7 +819,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
                     continue;
                 }
                 if (flat && mode == 0) {
-                    const unsigned lp = c->flat_lds_pad;
+                    const unsigned lp = 0;
                     if (narrow) switch (na) {
                     case 1: TGSF_LAUNCH_LDS((k_mid_flat<1, Hot32>), gflat, T, lp, ms, P, Bm, a, na); break;
                     case 2: TGSF_LAUNCH_LDS((k_mid_flat<2, Hot32>), gflat, T, lp, ms, P, Bm, a, na); break;
@@ -927,7 +890,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
                     B.pool = c->B.pool; B.pool_cap = c->B.pool_cap;
                     c->pool_regrown++;
                 }
-                if (getenv("TGSF_TRACE_POOL"))
+                if (knob("TGSF_TRACE_POOL"))
                     fprintf(stderr, "tgsf: candidate pool overflow (or a read with a long candidate list): %u columns at their reads' minima, pool of %u slots%s; scanning again in position order\n", need, B.pool_cap,
                             c->pool_regrown ? " (grown)" : "");
                 rt_memset(B.ovf, 0, 4, ms);
@@ -953,9 +916,6 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
             B.seg_n = nullptr;
             if (rc) return rc;
         }
-#if !defined(TGSF_EMUL)
-        if (c->hp && c->side_mid) { (void)hipEventRecord(c->ev_hp[1], ms); (void)hipStreamWaitEvent(st, c->ev_hp[1], 0); }
-#endif
     }
     STAGE_MARK();
     if (P.filter && A > 0 && !redo) {
@@ -976,7 +936,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
         // 4^k-bit set swept as LDS bitmaps; above: a hashed map + the full keys of the few it cannot tell apart (k = 12
         // would be 16 sweeps: 18 ms a batch against 5)
         rt_memset(B.rep_next, 0, 2 * sizeof(uint32_t), st);
-        static const int keys_from = getenv("TGSF_REPEAT_KEYS_FROM") ? atoi(getenv("TGSF_REPEAT_KEYS_FROM")) : 12;   // (measurements)
+        const int keys_from = 12;
         if (P.kmer < keys_from && P.kmer <= 13) TGSF_LAUNCH(k_repeat, grid_cap(256u), kRepThreads, st, P, B);
         else {
             TGSF_LAUNCH(k_repeat_long, gsmall, T, st, P, B);
@@ -996,14 +956,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     TGSF_LAUNCH_COOP(k_tile_scan, 1, 64, st, B);       // a few hundred buckets: one wave
     TGSF_LAUNCH(k_tile_scatter<true>, gfr, T, st, P, B);
     TGSF_LAUNCH((k_build_work<true, false>), gwork, T, st, P, B);
-#if !defined(TGSF_EMUL)
-    if (c->hp) { (void)hipEventRecord(c->ev_hp[0], st); (void)hipStreamWaitEvent(ss, c->ev_hp[0], 0); }
-#endif
-    if (c->stats_nt) TGSF_LAUNCH((k_stats<true, true>), gstats, 64 * kStatsWaves, ss, P, B);
-    else TGSF_LAUNCH((k_stats<true, false>), gstats, 64 * kStatsWaves, ss, P, B);
-#if !defined(TGSF_EMUL)
-    if (c->hp) { (void)hipEventRecord(c->ev_hp[1], ss); (void)hipStreamWaitEvent(st, c->ev_hp[1], 0); }
-#endif
+    TGSF_LAUNCH((k_stats<true, true>), gstats, 64 * kStatsWaves, st, P, B);
     STAGE_MARK();
     TGSF_LAUNCH(k_gate_frags, gfr, T, st, P, B);
     for (uint32_t slab = 0; slab * (uint32_t)kMaxBcLen < (uint32_t)P.bc_len; slab++)

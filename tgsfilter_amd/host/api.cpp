@@ -103,7 +103,6 @@ std::thread g_rccl_thread;
 
 void load_rccl()
 {
-    if (getenv("TGSF_NO_RCCL")) return;                         // test knob: a box without the collective library
     std::string path = lib_path();
     const size_t slash = path.rfind('/');
     path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/libtgsf_rccl.so";

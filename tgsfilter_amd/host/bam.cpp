@@ -1,4 +1,5 @@
 #include "bam.h"
+#include "fatal.h"
 
 #include <dlfcn.h>
 #include <sys/mman.h>
@@ -248,7 +249,7 @@ public:
     void free_(void* d) const { free__(d); }
 private:
     Inflater() {
-        if (getenv("TGSF_ZLIB_INPUT")) return;                  // test knob: zlib only
+        if (knob("TGSF_ZLIB_INPUT")) return;                  // test knob: zlib only
         for (const char* name : {"libdeflate.so.0", "libdeflate.so"}) {
             void* h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (!h) continue;
@@ -317,7 +318,7 @@ public:
             }
         }
         // any other gzip, member after member (:632-639): whole members through libdeflate while they fit ...
-        static const size_t member_cap = [] { const char* e = getenv("TGSF_GZ_MEMBER_CAP"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)(512u << 20); }();
+        static const size_t member_cap = [] { const char* e = knob("TGSF_GZ_MEMBER_CAP"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)(512u << 20); }();
         const Inflater& fast = Inflater::get();
         while (fast.ok() && !in_member_ && got < cap) {
             if (mem_at_ < mem_.size()) {                             // what is left of the member decoded last

@@ -81,7 +81,7 @@ bool InputBytes::open_plain(const std::string& path)
 
 int FastxReader::scan_threads_from_env(int dflt)
 {
-    const char* e = getenv("TGSF_SCAN_THREADS");
+    const char* e = knob("TGSF_SCAN_THREADS");
     const int v = e ? atoi(e) : 0;
     return v > 0 ? std::min(v, 64) : dflt;
 }
@@ -89,7 +89,7 @@ int FastxReader::scan_threads_from_env(int dflt)
 static size_t scan_block_bytes()
 {
     static const size_t kBlock = [] {                      // TGSF_SCAN_BLOCK: test knob (block edges on small inputs)
-        const char* e = getenv("TGSF_SCAN_BLOCK");
+        const char* e = knob("TGSF_SCAN_BLOCK");
         const size_t v = e ? (size_t)strtoull(e, nullptr, 10) : 0;
         return v ? v : (size_t)(16u << 20);
     }();

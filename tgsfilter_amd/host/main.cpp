@@ -63,7 +63,7 @@ static int cpu_budget()
 static void work_in_a_child()
 {
     const char* d = getenv("TGSF_DETACH");
-    if (!d || !*d || *d == '0' || getenv("TGSF_SYNC_EXIT")) return;
+    if (!d || !*d || *d == '0') return;
     int fds[2];
     if (pipe(fds) != 0) return;
     const pid_t pid = fork();                          // before any thread or GPU state exists
@@ -205,7 +205,7 @@ int main(int argc, char** argv)
     // its kept fragments addressed in the input text, so it takes the whole-file way.
     const bool coded = o.in_type == 2 || (o.in_file.size() > 3 && o.in_file.compare(o.in_file.size() - 3, 3, ".gz") == 0);
     uint64_t stream_min = 256ull << 20;
-    if (const char* e = getenv("TGSF_STREAM_MIN_BYTES")) stream_min = strtoull(e, nullptr, 10);      // test knob
+    if (const char* e = knob("TGSF_STREAM_MIN_BYTES")) stream_min = strtoull(e, nullptr, 10);      // test knob
     InputBytes in;
     bool streaming = false;
     if (coded && !o.downsample) {
@@ -213,7 +213,7 @@ int main(int argc, char** argv)
         streaming = in.size() >= stream_min;
     }
     if (!streaming && !in.open(o.in_file, o.in_type == 2)) leave(1);   // SAM/BAM: decoded to FASTQ text (read_bam, :1872-1917)
-    const size_t chunk_bytes = [] { const char* e = getenv("TGSF_CHUNK_BYTES"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)(64u << 20); }();
+    const size_t chunk_bytes = [] { const char* e = knob("TGSF_CHUNK_BYTES"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)(64u << 20); }();
     auto open_stream = [&]() {
         std::string err;
         std::unique_ptr<TextSource> src = open_text(in.data(), in.size(), o.in_type == 2, err);
@@ -255,10 +255,10 @@ int main(int argc, char** argv)
     {
         const char* w = getenv("TGSF_WRITER");                         // "writev": always the single-stream writer
         uint64_t early_min = 256ull << 20;
-        if (const char* e = getenv("TGSF_EARLY_OPEN_MIN")) early_min = strtoull(e, nullptr, 10);           // tests: small inputs too
+        if (const char* e = knob("TGSF_EARLY_OPEN_MIN")) early_min = strtoull(e, nullptr, 10);           // tests: small inputs too
         const bool may_map_early = !o.only_qc && !o.out_gz && !o.downsample && (o.filter || o.only_qc) && !o.out_file.empty() &&
                                    !(w && !strcmp(w, "writev")) && !o.only_adapters && !streaming && in.mapped() &&
-                                   (uint64_t)text_size >= early_min && !getenv("TGSF_NO_EARLY_RESERVE");
+                                   (uint64_t)text_size >= early_min;
         if (may_map_early && sink.open(out_path, 4 * (uint64_t)text_size + (1ull << 30), true))
             early = std::thread([&] {
                 const uint64_t limit = (uint64_t)text_size / 4;        // what a run keeps is not known yet; a surplus is cut off at the end
@@ -353,7 +353,7 @@ int main(int argc, char** argv)
     // batches are slices of the input text: sized in text bytes (about 2 bytes per base + headers)
     uint64_t batch_text = streaming ? std::min<uint64_t>(256ull << 20, chunk_bytes)
                                     : std::min<uint64_t>(256ull << 20, std::max<uint64_t>(text_size / 8 + 4096, 1 << 16));
-    if (const char* e = getenv("TGSF_BATCH_BYTES")) { const long long v = atoll(e); if (v > 0) batch_text = (uint64_t)v; }   // tuning / test knob
+    if (const char* e = knob("TGSF_BATCH_BYTES")) { const long long v = atoll(e); if (v > 0) batch_text = (uint64_t)v; }   // tuning / test knob
     // reads per batch: the library keeps traceback scratch for every (read, adapter, end) of a batch -- columns x words of
     // the longest alignment each; with the library adapters that is ~12 KB per read, with 256-bp adapters and loose
     // match lengths ~350 KB: keep it under 4 GB per context
@@ -641,27 +641,22 @@ int main(int argc, char** argv)
     // reference's -t 1 order), lays the records of a batch out in the output file and hands runs of them to the fill
     // threads (MappedSink); or, for the other kinds of output, gathers the pieces and writes them itself (Output).
     int fill_threads = std::max(1, std::min(o.n_thread, 16));
-    if (const char* e = getenv("TGSF_FILL_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) fill_threads = v; }   // tuning knob
     uint64_t fill_min = 1u << 20;                                      // bytes worth a job of their own
-    if (const char* e = getenv("TGSF_FILL_MIN_BYTES")) { const long long v = atoll(e); if (v > 0) fill_min = (uint64_t)v; }   // test knob
+    if (const char* e = knob("TGSF_FILL_MIN_BYTES")) { const long long v = atoll(e); if (v > 0) fill_min = (uint64_t)v; }   // test knob
     Pool pool(sink.is_open() ? fill_threads : 1);
     int populate_threads = std::max(1, std::min(o.n_thread, 32));      // short bursts between two fallocates: the more the shorter
-    if (const char* e = getenv("TGSF_POPULATE_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) populate_threads = v; }   // tuning knob
-    // Mapping the pages of a reserved stride: by many threads between two fallocates, or (TGSF_POPULATE_BESIDE=n) by n
-    // threads beside the next stride's fallocate.
-    int populate_beside = 0;
-    if (const char* e = getenv("TGSF_POPULATE_BESIDE")) { const int v = atoi(e); if (v >= 0 && v <= 64) populate_beside = v; }
-    if (populate_beside > 0) populate_threads = populate_beside;
+    // (the pages of a reserved stride are mapped by many threads BETWEEN two fallocates: beside one, page faults on the file
+    // take its inode's lock and both crawl -- measured, DESIGN appendix)
     Pool populate(sink.is_open() ? populate_threads : 0);
     // (a streamed input is decoder-bound: small strides keep the mapped part of the output -- it counts as resident -- small)
     uint64_t stride_bytes = streaming ? (128ull << 20) : (2ull << 30);
-    if (const char* e = getenv("TGSF_STRIDE_BYTES")) { const long long v = atoll(e); if (v > 0) stride_bytes = (uint64_t)v; }   // tuning / test knob
+    if (const char* e = knob("TGSF_STRIDE_BYTES")) { const long long v = atoll(e); if (v > 0) stride_bytes = (uint64_t)v; }   // tuning / test knob
     // While the library loads and the device comes up pages of the output file are instantiated already, up to a quarter
     // of the input's size (what a run keeps is not known yet; a surplus is cut off at the end).
     end_early();                                                       // (what it reserved is mapped by the reserver's first round)
-    Reserver reserver(sink, populate, stride_bytes, populate_beside > 0);
+    Reserver reserver(sink, populate, stride_bytes, false);
     if (sink.is_open())
-        reserver.start((!streaming && text_size > (256u << 20) && !getenv("TGSF_NO_EARLY_RESERVE")) ? (uint64_t)text_size / 4 : 0);
+        reserver.start((!streaming && text_size > (256u << 20)) ? (uint64_t)text_size / 4 : 0);
     // A downsampling run writes its output only after the whole filter pass (the selection needs every fragment's length,
     // :2297-2344) -- but the file can be instantiated meanwhile: while the filter pass is busy with the link to the device,
     // pages for what the selection may keep are reserved and mapped (a quarter of the input at most, and no more than twice
@@ -682,8 +677,8 @@ int main(int argc, char** argv)
     };
     {
         uint64_t early_min = 1ull << 30;
-        if (const char* e = getenv("TGSF_DOWN_EARLY_MIN")) early_min = strtoull(e, nullptr, 10);          // tests: small inputs too
-        if (o.downsample && !streaming && in.mapped() && (uint64_t)in.size() >= early_min && !getenv("TGSF_NO_EARLY_RESERVE")) {
+        if (const char* e = knob("TGSF_DOWN_EARLY_MIN")) early_min = strtoull(e, nullptr, 10);          // tests: small inputs too
+        if (o.downsample && !streaming && in.mapped() && (uint64_t)in.size() >= early_min) {
             uint64_t spec = (uint64_t)in.size() / 4;
             if (o.genome_size > 0 && o.desired_depth > 0) spec = std::min<uint64_t>(spec, 2 * o.genome_size * (uint64_t)o.desired_depth + (uint64_t)in.size() / 64);
             open_dsink(4 * (uint64_t)in.size() + (1ull << 30), spec);
@@ -699,12 +694,7 @@ int main(int argc, char** argv)
     const bool sync_exit = g_done_fd < 0;                              // one process (the default): the teardown is on the clock
     bool release_input = sync_exit && !streaming && in.mapped() && !o.downsample;
     bool release_output = sync_exit || streaming;
-    if (const char* e = getenv("TGSF_RELEASE")) {                      // experiment knob: none | in | out | both
-        release_input = release_input && (!strcmp(e, "in") || !strcmp(e, "both"));
-        release_output = (release_output && (!strcmp(e, "out") || !strcmp(e, "both"))) || streaming;
-    }
-    uint64_t release_piece = 16u << 20;
-    if (const char* e = getenv("TGSF_RELEASE_PIECE")) { const long long v = atoll(e); if (v >= 4096) release_piece = (uint64_t)v; }   // experiment knob
+    const uint64_t release_piece = 16u << 20;
     Channel<std::pair<const char*, uint64_t>> to_release(1 << 16);
     std::thread releaser([&] {
         for (;;) {
@@ -908,7 +898,7 @@ int main(int argc, char** argv)
         const bool down_no_qual = fasta_in || (run_filter_pass && !fastq_out);
         qp.no_qual = down_no_qual ? 1 : 0;
         qp.max_batch_bases = (1ull << 30); qp.max_batch_reads = 1u << 16;
-        if (const char* e = getenv("TGSF_DOWN_BATCH_BYTES")) { const long long v = atoll(e); if (v > (1 << 20) + 65536) qp.max_batch_bases = (uint64_t)v; }   // test knob: several slices of a small input
+        if (const char* e = knob("TGSF_DOWN_BATCH_BYTES")) { const long long v = atoll(e); if (v > (1 << 20) + 65536) qp.max_batch_bases = (uint64_t)v; }   // test knob: several slices of a small input
         tgsf_ctx *qctx = nullptr, *qctx2 = nullptr;
         std::vector<uint8_t> bs, bq; std::vector<uint64_t> boff; std::vector<uint32_t> blen;
         std::vector<tgsf_read_result> bres; std::vector<tgsf_fragment> bfr(16);
@@ -943,7 +933,7 @@ int main(int argc, char** argv)
             kept_span = (uint64_t)((down_no_qual ? z.seq : std::max(z.seq, z.qual)) + z.len - a.seq);
             for (uint32_t i : by_addr) if (!down_no_qual && clean_recs[i].qual < clean_recs[i].seq) kept_span = 0;   // (never: FASTQ text)
         }
-        const char* force = getenv("TGSF_DOWN_QC");                     // "text" / "packed": tests run both ways
+        const char* force = knob("TGSF_DOWN_QC");                     // "text" / "packed": tests run both ways
         const bool in_place = kept_span > 0 && (force ? !strcmp(force, "text") : kept_bytes * 12 >= kept_span);   // (packing runs at a tenth of the copy to the device)
         d_in_place = in_place; d_kept = (double)kept_bytes; d_span = (double)kept_span;
         std::thread qc_pass([&] {
@@ -956,7 +946,7 @@ int main(int argc, char** argv)
                 // together about what it carries (as in the filter pass).
                 struct TextBatch { const char* base = nullptr; uint64_t span = 0; std::vector<uint64_t> off, qoff; std::vector<uint32_t> len; };
                 int workers = kept_span >= (2ull << 30) ? 2 : 1;
-                if (const char* e = getenv("TGSF_DOWN_FEEDERS")) workers = atoi(e) >= 2 ? 2 : 1;      // tests run both on small inputs
+                if (const char* e = knob("TGSF_DOWN_FEEDERS")) workers = atoi(e) >= 2 ? 2 : 1;      // tests run both on small inputs
                 Channel<std::shared_ptr<TextBatch>> todo(2);
                 std::mutex tm;
                 auto work = [&](tgsf_ctx* c) {
@@ -1029,7 +1019,7 @@ int main(int argc, char** argv)
         // 6-GB/s copy under the inode lock.
         bool down_mapped = false;
         {
-            const char* mn = getenv("TGSF_DOWN_MAP_MIN");              // tests force the mapped way on small outputs
+            const char* mn = knob("TGSF_DOWN_MAP_MIN");              // tests force the mapped way on small outputs
             const uint64_t map_min = mn ? strtoull(mn, nullptr, 10) : (256ull << 20);
             std::vector<uint32_t> kept;
             std::vector<uint64_t> at;
@@ -1293,7 +1283,7 @@ int main(int argc, char** argv)
                         "pipeline %.3f (batching %.3f, tgsf_submit summed over %zu feeders %.3f, plan+write %.3f, planner waiting %.3f, "
                         "first batch filtered after %.3f, fill tail %.3f, closing the output %.3f; stages overlap) | stats+report %.3f | %s (fallocate %.3f, mapping the reserved pages %.3f, fill threads busy %.3f summed)\n",
                 now_s() - t_start, t_prepass, t_libwait, t_load, t_dev, t_pipe, t_parse, ctxs.size(), t_gpu, t_write, t_widle, t_first,
-                t_fill_tail, t_close, now_s() - t_p0 - t_pipe, mapped_out ? (populate_beside > 0 ? "output: fallocate + mapped fill, pages mapped beside the fallocate" : "output: fallocate + mapped fill") : "output: writev", sink.t_falloc, reserver.t_populate_wait, t_busy);
+                t_fill_tail, t_close, now_s() - t_p0 - t_pipe, mapped_out ? "output: fallocate + mapped fill" : "output: writev", sink.t_falloc, reserver.t_populate_wait, t_busy);
         fprintf(stderr, "RESERVE: planner waited %.3f s for pages of the output file\n", t_drain);
     }
     if (timing) {

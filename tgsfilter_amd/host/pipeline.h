@@ -155,7 +155,7 @@ public:
     void free_(void* c) const { free__(c); }
 private:
     Deflater() {
-        if (getenv("TGSF_ZLIB_OUTPUT")) return;                 // test knob: the zlib path
+        if (knob("TGSF_ZLIB_OUTPUT")) return;                 // test knob: the zlib path
         for (const char* name : {"libdeflate.so.0", "libdeflate.so"}) {
             void* h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (!h) continue;
@@ -323,11 +323,7 @@ public:
             // Every page of this mapping is written once and never looked at again: say so.  Without the advice, dropping
             // the mappings (MADV_DONTNEED behind the fill jobs, or the exit) marks each page accessed -- 20 M pages moved
             // between the LRU lists under the lock the fallocate beside it needs for every page it adds.
-            if (ok) {
-                const char* adv = getenv("TGSF_SINK_ADVICE");                                      // experiment knob: seq | random | none
-                if (!adv || !strcmp(adv, "seq")) madvise(map_, cap_, MADV_SEQUENTIAL);
-                else if (!strcmp(adv, "random")) madvise(map_, cap_, MADV_RANDOM);
-            }
+            if (ok) madvise(map_, cap_, MADV_SEQUENTIAL);
         }
         if (!ok) { ::close(fd_); fd_ = -1; if (created_) unlink(path_.c_str()); return false; }
         live() = this;
@@ -420,7 +416,7 @@ __attribute__((target("avx2"))) inline void stream_copy_avx2(char* d, const char
 }
 inline void stream_copy(char* d, const char* s, size_t n)
 {
-    static const bool avx2 = __builtin_cpu_supports("avx2") && getenv("TGSF_PLAIN_COPY") == nullptr;
+    static const bool avx2 = __builtin_cpu_supports("avx2");
     if (avx2 && n >= 4096) stream_copy_avx2(d, s, n); else memcpy(d, s, n);
 }
 inline void stream_fence() { _mm_sfence(); }

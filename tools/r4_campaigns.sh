@@ -3,6 +3,7 @@
 # against the oracle (tests/fuzz.py: random parameter sets, every record and tally word) on the new middle scan -- the default
 # schedule, tiny stretches (every read cut into many stretches, stretches across read boundaries), pools of 3 slots (every batch
 # through the replay), long reads --, and the command line against the reference binary.
+export TGSF_DEBUG_KNOBS=1   # the test settings below are read only under this switch
 cd $GRAFT_REPO_ROOT
 TGSF_FUZZ_WIDE=1 TGSF_FUZZ_GATE_P=0.4 timeout 900 python tests/manual/fuzz_campaign.py 400000 401200 150 > gpurun_out/r4_fuzz_default.txt 2>&1; tail -2 gpurun_out/r4_fuzz_default.txt
 TGSF_FLAT_PMIN=1 TGSF_FLAT_PMAX=4 TGSF_FLAT_F0=100 TGSF_FUZZ_WIDE=1 TGSF_FUZZ_GATE_P=0.3 timeout 900 python tests/manual/fuzz_campaign.py 410000 411000 150 > gpurun_out/r4_fuzz_tiny_stretches.txt 2>&1; tail -2 gpurun_out/r4_fuzz_tiny_stretches.txt

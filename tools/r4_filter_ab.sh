@@ -2,6 +2,7 @@
 # round 4: A/B of the middle scan's 32-row filter (TGSF_MID_FILTER = 0 off, 1 / 2 test stride), kernel path only, on the
 # HiFi shape (--config c3: the two 45-bp PacBio adapters, k = 11) and on the default ONT shape (k = 16: filter not used).
 #   gpurun -- 'bash tools/r4_filter_ab.sh [tests]'   -> gpurun_out/r4_filter_ab.txt
+export TGSF_DEBUG_KNOBS=1   # the test settings below are read only under this switch
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/r4_filter_ab.txt; : > $out
 brief() { python3 -c "

@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 4: A/B of the middle scan (k_mid_scan1 against k_mid_flat and its knobs), single stream, kernel path only.
 #   gpurun -- 'bash tools/r4_scan_ab.sh [tests]'   -> gpurun_out/r4_scan_ab.txt
+export TGSF_DEBUG_KNOBS=1   # the test settings below are read only under this switch
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/r4_scan_ab.txt; : > $out
 brief() { python3 -c "

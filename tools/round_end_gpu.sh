@@ -3,6 +3,7 @@
 #   tools/round_end_gpu.sh profile <tag>   tools/profile_round.sh + gated profiles + kernel-path variants
 #   tools/round_end_gpu.sh bench           the full default bench line (as the driver runs it) + --config c5
 #   tools/round_end_gpu.sh suite           the GPU test suite
+export TGSF_DEBUG_KNOBS=1   # the test settings below are read only under this switch
 cd $GRAFT_REPO_ROOT
 what=${1:-suite}; tag=${2:-r04}
 R=$GRAFT_REPO_ROOT

@@ -1,4 +1,5 @@
 #!/bin/bash
+export TGSF_DEBUG_KNOBS=1   # the test settings below are read only under this switch
 out=gpurun_out/sweep_seg.txt; : > $out
 for sc in 768 1024 1280 1536 2048; do
   for rep in 1 2; do
