@@ -37,9 +37,10 @@ extern "C" {
 
 #define TGSF_ABI_VERSION 3
 #define TGSF_MAX_ADAPTERS 32      /* adapters.size(): 2 or 4 in practice (src/TGSFilter.cpp:3105-3125) */
-#define TGSF_MAX_ADAPTER_LEN 1280 /* library adapters are 22..64 bp (:2970-2991); up to 256 bp (four 64-row blocks) the searches run in
-                                     registers, beyond that (-a accepts any length) in 20-word arrays: correct, not fast.  Above 20 blocks
-                                     edlib may switch from traceback to Hirschberg for the path (include/edlib.cpp:1191-1193): refused */
+#define TGSF_MAX_ADAPTER_LEN 8192 /* library adapters are 22..64 bp (:2970-2991); up to 256 bp (four 64-row blocks) the searches run in
+                                     registers, beyond that (-a accepts any length) in word arrays walked by run-time loops: correct, not
+                                     fast.  The first location's path: by traceback below 1 MiB of traceback state, by Hirschberg's
+                                     divide and conquer beyond, exactly as edlib chooses (include/edlib.cpp:1191-1210) */
 #define TGSF_N_DROPINFO 17        /* DropInfo row, src/TGSFilter.cpp:1776 */
 #define TGSF_N_QBINS 256          /* raw/cleanDiffQualReadsBases, :1777-1778 */
 #define TGSF_BIN_WIDTH 100        /* int(i/100) in CalcAvgQuality, :1460 */

@@ -148,6 +148,66 @@ static int path_length(const uint8_t* q, int Q, const uint8_t* t, int T)
     return len;
 }
 
+/*
+ * Last column of the global DP, O(Q) memory: col[i] = NW(q[0..i), t[0..T)) for i = 0..Q.
+ * rev != 0: of the REVERSED strings, i.e. col[i] = NW(last i chars of q, last T chars ... all of t reversed).
+ */
+static void global_last_column(const uint8_t* q, int Q, const uint8_t* t, int T, int rev, int* col)
+{
+    for (int i = 0; i <= Q; i++) col[i] = i;
+    for (int j = 1; j <= T; j++) {
+        const uint8_t tc = rev ? t[T - j] : t[j - 1];
+        int diag = col[0];
+        col[0] = j;
+        for (int i = 1; i <= Q; i++) {
+            const int left = col[i];
+            int v = diag + ((rev ? q[Q - i] : q[i - 1]) != tc);
+            v = imin(v, left + 1);
+            v = imin(v, col[i - 1] + 1);
+            diag = left;
+            col[i] = v;
+        }
+    }
+}
+
+/*
+ * obtainAlignment, include/edlib.cpp:1164-1216: the path of the first location is found by traceback while the
+ * traceback state -- (2 words + 1 int) per 64-row block and column, + 2 ints per column -- stays below 1 MiB
+ * (:1191-1193), and by Hirschberg's divide and conquer otherwise (obtainAlignmentHirschberg, :1234-1400):
+ *   the target is cut in the middle (left half targetLength / 2 columns, :1250-1251); with
+ *   L[h] = NW(q[0..h), left half) and R[h] = NW(q[h..Q), right half) the query is cut at the SMALLEST h in 1..Q-1
+ *   with L[h] + R[h] == best (:1321-1331: queryIdx = h - 1 ascending, first hit), else at h = 0 if
+ *   leftHalfWidth + R[0] == best (:1333-1340), else at h = Q if L[Q] + rightHalfWidth == best (:1341-1349); the
+ *   two quadrants recurse with their own scores (:1366-1384) and the lengths add up (:1392).
+ * (edlib computes L and R inside a band of width `best`; a cell on an optimal path lies inside both bands and holds its
+ * exact value there, a cell that holds more than its exact value holds more than `best` -- so the first h is the same.)
+ * Degenerate quadrants (:1171-1179): an empty query or target is all deletions / insertions.
+ */
+static int obtain_alignment_length(const uint8_t* q, int Q, const uint8_t* t, int T, int best)
+{
+    if (Q == 0 || T == 0) return Q + T;
+    const long long blocks = (Q + 63) / 64;
+    const long long data = (2ll * 8 + 4) * blocks * T + 2ll * 4 * T;
+    if (data < 1024 * 1024) return path_length(q, Q, t, T);
+    const int lw = T / 2, rw = T - lw;
+    int* L = (int*)malloc(sizeof(int) * (size_t)(Q + 1));
+    int* Rr = (int*)malloc(sizeof(int) * (size_t)(Q + 1));
+    global_last_column(q, Q, t, lw, 0, L);
+    global_last_column(q, Q, t + lw, rw, 1, Rr);          /* Rr[i] = NW(last i chars of q, right half) = R[Q - i] */
+    int h = -1;
+    for (int x = 1; x <= Q - 1 && h < 0; x++)
+        if (L[x] + Rr[Q - x] == best) h = x;
+    if (h < 0 && lw + Rr[Q] == best) h = 0;
+    if (h < 0 && L[Q] + rw == best) h = Q;
+    int len = -1;
+    if (h >= 0) {
+        const int ls = h == 0 ? lw : L[h], rs = h == Q ? rw : Rr[Q - h];
+        len = obtain_alignment_length(q, h, t, lw, ls) + obtain_alignment_length(q + h, Q - h, t + lw, rw, rs);
+    }
+    free(L); free(Rr);
+    return len;           /* (-1: no cut adds up to `best` -- the reference returns EDLIB_STATUS_ERROR; never seen) */
+}
+
 int orc_align_hw(const uint8_t* q, int Q, const uint8_t* t, int T, int k,
                  orc_alignment* out)
 {
@@ -173,7 +233,7 @@ int orc_align_hw(const uint8_t* q, int Q, const uint8_t* t, int T, int k,
     for (int i = 0; i < n; i++)
         out->starts[i] = start_location(q, Q, t, out->ends[i], best);
     int s0 = out->starts[0], e0 = out->ends[0];
-    out->alignment_length = path_length(q, Q, t + s0, e0 - s0 + 1);
+    out->alignment_length = obtain_alignment_length(q, Q, t + s0, e0 - s0 + 1, best);
     return 0;
 }
 

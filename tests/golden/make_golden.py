@@ -112,11 +112,38 @@ CASES.update({
     "ont_high_qual": (dict(seed=39, n=90, kind="ont", mean_len=3000, zoo=True, pmid=0.05), [synth.ONT_RAPID], "-x ont -l 1000 -q 10 -5 6 -3 3", "fq", "high_bytes"),
 })
 
+GIANT_A = bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[np.random.default_rng(20481).integers(0, 4, 2048)])
+GIANT_B = bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[np.random.default_rng(50001).integers(0, 4, 5000)])
+CASES.update({
+    # adapters beyond 1 280 bp (round 5): where the traceback state of the first location reaches 1 MiB (from ~1 800 bp) edlib
+    # finds its path by Hirschberg's divide and conquer (include/edlib.cpp:1191-1210, 1234-1400): 2 048 and 5 000 bp, planted
+    # at the ends and in the middle of reads of 12-30 kb with 0-10 % errors and long insertions
+    "giant_adapter": (dict(seed=40, n=36, kind="ont", mean_len=16000, p5=0.0, pmid=0.0), [GIANT_A, GIANT_B],
+                      "-x ont -l 1000 -q 7 -5 0 -3 2 -M 1200 -m 900 -E 2600 -T 40", "fq", "giant"),
+})
+
 IN_EXT = {"fq": "in.fq", "bam": "in.bam", "sam": "in.sam", "fa": "in.fa"}
 
 
 def tweak(reads, how):
     out = []
+    if how == "giant":
+        rng = np.random.default_rng(4040)
+        acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+        for i, (name, sq, q) in enumerate(reads):
+            L = int(rng.integers(12000, 30000))
+            sq = bytearray(acgt[rng.integers(0, 4, L)].tobytes())
+            q = bytes((rng.integers(12, 35, L) + 33).astype(np.uint8))
+            ad = GIANT_A if i % 2 == 0 else GIANT_B
+            m = synth.mutate(rng, ad, float(rng.choice([0.0, 0.03, 0.1])))
+            if i % 4 == 3:
+                h = len(m) // 2
+                m = m[:h] + bytes(acgt[rng.integers(0, 4, int(rng.integers(1, 300)))]) + m[h:]
+            pos = int(rng.integers(0, 40)) if i % 3 == 0 else (int(rng.integers(3000, L - 3000 - len(m))) if i % 3 == 1 else L - len(m) - int(rng.integers(0, 40)))
+            if i % 9 != 8:
+                sq[pos:pos + len(m)] = m
+            out.append((name, bytes(sq), q))
+        return out
     for i, (name, sq, q) in enumerate(reads):
         if how == "phred64":
             q = bytes(min(max(c, 33 + 16) + 31, 126) for c in q)     # every quality >= 16: min char 80 > 78 decides Phred64 (:1050)

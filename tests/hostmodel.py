@@ -155,7 +155,7 @@ class GoldenCase:
 
 
 GOLDEN_CASES = ["ont_zoo", "ont_trim", "ont_discard", "hifi_zoo", "long_adapter", "ont_auto",
-                "hifi_auto", "qc_only", "ont_m1", "huge_adapter", "ont_phred64", "hifi_phred64_auto", "ont_e1300", "wide_adapter", "ont_high_qual"]
+                "hifi_auto", "qc_only", "ont_m1", "huge_adapter", "ont_phred64", "hifi_phred64_auto", "ont_e1300", "wide_adapter", "ont_high_qual", "giant_adapter"]
 # whole-program cases that involve the host-side second pass (checked through the CLI only)
 # ... or a non-FASTQ input format (SAM / unaligned BAM decoded by the host; FASTA = records without qualities)
 GOLDEN_CLI_ONLY = ["ont_repeat", "repeat_k15", "repeat_k21", "repeat_k32", "repeat_k32b", "down_gd", "down_r", "down_R", "down_F", "hifi_bam", "ont_sam", "hifi_bam_auto",

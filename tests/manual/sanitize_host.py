@@ -27,10 +27,15 @@ for kind, target, opts in (("asan", "tgsfilter_asan", {"ASAN_OPTIONS": "detect_l
             for k in list(os.environ):
                 if k.startswith("TGSF_"):
                     del os.environ[k]
+            os.environ["TGSF_DEBUG_KNOBS"] = "1"
             os.environ.update(env)
             os.environ.update(opts)
             try:
                 cli_check.run_case(binary, GOLD, name, extra_args=["-t", "8"], compress=comp)
+                # ... and as a job of three rank processes (fork, sockets, part files, the pre-pass broadcast, the tally exchange)
+                if env is THREADED and comp is None and cli_check.shardable(GOLD, name):
+                    cli_check.run_case(binary, GOLD, name, extra_args=["-t", "8"], ranks=3)
+                    cli_check.run_case(binary, GOLD, name, extra_args=["-t", "8"], ranks=2, launcher="external")
             except AssertionError as e:
                 bad += 1
                 print(kind, "FAIL", name, comp, str(e)[-2000:])

@@ -545,7 +545,7 @@ def async_two_contexts(lib_path):
         c.close()
 
 
-def align_windows_random(lib_path, n, seed=9, golden_dir=None, lengths=None, max_window=400):
+def align_windows_random(lib_path, n, seed=9, golden_dir=None, lengths=None, max_window=400, plant_whole=False):
     """tgsf_align_windows against edlib itself where oracle/_ref/libedlib_ref.so exists (compiled from the
     reference's include/edlib.cpp), else against the oracle's DP restatement: random adapters of 20..256 bp,
     windows of 5..400 bp with planted mutated copies, homopolymers and Ns, assorted k."""
@@ -557,7 +557,7 @@ def align_windows_random(lib_path, n, seed=9, golden_dir=None, lengths=None, max
     adapters += [bytes(acgt[rng.integers(0, 4, int(L))]) for L in (lengths or (20, 33, 64, 65, 90, 127, 128, 129, 150, 192, 193, 230, 256))]
     if lengths:                                   # (adapters beyond 256 bp: the wide path; a few short ones ride along)
         adapters = adapters[4:] + adapters[:2]
-    p = abi.make_params("ont", adapters=adapters, max_batch_bases=1 << 22, max_batch_reads=4096 if not lengths else 256, max_read_len=4096,
+    p = abi.make_params("ont", adapters=adapters, max_batch_bases=1 << 22, max_batch_reads=4096 if not lengths else (256 if max_window <= 2600 else 16), max_read_len=4096,
                         **({"mid_match_len": 1, "end_match_len": 1} if lengths else {}))
     ctx = capi.Context(p, 0, lib_path)
     buf, off, ln, aid, ks, trip = bytearray(), [], [], [], [], []
@@ -569,9 +569,15 @@ def align_windows_random(lib_path, n, seed=9, golden_dir=None, lengths=None, max
         t = bytearray(acgt[rng.integers(0, 4, T)].tobytes())
         if i % 11 == 5:
             t = bytearray(b"T" * T)
-        for _ in range(int(rng.integers(0, 3))):
+        if plant_whole:                            # a whole (mutated) copy in a window that holds it: the path spans ~Q columns
+            T = int(rng.integers(Q // 2, min(max_window, 2 * Q + 200)))
+            t = bytearray(acgt[rng.integers(0, 4, T)].tobytes())
+        for _ in range(int(rng.integers(0, 3)) if not plant_whole else 1):
             m = synth.mutate(rng, q, float(rng.choice([0.0, 0.05, 0.15, 0.3])))
-            if rng.random() < 0.3:
+            if plant_whole and rng.random() < 0.3:   # ... with a long stretch of other text in its middle
+                h = len(m) // 2
+                m = m[:h] + bytes(acgt[rng.integers(0, 4, int(rng.integers(1, 400)))]) + m[h:]
+            if rng.random() < 0.3 and not plant_whole:
                 m = m[int(rng.integers(0, len(m))):]
             pos = int(rng.integers(0, T))
             t[pos:pos + len(m)] = m

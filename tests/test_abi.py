@@ -64,7 +64,7 @@ def test_no_device_fails_loudly(lib):
 
 
 def test_parameter_validation(lib):
-    p = abi.make_params("ont", adapters=[b"A" * 1281], max_batch_bases=1000, max_batch_reads=4, max_read_len=500)      # beyond TGSF_MAX_ADAPTER_LEN
+    p = abi.make_params("ont", adapters=[b"A" * 8193], max_batch_bases=1000, max_batch_reads=4, max_read_len=500)      # beyond TGSF_MAX_ADAPTER_LEN
     with pytest.raises(capi.TgsfError) as ei:
         capi.Context(p, 0)
     assert ei.value.code == abi.E_UNSUPPORTED

@@ -444,3 +444,39 @@ def test_gpu_by_product_through_a_pool_overflow(kind, head, tail, monkeypatch):
     """A batch whose candidate pool overflows is run a second time from its inputs: what its first run tallied into the
     clean tables as a by-product is not tallied again, and the second run takes the same decisions."""
     parity.by_product_run(None, kind, head, tail, monkeypatch=monkeypatch, mode="byproduct", pool_cap=3)
+
+
+@pytest.mark.parametrize("lengths,n,win", [((1281, 1500, 1800, 1857, 1900, 2048), 60, 4300), ((3000, 5000, 8192), 14, 17000)])
+def test_gpu_align_windows_beyond_1280_bp( lengths, n, win):
+    """Adapters beyond 1 280 bp: where the traceback state of the first location reaches 1 MiB edlib finds its path by
+    Hirschberg's divide and conquer (include/edlib.cpp:1191-1210, 1234-1400) and so does alignment_length_w: edit distance,
+    locations, start and alignmentLength as the reference's own edlib reports them (the oracle's restatement where
+    oracle/_ref is absent)."""
+    parity.align_windows_random(None, n, seed=23, lengths=lengths, max_window=win, plant_whole=True)
+
+
+def test_gpu_batch_with_adapters_beyond_1280_bp():
+    """Whole batches with a 2 048-bp and a 3 000-bp adapter (planted in the middle and at the ends) against the oracle."""
+    rng = np.random.default_rng(5)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    a2k, a3k = bytes(acgt[rng.integers(0, 4, 2048)]), bytes(acgt[rng.integers(0, 4, 3000)])
+    reads = []
+    for i in range(14):
+        L = int(rng.integers(9000, 20000))
+        sq = bytearray(acgt[rng.integers(0, 4, L)].tobytes())
+        ad = a2k if i % 2 == 0 else a3k
+        m = synth.mutate(rng, ad, float(rng.choice([0.0, 0.03, 0.1])))
+        if i % 3 == 0:                                  # at the 5' end, after a few bases
+            pos = int(rng.integers(0, 40))
+        elif i % 3 == 1:                                # in the middle
+            pos = int(rng.integers(3000, L - 3000 - len(m)))
+        else:                                           # at the 3' end
+            pos = L - len(m) - int(rng.integers(0, 40))
+        if i < 12:
+            sq[pos:pos + len(m)] = m
+        reads.append((b"giant%d" % i, bytes(sq), bytes((rng.integers(15, 35, L) + 33).astype(np.uint8))))
+    p = parity.sized(abi.make_params("ont", adapters=[a2k, a3k], min_q=7.0, mid_match_len=1200, end_match_len=900, end_len=2600), reads)
+    ctx = capi.Context(p, 0)
+    r, f, _ = parity.compare_batch(ctx, p, reads)
+    assert (r["flags"] & (abi.RF_ADMID | abi.RF_AD5P)).any()
+    ctx.close()

@@ -10,7 +10,7 @@ import numpy as np
 
 ABI_VERSION = 3
 MAX_ADAPTERS = 32
-MAX_ADAPTER_LEN = 1280
+MAX_ADAPTER_LEN = 8192
 N_DROPINFO = 17
 N_QBINS = 256
 BIN_WIDTH = 100

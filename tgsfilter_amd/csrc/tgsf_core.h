@@ -21,12 +21,11 @@
 namespace tgsf {
 
 constexpr int kMaxAdapters = 32;
-constexpr int kMaxQ = 1280;        // adapters up to 256 bp run in registers (1..4 words); longer ones (-a accepts any length, the
-                                   // reference's edlib is multi-block, include/edlib.cpp:182-185) in kWideNW-word arrays.  1 280 bp is
-                                   // where exactness ends: edlib finds the path of the first location by traceback while
-                                   // (2*8+4)*blocks*T + 8*T < 1 MiB (include/edlib.cpp:1191-1193; T <= 2Q-1 columns) -- true for every
-                                   // adapter up to 20 blocks -- and by Hirschberg's divide and conquer beyond, which may choose another
-                                   // of the equally good paths (a different match count): not restated, refused
+constexpr int kMaxQ = 8192;        // adapters up to 256 bp run in registers (1..4 words); longer ones (-a accepts any length, the
+                                   // reference's edlib is multi-block, include/edlib.cpp:182-185) in kWideNW-word arrays walked by
+                                   // run-time loops.  The path of the first location comes from a traceback while
+                                   // (2*8+4)*blocks*T + 8*T < 1 MiB (include/edlib.cpp:1191-1193: every adapter up to 1 280 bp), and
+                                   // from Hirschberg's divide and conquer beyond, as in edlib (alignment_length_w)
 constexpr int kPeqW = 4;           // words per symbol in the standard-layout Peq tables (adapters <= 256 bp)
 constexpr int kWideNW = kMaxQ / 64;   // words per symbol in the wide tables (built only when an adapter needs them)
 constexpr int kBin = 100;          // CalcAvgQuality bin width

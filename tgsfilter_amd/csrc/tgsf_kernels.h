@@ -217,16 +217,16 @@ TGSF_KERNEL k_clean_plan(DevParams P, DevBatch B)
 // ones shifted by head_trim), which makes it VALU-bound -- measured on the C2 / C3 shapes (profiles/r05_clean_tables_ab.txt):
 // raw pass 2.1 -> 3.5 ms / 1.8 -> 3.5 ms, clean pass 1.47 -> 0.83 ms / 2.1 -> 0.37 ms.  It pays (a little: +1..4 % with three
 // batches in flight, 8 GB less fetched per batch) where nearly every read is kept as expected -- HiFi-shaped batches -- and
-// loses 8 % on C2's, where 40 % of the kept bases are looked at again anyway (adapters reaching beyond the 5' trim).  So:
-// go on only while the bases scanned a second time (ranges taken back out + the real fragments of those reads) stay
-// below a fifth of what scanning every fragment costs.  (A batch that did not speculate tries again after a while.)
+// loses 8 % on C2's, where a fifth to two fifths of the kept bases are looked at again anyway (adapters reaching beyond
+// the 5' trim).  So: go on only while the bases scanned a second time (ranges taken back out + the real fragments of those
+// reads) stay below 1/32 of what scanning every fragment costs.  (A batch that did not speculate tries again after a while.)
 TGSF_KERNEL k_clean_plan_next(DevBatch B)
 {
     if (gtid() != 0 || !B.bp_allowed || B.clean_force) return;
     if (pool_overflowed(B)) return;
     if (clean_by_product(B)) {
         const uint64_t direct = B.plan[2], again = B.plan[3];
-        B.bp_state[0] = (5 * again <= direct) ? 1u : 0u;
+        B.bp_state[0] = (32 * again <= direct) ? 1u : 0u;
         B.bp_state[2] = 0;
     } else if (++B.bp_state[2] >= 64u) { B.bp_state[0] = 1u; B.bp_state[2] = 0; }     // (inputs change: look again now and then)
 }
@@ -1150,6 +1150,117 @@ TGSF_D int start_of_w(const DevParams& P, int a, const uint8_t* t, int end, int 
     }
     return end - best_l + 1;
 }
+// ---- the path of the first location beyond 1 MiB of traceback state: Hirschberg's divide and conquer as edlib does it ----
+// 64 rows of a RANGE of the adapter (from row q0 + 64 w on) for one symbol; `row`: the symbol's kWideNW words of the wide
+// table.  Rows below the range come along in the last word: they sit below every row that counts (carries run downwards).
+TGSF_D uint64_t eq_range(const uint64_t* row, int q0, int w) {
+    const int bit = q0 + 64 * w, wi = bit >> 6, sh = bit & 63;
+    uint64_t v = wi < kWideNW ? row[wi] >> sh : 0ull;
+    if (sh && wi + 1 < kWideNW) v |= row[wi + 1] << (64 - sh);
+    return v;
+}
+// one text column of the GLOBAL alignment (hin = +1 at the top) of the Qn adapter rows from row q0 on
+TGSF_D void bvw_step_range(BvW& s, const uint64_t* row, int q0, int Qn, int nw, uint64_t* ph_out) {
+    int hin = 1;
+    for (int w = 0; w < nw; w++) {
+        uint64_t Eq = eq_range(row, q0, w), Pv = s.p[w], Mv = s.m[w];
+        uint64_t Xv = Eq | Mv;
+        if (hin < 0) Eq |= 1ull;
+        uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+        uint64_t Ph = Mv | ~(Xh | Pv);
+        uint64_t Mh = Pv & Xh;
+        if (ph_out) ph_out[w] = Ph;
+        const int bit = (w == nw - 1) ? ((Qn - 1) & 63) : 63;
+        int hout = (int)((Ph >> bit) & 1ull) - (int)((Mh >> bit) & 1ull);
+        Ph <<= 1; Mh <<= 1;
+        if (hin < 0) Mh |= 1ull;
+        if (hin > 0) Ph |= 1ull;
+        s.p[w] = Mh | ~(Xv | Ph);
+        s.m[w] = Ph & Xv;
+        hin = hout;
+    }
+    s.score += hin;
+}
+// columns of the path edlib's traceback takes through the global alignment of adapter rows [q0, q0 + Qn) against
+// t[0, Tn): from the bottom-right cell, up before left before diagonal (include/edlib.cpp:1023 / 1057 / 1088)
+TGSF_D int path_columns_range(const uint64_t* pf, int q0, int Qn, const uint8_t* t, int Tn, LaneScratch sc)
+{
+    const int nw = (Qn + 63) >> 6;
+    BvW s;
+    bvw_init(s, Qn, nw);
+    uint64_t ph[kWideNW];
+    for (int j = 1; j <= Tn; j++) {
+        bvw_step_range(s, pf + (size_t)t[j - 1] * kWideNW, q0, Qn, nw, ph);
+        for (int w = 0; w < nw; w++) { sc.at(j, w, 2 * nw) = s.p[w]; sc.at(j, nw + w, 2 * nw) = ph[w]; }
+    }
+    int i = Qn, j = Tn, len = 0;
+    while (i > 0 && j > 0) {
+        const int r = i - 1;
+        if ((sc.at(j, r >> 6, 2 * nw) >> (r & 63)) & 1ull) { i--; }
+        else if ((sc.at(j, nw + (r >> 6), 2 * nw) >> (r & 63)) & 1ull) j--;
+        else { i--; j--; }
+        len++;
+    }
+    return len + i + j;
+}
+// alignmentLength of edlib's path for adapter a against t[0, T) with distance `best` (obtainAlignment,
+// include/edlib.cpp:1164-1216): by traceback while (2*8+4)*blocks*columns + 8*columns < 1 MiB (:1191-1193), else the
+// target is cut in the middle (:1250-1251), the query at the SMALLEST row h in 1..Qn-1 whose two half scores
+// L[h] = NW(rows [0,h), left half) and R[h] = NW(rows [h,Qn), right half) add up to the score (:1321-1331), else at
+// h = 0 (:1333-1340), else at h = Qn (:1341-1349); the quadrants recurse with their own scores (:1366-1384) and the
+// lengths add up (:1392).  (edlib computes L and R inside a band; a row on an optimal path lies inside both bands and
+// holds its exact value there, so the first h is the same: oracle/tgsf_oracle.c against the reference's own edlib.)
+// The two half columns take 4 * nw words of the lane's scratch region, a leaf's traceback less than 1 MiB of it.
+// -1: the scores are inconsistent (edlib: EDLIB_STATUS_ERROR) or the recursion outgrew its stack -- never seen.
+TGSF_D int alignment_length_w(const DevParams& P, int a, const uint8_t* t, int T, int best, LaneScratch sc)
+{
+    const int Q = P.Q[a];
+    const uint64_t* pf = P.peq_fwd_w + (size_t)a * 256 * kWideNW;
+    const uint64_t* pr = P.peq_rev_w + (size_t)a * 256 * kWideNW;
+    struct Node { int q0, qn, t0, tn, best; };
+    Node st[40];
+    int sp = 0, total = 0;
+    st[sp++] = Node{0, Q, 0, T, best};
+    while (sp > 0) {
+        const Node nd = st[--sp];
+        if (nd.qn == 0 || nd.tn == 0) { total += nd.qn + nd.tn; continue; }                       // :1171-1179
+        const int nw = (nd.qn + 63) >> 6;
+        const long long data = (2ll * 8 + 4) * nw * nd.tn + 8ll * nd.tn;
+        if (data < (1ll << 20)) { total += path_columns_range(pf, nd.q0, nd.qn, t + nd.t0, nd.tn, sc); continue; }
+        const int lw = nd.tn / 2, rw = nd.tn - lw;
+        BvW s;
+        bvw_init(s, nd.qn, nw);
+        for (int j = 0; j < lw; j++) bvw_step_range(s, pf + (size_t)t[nd.t0 + j] * kWideNW, nd.q0, nd.qn, nw, nullptr);
+        for (int w = 0; w < nw; w++) { sc.at(0, w, 1) = s.p[w]; sc.at(0, nw + w, 1) = s.m[w]; }     // the left half's last column
+        // the right half: the reversed rows against the reversed text (rows [q0, q0+qn) reversed = rows
+        // [Q - q0 - qn, Q - q0) of the reversed adapter)
+        bvw_init(s, nd.qn, nw);
+        const int q0r = Q - nd.q0 - nd.qn;
+        for (int j = 0; j < rw; j++) bvw_step_range(s, pr + (size_t)t[nd.t0 + nd.tn - 1 - j] * kWideNW, q0r, nd.qn, nw, nullptr);
+        auto dl = [&](int i) { return (int)((sc.at(0, i >> 6, 1) >> (i & 63)) & 1ull) - (int)((sc.at(0, nw + (i >> 6), 1) >> (i & 63)) & 1ull); };
+        auto dr = [&](int i) { return (int)((s.p[i >> 6] >> (i & 63)) & 1ull) - (int)((s.m[i >> 6] >> (i & 63)) & 1ull); };
+        int Rm = rw;                                    // R[1]: the last qn - 1 rows against the right half
+        for (int i = 0; i + 1 < nd.qn; i++) Rm += dr(i);
+        const int Rfull = Rm + dr(nd.qn - 1);           // R[0]
+        int Lh = lw, h = -1, ls = 0, rs = 0;
+        for (int x = 1; x <= nd.qn - 1; x++) {
+            Lh += dl(x - 1);                            // L[x]
+            if (Lh + Rm == nd.best) { h = x; ls = Lh; rs = Rm; break; }
+            Rm -= dr(nd.qn - x - 1);                    // R[x + 1]
+        }
+        if (h < 0 && lw + Rfull == nd.best) { h = 0; ls = lw; rs = Rfull; }
+        if (h < 0) {
+            int Lq = lw;
+            for (int i = 0; i < nd.qn; i++) Lq += dl(i);
+            if (Lq + rw == nd.best) { h = nd.qn; ls = Lq; rs = rw; }
+        }
+        if (h < 0 || sp + 2 > 40) return -1;
+        st[sp++] = Node{nd.q0 + h, nd.qn - h, nd.t0 + lw, rw, rs};
+        st[sp++] = Node{nd.q0, h, nd.t0, lw, ls};
+    }
+    return total;
+}
+
 TGSF_D int first_mlen_w(const DevParams& P, int a, const uint8_t* t, int start0, int end0, int best, int need, LaneScratch sc, bool exact)
 {
     const int Q = P.Q[a], nw = (Q + 63) >> 6;
@@ -1160,6 +1271,10 @@ TGSF_D int first_mlen_w(const DevParams& P, int a, const uint8_t* t, int start0,
         const int hi = T - best + (slack > 0 ? slack / 2 : 0);
         if (lo >= need) return lo;
         if (hi < need) return -1;
+    }
+    if ((2ll * 8 + 4) * nw * T + 8ll * T >= (1ll << 20)) {                 // beyond 1 MiB of traceback state: as edlib, include/edlib.cpp:1191-1210
+        const int len = alignment_length_w(P, a, t + start0, T, best, sc);
+        return len < 0 ? -1 : len - best;
     }
     const uint64_t* pf = P.peq_fwd_w + (size_t)a * 256 * kWideNW;
     const uint8_t* tt = t + start0;

@@ -571,7 +571,15 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
             maxcols = std::max(maxcols, P.Q[a] + std::min(P.Q[a], kmax) + 1);
         }
         c->scratch_cols = maxcols;
-        B.scratch_wave_words = (size_t)(maxcols + 1) * 2 * P.max_nw * 64;
+        // words per column: those of the widest adapter (1 / 2 / 4 in the register classes, ceil(Q / 64) beyond 256 bp).
+        // An alignment whose columns would take 1 MiB and more is not traced back whole: edlib -- and alignment_length_w --
+        // cut it by Hirschberg's scheme into pieces below that (include/edlib.cpp:1191-1193), so a lane's region never
+        // needs more than 1 MiB (+ the two half columns of a cut).
+        int col_words = P.max_nw;
+        if (P.max_nw > 4) { col_words = 1; for (int a = 0; a < p->n_adapters; a++) col_words = std::max(col_words, (P.Q[a] + 63) / 64); }
+        size_t lane_words = (size_t)(maxcols + 1) * 2 * (size_t)col_words;
+        if (P.max_nw > 4) lane_words = std::min<size_t>(lane_words, (1u << 17) + 2 * (size_t)col_words) + 4 * (size_t)col_words + 64;
+        B.scratch_wave_words = lane_words * 64;
         B.scratch_mid_wave0 = ((size_t)n * A * 2 + 63) / 64 + 1;
         const size_t waves = B.scratch_mid_wave0 + ((size_t)n * A + 63) / 64 + 1;
         if (!e) e = dev_alloc(c, &B.scratch, waves * B.scratch_wave_words);

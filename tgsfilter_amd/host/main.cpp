@@ -366,9 +366,10 @@ int main(int argc, char** argv)
             const int Q = (int)a.size();
             const int kmax = std::max(0, std::min(Q - 1, std::max(Q - o.end_match_len + 1, Q - o.mid_match_len + 1)));
             cols = std::max<uint64_t>(cols, (uint64_t)(Q + kmax + 2));
-            nw = std::max<uint64_t>(nw, Q > 256 ? 20 : Q > 128 ? 4 : Q > 64 ? 2 : 1);
+            nw = std::max<uint64_t>(nw, Q > 256 ? (uint64_t)(Q + 63) / 64 : Q > 128 ? 4 : Q > 64 ? 2 : 1);
         }
         per_read = cols * 2 * nw * 8;
+        if (nw > 4) per_read = std::min<uint64_t>(per_read, (1ull << 20) + 16 * nw) + 32 * nw + 512;   // (beyond 1 MiB an alignment is cut by Hirschberg's scheme, as in edlib)
         per_read *= 3 * std::max<size_t>(adapters.size(), 1);          // two end windows + one middle alignment per adapter
         if (per_read) batch_reads = (uint32_t)std::min<uint64_t>(batch_reads, std::max<uint64_t>(256, (4ull << 30) / per_read));
     }
