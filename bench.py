@@ -318,6 +318,7 @@ def e2e_leg(args, n_gpus):
     want_ranks = int(getattr(args, "e2e_ranks", 0) or 0) or (n_gpus if n_gpus > 1 else 0)
     rank_devs = devs if n_gpus > 1 else "0"
 
+
     def rm(path):
         for p in [path] + ["%s.part%d" % (path, r) for r in range(64)]:
             if os.path.isfile(p) and not os.path.islink(p):
@@ -914,7 +915,7 @@ def main():
                     "c5: ultra-long reads, repeat gate and downsampling)")
     ap.add_argument("--e2e-reads", type=int, default=None, help="reads in the end-to-end FASTQ file (default: the configuration's -- C2: 4 M reads, ~90 KB "
                     "of text each); reduced -- and said so in config.workload -- to what the staging file system / the box's memory control group holds")
-    ap.add_argument("--e2e-budget-s", type=float, default=1500.0, help="seconds the end-to-end leg may take: optional legs are dropped (and named in "
+    ap.add_argument("--e2e-budget-s", type=float, default=1350.0, help="seconds the end-to-end leg may take: optional legs are dropped (and named in "
                     "e2e.skipped) when it runs short; the K timed steps never are")
     ap.add_argument("--pinned-variant", action="store_true", help="also run the pinned-pre-pass variant (-5 0 -3 0 -a rapid.fa on 400 000 reads: round 2's headline)")
     ap.add_argument("--e2e-files", type=int, default=0, help="stage the end-to-end reads as this many consecutive files (default: as few as the box's memory allows)")
@@ -977,6 +978,8 @@ def main():
         if rank == 0:
             if world > 1:
                 args.no_cpu_baseline = True          # the reference is timed at N = 1 only (the contract: cpu_baseline on rank 0 at N=1)
+            if args.share_gpu and not args.e2e_ranks:
+                args.e2e_ranks = world               # (validation on a 1-GPU box: the N rank processes share device 0)
             e2e = e2e_leg(args, 1 if args.share_gpu else world)
         if world > 1:
             dist.barrier(group=host_group)

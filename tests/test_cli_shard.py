@@ -44,6 +44,21 @@ def test_cli_sharded_by_another_launcher(binary, golden_dir, name):
     cli_check.run_case(binary, golden_dir, name, ranks=3, launcher="external")
 
 
+@pytest.mark.parametrize("name", ["down_gd", "down_r", "down_R", "down_F", "fasta_down"])
+@pytest.mark.parametrize("how", ["text", "packed"])
+def test_cli_sharded_downsampling(binary, golden_dir, name, how, monkeypatch):
+    """A downsampling run selects among ALL reads of the job: rank 0 makes the reference's selection over every rank's kept
+    fragments and hands each rank its keep flags; the second (QC) pass and the writing are per rank (the kept reads read in
+    place from the text or packed; written by threads into a mapping of the part file reserved early, or by the single-stream
+    writer), its tallies summed on rank 0."""
+    monkeypatch.setenv("TGSF_DOWN_QC", how)
+    monkeypatch.setenv("TGSF_DOWN_MAP_MIN", "1" if how == "text" else "1000000000000")
+    if how == "text":
+        monkeypatch.setenv("TGSF_DOWN_EARLY_MIN", "1")
+        monkeypatch.setenv("TGSF_STRIDE_BYTES", "40000")
+    cli_check.run_case(binary, golden_dir, name, ranks=3, extra_args=["-t", "6"])
+
+
 def test_cli_one_rank_is_a_job_too(binary, golden_dir):
     cli_check.run_case(binary, golden_dir, "ont_zoo", ranks=1)
 
@@ -132,8 +147,7 @@ def test_cli_sharded_refusals(binary, golden_dir, tmp_path):
     gz = tmp_path / "in2.fq.gz"
     gz.write_bytes(gzip.compress(raw))
     base = [binary, "-x", "ont", "-o", str(tmp_path / "o.fq")]
-    for extra, what in ((["-i", str(fin), "--ranks", "2", "-r", "10"], b"downsampling"),
-                        (["-i", str(gz), "--ranks", "2"], b"plain FASTQ"),
+    for extra, what in ((["-i", str(gz), "--ranks", "2"], b"plain FASTQ"),
                         (["-i", str(fin), "--shard", "0/2"], b"--rendezvous"),
                         (["-i", str(fin), "--shard", "2/2", "--rendezvous", str(tmp_path / "s")], b"no such rank"),
                         (["-i", str(fin), "--ranks", "2", "--shard", "0/2", "--rendezvous", str(tmp_path / "s")], b"--ranks starts the ranks itself")):
@@ -230,3 +244,30 @@ def test_cli_gpu_three_ranks_on_a_real_file_against_the_reference(tmp_path):
         assert three[0] == one[0] == ref[0]
         assert three[2] == one[2] == ref[2]
         assert three[3].count("SHARD ") == 3 and "summed on rank 0 over the ranks' sockets" in three[3]
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/tgsfilter_ref not built (make -C oracle ref)")
+def test_cli_gpu_three_ranks_config5_shape_against_the_reference(tmp_path):
+    """Config C5's flags (repeat gate on the GPU, longest-first downsampling) as a job of three ranks: the selection is made
+    on rank 0 over every rank's kept fragments; parts concatenated, INFO lines equal the reference's (-t 1)."""
+    import tempfile
+    from tgsfilter_amd import synth
+    shm = "/dev/shm" if os.access("/dev/shm", os.W_OK) else None
+    with tempfile.TemporaryDirectory(dir=shm) as td:
+        fq = os.path.join(td, "c5.fq")
+        bases, _ = synth.write_ont_fastq(fq, 800, seed=5, mean_len=150000.0, max_len=2_000_000, reads_per_job=64)
+        assert bases > 4e7
+        fa = os.path.join(td, "rapid.fa")
+        open(fa, "wb").write(b">rapid\n" + synth.ONT_RAPID + b"\n")
+        common = ["-i", fq, "-x", "ont", "-l", "1000", "-q", "10", "-5", "0", "-3", "0", "-a", fa, "-p", "100", "-k", "11", "-g", "30m", "-d", "2"]
+        outs = {}
+        for tag, exe, extra, parts in (("ref", REF, ["-t", "1"], 0), ("ours", GPU_BINARY, ["-t", "16", "--ranks", "3", "--devices", "0"], 3)):
+            out = os.path.join(td, tag + ".fq")
+            p = subprocess.run([exe, "-o", out] + extra + common, capture_output=True)
+            assert p.returncode == 0, p.stderr.decode()[-2000:]
+            info = [l for l in p.stderr.decode().splitlines() if l.startswith("INFO: ") and "written to" not in l and "input adapter" not in l]
+            data = b"".join(open(f, "rb").read() for f in ([out] if not parts else ["%s.part%d" % (out, r) for r in range(parts)]))
+            outs[tag] = (data, info)
+        assert outs["ours"][1] == outs["ref"][1]
+        assert outs["ours"][0] == outs["ref"][0] and len(outs["ref"][0]) > 1e6

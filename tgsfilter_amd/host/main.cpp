@@ -127,8 +127,7 @@ int main(int argc, char** argv)
     if (o.ranks >= 1 || o.shard_world >= 1) {
         const int world = o.ranks >= 1 ? o.ranks : o.shard_world;
         const char* why = nullptr;
-        if (o.downsample) why = "downsampling (-g/-d, -r, -R) selects among ALL reads of the input";
-        else if (o.out_file.empty() && !o.only_qc && !o.only_adapters) why = "every rank writes a part file of its own: -o is needed";
+        if (o.out_file.empty() && !o.only_qc && !o.only_adapters) why = "every rank writes a part file of its own: -o is needed";
         else if (file_type(o.in_file) == 2 || (o.in_file.size() > 3 && o.in_file.compare(o.in_file.size() - 3, 3, ".gz") == 0))
             why = "the ranks take byte ranges of a plain FASTQ / FASTA text";
         if (why) { std::cerr << "Error: --ranks / --shard: " << why << std::endl; return 1; }
@@ -669,7 +668,7 @@ int main(int argc, char** argv)
         const char* w = getenv("TGSF_WRITER");
         if (o.out_gz || o.out_file.empty() || (w && !strcmp(w, "writev"))) return false;
         std::unique_ptr<MappedSink> d(new MappedSink);
-        if (!d->open(o.out_file, capacity)) return false;
+        if (!d->open(out_path, capacity)) return false;
         dsink = std::move(d);
         dpop.reset(new Pool(populate_threads));
         dres.reset(new Reserver(*dsink, *dpop, stride_bytes, false));
@@ -679,10 +678,10 @@ int main(int argc, char** argv)
     {
         uint64_t early_min = 1ull << 30;
         if (const char* e = knob("TGSF_DOWN_EARLY_MIN")) early_min = strtoull(e, nullptr, 10);          // tests: small inputs too
-        if (o.downsample && !streaming && in.mapped() && (uint64_t)in.size() >= early_min) {
-            uint64_t spec = (uint64_t)in.size() / 4;
-            if (o.genome_size > 0 && o.desired_depth > 0) spec = std::min<uint64_t>(spec, 2 * o.genome_size * (uint64_t)o.desired_depth + (uint64_t)in.size() / 64);
-            open_dsink(4 * (uint64_t)in.size() + (1ull << 30), spec);
+        if (o.downsample && !streaming && in.mapped() && (uint64_t)text_size >= early_min) {
+            uint64_t spec = (uint64_t)text_size / 4;
+            if (o.genome_size > 0 && o.desired_depth > 0) spec = std::min<uint64_t>(spec, (2 * o.genome_size * (uint64_t)o.desired_depth) / (uint64_t)link.world + (uint64_t)text_size / 64);
+            open_dsink(4 * (uint64_t)text_size + (1ull << 30), spec);
         }
     }
     // Mappings of written batches (input text, output file).  One process (the default): the teardown is on the caller's
@@ -851,10 +850,37 @@ int main(int argc, char** argv)
     t_pipe = now_s() - t_p0;
     tgsf_ctx* ctx = ctxs[0];
 
+    // A rank's tally vector as it travels to rank 0 over the sockets: everything in front of the four per-100-bp tables, then
+    // of each of those only the rows in use; and its sum into rank 0's vector (the four "rows used" words are maxima).
+    auto pack_rows = [](const std::vector<uint64_t>& v, int32_t bc2, uint32_t nb2) {
+        const size_t head = tgsf_ctr_bin_table(0, bc2, nb2);
+        std::vector<uint64_t> out(v.begin(), v.begin() + (long)head);
+        for (int b = 0; b < 4; b++) {
+            const size_t at = tgsf_ctr_bin_table(b, bc2, nb2), n = (size_t)std::min<uint64_t>(v[TGSF_CTR_ROWS + (b >> 1)], nb2) * 5;
+            out.insert(out.end(), v.begin() + (long)at, v.begin() + (long)(at + n));
+        }
+        return out;
+    };
+    auto add_rows = [](std::vector<uint64_t>& v, const std::vector<uint64_t>& ru, int32_t bc2, uint32_t nb2) {
+        const size_t head = tgsf_ctr_bin_table(0, bc2, nb2);
+        if (ru.size() < head) die("a rank of the job sent a tally vector of another layout");
+        uint64_t rows[4];
+        for (int q = 0; q < 4; q++) rows[q] = std::max(v[TGSF_CTR_ROWS + q], ru[TGSF_CTR_ROWS + q]);
+        for (size_t i = 0; i < head; i++) v[i] += ru[i];
+        size_t from = head;
+        for (int b = 0; b < 4; b++) {
+            const size_t at = tgsf_ctr_bin_table(b, bc2, nb2), n = (size_t)std::min<uint64_t>(ru[TGSF_CTR_ROWS + (b >> 1)], nb2) * 5;
+            if (from + n > ru.size()) die("a rank of the job sent a tally vector of another layout");
+            for (size_t i = 0; i < n; i++) v[at + i] += ru[from + i];
+            from += n;
+        }
+        for (int q = 0; q < 4; q++) v[TGSF_CTR_ROWS + q] = rows[q];
+    };
+
     // ---- downsampling: DownSampleTask, :2164-2568 ----
     // keep the longest reads until the target is met (:2297-2344), then a QC-only pass over the kept reads
     // (CalcAvgQuality / Get_5p/3p_base_qual again, :2436-2447) which also writes them, in input order.
-    uint64_t down_bases = 0;
+    uint64_t down_bases = 0, down_job_recs = 0, down_job_bases = 0;
     std::vector<int> down_lens;
     std::vector<uint64_t> down_t;
     double t_d0 = now_s(), t_dsel = 0, t_dcreate = 0, t_dqc = 0, t_dwrite = 0, t_dclose = 0, t_dsubmit = 0, t_dfirst = 0, d_kept = 0, d_span = 0; int n_dsubmit = 0; bool d_in_place = false, d_mapped = false;
@@ -869,9 +895,39 @@ int main(int argc, char** argv)
             append_name(nm, c.name, c.pass_num);
             return nm;
         };
+        // (one process per GPU: the selection is over the kept fragments of ALL ranks, in input order = rank order; rank 0
+        // receives every rank's names and lengths and makes it, the others wait for their keep flags)
+        std::vector<std::string> all_names;                            // rank 0 of a sharded job: every fragment of the job, in input order
+        std::vector<int> all_lens;
+        std::vector<size_t> rank_first;                                // ... and where each rank's begin
+        if (sharded) {
+            BlobOut mine;
+            std::vector<uint32_t> lens;
+            std::string names;
+            for (const CleanRec& c : clean_recs) { lens.push_back(c.len); const std::string nm = full_name(c); const uint32_t n = (uint32_t)nm.size(); names.append((const char*)&n, 4); names += nm; }
+            mine.vec(lens); mine.str(names);
+            const std::vector<std::string> all = link.gather(mine.s);
+            for (const std::string& b : all) {
+                BlobIn in2(b);
+                std::vector<uint32_t> l2; std::string n2;
+                in2.vec(l2); in2.str(n2);
+                rank_first.push_back(all_names.size());
+                size_t at = 0;
+                for (uint32_t L : l2) {
+                    uint32_t n = 0;
+                    if (at + 4 > n2.size()) die("a rank of the job sent a list of names shorter than its lengths");
+                    memcpy(&n, n2.data() + at, 4); at += 4;
+                    all_names.emplace_back(n2.data() + at, n); at += n;
+                    all_lens.push_back((int)L);
+                }
+            }
+            rank_first.push_back(all_names.size());
+        }
+        const bool selects = !sharded || link.rank == 0;
         std::unordered_map<std::string, int> seq_lens;
         uint64_t total = 0;
-        for (const CleanRec& c : clean_recs) { seq_lens[full_name(c)] = (int)c.len; total += c.len; }
+        if (!sharded) for (const CleanRec& c : clean_recs) { seq_lens[full_name(c)] = (int)c.len; total += c.len; }
+        else for (size_t i = 0; i < all_names.size(); i++) { seq_lens[all_names[i]] = all_lens[i]; total += (uint64_t)all_lens[i]; }
         const std::unordered_map<std::string, int> handed(seq_lens), task_lens(handed);
         std::vector<std::pair<std::string, int>> vec(task_lens.begin(), task_lens.end());
         std::sort(vec.begin(), vec.end(), [](const std::pair<std::string, int>& a, const std::pair<std::string, int>& b) {
@@ -884,13 +940,30 @@ int main(int argc, char** argv)
         std::unordered_set<std::string> chosen;
         uint64_t added = 0; int added_num = 0;
         for (const auto& pr : vec) {
+            if (!selects) break;
             chosen.insert(pr.first);
             added += (uint64_t)pr.second; added_num++;
             down_bases += (uint64_t)pr.second; down_lens.push_back(pr.second);
             if (by_size ? added >= desired : added_num >= want_num) break;
         }
         std::vector<char> keep(clean_recs.size(), 0);
-        for (size_t i = 0; i < clean_recs.size(); i++) keep[i] = chosen.count(full_name(clean_recs[i])) ? 1 : 0;
+        if (!sharded) for (size_t i = 0; i < clean_recs.size(); i++) keep[i] = chosen.count(full_name(clean_recs[i])) ? 1 : 0;
+        else {
+            std::vector<std::string> flags;
+            if (link.rank == 0)
+                for (int k = 0; k < link.world; k++) {
+                    std::string f(rank_first[(size_t)k + 1] - rank_first[(size_t)k], '\0');
+                    for (size_t i = 0; i < f.size(); i++) f[i] = chosen.count(all_names[rank_first[(size_t)k] + i]) ? 1 : 0;
+                    flags.push_back(std::move(f));
+                }
+            std::string mine;
+            link.scatter(flags, mine);
+            if (mine.size() != keep.size()) die("the selection handed to this rank does not fit its fragments");
+            memcpy(keep.data(), mine.data(), keep.size());
+            // (the job's totals, for rank 0's statistics: every fragment that entered the selection)
+            if (link.rank == 0) { down_job_recs = all_names.size(); down_job_bases = total; }
+            std::vector<std::string>().swap(all_names);
+        }
         t_dsel = now_s() - t_d0;
         tgsf_params qp = p;
         qp.filter = 0; qp.only_qc = 1; qp.n_adapters = 0; qp.min_repeat = 0;
@@ -1116,6 +1189,17 @@ int main(int argc, char** argv)
             for (uint64_t i = 0; i < qnw; i++)
                 down_t[i] = (i >= TGSF_CTR_ROWS && i < TGSF_CTR_ROWS + 4) ? std::max(down_t[i], t2[i]) : down_t[i] + t2[i];
         }
+        if (sharded) {                                                 // the second pass's tallies of the whole job, on rank 0
+            BlobOut mine;
+            mine.vec(pack_rows(down_t, qbc, qnb));
+            const std::vector<std::string> all = link.gather(mine.s);
+            for (int k = 1; k < (int)all.size(); k++) {
+                BlobIn in2(all[(size_t)k]);
+                std::vector<uint64_t> ru;
+                in2.vec(ru);
+                add_rows(down_t, ru, qbc, qnb);
+            }
+        }
     }
     { const double c0 = now_s(); if (!o.only_qc && !mapped_out) out.close(); t_dclose = now_s() - c0; }
 
@@ -1161,18 +1245,11 @@ int main(int argc, char** argv)
     const bool reports = !sharded || link.rank == 0;
     uint64_t job_reads = raw_lens.size();
     if (sharded) {
-        const size_t head = tgsf_ctr_bin_table(0, bc, nbins);
         BlobOut mine;
         mine.pod(raw_bases); mine.pod(clean_bases);
         mine.vec(raw_lens); mine.vec(clean_lens);                      // (each sorted already, beside the pipeline)
         std::vector<uint64_t> rows_used;
-        if (!use_rccl) {
-            rows_used.assign(t.begin(), t.begin() + (long)head);
-            for (int b = 0; b < 4; b++) {
-                const size_t at = tgsf_ctr_bin_table(b, bc, nbins), n = (size_t)std::min<uint64_t>(t[TGSF_CTR_ROWS + (b >> 1)], nbins) * 5;
-                rows_used.insert(rows_used.end(), t.begin() + (long)at, t.begin() + (long)(at + n));
-            }
-        }
+        if (!use_rccl) rows_used = pack_rows(t, bc, nbins);
         mine.vec(rows_used);
         const std::vector<std::string> all = link.gather(mine.s);
         for (int k = 1; k < (int)all.size(); k++) {                    // (rank 0 only)
@@ -1186,21 +1263,8 @@ int main(int argc, char** argv)
             raw_lens.insert(raw_lens.end(), rl.begin(), rl.end());
             clean_lens.insert(clean_lens.end(), cl.begin(), cl.end());
             std::inplace_merge(raw_lens.begin(), raw_lens.begin() + (long)r0, raw_lens.end());
-            std::inplace_merge(clean_lens.begin(), clean_lens.begin() + (long)c0, clean_lens.end());
-            if (!use_rccl) {
-                if (ru.size() < head) die("a rank of the job sent a tally vector of another layout");
-                uint64_t rows[4];
-                for (int q = 0; q < 4; q++) rows[q] = std::max(t[TGSF_CTR_ROWS + q], ru[TGSF_CTR_ROWS + q]);
-                for (size_t i = 0; i < head; i++) t[i] += ru[i];
-                size_t from = head;
-                for (int b = 0; b < 4; b++) {
-                    const size_t at = tgsf_ctr_bin_table(b, bc, nbins), n = (size_t)std::min<uint64_t>(ru[TGSF_CTR_ROWS + (b >> 1)], nbins) * 5;
-                    if (from + n > ru.size()) die("a rank of the job sent a tally vector of another layout");
-                    for (size_t i = 0; i < n; i++) t[at + i] += ru[from + i];
-                    from += n;
-                }
-                for (int q = 0; q < 4; q++) t[TGSF_CTR_ROWS + q] = rows[q];
-            }
+            if (!o.downsample) std::inplace_merge(clean_lens.begin(), clean_lens.begin() + (long)c0, clean_lens.end());   // (a downsampling run reports the selected reads' lengths instead)
+            if (!use_rccl) add_rows(t, ru, bc, nbins);
         }
         job_reads = raw_lens.size();
         if (timing)
@@ -1259,15 +1323,19 @@ int main(int argc, char** argv)
             }
         }
     }
-    if (o.downsample) {                                                // :3240-3279
+    if (o.downsample && reports) {                                     // :3240-3279
         if (down_lens.empty()) die("no reads to downsample");
         std::sort(down_lens.begin(), down_lens.end());
         side_stats(bc, down_lens, down_bases, tables(down_t, false), clean);
         clean.tab[8] = limit_decimals(std::round(clean.mean_qual * 1000) / 1000.0, 2);      // two places here, :3268
         if (!o.filter)
-            std::cerr << "INFO: " << clean_recs.size() << " reads with a total of " << clean_bases << " bases were input." << std::endl;
+            std::cerr << "INFO: " << (sharded ? down_job_recs : clean_recs.size()) << " reads with a total of " << (sharded ? down_job_bases : clean_bases) << " bases were input." << std::endl;
         std::cerr << "INFO: " << down_lens.size() << " reads with a total of " << down_bases << " bases after downsampling." << std::endl;
-        if (!o.out_file.empty()) std::cerr << "INFO: Downsampled reads were written to: " << o.out_file << "." << std::endl;
+        if (!o.out_file.empty()) {
+            if (!sharded) std::cerr << "INFO: Downsampled reads were written to: " << o.out_file << "." << std::endl;
+            else std::cerr << "INFO: Downsampled reads were written to: " << o.out_file << ".part0 ... " << o.out_file << ".part" << link.world - 1
+                           << " (" << link.world << " parts; concatenated in this order they are the reads in input order)." << std::endl;
+        }
     }
     std::string qc = fasta_in ? "0" : "1";                             // :3286-3291
     qc += o.only_qc ? "0" : ((!o.filter && o.downsample) ? "1" : "2"); // :3293-3299

@@ -15,7 +15,10 @@
 //   * at the end the tally vectors are summed -- on the devices, one RCCL all-reduce over xGMI (libtgsf_rccl), when
 //     every rank has a GPU of its own; over the ranks' sockets when ranks share a GPU (the 1-GPU test set-up: RCCL
 //     refuses two ranks on one device) -- and rank 0, which also receives the read-length vectors, prints the
-//     statistics and writes the one report.
+//     statistics and writes the one report;
+//   * a downsampling run (-g/-d, -r, -R) selects among ALL reads: rank 0 receives every rank's kept fragments (name, length,
+//     in input order), makes the reference's selection over them, container for container, and hands every rank the keep
+//     flags of its own; the second (QC) pass and the writing are per rank again, its tallies summed like the first's.
 // What travels between the ranks on the host is small (a few hundred bytes of constants, 4 bytes per read of
 // lengths, the tally rows in use): a star of stream sockets around rank 0 (RankLink) carries it.
 #pragma once
@@ -96,6 +99,12 @@ public:
             for (int k = 1; k < world; k++) recv_blob(fds_[(size_t)k], all[(size_t)k], k);
         } else send_blob(fds_[0], mine, 0);
         return all;
+    }
+    // rank 0's k-th blob to rank k (its own stays with it)
+    void scatter(std::vector<std::string>& blobs, std::string& mine) {
+        if (!active()) { if (!blobs.empty()) mine = blobs[0]; return; }
+        if (rank == 0) { mine = blobs[0]; for (int k = 1; k < world; k++) send_blob(fds_[(size_t)k], blobs[(size_t)k], k); }
+        else recv_blob(fds_[0], mine, 0);
     }
     uint64_t max_u64(uint64_t v) {
         if (!active()) return v;
