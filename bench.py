@@ -457,7 +457,7 @@ def e2e_leg(args, n_gpus):
                     log("bench: e2e dev_null: %s" % json.dumps({k2: v for k2, v in d.items() if k2 not in ("timing_line", "shard_lines")}))
                 # N = 1: the program path of N GPUs on this box -- rank processes sharing the GPU, a part file each (the tallies
                 # go over the ranks' sockets: RCCL refuses two ranks on one device).  Same records, same INFO lines.
-                if n_gpus == 1 and not want_ranks and not cfg["flags"].count("-g") and getattr(args, "sharded_leg", True):
+                if n_gpus == 1 and not want_ranks and getattr(args, "sharded_leg", True):
                     k_sh = min(args.steps, 3)
                     for nr in (3,):
                         if not budget.allows("sharded leg, %d ranks on one GPU" % nr, (k_sh + 1) * s["wall_s_mean"] + 10 + reserve(f)):

@@ -276,3 +276,23 @@ def test_bench_two_ranks_share_one_gpu_same_totals(tmp_path):
     assert j2["kernel_path"]["tallies"] == j1["kernel_path"]["tallies"]
     assert j2["kernel_path"]["tallies"]["reads"] == 6 * 4096
     assert "all-reduce" in j2["kernel_path"]["tally_exchange"] and j2["kernel_path"]["rccl_ranks"] is None
+
+
+def test_bench_two_ranks_end_to_end_leg_runs_one_process_per_gpu(tmp_path):
+    """bench.py --gpus N: the end-to-end leg runs the command line as N rank processes (tgsfilter --ranks N, a part file
+    each) -- here N = 2 sharing device 0, on a small file: the line says so, carries the per-rank SHARD lines and a value."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("TGSF_DEBUG_KNOBS", None)                     # (the bench runs the product as a user would)
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29543", os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "gloo",
+                          "--e2e-reads", "3000", "--steps", "2", "--warmup", "1", "--no-kernel-path"], capture_output=True, timeout=1200, env=env)
+    assert two.returncode == 0, two.stderr.decode()[-3000:]
+    j = json.loads([l for l in two.stdout.decode().splitlines() if l.startswith("{")][-1])
+    s = j["e2e"]["sinks"]["tmpfs_file"]
+    assert j["n_gpus"] == 2 and j["e2e"]["ranks"] == 2 and s["ranks"] == 2 and j["steps"] == 2 and j["value"] > 0
+    assert len(s["per_file"][0]["shard_lines"]) == 2 and "tgsfilter --ranks 2" in j["config"]["workload"]
+    assert j["e2e"]["sinks"]["dev_null"]["same_counters_as_the_file_run"] and "cpu_baseline" not in j

@@ -31,6 +31,7 @@
 
 #include <cerrno>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -218,6 +219,9 @@ inline void fork_ranks(int world, RankLink& link)
                 for (int k = 1; k < world; k++) { ::close(hub[(size_t)k]); if (k != r) ::close(spoke[(size_t)k]); }
             }
             link.adopt(r, world, std::move(fds));
+            // (several processes on the GPUs of one node: the host driver of this pool only supports dmabuf IPC -- without this
+            // RCCL's and HIP's cross-process sharing fails with "hipIpcGetMemHandle: invalid argument"; a value already set stays)
+            setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
             return;
         }
         kids[(size_t)r] = pid;
