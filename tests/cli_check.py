@@ -103,8 +103,9 @@ def _first_diff(a, b):
     return "var data lengths differ: %d vs %d" % (len(a), len(b))
 
 
-def _run(binary, td, sub, fin, flags, adapters, out_name="out.fq", to_stdout=False):
-    """One run of `binary` in its own sub-directory; returns (returncode, output bytes, stderr text, html text)."""
+def _run(binary, td, sub, fin, flags, adapters, out_name="out.fq", to_stdout=False, ranks=None, own_args=()):
+    """One run of `binary` in its own sub-directory; returns (returncode, output bytes, stderr text, html text).
+    ranks: as a job of that many rank processes (--ranks N): the output is the parts concatenated in rank order."""
     d = os.path.join(td, sub)
     os.makedirs(d)
     qc = "--qc" in flags or to_stdout          # no -o: the report is named after the input
@@ -118,10 +119,20 @@ def _run(binary, td, sub, fin, flags, adapters, out_name="out.fq", to_stdout=Fal
             for i, a in enumerate(adapters):
                 f.write(">a%d\n%s\n" % (i, a.decode()))
         args += ["-a", fa]
+    if ranks:
+        args += ["--ranks", str(ranks)]
+    args += list(own_args)
     p = subprocess.run(args, capture_output=True, cwd=d)
     err = p.stderr.decode().replace(d + "/", "").replace(os.path.dirname(fin) + "/", "")
     data = p.stdout if to_stdout else b""
-    if not qc and os.path.exists(out):
+    if ranks and not qc and p.returncode == 0:
+        assert not os.path.exists(out)
+        data = b""
+        for r in range(ranks):
+            part = open("%s.part%d" % (out, r), "rb").read()
+            data += (gzip.decompress(part) if part else b"") if out.endswith(".gz") else part
+        err = re.sub(r"(INFO: (?:Filtered|Downsampled) reads were written to: \S+?)\.part0 \.\.\. .*", r"\1.", err)
+    elif not qc and os.path.exists(out):
         data = open(out, "rb").read()
         if out.endswith(".gz"):
             data = gzip.decompress(data) if data else b""
@@ -139,7 +150,7 @@ def _run(binary, td, sub, fin, flags, adapters, out_name="out.fq", to_stdout=Fal
 
 
 def compare_live(binary, ref_binary, reads, flags, adapters, fasta=False, in_fmt=None, out_name=None, to_stdout=False,
-                 raw_input=None):
+                 raw_input=None, ranks=None, own_args=()):
     """Run the reference binary and ours on the same freshly written input: output file, INFO lines and the
     report's table / data object must be identical.  in_fmt: fq | fq.gz | fa | bam | sam."""
     from tgsfilter_amd import synth
@@ -167,7 +178,7 @@ def compare_live(binary, ref_binary, reads, flags, adapters, fasta=False, in_fmt
         else:
             synth.write_fastq(fin, reads)
         rc_r, out_r, err_r, html_r = _run(ref_binary, td, "ref", fin, flags, adapters, out_name, to_stdout)
-        rc_o, out_o, err_o, html_o = _run(binary, td, "own", fin, flags, adapters, out_name, to_stdout)
+        rc_o, out_o, err_o, html_o = _run(binary, td, "own", fin, flags, adapters, out_name, to_stdout, ranks=ranks, own_args=own_args)
     if rc_r != 0:
         # parameter sets the reference itself cannot finish (e.g. nothing passes the filters: it dereferences an
         # empty vector, src/TGSFilter.cpp:3183): this side must refuse too, there is nothing else to compare

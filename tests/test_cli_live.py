@@ -132,6 +132,41 @@ def test_cli_live_formats_gpu(seed):
 
 
 @needs_ref
+@pytest.mark.parametrize("seed", range(8000, 8016))
+def test_cli_live_sharded_emul(seed):
+    """The same random inputs and flag sets (downsampling, repeat gate, -D, several adapters, FASTA, .gz output ...) as a job
+    of 2 or 3 rank processes: the parts concatenated in rank order, the INFO lines and the report equal the reference's."""
+    import subprocess
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tgsfilter_amd", "host"), "emul"], check=True)
+    if seed % 2:
+        reads, flags, adapters, fasta = case(seed, 60)
+        cli_check.compare_live(os.path.join(ROOT, "tests", "emul", "tgsfilter_emul"), REF, reads, flags, adapters, fasta, ranks=2 + seed % 3 % 2)
+    else:
+        reads, flags, adapters, in_fmt, out_name = case2(seed, 60)
+        if in_fmt not in ("fq", "fa"):
+            in_fmt = "fq"                          # (a sharded job takes plain text)
+            out_name = out_name.replace(".fa", ".fq") if "-f" not in flags else out_name
+        cli_check.compare_live(os.path.join(ROOT, "tests", "emul", "tgsfilter_emul"), REF, reads, flags, adapters,
+                               in_fmt=in_fmt, out_name=out_name, ranks=3)
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8000, 8024))
+def test_cli_live_sharded_gpu(seed):
+    binary = os.path.join(ROOT, "tgsfilter_amd", "bin", "tgsfilter")
+    if seed % 2:
+        reads, flags, adapters, fasta = case(seed, 300)
+        cli_check.compare_live(binary, REF, reads, flags, adapters, fasta, ranks=2 + seed % 3 % 2, own_args=["--devices", "0"])
+    else:
+        reads, flags, adapters, in_fmt, out_name = case2(seed, 300)
+        if in_fmt not in ("fq", "fa"):
+            in_fmt = "fq"
+            out_name = out_name.replace(".fa", ".fq") if "-f" not in flags else out_name
+        cli_check.compare_live(binary, REF, reads, flags, adapters, in_fmt=in_fmt, out_name=out_name, ranks=3, own_args=["--devices", "0"])
+
+
+@needs_ref
 @pytest.mark.parametrize("seed", range(5000, 5008))
 def test_cli_live_stdout_and_adapters_only_emul(seed):
     """No -o (records on stdout, report named after the input) and -A (adapter identification only)."""
