@@ -291,7 +291,8 @@ int main(int argc, char** argv)
     } else if (sharded && link.world > 1) {
         // the sample may reach beyond this rank's part: an index of its own over the whole text, kept a little ahead of
         // the pre-pass and dropped when that has seen enough
-        RecordIndex whole(in.data(), in.size(), !fasta_in, scan_threads, 1u << 14);
+        // (every other rank waits for what this pass finds: it may use more than this rank's share of the CPUs for a moment)
+        RecordIndex whole(in.data(), in.size(), !fasta_in, std::max(scan_threads, std::min(8, cpu_budget() / 2)), 1u << 14);
         RecordIndex::Cursor cur(whole);
         pp = run_prepass(o, [&](Rec& r) { return cur.next(r); });
     } else {
