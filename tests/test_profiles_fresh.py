@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_traffic_json_is_of_the_current_kernel_sources():
     t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-    assert t["kernel_source_hash"] == bench.kernel_source_hash(), "re-run tools/profile_round.sh (r04, r04_c3 --config c3, r04_c5 --config c5) and tools/merge_traffic.py"
+    assert t["kernel_source_hash"] == bench.kernel_source_hash(), "re-run tools/round_end_gpu.sh profile (tools/profile_round.sh for the four shapes + tools/merge_traffic.py)"
     # one entry per kernel-path shape bench.py can be asked for, each with the scan's figures
     sigs = t["signatures"]
     assert any(s.startswith("ont:") and ":p=0:" in s for s in sigs) and any(s.startswith("hifi:") for s in sigs)

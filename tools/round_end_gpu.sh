@@ -1,34 +1,32 @@
 #!/bin/bash
-# The GPU sittings behind a round's profiles/ (run through gpurun from the repo root; outputs under gpurun_out/):
-#   tools/round_end_gpu.sh profile <tag>   tools/profile_round.sh + gated profiles + kernel-path variants
-#   tools/round_end_gpu.sh bench           the full default bench line (as the driver runs it) + --config c5
+# The GPU sittings behind a round's profiles/ (run through gpurun from the repo root; outputs under gpurun_out/, the
+# summaries to be judged are then copied into profiles/ by hand -- profiles/README.md says which):
 #   tools/round_end_gpu.sh suite           the GPU test suite
-export TGSF_DEBUG_KNOBS=1   # the test settings below are read only under this switch
+#   tools/round_end_gpu.sh profile <tag>   kernel trace + PMC passes of the four kernel-path shapes (tools/profile_round.sh:
+#                                          C2 and C3 with the pre-pass's trims, C5, 4 adapters), their traffic.json merged,
+#                                          the short-adapter shapes, the clean-table A/B
+#   tools/round_end_gpu.sh bench           the full bench line as the driver runs it + --config c3 + --config c5
+#   tools/round_end_gpu.sh shard           rank processes sharing the one GPU against the single process (tests/manual/e2e_shard.py)
 cd $GRAFT_REPO_ROOT
-what=${1:-suite}; tag=${2:-r04}
+what=${1:-suite}; tag=${2:-r05}
 R=$GRAFT_REPO_ROOT
-brief() { python3 -c "
-import json,sys
-j=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=j['roofline']
-print('value %.1f Gbases/s  ms/step %.3f  sum_kernel_ms %.3f  critical_path_ms %.3f  frac %.4f' % (j['value'], j['ms_per_step'], r['sum_kernel_ms'], r['critical_path_ms'], r['frac']))
-print({k: round(v,3) for k,v in r['stage_ms_per_step'].items()})"; }
 case $what in
 suite)
   python -m pytest tests -x -q -m gpu --durations=10 > gpurun_out/gpu_suite.txt 2>&1; tail -4 gpurun_out/gpu_suite.txt ;;
 profile)
-  bash tools/profile_round.sh $tag > gpurun_out/profile_round.log 2>&1; tail -2 gpurun_out/profile_round.log
-  cp gpurun_out/prof_$tag/traffic.json profiles/traffic.json      # (on the box: later bench lines quote the traffic of THIS build)
-  cd /tmp && export TMPDIR=/tmp
-  for k in 11 21; do
-    rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_gate$k -- python3 $R/bench.py --no-e2e --no-cpu-baseline --no-oracle-check --min-repeat 100 --kmer $k --streams 1 --kernel-steps 6 > $R/gpurun_out/gate${k}_single.json 2> $R/gpurun_out/gate$k.err
-  done
+  bash tools/profile_round.sh $tag > gpurun_out/profile_$tag.log 2>&1
+  bash tools/profile_round.sh ${tag}_c3 --config c3 > gpurun_out/profile_${tag}_c3.log 2>&1
+  bash tools/profile_round.sh ${tag}_c5 --config c5 > gpurun_out/profile_${tag}_c5.log 2>&1
+  bash tools/profile_round.sh ${tag}_a4 --adapters 4 > gpurun_out/profile_${tag}_a4.log 2>&1
   cd $R
-  for k in 11 12 13 16 31; do python bench.py --no-e2e --no-cpu-baseline --min-repeat 100 --kmer $k --kernel-steps 6 > gpurun_out/b_repeat_k$k.json 2> gpurun_out/b_repeat.err; done
-  python bench.py --no-e2e --no-cpu-baseline --kernel-steps 12 > gpurun_out/b_nogate.json 2>> gpurun_out/b_repeat.err
-  for v in "" "TGSF_NO_HOT32=1"; do echo "== --short-adapters $v"; env $v python bench.py --no-e2e --no-cpu-baseline --short-adapters --kernel-steps 12 2>/dev/null | brief; done > gpurun_out/short_adapters.txt 2>&1
-  for v in "" "TGSF_STATS_NT=0" "TGSF_SEG_COLS=2048" "TGSF_SEG_COLS=4096"; do echo "== $v"; env $v python bench.py --no-e2e --no-cpu-baseline --no-oracle-check --kernel-steps 12 --streams 1 2>/dev/null | brief; done > gpurun_out/kernel_knobs.txt 2>&1
-  cat gpurun_out/short_adapters.txt gpurun_out/kernel_knobs.txt ;;
+  python3 tools/merge_traffic.py gpurun_out/prof_$tag gpurun_out/prof_${tag}_c3 gpurun_out/prof_${tag}_c5 gpurun_out/prof_${tag}_a4
+  python3 bench.py --no-e2e --no-cpu-baseline --adapters 4 --short-adapters --streams 1 > gpurun_out/${tag}_a4short_bench.json 2> gpurun_out/a4short.err
+  python3 bench.py --no-e2e --no-cpu-baseline --short-adapters --streams 1 > gpurun_out/${tag}_a2short_bench.json 2> gpurun_out/a2short.err
+  bash tools/r5_ab_clean.sh > gpurun_out/${tag}_clean_tables_ab.txt 2>&1; head -30 gpurun_out/${tag}_clean_tables_ab.txt ;;
 bench)
-  python bench.py --config c5 --steps 2 --warmup 1 > gpurun_out/bench_c5.json 2> gpurun_out/bench_c5.err; tail -c 600 gpurun_out/bench_c5.json
-  python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err; tail -c 600 gpurun_out/bench_final.json ;;
+  python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${tag}_bench.json 2> gpurun_out/bench.err; tail -c 600 gpurun_out/${tag}_bench.json
+  python bench.py --config c3 --steps 3 --warmup 1 > gpurun_out/${tag}_bench_c3.json 2> gpurun_out/bench_c3.err; tail -c 400 gpurun_out/${tag}_bench_c3.json
+  python bench.py --config c5 --steps 2 --warmup 1 > gpurun_out/${tag}_bench_c5.json 2> gpurun_out/bench_c5.err; tail -c 400 gpurun_out/${tag}_bench_c5.json ;;
+shard)
+  REPS=3 python tests/manual/e2e_shard.py 1333334 2 3 > gpurun_out/${tag}_shard_one_gpu.txt 2>&1; head -12 gpurun_out/${tag}_shard_one_gpu.txt ;;
 esac
