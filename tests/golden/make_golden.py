@@ -117,8 +117,8 @@ GIANT_B = bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[np.random.default_rng(500
 CASES.update({
     # adapters beyond 1 280 bp (round 5): where the traceback state of the first location reaches 1 MiB (from ~1 800 bp) edlib
     # finds its path by Hirschberg's divide and conquer (include/edlib.cpp:1191-1210, 1234-1400): 2 048 and 5 000 bp, planted
-    # at the ends and in the middle of reads of 12-30 kb with 0-10 % errors and long insertions
-    "giant_adapter": (dict(seed=40, n=36, kind="ont", mean_len=16000, p5=0.0, pmid=0.0), [GIANT_A, GIANT_B],
+    # at the ends and in the middle of reads of 12-16 kb with 0-10 % errors and long insertions
+    "giant_adapter": (dict(seed=40, n=9, kind="ont", mean_len=16000, p5=0.0, pmid=0.0), [GIANT_A, GIANT_B],
                       "-x ont -l 1000 -q 7 -5 0 -3 2 -M 1200 -m 900 -E 2600 -T 40", "fq", "giant"),
 })
 
@@ -131,7 +131,7 @@ def tweak(reads, how):
         rng = np.random.default_rng(4040)
         acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
         for i, (name, sq, q) in enumerate(reads):
-            L = int(rng.integers(12000, 30000))
+            L = int(rng.integers(12000, 16000))
             sq = bytearray(acgt[rng.integers(0, 4, L)].tobytes())
             q = bytes((rng.integers(12, 35, L) + 33).astype(np.uint8))
             ad = GIANT_A if i % 2 == 0 else GIANT_B
@@ -139,7 +139,7 @@ def tweak(reads, how):
             if i % 4 == 3:
                 h = len(m) // 2
                 m = m[:h] + bytes(acgt[rng.integers(0, 4, int(rng.integers(1, 300)))]) + m[h:]
-            pos = int(rng.integers(0, 40)) if i % 3 == 0 else (int(rng.integers(3000, L - 3000 - len(m))) if i % 3 == 1 else L - len(m) - int(rng.integers(0, 40)))
+            pos = int(rng.integers(0, 40)) if i % 3 == 0 else (int(rng.integers(2700, L - 2700 - len(m))) if i % 3 == 1 else L - len(m) - int(rng.integers(0, 40)))
             if i % 9 != 8:
                 sq[pos:pos + len(m)] = m
             out.append((name, bytes(sq), q))
