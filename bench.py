@@ -402,17 +402,20 @@ def e2e_leg(args, n_gpus):
                 # the budget allows (the first run's output and INFO lines are compared with ours); later files: once.
                 plan = [hw_cores] + ([quota_cores] if quota_cores != hw_cores else []) if first else [ref_t]
                 compared = False
-                for t in plan:
-                    rw, rc = [], []
-                    for rr in range(REF_RUNS if first else 1):
-                        known = [w for v in runs_by_threads.values() for w in v["wall_s_runs"]] + rw
+                walls = {t: [] for t in plan}
+                cpus = {t: [] for t in plan}
+                # (every thread count once before any of them a second time: should the budget run short, the comparison of
+                # the two counts is what stays)
+                for rr in range(REF_RUNS if first else 1):
+                    for t in plan:
+                        known = [w for v in walls.values() for w in v]
                         if known and first and not budget.allows("reference -t %d run %d on file %d" % (t, rr + 1, f + 1), 1.15 * max(known) + 5 + reserve(f)):
-                            break
+                            continue
                         dt, rerr = theirs(fq, out_r, flags, t)
-                        rw.append(dt)
+                        walls[t].append(dt)
                         if first:
                             est["ref_s"] = max(est["ref_s"], dt)
-                        rc.append(dict(LAST_RUN_CPU))
+                        cpus[t].append(dict(LAST_RUN_CPU))
                         if not compared:
                             compared = True
                             s["same_counters"] = info_lines(rerr) == info
@@ -423,6 +426,8 @@ def e2e_leg(args, n_gpus):
                             if mine != theirs_ms:
                                 raise SystemExit("bench: output differs from the reference's (records sum xor bytes): %s vs %s" % (mine, theirs_ms))
                         rm(out_r)
+                for t in plan:
+                    rw, rc = walls[t], cpus[t]
                     if not rw:
                         continue
                     if first:
