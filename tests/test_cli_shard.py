@@ -164,8 +164,10 @@ def test_cli_shard_env_as_torchrun_sets_it(binary, golden_dir, tmp_path):
     fin.write_bytes(raw)
     cmd = json.load(open(os.path.join(golden_dir, "hifi_auto.cmd.json")))
     assert not cmd["adapters"]
-    args = [binary, "-i", str(fin), "-o", str(tmp_path / "o.fq"), "-t", "1"] + cmd["flags"].split() + ["--shard", "env", "--rendezvous", str(tmp_path / "r.sock")]
-    procs = [subprocess.Popen(args, stderr=subprocess.PIPE, env=dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r))) for r in range(2)]
+    # (no --rendezvous: the ranks meet at a socket named after the launcher's MASTER_PORT)
+    args = [binary, "-i", str(fin), "-o", str(tmp_path / "o.fq"), "-t", "1"] + cmd["flags"].split() + ["--shard", "env"]
+    port = str(20000 + os.getpid() % 20000)
+    procs = [subprocess.Popen(args, stderr=subprocess.PIPE, env=dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_PORT=port)) for r in range(2)]
     errs = [q.communicate(timeout=600)[1] for q in procs]
     assert all(q.returncode == 0 for q in procs), errs
     parts = b"".join((tmp_path / ("o.fq.part%d" % r)).read_bytes() for r in range(2))

@@ -152,6 +152,9 @@ int parse_args(int argc, char** argv, Options& o)
                  if (!r || !w) { std::cerr << "Error: --shard env needs RANK and WORLD_SIZE" << std::endl; return 1; }
                  o.shard_rank = atoi(r); o.shard_world = atoi(w);
                  if (l) o.device = atoi(l);
+                 // (a launcher that hands out RANK / WORLD_SIZE also names the job by its rendezvous port: the ranks of one node
+                 // meet at a socket named after it unless --rendezvous says where)
+                 if (o.rendezvous.empty()) { const char* port = getenv("MASTER_PORT"); if (port && *port) o.rendezvous = std::string("/tmp/tgsfilter.") + port + ".sock"; }
              } else {
                  const char* slash = strchr(v, '/');
                  if (!slash) { std::cerr << "Error: --shard takes <rank>/<ranks>" << std::endl; return 1; }
