@@ -155,6 +155,9 @@ def test_cli_sharded_refusals(binary, golden_dir, tmp_path):
         assert p.returncode != 0 and what in p.stderr, (extra, p.stderr)
     p = subprocess.run([binary, "-x", "ont", "-i", str(fin), "--ranks", "2"], capture_output=True, timeout=120)
     assert p.returncode != 0 and b"-o is needed" in p.stderr
+    # a rendezvous path that names a file of the user's is refused, and the file is still there
+    p = subprocess.run(base + ["-i", str(fin), "--shard", "0/2", "--rendezvous", str(gz)], capture_output=True, timeout=120)
+    assert p.returncode != 0 and b"is not a socket" in p.stderr and gz.exists()
 
 
 def test_cli_shard_env_as_torchrun_sets_it(binary, golden_dir, tmp_path):

@@ -25,6 +25,7 @@
 #include <poll.h>
 #include <signal.h>
 #include <sys/socket.h>
+#include <sys/stat.h>
 #include <sys/un.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -56,8 +57,12 @@ public:
         if (path.size() >= sizeof sa.sun_path) die("--rendezvous: path too long for a unix socket");
         memcpy(sa.sun_path, path.c_str(), path.size());
         if (r == 0) {
+            struct stat st;
+            if (lstat(path.c_str(), &st) == 0) {        // a socket a job that was killed left behind goes; anything else is the user's
+                if (!S_ISSOCK(st.st_mode)) die("--rendezvous: " + path + " exists and is not a socket");
+                unlink(path.c_str());
+            }
             const int ls = socket(AF_UNIX, SOCK_STREAM, 0);
-            unlink(path.c_str());
             if (ls < 0 || bind(ls, (sockaddr*)&sa, sizeof sa) != 0 || listen(ls, w) != 0)
                 die("--rendezvous: cannot listen on " + path + ": " + strerror(errno));
             fds_.assign((size_t)w, -1);
@@ -66,7 +71,8 @@ public:
                 if (poll(&pf, 1, (int)(timeout_s * 1000)) <= 0) { unlink(path.c_str()); die("--rendezvous: " + std::to_string(w - k) + " of " + std::to_string(w) + " ranks did not show up at " + path); }
                 const int c = accept(ls, nullptr, nullptr);
                 int32_t who = -1;
-                if (c < 0 || !io(c, &who, sizeof who, false) || who < 1 || who >= w || fds_[(size_t)who] >= 0) { unlink(path.c_str()); die("--rendezvous: bad greeting at " + path); }
+                pollfd pc{c, POLLIN, 0};                // (a peer that connects and says nothing does not hold the job for ever)
+                if (c < 0 || poll(&pc, 1, (int)(timeout_s * 1000)) <= 0 || !io(c, &who, sizeof who, false) || who < 1 || who >= w || fds_[(size_t)who] >= 0) { unlink(path.c_str()); die("--rendezvous: bad greeting at " + path); }
                 fds_[(size_t)who] = c;
             }
             ::close(ls);
