@@ -71,8 +71,12 @@ def test_cli_sharded_more_ranks_than_reads(binary, golden_dir, tmp_path):
     fin.write_bytes(b"\n".join(recs[:4 * 5]) + b"\n")                # five reads
     common = ["-i", str(fin), "-x", "ont", "-l", "500", "-q", "7", "-5", "0", "-3", "0"]
     p1 = subprocess.run([binary, "-o", str(tmp_path / "one.fq")] + common, capture_output=True, timeout=300)
+    for k in (9, 10, 12):                                             # parts 9 and 10 of an earlier, larger job (12: not in line, stays)
+        (tmp_path / ("nine.fq.part%d" % k)).write_bytes(b"@old\nA\n+\n!\n")
     p9 = subprocess.run([binary, "-o", str(tmp_path / "nine.fq"), "--ranks", "9"] + common, capture_output=True, timeout=300)
     assert p1.returncode == 0 and p9.returncode == 0, p9.stderr.decode()[-2000:]
+    assert sorted(f.name for f in tmp_path.glob("nine.fq.part*")) == sorted(["nine.fq.part%d" % k for k in list(range(9)) + [12]])
+    assert p9.stderr.count(b"of an earlier job with more ranks, was removed") == 2
     parts = b"".join((tmp_path / ("nine.fq.part%d" % r)).read_bytes() for r in range(9))
     assert parts == (tmp_path / "one.fq").read_bytes() and len(parts) > 0
     info = lambda e: [l for l in e.decode().splitlines() if l.startswith("INFO:") and "written to" not in l]

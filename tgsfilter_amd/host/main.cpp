@@ -11,6 +11,7 @@
 #include "prepass.h"
 #include "report.h"
 #include "shard.h"
+#include <sys/stat.h>
 
 #include <sched.h>
 #include <signal.h>
@@ -1335,6 +1336,14 @@ int main(int argc, char** argv)
             }
         }
     }
+    // (parts of an earlier job with MORE ranks beside this job's would end up in a `cat <out>.part*`: they go, with a word)
+    if (reports && sharded && !o.out_file.empty() && !o.only_qc && !o.only_adapters)
+        for (int k = link.world;; k++) {
+            const std::string stale = o.out_file + ".part" + std::to_string(k);
+            struct stat st;
+            if (lstat(stale.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) break;
+            if (unlink(stale.c_str()) == 0) std::cerr << "Warning: " << stale << ", a part of an earlier job with more ranks, was removed." << std::endl;
+        }
     if (o.downsample && reports) {                                     // :3240-3279
         if (down_lens.empty()) die("no reads to downsample");
         std::sort(down_lens.begin(), down_lens.end());

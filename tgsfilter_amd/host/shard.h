@@ -10,6 +10,7 @@
 //   * rank r writes <out>.part<r>: the parts, concatenated in rank order, are byte for byte the file the single
 //     process writes (= the reference's -t 1 order) -- N files from N processes, no shared inode (ONE
 //     tmpfs file is bound by the kernel's page instantiation under one inode lock whatever the number of GPUs);
+//     parts numbered from N upward that an earlier job with more ranks left beside them are removed, with a warning;
 //   * the pre-pass (quality encoding, trims, adapter identification) runs on rank 0 only and its constants are
 //     broadcast;
 //   * at the end the tally vectors are summed -- on the devices, one RCCL all-reduce over xGMI (libtgsf_rccl), when
