@@ -290,7 +290,8 @@ ONT_LIGATION_22_RC = b"ACTTCGTTCAGTTACGTATTGC"
 
 
 @pytest.mark.parametrize("ads", [[ONT_LIGATION_28, ONT_LIGATION_28_RC], [ONT_LIGATION_22, ONT_LIGATION_22_RC, ONT_LIGATION_28, ONT_LIGATION_28_RC],
-                                 [ONT_LIGATION_22, ONT_LIGATION_22_RC, synth.ONT_RAPID, synth.ONT_RAPID_RC], [b"ACGTTGCA" * 4, ONT_LIGATION_22]])
+                                 [ONT_LIGATION_22, ONT_LIGATION_22_RC, synth.ONT_RAPID, synth.ONT_RAPID_RC], [b"ACGTTGCA" * 4, ONT_LIGATION_22],
+                                 [ONT_LIGATION_28, ONT_LIGATION_22_RC, b"ACGTTGCA" * 4]])      # three: passes of two and one
 @pytest.mark.parametrize("no32", ["0", "1"])
 def test_emul_short_adapters_dword_column(emul, ads, no32, monkeypatch):
     """Adapters of at most 32 bp run the middle scan with the one-dword column (Hot32): same locations as the 64-bit column

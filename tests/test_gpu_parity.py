@@ -346,14 +346,15 @@ def test_gpu_pool_overflow_device_batches(monkeypatch):
     ctx.close()
 
 
-@pytest.mark.parametrize("ads_key", ["lig28", "lig22+28", "lig22+rapid", "mixed"])
+@pytest.mark.parametrize("ads_key", ["lig28", "lig22+28", "lig22+rapid", "mixed", "three"])
 @pytest.mark.parametrize("no32", ["0", "1"])
 def test_gpu_short_adapters_dword_column(ads_key, no32, monkeypatch):
     """Adapters of at most 32 bp (the reference's ligation-kit library entries, src/TGSFilter.cpp:2974-2977) run the middle scan
-    with the one-dword column: same locations as the 64-bit column (TGSF_NO_HOT32=1) and as the oracle."""
+    with the one-dword column, two adapters a pass: same locations as the 64-bit column (TGSF_NO_HOT32=1) and as the oracle."""
     from tests.test_emul_parity import ONT_LIGATION_22, ONT_LIGATION_22_RC, ONT_LIGATION_28, ONT_LIGATION_28_RC
     ads = {"lig28": [ONT_LIGATION_28, ONT_LIGATION_28_RC], "lig22+28": [ONT_LIGATION_22, ONT_LIGATION_22_RC, ONT_LIGATION_28, ONT_LIGATION_28_RC],
-           "lig22+rapid": [ONT_LIGATION_22, ONT_LIGATION_22_RC, synth.ONT_RAPID, synth.ONT_RAPID_RC], "mixed": [b"ACGTTGCA" * 4, ONT_LIGATION_22]}[ads_key]
+           "lig22+rapid": [ONT_LIGATION_22, ONT_LIGATION_22_RC, synth.ONT_RAPID, synth.ONT_RAPID_RC], "mixed": [b"ACGTTGCA" * 4, ONT_LIGATION_22],
+           "three": [ONT_LIGATION_28, ONT_LIGATION_22_RC, b"ACGTTGCA" * 4]}[ads_key]     # (at most two of <= 32 bp a pass: passes of two and one)
     monkeypatch.setenv("TGSF_NO_HOT32", no32)
     reads = synth.make_reads(31, 400, "ont", mean_len=9000, zoo=True, pmid=0.5, adapter=ads[0], err=0.06)
     p = parity.sized(abi.make_params("ont", adapters=ads, min_q=7.0, mid_match_len=14, end_match_len=4), reads)

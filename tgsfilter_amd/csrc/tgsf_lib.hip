@@ -792,8 +792,9 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
                 if (P.Q[a] > 192) { TGSF_LAUNCH(k_mid_scanw<4>, gseg, T, ms, P, Bm, a); a++; continue; }
                 if (P.Q[a] > 128) { TGSF_LAUNCH(k_mid_scanw<3>, gseg, T, ms, P, Bm, a); a++; continue; }
                 if (P.Q[a] > 64) { TGSF_LAUNCH(k_mid_scanw<2>, gseg, T, ms, P, Bm, a); a++; continue; }
-                // up to four adapters of one word class per pass: <= 32 bp (one dword per column), 33..64 bp (one qword), or --
-                // the flat scan only -- 33..64 bp within few differences (the last 32 rows as a filter, the rest rechecked)
+                // up to four adapters of one word class per pass: <= 32 bp (one dword per column; two a pass, below), 33..64 bp
+                // (one qword), or -- the flat scan only -- 33..64 bp within few differences (the last 32 rows as a filter, the
+                // rest rechecked)
                 auto cls = [&](int x) {
                     if (P.Q[x] <= 32 && !c->no_hot32) return 0;
                     if (flat && mode == 0 && c->suffix_filter && P.Q[x] > 32 && P.k_mid[x] >= 0 && P.k_mid[x] <= kSuffixMaxK) return 2;
@@ -801,8 +802,12 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
                 };
                 const int kind = cls(a);
                 const bool narrow = kind == 0;
+                // (measured, ligation 28- + 22-bp pairs at -M 22: four one-dword columns a lane take 193 registers = 2 waves per
+                // SIMD and scan in 11.3 ms; two passes of two in 6.3 ms, 394 -> 610 Gbases/s.  Four qword columns a pass and
+                // two passes of two are equal, 8.6 / 8.4 ms: those stay one pass.  profiles/r05_pass_width_ab.txt)
+                const int width = narrow ? 2 : 4;
                 int na = 0;
-                while (a + na < A && na < 4 && P.Q[a + na] <= 64 && cls(a + na) == kind) na++;
+                while (a + na < A && na < width && P.Q[a + na] <= 64 && cls(a + na) == kind) na++;
                 if (kind == 2) {
                     const unsigned lp = 0;
                     Bm.mark_stride = (uint32_t)((flat_chunks / 32u + 7u) & ~3ull);            // (k_mid_marks reads four words a load)
@@ -830,9 +835,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
                     const unsigned lp = 0;
                     if (narrow) switch (na) {
                     case 1: TGSF_LAUNCH_LDS((k_mid_flat<1, Hot32>), gflat, T, lp, ms, P, Bm, a, na); break;
-                    case 2: TGSF_LAUNCH_LDS((k_mid_flat<2, Hot32>), gflat, T, lp, ms, P, Bm, a, na); break;
-                    case 3: TGSF_LAUNCH_LDS((k_mid_flat<3, Hot32>), gflat, T, lp, ms, P, Bm, a, na); break;
-                    default: TGSF_LAUNCH_LDS((k_mid_flat<4, Hot32>), gflat, T, lp, ms, P, Bm, a, na); break;
+                    default: TGSF_LAUNCH_LDS((k_mid_flat<2, Hot32>), gflat, T, lp, ms, P, Bm, a, na); break;
                     }
                     else switch (na) {
                     case 1: TGSF_LAUNCH_LDS((k_mid_flat<1, Hot>), gflat, T, lp, ms, P, Bm, a, na); break;
@@ -845,9 +848,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
                 }
                 if (narrow) switch (na) {
                 case 1: TGSF_LAUNCH((k_mid_scan1<1, Hot32>), gmid, T, ms, P, Bm, a, na); break;
-                case 2: TGSF_LAUNCH((k_mid_scan1<2, Hot32>), gmid, T, ms, P, Bm, a, na); break;
-                case 3: TGSF_LAUNCH((k_mid_scan1<3, Hot32>), gmid, T, ms, P, Bm, a, na); break;
-                default: TGSF_LAUNCH((k_mid_scan1<4, Hot32>), gmid, T, ms, P, Bm, a, na); break;
+                default: TGSF_LAUNCH((k_mid_scan1<2, Hot32>), gmid, T, ms, P, Bm, a, na); break;
                 }
                 else switch (na) {
                 case 1: TGSF_LAUNCH((k_mid_scan1<1, Hot>), gmid, T, ms, P, Bm, a, na); break;
