@@ -977,6 +977,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.share_gpu:
         local_rank = 0
+    # (several processes on the GPUs of one node: this pool's host driver only supports dmabuf IPC -- RCCL's and HIP's
+    # cross-process sharing need this; a value already set stays.  Before torch / any child process is started.)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import torch
     import torch.distributed as dist

@@ -149,6 +149,7 @@ int main(int argc, char** argv)
             o.device = o.devices.empty() ? link.rank : o.devices[(size_t)link.rank % o.devices.size()];
         } else {
             if (o.rendezvous.empty()) { std::cerr << "Error: --shard needs --rendezvous <path>: where the ranks of the job meet (a unix socket)" << std::endl; return 1; }
+            setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);                    // (as fork_ranks does for its children: shard.h)
             link.rendezvous(o.shard_rank, world, o.rendezvous);
         }
         o.devices.assign(1, o.device);
