@@ -987,7 +987,9 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # host-side group (barriers, timing) first: it does not touch the GPU
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # (the other ranks wait at a barrier while rank 0 runs the end-to-end leg: well beyond gloo's default 30 minutes)
+        import datetime
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(hours=3))
         host_group = dist.group.WORLD
 
     # ---- end-to-end leg first (rank 0; subprocesses only, this process has not touched the GPU yet) ----

@@ -962,7 +962,7 @@ int main(int argc, char** argv)
             std::string mine;
             link.scatter(flags, mine);
             if (mine.size() != keep.size()) die("the selection handed to this rank does not fit its fragments");
-            memcpy(keep.data(), mine.data(), keep.size());
+            if (!keep.empty()) memcpy(keep.data(), mine.data(), keep.size());
             // (the job's totals, for rank 0's statistics: every fragment that entered the selection)
             if (link.rank == 0) { down_job_recs = all_names.size(); down_job_bases = total; }
             std::vector<std::string>().swap(all_names);

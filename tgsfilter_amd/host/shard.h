@@ -155,7 +155,7 @@ struct BlobOut {
     std::string s;
     template <class T> void pod(const T& v) { s.append((const char*)&v, sizeof v); }
     void str(const std::string& v) { const uint64_t n = v.size(); pod(n); s.append(v); }
-    template <class T> void vec(const std::vector<T>& v) { const uint64_t n = v.size(); pod(n); s.append((const char*)v.data(), n * sizeof(T)); }
+    template <class T> void vec(const std::vector<T>& v) { const uint64_t n = v.size(); pod(n); if (n) s.append((const char*)v.data(), n * sizeof(T)); }
 };
 struct BlobIn {
     const std::string& s;
@@ -164,7 +164,7 @@ struct BlobIn {
     void need(size_t n) const { if (at + n > s.size()) die("a message between the ranks of the job is shorter than it says"); }
     template <class T> void pod(T& v) { need(sizeof v); memcpy(&v, s.data() + at, sizeof v); at += sizeof v; }
     void str(std::string& v) { uint64_t n = 0; pod(n); need((size_t)n); v.assign(s.data() + at, (size_t)n); at += (size_t)n; }
-    template <class T> void vec(std::vector<T>& v) { uint64_t n = 0; pod(n); need((size_t)n * sizeof(T)); v.resize((size_t)n); memcpy(v.data(), s.data() + at, (size_t)n * sizeof(T)); at += (size_t)n * sizeof(T); }
+    template <class T> void vec(std::vector<T>& v) { uint64_t n = 0; pod(n); need((size_t)n * sizeof(T)); v.resize((size_t)n); if (n) memcpy(v.data(), s.data() + at, (size_t)n * sizeof(T)); at += (size_t)n * sizeof(T); }
 };
 
 // First byte of the first record that starts at or after `from`: the start of a line that begins with '@' whose
