@@ -922,6 +922,7 @@ def h2d_peak(torch, device, seconds=0.6):
 
 
 def main():
+    t_bench0 = time.perf_counter()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3, help="timed end-to-end runs of the command line")
@@ -1109,6 +1110,9 @@ def main():
             "e2e_3_ranks_sharing_one_gpu_part_files_gbases_per_s": sharded[0]["gbases_per_s"] if sharded else None,
             "kernel_path_gbases_per_s": kp["value"] if kp else None,
             "kernel_path_rccl_ranks": kp.get("rccl_ranks") if kp else None}
+        # (what the whole invocation took, staging of the synthetic files and the reference's runs included: the driver's clock
+        # around this process reads a little more -- interpreter start, the first import of torch)
+        out["bench_wall_s"] = round(time.perf_counter() - t_bench0, 1)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1:
