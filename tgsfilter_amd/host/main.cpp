@@ -153,7 +153,9 @@ int main(int argc, char** argv)
             link.rendezvous(o.shard_rank, world, o.rendezvous);
         }
         o.devices.assign(1, o.device);
-        o.n_thread = std::max(2, o.n_thread / world);                      // -t is the job's: every rank takes its share
+        // -t is the job's: every rank takes its share -- or, on a node whose CPUs outnumber it (the reference clamps -t to 32:
+        // 4 threads a rank with 8 GPUs), its share of the CPUs this job may use, up to -t
+        o.n_thread = std::max(2, std::min(o.n_thread, std::max(o.n_thread / world, cpu_budget() / world)));
     }
     const bool sharded = o.ranks >= 1 || o.shard_world >= 1;             // (also with one rank: the same program path, one part file)
     if (!sharded) work_in_a_child();
