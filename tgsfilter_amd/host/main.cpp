@@ -576,7 +576,8 @@ int main(int argc, char** argv)
     // Several GPUs: a device's feeders -- and the pinned staging buffers tgsf_create allocates from them -- stay
     // on the CPUs of the GPU's own NUMA node, so that no feeder pushes its copies across the socket link.  With one GPU
     // binding was measured within noise and is left off; TGSF_NUMA=1 / 0 forces it on / off.
-    bool numa_bind = o.devices.size() > 1;
+    // (a job of rank processes on GPUs of their own is the same case, one device per process)
+    bool numa_bind = o.devices.size() > 1 || (link.world > 1 && shard_may_use_rccl);
     if (const char* e = getenv("TGSF_NUMA")) numa_bind = atoi(e) > 0;
     std::vector<int> dev_node(ctx_dev.size(), -1);
     std::vector<double> dev_submit_s(ctx_dev.size(), 0.0);
