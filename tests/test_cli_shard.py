@@ -212,6 +212,31 @@ def test_cli_gpu_one_rank_all_reduces_over_rccl(golden_dir, name, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_cli_gpu_a_communicator_that_does_not_come_up_does_not_hold_the_job(golden_dir, tmp_path):
+    """The RCCL communicator is set up by a helper beside the filtering.  One that is still not there some time after the
+    filtering is over (here: a helper that sleeps, and no patience) is given up: a warning, the tallies summed over the
+    ranks' sockets, the same output -- and the run does not wait for the helper."""
+    import time
+    if not os.path.exists(os.path.join(ROOT, "tgsfilter_amd", "libtgsf_rccl.so")):
+        pytest.skip("libtgsf_rccl.so not built (no librccl)")
+    raw = gzip.open(os.path.join(golden_dir, "hifi_auto.in.fq.gz"), "rb").read()
+    fin = tmp_path / "in.fq"
+    fin.write_bytes(raw)
+    cmd = json.load(open(os.path.join(golden_dir, "hifi_auto.cmd.json")))
+    env = dict(os.environ, TGSF_DEBUG_KNOBS="1", TGSF_RCCL_STALL_S="60", TGSF_RCCL_INIT_TIMEOUT_S="0.5")
+    env.pop("TGSF_SHARD_EXCHANGE", None)
+    t0 = time.time()
+    p = subprocess.run([GPU_BINARY, "-i", str(fin), "-o", str(tmp_path / "o.fq"), "-t", "1"] + cmd["flags"].split() + ["--ranks", "1"],
+                       capture_output=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert time.time() - t0 < 45
+    assert b"the communicator was not up" in p.stderr and b"summed over the ranks' sockets" in p.stderr
+    assert (tmp_path / "o.fq.part0").read_bytes() == gzip.open(os.path.join(golden_dir, "hifi_auto.out.fq.gz"), "rb").read()
+    ref_info = [l for l in open(os.path.join(golden_dir, "hifi_auto.stderr.txt")).read().splitlines() if l.startswith("INFO:") and "written to" not in l]
+    assert [l for l in p.stderr.decode().splitlines() if l.startswith("INFO:") and "written to" not in l] == ref_info
+
+
+@pytest.mark.gpu
 def test_cli_gpu_sharded_by_another_launcher(golden_dir):
     cli_check.run_case(GPU_BINARY, golden_dir, "ont_auto", ranks=2, launcher="external", extra_args=["--device", "0"])
 

@@ -11,6 +11,7 @@
 #include "prepass.h"
 #include "report.h"
 #include "shard.h"
+#include <memory>
 #include <sys/stat.h>
 
 #include <sched.h>
@@ -406,6 +407,8 @@ int main(int argc, char** argv)
     int rccl_rc = TGSF_OK;
     std::string rccl_err;
     std::thread rccl_up;
+    struct RcclUp { std::atomic<int> done{0}; int rc = TGSF_OK; std::string err; void* comm = nullptr; };
+    const std::shared_ptr<RcclUp> rccl_state = std::make_shared<RcclUp>();
     bool use_rccl = false;
     if (sharded) {
         const char* ex = getenv("TGSF_SHARD_EXCHANGE");
@@ -437,9 +440,13 @@ int main(int argc, char** argv)
         link.bcast(verdict);
         use_rccl = verdict[0] == '1' && verdict.size() == 1 + TGSF_RCCL_ID_BYTES;
         if (use_rccl)
-            rccl_up = std::thread([&, verdict] {
-                rccl_rc = R->comm_init(o.device, verdict.data() + 1, link.rank, link.world, &rccl_comm);
-                if (rccl_rc != TGSF_OK) rccl_err = R->last_error();     // (thread-local text: taken on this thread)
+            // (the helper owns its state: should the communicator never come up, the run goes on without it -- below -- and the
+            // helper is left behind where it waits)
+            rccl_up = std::thread([R, up = rccl_state, verdict, device = o.device, rank = link.rank, world = link.world] {
+                if (const char* e = knob("TGSF_RCCL_STALL_S")) usleep((useconds_t)(atof(e) * 1e6));       // test knob: a communicator that is late
+                up->rc = R->comm_init(device, verdict.data() + 1, rank, world, &up->comm);
+                if (up->rc != TGSF_OK) up->err = R->last_error();       // (thread-local text: taken on this thread)
+                up->done.store(1, std::memory_order_release);
             });
     }
     tgsf_params p;
@@ -1221,7 +1228,20 @@ int main(int argc, char** argv)
     int rccl_ranks = 0;
     std::vector<tgsf_ctx*> sum_ctxs = ctxs;
     if (sharded && use_rccl) {
-        rccl_up.join();
+        // The communicator has had the whole run to come up.  One that is still not there some time after the filtering is
+        // over (a peer that cannot be reached, a fabric that does not answer) must not hold the job for ever: this rank says
+        // so below, every rank then sums over the sockets, and the helper is left where it waits (the process leaves with _exit).
+        double rccl_patience = 120.0;
+        if (const char* e = knob("TGSF_RCCL_INIT_TIMEOUT_S")) rccl_patience = atof(e);          // test knob
+        while (!rccl_state->done.load(std::memory_order_acquire) && now_s() - t_x0 < rccl_patience) usleep(2000);
+        if (rccl_state->done.load(std::memory_order_acquire)) {
+            rccl_up.join();
+            rccl_rc = rccl_state->rc; rccl_err = rccl_state->err; rccl_comm = rccl_state->comm;
+        } else {
+            rccl_up.detach();
+            rccl_rc = TGSF_E_HIP;
+            rccl_err = "the communicator was not up " + std::to_string((int)rccl_patience) + " s after the filtering ended";
+        }
         t_rccl_wait = now_s() - t_x0;
         // the communicator came up on every rank, or nobody uses it: the sockets carry the rows in use instead (the run's
         // results do not depend on which way the tallies travel)
@@ -1229,7 +1249,7 @@ int main(int argc, char** argv)
             const char* ex = getenv("TGSF_SHARD_EXCHANGE");
             if (ex && !strcmp(ex, "rccl")) die("RCCL communicator: " + (rccl_err.empty() ? std::string("it failed on another rank") : rccl_err));
             if (rccl_rc != TGSF_OK) std::cerr << "Warning: rank " << link.rank << ": RCCL communicator: " << rccl_err << " -- the tallies are summed over the ranks' sockets" << std::endl;
-            if (rccl_comm) R->comm_destroy(rccl_comm);
+            // (a communicator that did come up here is left as it is: taking it down may wait for peers that are stuck)
             rccl_comm = nullptr;
             use_rccl = false;
         }
