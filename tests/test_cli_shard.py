@@ -59,6 +59,26 @@ def test_cli_sharded_downsampling(binary, golden_dir, name, how, monkeypatch):
     cli_check.run_case(binary, golden_dir, name, ranks=3, extra_args=["-t", "6"])
 
 
+@pytest.mark.parametrize("name", ["ont_zoo", "down_gd", "ont_fasta"])
+def test_cli_sharded_gzip_output(binary, golden_dir, name, tmp_path):
+    """-o <name>.gz: every rank writes gzip members into its part; the parts concatenated are one gzip stream of the
+    single process's records."""
+    cmd = json.load(open(os.path.join(golden_dir, name + ".cmd.json")))
+    fmt = cmd.get("in_format", "fq")
+    fin = tmp_path / ("in." + fmt)
+    fin.write_bytes(gzip.open(os.path.join(golden_dir, "%s.in.%s.gz" % (name, fmt)), "rb").read())
+    out = tmp_path / ("out.%s.gz" % ("fa" if fmt == "fa" else "fq"))
+    args = [binary, "-i", str(fin), "-o", str(out)] + cmd["flags"].split()
+    if cmd.get("adapters"):
+        fa = tmp_path / "ad.fa"
+        fa.write_text("".join(">a%d\n%s\n" % (i, a) for i, a in enumerate(cmd["adapters"])))
+        args += ["-a", str(fa)]
+    p = subprocess.run(args + ["--ranks", "3"], capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    cat = b"".join((tmp_path / ("%s.part%d" % (out.name, r))).read_bytes() for r in range(3))
+    assert gzip.decompress(cat) == gzip.open(os.path.join(golden_dir, name + ".out.fq.gz"), "rb").read()
+
+
 def test_cli_one_rank_is_a_job_too(binary, golden_dir):
     cli_check.run_case(binary, golden_dir, "ont_zoo", ranks=1)
 
