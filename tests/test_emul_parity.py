@@ -13,7 +13,7 @@ from tgsfilter_amd import abi, capi, synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMUL_DIR = os.path.join(ROOT, "tests", "emul")
-EMUL = os.path.join(EMUL_DIR, "libtgsf_emul.so")
+EMUL = os.environ.get("TGSF_EMUL_LIB") or os.path.join(EMUL_DIR, "libtgsf_emul.so")     # (tests/manual/sanitize_emul.py: the sanitizer build)
 
 
 @pytest.fixture(scope="module")

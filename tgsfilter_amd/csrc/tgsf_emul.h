@@ -23,7 +23,7 @@
 constexpr bool kTgsfEmul = true;
 #define TGSF_WAVE_PRIO(p) ((void)0)
 
-struct uint4 { uint32_t x, y, z, w; };
+struct alignas(16) uint4 { uint32_t x, y, z, w; };      // (HIP's uint4 is 16-byte aligned: LDS arrays of it are reinterpreted as 64-bit words)
 namespace tgsf_emul {
 struct Dim3 { unsigned x, y, z; };
 extern thread_local Dim3 threadIdx, blockIdx, blockDim, gridDim;
