@@ -23,7 +23,7 @@ def build():
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "liborc.so")
+        path = os.environ.get("ORC_LIB") or os.path.join(_HERE, "liborc.so")      # (ORC_LIB: a sanitizer build, tests/manual/sanitize_emul.py)
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)

@@ -451,7 +451,7 @@ static void adapter_map(const tgsf_params* p, const uint8_t* read, int L,
         free(regs.r);
         return;
     }
-    qsort(regs.r, (size_t)regs.n, sizeof(region), region_cmp);                               /* :1376-1381 */
+    if (regs.n > 1) qsort(regs.r, (size_t)regs.n, sizeof(region), region_cmp);               /* :1376-1381 */
     region_vec merged = {0, 0, 0};
     for (int i = 0; i < regs.n; i++) {                                                       /* :1383-1390 */
         if (merged.n > 0 && merged.r[merged.n - 1].e >= regs.r[i].s)

@@ -15,4 +15,14 @@ env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:halt_on_err
 args = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_emul_parity.py"), os.path.join(ROOT, "tests", "test_fuzz_emul.py"), "-x", "-q", "-p", "no:cacheprovider"]
 if len(sys.argv) > 1:
     args += ["-k", sys.argv[1]]
-sys.exit(subprocess.run(args, env=env, cwd=ROOT).returncode)
+rc = subprocess.run(args, env=env, cwd=ROOT).returncode
+# ... and the oracle itself (oracle/tgsf_oracle.c): its pinning tests, and the emulation suites once more with the sanitized checker
+ORC = os.path.join(ROOT, "oracle", "liborc_asan.so")
+subprocess.run(["gcc", "-O1", "-g", "-std=c11", "-fPIC", "-shared", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+                "-o", ORC, os.path.join(ROOT, "oracle", "tgsf_oracle.c")], check=True)
+env2 = dict(env, ORC_LIB=ORC)
+env2.pop("TGSF_EMUL_LIB")
+if len(sys.argv) <= 1:
+    rc = rc or subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_oracle_pinned.py"), os.path.join(ROOT, "tests", "test_emul_parity.py"),
+                               os.path.join(ROOT, "tests", "test_fuzz_emul.py"), "-x", "-q", "-p", "no:cacheprovider"], env=env2, cwd=ROOT).returncode
+sys.exit(rc)
