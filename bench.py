@@ -26,6 +26,7 @@ import argparse
 import hashlib
 import json
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -359,7 +360,8 @@ def e2e_leg(args, n_gpus):
             s["bound"] = "%s: %.2f s of %.2f s" % (top, parts[top], t["total_s"])
             if "gpu_kernel_s_summed" in t:
                 s["gpu_busy_frac"] = t["gpu_kernel_s_summed"] / t["total_s"]      # upper bound: contexts overlap
-        shard = [l for l in err.splitlines() if l.startswith("SHARD ")]
+        # (the ranks share one stderr: a line is one write in the program, but take it wherever it starts)
+        shard = re.findall(r"SHARD \d+/\d+: [^\n]*", err)
         if shard:
             s["shard_lines"] = [l[:400] for l in shard]
         return s

@@ -1411,10 +1411,15 @@ int main(int argc, char** argv)
         }
         double sum = 0;
         for (int i = 0; i < TGSF_N_STAGES; i++) sum += tot[i];
-        fprintf(stderr, "GPU: kernels %.3f s summed over %zu contexts and %u batches (upper bound of the busy time: contexts overlap) = %.4f of the run |", sum * 1e-3, ctxs.size(), nb,
-                sum * 1e-3 / std::max(1e-9, now_s() - t_start));
-        for (int i = 0; i < TGSF_N_STAGES; i++) if (tot[i] > 0) fprintf(stderr, " %s %.1f ms", L.stage_name(i), tot[i]);
-        fprintf(stderr, "\n");
+        // (ONE write for the line: the ranks of a sharded job share this stderr, and a line put together from several writes gets
+        // another rank's lines into its middle)
+        char piece[256];
+        snprintf(piece, sizeof piece, "GPU: kernels %.3f s summed over %zu contexts and %u batches (upper bound of the busy time: contexts overlap) = %.4f of the run |", sum * 1e-3, ctxs.size(), nb,
+                 sum * 1e-3 / std::max(1e-9, now_s() - t_start));
+        std::string line = piece;
+        for (int i = 0; i < TGSF_N_STAGES; i++) if (tot[i] > 0) { snprintf(piece, sizeof piece, " %s %.1f ms", L.stage_name(i), tot[i]); line += piece; }
+        line += "\n";
+        fputs(line.c_str(), stderr);
     }
     if (timing) {
         // per device: what its feeders moved (text in, records out: H2D + kernels + D2H inside tgsf_submit)
