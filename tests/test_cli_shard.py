@@ -79,6 +79,21 @@ def test_cli_sharded_gzip_output(binary, golden_dir, name, tmp_path):
     assert gzip.decompress(cat) == gzip.open(os.path.join(golden_dir, name + ".out.fq.gz"), "rb").read()
 
 
+def test_cli_sharded_ranks_hand_their_stderr_lines_over_whole(binary, golden_dir, tmp_path):
+    """The ranks of a job share one stderr: every line -- rank 0's INFO lines, every rank's TGSF_TIMING lines -- is one write,
+    none lands in the middle of another (bench.py reads the INFO, SHARD and TIMING lines of a job)."""
+    fin = tmp_path / "in.fq"
+    fin.write_bytes(gzip.open(os.path.join(golden_dir, "ont_zoo.in.fq.gz"), "rb").read())
+    known = ("INFO:", "SHARD ", "TIMING:", "POOL:", "GPU:", "RESERVE:", "DEVICE ", "DOWN:", "CLOCK:", "Warning:", "PREPASS:")
+    for _ in range(25):
+        p = subprocess.run([binary, "-i", str(fin), "-o", str(tmp_path / "o.fq"), "-x", "ont", "-t", "12", "--ranks", "6"],
+                           capture_output=True, timeout=120, env=dict(os.environ, TGSF_TIMING="1"))
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        lines = p.stderr.decode().splitlines()
+        assert all(l.startswith(known) for l in lines), [l for l in lines if not l.startswith(known)][:3]
+        assert sum(l.startswith("SHARD ") for l in lines) == 6
+
+
 def test_cli_one_rank_is_a_job_too(binary, golden_dir):
     cli_check.run_case(binary, golden_dir, "ont_zoo", ranks=1)
 

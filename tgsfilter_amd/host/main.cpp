@@ -87,10 +87,12 @@ static void work_in_a_child()
 
 
 // Ranks above 0 of a sharded job (shard.h) run the same code as rank 0 but leave the run's INFO lines to it: a filter in
-// front of std::cerr drops the lines that begin with "INFO:" (errors and warnings still pass).
+// front of std::cerr drops the lines that begin with "INFO:" (errors and warnings still pass).  Every rank, rank 0 too,
+// hands its lines over WHOLE: the ranks share one stderr, and std::cerr on its own writes a line piece by piece -- another
+// rank's line would land in its middle.
 class InfoFilter : public std::streambuf {
 public:
-    explicit InfoFilter(std::streambuf* to) : to_(to) {}
+    explicit InfoFilter(std::streambuf* to, bool drop_info = true) : to_(to), drop_info_(drop_info) {}
 protected:
     int overflow(int c) override {
         if (c == traits_type::eof()) return sync() == 0 ? 0 : c;
@@ -101,10 +103,11 @@ protected:
     int sync() override { flush_line(); return to_->pubsync(); }
 private:
     void flush_line() {
-        if (!line_.empty() && line_.back() == '\n' && line_.compare(0, 5, "INFO:") == 0) { line_.clear(); return; }
+        if (drop_info_ && !line_.empty() && line_.back() == '\n' && line_.compare(0, 5, "INFO:") == 0) { line_.clear(); return; }
         if (!line_.empty() && line_.back() == '\n') { to_->sputn(line_.data(), (std::streamsize)line_.size()); line_.clear(); }
     }
     std::streambuf* to_;
+    bool drop_info_;
     std::string line_;
 };
 
@@ -118,7 +121,7 @@ int main(int argc, char** argv)
         f.erase(std::remove(f.begin(), f.end(), '-'), f.end());
         if (f != "shard") continue;
         const char* r = !strcmp(argv[i + 1], "env") ? getenv("RANK") : argv[i + 1];
-        if (r && atoi(r) > 0) std::cerr.rdbuf(new InfoFilter(std::cerr.rdbuf()));
+        if (r) std::cerr.rdbuf(new InfoFilter(std::cerr.rdbuf(), atoi(r) > 0));
     }
     Options o;
     if (parse_args(argc, argv, o)) return 1;
@@ -145,7 +148,7 @@ int main(int argc, char** argv)
         }
         if (o.ranks >= 1) {
             fork_ranks(world, link);                                       // returns in the N children only
-            if (link.rank > 0) std::cerr.rdbuf(new InfoFilter(std::cerr.rdbuf()));
+            std::cerr.rdbuf(new InfoFilter(std::cerr.rdbuf(), link.rank > 0));
             // rank r on device r, or on the r-th entry of --devices (cyclically: several ranks may share a GPU)
             o.device = o.devices.empty() ? link.rank : o.devices[(size_t)link.rank % o.devices.size()];
         } else {
