@@ -94,13 +94,20 @@ class InfoFilter : public std::streambuf {
 public:
     explicit InfoFilter(std::streambuf* to, bool drop_info = true) : to_(to), drop_info_(drop_info) {}
 protected:
+    // (any thread may write to std::cerr -- a feeder that ends the run with an error, the reader's messages: one at a time)
     int overflow(int c) override {
-        if (c == traits_type::eof()) return sync() == 0 ? 0 : c;
+        std::lock_guard<std::mutex> g(m_);
+        if (c == traits_type::eof()) { flush_line(); return to_->pubsync() == 0 ? 0 : c; }
         line_.push_back((char)c);
         if (c == '\n') flush_line();
         return c;
     }
-    int sync() override { flush_line(); return to_->pubsync(); }
+    std::streamsize xsputn(const char* s, std::streamsize n) override {
+        std::lock_guard<std::mutex> g(m_);
+        for (std::streamsize i = 0; i < n; i++) { line_.push_back(s[i]); if (s[i] == '\n') flush_line(); }
+        return n;
+    }
+    int sync() override { std::lock_guard<std::mutex> g(m_); flush_line(); return to_->pubsync(); }
 private:
     void flush_line() {
         if (drop_info_ && !line_.empty() && line_.back() == '\n' && line_.compare(0, 5, "INFO:") == 0) { line_.clear(); return; }
@@ -109,6 +116,7 @@ private:
     std::streambuf* to_;
     bool drop_info_;
     std::string line_;
+    std::mutex m_;
 };
 
 int main(int argc, char** argv)
