@@ -216,7 +216,8 @@ class Budget:
 # mean 150 kb, max 2 Mb) through the repeat gate (-p/-k; `-k` only acts with `-p` > 0, src/TGSFilter.cpp:1982: -p 100 is
 # this bench's choice, said in SURVEY 8d) and the longest-first downsampling (-g 3g -d 40).  The reference keeps a copy of
 # the filtered reads (<inprefix>.tmp.XXXXX.fq, :3129-3137) beside its output: three files on tmpfs at once.
-REF_RUNS = 2                                  # runs of the reference per thread count on the first file, budget permitting
+REF_RUNS = 1                                  # runs of the reference per thread count on the first file (round 5 ran 2 x 2: -t 32 and
+                                              # -t 15 differ by < 1 % on this pool's boxes, the question is settled)
 E2E_CONFIGS = {
     "c2": {"name": "C2 (BASELINE.json configs[1])", "reads": 4_000_000, "mean_len": 45000.0, "max_len": 2_000_000, "per_read": 90_300, "files": 2.0,
            "flags": ["-x", "ont", "-l", "1000", "-q", "10"], "seed": 2, "what": "automatic trims and adapter identification", "split": True},
@@ -249,14 +250,19 @@ def multiset_of(paths):
 def e2e_leg(args, n_gpus):
     """The command line end to end on the configuration's reads (default: C2's 4 M), staged on tmpfs as ONE file when the
     box's memory holds input + output, as CONSECUTIVE files (same generator, seeds in a row) otherwise -- C2 as written is
-    360 GB of text + 215 GB of output, more than the box's memory control group allows at once.  A step = one pass of
-    the command line over ALL the files (one run per file; wall times summed); W warm-up passes, K timed passes.
+    360 GB of text + 215 GB of output, more than the box's memory control group allows at once.
+    A STEP = one run of the command line over ONE staged file (C2 on this pool: a third of the 4 M reads, 60 Gbases, 120 GB
+    of text); the K timed steps are dealt over the files in staging order (K = 20, 3 files: 7 + 7 + 6), so that K steps pass
+    over all the configuration's reads as long as K >= the number of files (fewer steps stage fewer files, and the line says
+    so).  value = bases of the K timed steps / their summed wall time.  (Rounds 4-5 called a pass over ALL files a step: 3 K
+    runs, each preceded by the removal of the previous 72-GB output -- 5 s of tmpfs page freeing outside any timed region --
+    which took the driver's run to 1 450 s of its 1 800-s limit.)
     Per file, in this order:
-      ours     W (first file: the others 1) warm-up runs + K timed runs into a tmpfs file (N > 1: `--ranks N`, one process
-               per GPU, a part file each);
+      ours     W (first file: the others 1) warm-up runs + its share of the K timed runs into a tmpfs file (N > 1:
+               `--ranks N`, one process per GPU, a part file each);
       theirs   the reference binary on the same file, same flags, same sink: on the first file at its own thread clamp
                (-t min(hw-1, 32), src/TGSFilter.cpp:488-499) AND at what the box's CPU quota lets run unthrottled
-               (-t min(cpu.max - 1, 32)), REF_RUNS runs each; on the other files once, at the faster of the two.  Output
+               (-t min(cpu.max - 1, 32)), REF_RUNS run(s) each; on the other files once, at the faster of the two.  Output
                multisets and INFO lines compared with ours for every file;
     then, on the first file only and budget permitting: the /dev/null sink, and (N = 1) the same run as 3 rank processes
     sharing the GPU with a part file each (`sharded`: the program path of N GPUs on this box)."""
@@ -301,6 +307,10 @@ def e2e_leg(args, n_gpus):
                     cfg["files"], n_reads * per_read / 1e9)
                 log("bench: " + reduced)
     per_file = [n_reads // n_files + (1 if f < n_reads % n_files else 0) for f in range(n_files)]
+    # the K timed steps dealt over the files (a step = one run over one file); fewer steps than files stage fewer files
+    n_staged = max(1, min(n_files, args.steps))
+    steps_of = [args.steps // n_staged + (1 if f < args.steps % n_staged else 0) for f in range(n_staged)]
+    phase = {"generate": 0.0, "ours": 0.0, "reference": 0.0, "remove_outputs": 0.0, "digests": 0.0}     # where the leg's own time goes
     split_note = None
     if n_files > 1:
         split_note = "%s holds %.0f GB, input + one output of all %d reads need %.0f GB: the reads are staged as %d consecutive files of %s reads (same generator, seeds %s)" % (
@@ -321,18 +331,30 @@ def e2e_leg(args, n_gpus):
 
 
     def rm(path):
+        t0 = time.perf_counter()
         for p in [path] + ["%s.part%d" % (path, r) for r in range(64)]:
             if os.path.isfile(p) and not os.path.islink(p):
                 os.remove(p)          # dropping a previous run's GBs of tmpfs pages is not part of a run
+        phase["remove_outputs"] += time.perf_counter() - t0
+
+    def digest(paths):
+        t0 = time.perf_counter()
+        m = multiset_of(paths)
+        phase["digests"] += time.perf_counter() - t0
+        return m
 
     def ours(fq, out, flags, ranks=0, rdevs=None):
         rm(out)
         how = ["--ranks", str(ranks), "--devices", rdevs or rank_devs] if ranks else ["--devices", devs]
-        return run_cmd([CLI, "-i", fq, "-o", out, "-t", str(hw_cores)] + how + flags, env)
+        r = run_cmd([CLI, "-i", fq, "-o", out, "-t", str(hw_cores)] + how + flags, env)
+        phase["ours"] += r[0]
+        return r
 
     def theirs(fq, out, flags, t):
         rm(out)
-        return run_cmd([REF, "-i", fq, "-o", out, "-t", str(t)] + flags)
+        r = run_cmd([REF, "-i", fq, "-o", out, "-t", str(t)] + flags)
+        phase["reference"] += r[0]
+        return r
 
     def timed(fq, out, flags, warm, k, ranks=0, rdevs=None):
         for _ in range(warm):
@@ -368,34 +390,38 @@ def e2e_leg(args, n_gpus):
 
     files, sinks, runs_by_threads = [], {}, {}
     ref_t = None                                       # the thread count the reference is timed at on files after the first
-    est = {"gen_s": 0.0, "run_s": 0.0, "ref_s": 0.0}    # measured on the first file: what every further file will cost
+    est = {"gen_s": 0.0, "run_s": 0.0, "ref_s": 0.0, "rm_s": 0.0}    # measured on the first file: what every further file will cost
 
     def reserve(f):
         """Seconds the files after file f still need for what is never dropped (generation, warm-up, the K timed runs,
         the reference once with its digest): optional legs run only while that much stays in the budget."""
-        return (n_files - 1 - f) * (est["gen_s"] * 1.1 + (min(args.warmup, 1) + args.steps) * est["run_s"] * 1.1 + (est["ref_s"] * 1.2 + 30 if have_ref else 0))
+        return sum(est["gen_s"] * 1.1 + (min(args.warmup, 1) + steps_of[g]) * (est["run_s"] * 1.1 + est["rm_s"]) + (est["ref_s"] * 1.2 + 30 if have_ref else 0)
+                   for g in range(f + 1, n_staged))
     try:
         flags = list(cfg["flags"])                               # the configuration as BASELINE.json writes it
-        for f in range(n_files):
+        for f in range(n_staged):
             first = f == 0
             fq = os.path.join(td, "in%d.fq" % f)
             t0 = time.perf_counter()
             bases, nbytes = synth.write_ont_fastq(fq, per_file[f], seed=cfg["seed"] + 1000 * f, procs=gen_procs, mean_len=cfg["mean_len"], max_len=cfg["max_len"],
                                                   kind=cfg.get("kind", "ont"), reads_per_job=cfg.get("reads_per_job", 256))
+            phase["generate"] += time.perf_counter() - t0
             if first:
                 est["gen_s"] = time.perf_counter() - t0
             log("bench: file %d of %d: %d reads / %.2f Gbases / %.2f GB of FASTQ text written to %s in %.1f s by %d processes"
-                % (f + 1, n_files, per_file[f], bases / 1e9, nbytes / 1e9, fq, time.perf_counter() - t0, gen_procs))
+                % (f + 1, n_staged, per_file[f], bases / 1e9, nbytes / 1e9, fq, time.perf_counter() - t0, gen_procs))
             out_o, out_r = os.path.join(td, "ours.fq"), os.path.join(td, "ref.fq")
-            walls, err, cpu = timed(fq, out_o, flags, args.warmup if first else min(args.warmup, 1), args.steps, want_ranks)
+            rm0 = phase["remove_outputs"]
+            walls, err, cpu = timed(fq, out_o, flags, args.warmup if first else min(args.warmup, 1), steps_of[f], want_ranks)
             s = describe(walls, err, bases)
             if first:
                 est["run_s"] = s["wall_s_mean"]
+                est["rm_s"] = (phase["remove_outputs"] - rm0) / max(1, args.warmup + steps_of[f] - 1)
             s.update({"file": f, "reads": per_file[f], "bases": bases, "fastq_bytes": nbytes, "cpu_last_run": cpu[-1] if cpu else None})
             if want_ranks:
                 s["ranks"] = want_ranks
             info = info_lines(err)
-            mine = multiset_of(out_files(out_o, want_ranks)) if have_ref else None
+            mine = digest(out_files(out_o, want_ranks)) if have_ref else None
             if mine:
                 s["output_records"], s["output_bytes"] = int(mine[0]), int(mine[3])
             rm(out_o)
@@ -423,7 +449,7 @@ def e2e_leg(args, n_gpus):
                             s["same_counters"] = info_lines(rerr) == info
                             if not s["same_counters"]:
                                 raise SystemExit("bench: INFO lines differ from the reference's:\n%s\n---\n%s" % ("\n".join(info), "\n".join(info_lines(rerr))))
-                            theirs_ms = multiset(out_r)
+                            theirs_ms = digest([out_r])
                             s["same_output_multiset"] = mine == theirs_ms
                             if mine != theirs_ms:
                                 raise SystemExit("bench: output differs from the reference's (records sum xor bytes): %s vs %s" % (mine, theirs_ms))
@@ -474,7 +500,7 @@ def e2e_leg(args, n_gpus):
                         d["ranks"], d["devices"] = nr, "0 (shared by all ranks)"
                         d["same_counters_as_the_file_run"] = info_lines(e3) == info
                         if mine:
-                            d["same_output_multiset"] = multiset_of(out_files(out_o, nr)) == mine
+                            d["same_output_multiset"] = digest(out_files(out_o, nr)) == mine
                         rm(out_o)
                         if not d["same_counters_as_the_file_run"] or d.get("same_output_multiset") is False:
                             raise SystemExit("bench: the sharded run's records or INFO lines differ from the single process's")
@@ -482,11 +508,12 @@ def e2e_leg(args, n_gpus):
                         log("bench: e2e sharded: %s" % json.dumps({k2: v for k2, v in d.items() if k2 not in ("timing_line", "shard_lines")}))
             os.remove(fq)
         # ---- the whole workload: a step = one pass over all the files ----
-        K = len(files[0]["wall_s"])
-        step_walls = [sum(s["wall_s"][j] for s in files) for j in range(K)]
-        tot_bases = sum(s["bases"] for s in files)
+        step_walls = [w for s in files for w in s["wall_s"]]          # the K timed steps, in the order they ran
+        K = len(step_walls)
+        tot_bases = sum(s["bases"] for s in files)                     # one pass over the staged files (the reference's work)
+        step_bases = sum(s["bases"] * len(s["wall_s"]) for s in files)  # what the K steps filtered
         agg = {"runs": K, "exit_mode": DEFAULT_EXIT_MODE, "wall_s": step_walls, "wall_s_mean": sum(step_walls) / K,
-               "gbases_per_s": tot_bases * K / sum(step_walls) / 1e9, "files": n_files,
+               "gbases_per_s": step_bases / sum(step_walls) / 1e9, "files": n_staged, "steps_per_file": steps_of, "bases_per_step_mean": step_bases / K,
                "per_file": [{k2: v for k2, v in s.items() if k2 != "_info"} for s in files],
                "timing": files[0]["timing"], "timing_line": files[0]["timing_line"], "bound": files[0].get("bound"),
                "gpu_busy_frac": files[0].get("gpu_busy_frac"), "cpu_last_run": files[0].get("cpu_last_run"),
@@ -500,8 +527,8 @@ def e2e_leg(args, n_gpus):
                         "reference_wall_s": ref_total, "reference_threads": ref_t, "reference_gbases_per_s": tot_bases / ref_total / 1e9,
                         "reference_runs_by_threads_first_file": runs_by_threads,
                         "speedup_vs_reference": agg["gbases_per_s"] / (tot_bases / ref_total / 1e9),
-                        "speedup_note": "ours: mean of %d passes over %d file(s) / the reference at -t %d, the FASTER of the thread counts tried on the first file (%s), "
-                                        "every file once (the first: mean of its runs at that count)" % (K, n_files, ref_t, ", ".join("-t %s: %.3f Gbases/s" % (k2, v["gbases_per_s"]) for k2, v in runs_by_threads.items()))})
+                        "speedup_note": "ours: bases / wall time of %d timed runs over %d file(s) / the reference at -t %d, the FASTER of the thread counts tried on the first file (%s), "
+                                        "every file once" % (K, n_staged, ref_t, ", ".join("-t %s: %.3f Gbases/s" % (k2, v["gbases_per_s"]) for k2, v in runs_by_threads.items()))})
         elif have_ref:
             agg["reference_note"] = "the reference was not timed on every file (budget): no whole-workload baseline"
         sinks["tmpfs_file"] = agg
@@ -509,7 +536,8 @@ def e2e_leg(args, n_gpus):
             if k2 in sinks and "reference_wall_s" in files[0]:
                 sinks[k2]["speedup_vs_reference_file_run_first_file"] = files[0]["reference_wall_s"] / sinks[k2]["wall_s_mean"]
         res = {"config": cfg["name"], "config_what": cfg["what"], "box": {"cgroup_cpus": lim["cpus"], "cgroup_memory_gib": (lim["memory_bytes"] or 0) / 2**30 or None, "hw_threads": os.cpu_count()},
-               "reads": n_reads, "bases": tot_bases, "fastq_bytes": sum(s["fastq_bytes"] for s in files), "files": n_files, "reads_per_file": per_file,
+               "reads": sum(per_file[:n_staged]), "reads_of_config_split": n_reads, "bases": tot_bases, "fastq_bytes": sum(s["fastq_bytes"] for s in files),
+               "files": n_staged, "files_of_config_split": n_files, "reads_per_file": per_file[:n_staged], "steps_per_file": steps_of,
                "flags": " ".join(flags), "threads": hw_cores, "devices": devs, "ranks": want_ranks or None,
                "reduced": reduced, "split": split_note,
                "staging": "synthetic FASTQ text written to tmpfs (%s) by tgsfilter_amd/synth.write_ont_fastq before timing; "
@@ -536,6 +564,7 @@ def e2e_leg(args, n_gpus):
             res["variants"] = {"pinned_prepass": v}
         res["skipped"] = budget.skipped
         res["seconds"] = time.perf_counter() - budget.t0
+        res["seconds_by_phase"] = {k2: round(v, 1) for k2, v in phase.items()}
     finally:
         shutil.rmtree(td, ignore_errors=True)
     return res
@@ -923,6 +952,81 @@ def h2d_peak(torch, device, seconds=0.6):
         return None
 
 
+LINE_LIMIT = 4096            # bytes of the ONE stdout line (round 5's grew to 21 kB and the driver could not parse it)
+
+
+def _sig(x, digits=6):
+    """Floats to 6 significant digits, recursively (the line is read by a machine: no digits nobody measures)."""
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x))
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def _clip(text, n):
+    return text if text is None or len(text) <= n else text[:n - 3] + "..."
+
+
+def compact_line(out, detail_path=None):
+    """The one stdout line: the contract's keys, `roofline`, `cpu_baseline`, the speed-up and the scaling figures -- at most
+    LINE_LIMIT bytes.  Everything else bench.py measures (per-run wall times, control-group records, per-sink blocks,
+    tallies, the long descriptions) is in the detail file and on stderr."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    c = {k: out.get(k) for k in keep}
+    c["metric"] = _clip(c["metric"], 100)
+    cfg = out.get("config") or {}
+    c["config"] = {"workload": _clip(cfg.get("workload"), 300), "parallelism": _clip(cfg.get("parallelism"), 160)}
+    r = out.get("roofline")
+    if r:
+        c["roofline"] = {k: r.get(k) for k in ("bound", "kernel", "stage", "achieved", "peak", "unit", "frac", "kernel_ms", "algorithmic_bytes_per_launch",
+                                               "traffic", "traffic_all_kernels_per_batch", "fractions_of_hbm_peak", "sum_kernel_ms")}
+        c["roofline"]["kernel"] = _clip(r.get("kernel"), 80)
+    b = out.get("cpu_baseline")
+    if b:
+        c["cpu_baseline"] = {k: b.get(k) for k in ("value", "unit", "cores", "kind", "sample")}
+        c["cpu_baseline"]["sample"] = _clip(b.get("sample"), 200)
+    sp = out.get("e2e_speedup_vs_reference")
+    if sp:
+        c["e2e_speedup_vs_reference"] = {"tmpfs_file": sp.get("tmpfs_file")}
+    if out.get("scaling_figures"):
+        c["scaling_figures"] = out["scaling_figures"]
+    e2e = out.get("e2e") or {}
+    if e2e.get("skipped"):
+        c["skipped_legs"] = len(e2e["skipped"])
+    c["bench_wall_s"] = out.get("bench_wall_s")
+    if detail_path:
+        c["detail"] = os.path.relpath(detail_path, ROOT) if os.path.abspath(detail_path).startswith(ROOT + os.sep) else detail_path
+    c = _sig(c)
+    line = json.dumps(c, separators=(",", ":"))
+    for victim in ("detail", "scaling_figures", "e2e_speedup_vs_reference"):      # (never needed so far: a guard, not a plan)
+        if len(line) <= LINE_LIMIT:
+            break
+        c.pop(victim, None)
+        line = json.dumps(c, separators=(",", ":"))
+    if len(line) > LINE_LIMIT:
+        raise SystemExit("bench: the result line is %d bytes (limit %d)" % (len(line), LINE_LIMIT))
+    return line
+
+
+def emit(out, detail_path):
+    """Writes the full record to the detail file (and to stderr, one line, prefixed) and returns the compact stdout line."""
+    full = json.dumps(out)
+    written = None
+    if detail_path:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(detail_path)), exist_ok=True)
+            with open(detail_path, "w") as f:
+                f.write(full + "\n")
+            written = detail_path
+        except OSError as e:
+            log("bench: could not write %s: %r" % (detail_path, e))
+    log("bench: detail: " + full)
+    return compact_line(out, written)
+
+
 def main():
     t_bench0 = time.perf_counter()
     ap = argparse.ArgumentParser()
@@ -933,7 +1037,7 @@ def main():
                     "c5: ultra-long reads, repeat gate and downsampling)")
     ap.add_argument("--e2e-reads", type=int, default=None, help="reads in the end-to-end FASTQ file (default: the configuration's -- C2: 4 M reads, ~90 KB "
                     "of text each); reduced -- and said so in config.workload -- to what the staging file system / the box's memory control group holds")
-    ap.add_argument("--e2e-budget-s", type=float, default=1350.0, help="seconds the end-to-end leg may take: optional legs are dropped (and named in "
+    ap.add_argument("--e2e-budget-s", type=float, default=900.0, help="seconds the end-to-end leg may take: optional legs are dropped (and named in "
                     "e2e.skipped) when it runs short; the K timed steps never are")
     ap.add_argument("--pinned-variant", action="store_true", help="also run the pinned-pre-pass variant (-5 0 -3 0 -a rapid.fa on 400 000 reads: round 2's headline)")
     ap.add_argument("--e2e-files", type=int, default=0, help="stage the end-to-end reads as this many consecutive files (default: as few as the box's memory allows)")
@@ -960,6 +1064,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the tally all-reduce (nccl = RCCL)")
     ap.add_argument("--share-gpu", action="store_true", help="validation on a 1-GPU box: every rank uses device 0")
     ap.add_argument("--streams", type=int, default=3, help="kernel path: batches in flight per GPU")
+    ap.add_argument("--detail-file", default=os.path.join(ROOT, "bench_detail.json"), help="where the full record goes (per-run wall times, per-sink blocks, stage "
+                    "times, tallies ...): stdout carries ONE line of at most %d bytes" % LINE_LIMIT)
     args = ap.parse_args()
     if args.config == "c5":                # the kernel path in C5's shape: ultra-long reads through the repeat gate
         args.mean_len = args.mean_len or 150000.0
@@ -1039,17 +1145,18 @@ def main():
             value, ms, steps, warmup = s["gbases_per_s"], s["wall_s_mean"] * 1e3, s["runs"], args.warmup
             metric = "filtered Gbases/sec (end-to-end, excl. gzip I/O)"
             cfg = E2E_CONFIGS[args.config]
-            shape = "HiFi reads (N(%.0f kb, /6), Q ~ N(30, 6))" % (cfg["mean_len"] / 1e3) if cfg.get("kind") == "hifi" else "ONT reads (lognormal mean %.0f kb, max 2 Mb)" % (cfg["mean_len"] / 1e3)
+            shape = "HiFi reads N(%.0f kb,/6)" % (cfg["mean_len"] / 1e3) if cfg.get("kind") == "hifi" else "ONT reads, lognormal mean %.0f kb" % (cfg["mean_len"] / 1e3)
+            # (<= 300 characters: the long form -- why the reads are split, what was reduced -- is `workload_long` in the detail file)
+            workload = ("%s end to end: %d of its %d synthetic %s as %d tmpfs file(s); bin/tgsfilter %s -t %d%s -> FASTQ on tmpfs + report; "
+                        "step = one run over one file (%.0f Gbases), K steps dealt over the files%s"
+                        % (cfg["name"], e2e["reads"], cfg["reads"], shape, e2e["files"], e2e["flags"], e2e["threads"],
+                           " --ranks %d" % e2e["ranks"] if e2e.get("ranks") else "", s["bases_per_step_mean"] / 1e9, "; REDUCED to fit the box" if e2e.get("reduced") else ""))
             how = ("%d rank processes (tgsfilter --ranks %d, one per GPU: byte-range shards of each file, a part file per rank, pre-pass on rank 0, one "
                    "all-reduce of the tallies, rank 0 writes the report)" % (e2e["ranks"], e2e["ranks"])) if e2e.get("ranks") else \
                   "one process, every mapping taken down before it returns"
-            workload = ("%s END-TO-END: %d of its %d synthetic %s in %d file%s on tmpfs (%s reads each; %.2f Gbases, %.1f GB of FASTQ text%s%s) "
-                        "-> tgsfilter_amd/bin/tgsfilter %s -t %d (%s; %s) -> FASTQ on tmpfs (%.1f GB) + report; a step = one pass of the command "
-                        "line over all %d file%s (one run per file, wall times summed)"
-                        % (cfg["name"], e2e["reads"], cfg["reads"], shape, e2e["files"], "" if e2e["files"] == 1 else "s",
-                           "/".join(str(x) for x in sorted(set(e2e["reads_per_file"]), reverse=True)), e2e["bases"] / 1e9, e2e["fastq_bytes"] / 1e9,
-                           ("; REDUCED: " + e2e["reduced"]) if e2e.get("reduced") else "", ("; " + e2e["split"]) if e2e.get("split") else "",
-                           e2e["flags"], e2e["threads"], cfg["what"], how, s.get("output_bytes", 0) / 1e9, e2e["files"], "" if e2e["files"] == 1 else "s"))
+            e2e["workload_long"] = ("%s (%s; %s): %.2f Gbases, %.1f GB of FASTQ text%s%s; output %.1f GB" % (
+                workload, cfg["what"], how, e2e["bases"] / 1e9, e2e["fastq_bytes"] / 1e9, ("; REDUCED: " + e2e["reduced"]) if e2e.get("reduced") else "",
+                ("; " + e2e["split"]) if e2e.get("split") else "", s.get("output_bytes", 0) / 1e9))
         else:
             value, ms, steps, warmup = kp["value"], kp["ms_per_step"], kp["steps"], kp["warmup"]
             metric = "device-resident filter throughput (Gbases/sec, inputs in HBM; NOT end-to-end)"
@@ -1070,7 +1177,7 @@ def main():
                 # how far each sink is from the roof that binds the end-to-end run: the text crosses the link once
                 e2e["link"] = link
                 for name, leg in e2e["sinks"].items():
-                    text = e2e["fastq_bytes"] if name == "tmpfs_file" else s["per_file"][0]["fastq_bytes"]
+                    text = leg["bases_per_step_mean"] / e2e["bases"] * e2e["fastq_bytes"] if name == "tmpfs_file" else s["per_file"][0]["fastq_bytes"]
                     leg["text_gb_per_s"] = text / leg["wall_s_mean"] / 1e9
                     leg["link_fraction"] = leg["text_gb_per_s"] / (link["h2d_peak_gb_per_s"] * (world if leg.get("ranks") and world > 1 else 1))
             if world > 1:
@@ -1081,10 +1188,13 @@ def main():
                 rbt = s.get("reference_runs_by_threads_first_file") or {}
                 out["cpu_baseline"] = {
                     "value": s["reference_gbases_per_s"], "unit": "Gbases/s", "cores": s["reference_threads"], "kind": "reference",
+                    # (<= 200 characters; the long form is `sample_long`)
+                    "sample": "oracle/_ref/tgsfilter_ref -t %d on the same %d file(s) (%.0f Gbases), same flags and sink, once each: %.0f s; records and INFO lines equal ours (asserted)"
+                              % (s["reference_threads"], e2e["files"], e2e["bases"] / 1e9, s["reference_wall_s"]),
                     "runs_by_threads": rbt,
-                    "sample": "the whole end-to-end workload (%d reads in %d file(s), %.2f Gbases, %.1f GB FASTQ on tmpfs), same flags, same sink (tmpfs file), "
+                    "sample_long": "the whole end-to-end workload (%d reads in %d file(s), %.2f Gbases, %.1f GB FASTQ on tmpfs), same flags, same sink (tmpfs file), "
                               "oracle/_ref/tgsfilter_ref: on the first file at %s, %d run(s) each; value = all bases / the reference's wall time over all files at "
-                              "-t %d, the FASTER of them (first file: mean of its runs; other files: one run each): %.1f s; output multiset and INFO lines "
+                              "-t %d, the FASTER of them (one run per file): %.1f s; output multiset and INFO lines "
                               "(automatic trims, identified adapter, depths, counters) identical to ours for every file (asserted)"
                               % (e2e["reads"], e2e["files"], e2e["bases"] / 1e9, e2e["fastq_bytes"] / 1e9,
                                  " and ".join("-t %s (%s)" % (k2, v["why"]) for k2, v in rbt.items()), max([len(v["wall_s_runs"]) for v in rbt.values()] or [1]),
@@ -1116,7 +1226,8 @@ def main():
         # around this process reads a little more -- interpreter start, the first import of torch)
         out["bench_wall_s"] = round(time.perf_counter() - t_bench0, 1)
         sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        line = emit(out, args.detail_file)
+        os.write(real_stdout, (line + "\n").encode())
     if world > 1:
         dist.barrier(group=host_group)
         dist.destroy_process_group()

@@ -43,14 +43,23 @@ def test_e2e_leg_over_several_files_and_as_rank_processes(monkeypatch):
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tgsfilter_amd", "host"), "emul"], check=True)
     import bench
     monkeypatch.setattr(bench, "CLI", os.path.join(ROOT, "tests", "emul", "tgsfilter_emul"))
-    args = types.SimpleNamespace(e2e_reads=25, e2e_files=3, steps=2, warmup=1, no_cpu_baseline=False, sharded_leg=False)
+    args = types.SimpleNamespace(e2e_reads=25, e2e_files=3, steps=4, warmup=1, no_cpu_baseline=False, sharded_leg=False)
     r = bench.e2e_leg(args, 1)
     s = r["sinks"]["tmpfs_file"]
     assert r["files"] == 3 and r["reads_per_file"] == [9, 8, 8] and r["reads"] == 25 and len(s["per_file"]) == 3
-    assert len(s["wall_s"]) == 2 and abs(s["wall_s"][0] - sum(f["wall_s"][0] for f in s["per_file"])) < 1e-9
+    # a step = one run over one file; the K = 4 timed steps are dealt over the 3 files in staging order
+    assert r["steps_per_file"] == [2, 1, 1] and [len(f["wall_s"]) for f in s["per_file"]] == [2, 1, 1] and s["runs"] == 4
+    assert s["wall_s"] == [w for f in s["per_file"] for w in f["wall_s"]]
+    filtered = sum(f["bases"] * len(f["wall_s"]) for f in s["per_file"])
+    assert abs(s["gbases_per_s"] - filtered / sum(s["wall_s"]) / 1e9) < 1e-12 and abs(s["bases_per_step_mean"] - filtered / 4) < 1e-6
     assert r["bases"] == sum(f["bases"] for f in s["per_file"]) and s["same_counters"] and s["same_output_multiset"]
+    assert set(r["seconds_by_phase"]) == {"generate", "ours", "reference", "remove_outputs", "digests"}
     assert abs(s["reference_wall_s"] - sum(f["reference_wall_s"] for f in s["per_file"])) < 1e-9 and s["speedup_vs_reference"] > 0
     assert "tmpfs_part_files_3_ranks_one_gpu" not in r["sinks"]
+    # fewer steps than files: only as many files are staged as there are steps
+    args = types.SimpleNamespace(e2e_reads=25, e2e_files=3, steps=2, warmup=0, no_cpu_baseline=False, sharded_leg=False)
+    r = bench.e2e_leg(args, 1)
+    assert r["files"] == 2 and r["files_of_config_split"] == 3 and r["reads"] == 17 and r["steps_per_file"] == [1, 1]
     args = types.SimpleNamespace(e2e_reads=20, e2e_ranks=2, steps=1, warmup=0, no_cpu_baseline=False)
     r = bench.e2e_leg(args, 1)
     s = r["sinks"]["tmpfs_file"]
@@ -82,6 +91,34 @@ def test_e2e_leg_config_c3_with_the_emulated_cli(monkeypatch):
     s = r["sinks"]["tmpfs_file"]
     assert r["flags"] == "-x hifi -l 1000 -q 20 -M 35 -T 50" and "C3" in r["config"]
     assert s["same_counters"] and s["same_output_multiset"] and s["output_records"] > 0 and "variants" not in r
+
+
+def test_the_stdout_line_is_small_and_machine_readable(tmp_path):
+    """BENCH_r05.json: parsed = null -- round 5's line had grown to 21 kB.  The line carries the contract's keys, `roofline`,
+    `cpu_baseline`, the speed-up and the scaling figures in at most 4 kB; the whole record goes to the detail file."""
+    import json
+    import bench
+    full = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_record_r05.json")))       # the 21-kB record of round 5
+    # worst case on top: sentence-long strings everywhere
+    full["config"]["workload"] = full["config"]["workload"] * 3
+    full["cpu_baseline"]["sample"] = full["cpu_baseline"]["sample"] * 3
+    full["bench_wall_s"] = 1234.5
+    detail = str(tmp_path / "sub" / "detail.json")
+    line = bench.emit(full, detail)
+    assert "\n" not in line and len(line.encode()) <= bench.LINE_LIMIT < 6000
+    c = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert k in c
+    assert c["value"] == pytest.approx(full["value"], rel=1e-5) and c["vs_baseline"] is None and c["dtype"] == "u8"
+    assert len(c["config"]["workload"]) <= 300 and "model" not in c["config"]
+    r = c["roofline"]
+    assert r["bound"] in ("hbm", "valu", "mfma", "latency") and r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-4)
+    assert {"kernel", "stage", "kernel_ms", "algorithmic_bytes_per_launch", "traffic", "traffic_all_kernels_per_batch", "fractions_of_hbm_peak"} <= set(r)
+    b = c["cpu_baseline"]
+    assert b["kind"] == "reference" and b["cores"] >= 1 and b["value"] > 0 and len(b["sample"]) <= 200 and set(b) == {"value", "unit", "cores", "kind", "sample"}
+    assert c["e2e_speedup_vs_reference"]["tmpfs_file"] == pytest.approx(full["e2e_speedup_vs_reference"]["tmpfs_file"], rel=1e-5)
+    assert c["scaling_figures"]["n_gpus"] == 1 and c["detail"] == detail
+    assert json.load(open(detail))["e2e"]["sinks"]["tmpfs_file"]["per_file"][0]["wall_s"] == full["e2e"]["sinks"]["tmpfs_file"]["per_file"][0]["wall_s"]
 
 
 def test_write_ont_fastq_is_deterministic(tmp_path):

@@ -263,15 +263,20 @@ def test_bench_two_ranks_share_one_gpu_same_totals(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     common = ["--no-e2e", "--no-cpu-baseline", "--no-oracle-check", "--reads", "4096", "--kernel-warmup", "1", "--streams", "2"]
-    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--kernel-steps", "6"] + common, capture_output=True, timeout=900)
+    d1, d2 = str(tmp_path / "one.json"), str(tmp_path / "two.json")
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--kernel-steps", "6", "--detail-file", d1] + common, capture_output=True, timeout=900)
     assert one.returncode == 0, one.stderr.decode()[-2000:]
-    j1 = json.loads(one.stdout.decode().strip().splitlines()[-1])
+    l1 = one.stdout.decode().strip().splitlines()
+    assert len(l1) == 1 and len(l1[0]) <= 4096 and json.loads(l1[0])["roofline"]["frac"] > 0      # ONE small line on stdout
+    j1 = json.load(open(d1))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "gloo",
-                          "--job-steps", "6"] + common, capture_output=True, timeout=900, env=env)
+                          "--job-steps", "6", "--detail-file", d2] + common, capture_output=True, timeout=900, env=env)
     assert two.returncode == 0, two.stderr.decode()[-2000:]
-    j2 = json.loads([l for l in two.stdout.decode().splitlines() if l.startswith("{")][-1])
+    c2 = json.loads([l for l in two.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert c2["n_gpus"] == 2 and c2["scaling"] == "strong"
+    j2 = json.load(open(d2))
     assert j2["n_gpus"] == 2 and j2["scaling"] == "strong" and "strong" in j2["kernel_path"]["scaling"]
     assert j2["kernel_path"]["tallies"] == j1["kernel_path"]["tallies"]
     assert j2["kernel_path"]["tallies"]["reads"] == 6 * 4096
@@ -289,10 +294,13 @@ def test_bench_two_ranks_end_to_end_leg_runs_one_process_per_gpu(tmp_path):
     env.pop("TGSF_DEBUG_KNOBS", None)                     # (the bench runs the product as a user would)
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", "29543", os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "gloo",
-                          "--e2e-reads", "3000", "--steps", "2", "--warmup", "1", "--no-kernel-path"], capture_output=True, timeout=1200, env=env)
+                          "--e2e-reads", "3000", "--steps", "2", "--warmup", "1", "--no-kernel-path", "--detail-file", str(tmp_path / "d.json")],
+                         capture_output=True, timeout=1200, env=env)
     assert two.returncode == 0, two.stderr.decode()[-3000:]
-    j = json.loads([l for l in two.stdout.decode().splitlines() if l.startswith("{")][-1])
+    c = json.loads([l for l in two.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert c["n_gpus"] == 2 and c["steps"] == 2 and c["value"] > 0 and "cpu_baseline" not in c and "--ranks 2" in c["config"]["workload"]
+    j = json.load(open(str(tmp_path / "d.json")))
     s = j["e2e"]["sinks"]["tmpfs_file"]
     assert j["n_gpus"] == 2 and j["e2e"]["ranks"] == 2 and s["ranks"] == 2 and j["steps"] == 2 and j["value"] > 0
-    assert len(s["per_file"][0]["shard_lines"]) == 2 and "tgsfilter --ranks 2" in j["config"]["workload"]
+    assert len(s["per_file"][0]["shard_lines"]) == 2 and "tgsfilter --ranks 2" in j["e2e"]["workload_long"]
     assert j["e2e"]["sinks"]["dev_null"]["same_counters_as_the_file_run"] and "cpu_baseline" not in j

@@ -10,8 +10,8 @@ rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 # kernel-path runs only under the profiler (the end-to-end leg starts other programs; it is timed by bench.py itself)
 K="--no-e2e --no-cpu-baseline --no-oracle-check $*"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_default -- python3 $R/bench.py $K > $O/kt_default.json 2> $O/kt_default.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_single -- python3 $R/bench.py $K --streams 1 > $O/kt_single.json 2> $O/kt_single.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_default -- python3 $R/bench.py $K --detail-file $O/kt_default_detail.json > $O/kt_default.json 2> $O/kt_default.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_single -- python3 $R/bench.py $K --streams 1 --detail-file $O/kt_single_detail.json > $O/kt_single.json 2> $O/kt_single.err
 B="python3 $R/bench.py $K --kernel-steps 2 --kernel-warmup 1 --streams 1"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $B > $O/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $B > $O/pmc_write.log 2>&1
@@ -85,7 +85,7 @@ with open(O + "/%s_pmc_valu.csv" % tag, "w") as o:
     o.write("kernel," + ",".join(cols) + "\n")
     for k, d in sorted(sq.items(), key=lambda kv: -kv[1].get("SQ_INSTS_VALU", 0)):
         o.write(k + "," + ",".join("%.0f" % d.get(c, 0) for c in cols) + "\n")
-b = json.load(open(O + "/kt_single.json"))
+b = json.load(open(O + "/kt_single_detail.json"))      # (the full record: stdout carries the small line only)
 def named(d, prefix):
     """the dispatch-name entry that starts with `prefix` (template arguments vary: k_mid_scan1<2, tgsf::Hot>)"""
     for k in d:

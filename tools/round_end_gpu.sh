@@ -9,7 +9,7 @@
 #   tools/round_end_gpu.sh bench           the full bench line as the driver runs it + --config c3 + --config c5
 #   tools/round_end_gpu.sh shard           rank processes sharing the one GPU against the single process (tests/manual/e2e_shard.py)
 cd $GRAFT_REPO_ROOT
-what=${1:-suite}; tag=${2:-r05}
+what=${1:-suite}; tag=${2:-r06}
 R=$GRAFT_REPO_ROOT
 case $what in
 suite)
