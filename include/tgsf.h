@@ -207,6 +207,15 @@ typedef struct tgsf_ctx tgsf_ctx;
 int tgsf_abi_version(void);
 
 /*
+ * What executes the kernels behind this library: "hip:gfx950" for the product (tgsfilter_amd/libtgsf.so).  The serial
+ * emulation the tests build from the same kernel sources (tests/emul: test infrastructure for boxes without a GPU)
+ * answers "emulation".  A host program that binds the library at run time checks this: the command line and the
+ * Python binding refuse a library whose answer does not begin with "hip" -- a stray TGSF_LIB in the environment
+ * must not turn a GPU run into a CPU run.  Static storage; never NULL.
+ */
+const char* tgsf_backend(void);
+
+/*
  * Optional: bring the HIP runtime up on `device` and load the library's kernels (first use costs a few
  * tenths of a second).  Thread-safe; a host program can call it from a helper thread while it is still
  * reading its parameters, so that tgsf_create and the first batch do not pay for it.

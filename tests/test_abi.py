@@ -81,3 +81,35 @@ def test_rccl_library_exports():
     lib = rccl.load()
     for s in declared:
         assert hasattr(lib, s)
+
+
+def test_backend_symbol_names_what_runs_the_kernels(lib):
+    """include/tgsf.h: tgsf_backend() -- "hip:gfx950" for the product library, "emulation" for the tests' serial build."""
+    assert lib.tgsf_backend() == b"hip:gfx950"
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emul")], check=True)
+    emul = capi.load(os.path.join(ROOT, "tests", "emul", "libtgsf_emul.so"))          # (an explicit path: the tests' way in)
+    assert emul.tgsf_backend() == b"emulation"
+
+
+def test_a_stray_TGSF_LIB_never_turns_a_gpu_run_into_a_cpu_run(tmp_path):
+    """TGSF_LIB says where libtgsf.so is installed; pointing it at the emulation must not make the product
+    -- the command line or the Python binding -- run on the CPU, with or without the debug switch."""
+    import sys
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tgsfilter_amd", "host")], check=True)
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emul")], check=True)
+    emul = os.path.join(ROOT, "tests", "emul", "libtgsf_emul.so")
+    fq = tmp_path / "in.fq"
+    reads = synth.make_reads(5, 6, "ont", mean_len=3000)
+    fq.write_bytes(b"".join(b"@%s\n%s\n+\n%s\n" % (n, s, q) for n, s, q in reads))
+    cli = os.path.join(ROOT, "tgsfilter_amd", "bin", "tgsfilter")
+    for knobs in ({}, {"TGSF_DEBUG_KNOBS": "1"}):
+        env = dict(os.environ, TGSF_LIB=emul, **knobs)
+        if not knobs:
+            env.pop("TGSF_DEBUG_KNOBS", None)
+        out = tmp_path / "out.fq"
+        p = subprocess.run([cli, "-i", str(fq), "-o", str(out), "-x", "ont", "-5", "0", "-3", "0"], capture_output=True, env=env, timeout=120)
+        assert p.returncode != 0 and b"emulation" in p.stderr and b"no CPU fallback" in p.stderr, p.stderr[-500:]
+        assert not out.exists() or out.stat().st_size == 0
+        code = "from tgsfilter_amd import capi\ntry:\n    capi.load()\nexcept RuntimeError as e:\n    assert 'not the HIP build' in str(e), e\n    raise SystemExit(7)\n"
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, env=env, cwd=ROOT, timeout=120)
+        assert p.returncode == 7, p.stderr[-500:]

@@ -19,7 +19,7 @@ DEFAULT_LIB = os.path.join(_HERE, "libtgsf.so")
 _LIBS = {}
 
 SYMBOLS = [
-    "tgsf_abi_version", "tgsf_prepare_device", "tgsf_device_location", "tgsf_create", "tgsf_destroy", "tgsf_submit", "tgsf_submit_async", "tgsf_submit_device",
+    "tgsf_abi_version", "tgsf_backend", "tgsf_prepare_device", "tgsf_device_location", "tgsf_create", "tgsf_destroy", "tgsf_submit", "tgsf_submit_async", "tgsf_submit_device",
     "tgsf_wait",
     "tgsf_counters_len", "tgsf_counters", "tgsf_counters_used", "tgsf_counters_merge", "tgsf_counters_device", "tgsf_reset_counters", "tgsf_profile",
     "tgsf_stage_times", "tgsf_stage_name", "tgsf_align_windows", "tgsf_last_error",
@@ -33,8 +33,14 @@ class TgsfError(RuntimeError):
 
 
 def load(path: str | None = None):
+    """Loads the library: `path` if given (the tests hand the emulation's in), else $TGSF_LIB (where libtgsf.so is
+    installed, if not beside this file), else the in-tree build.  A library found through the environment or the default
+    must be the HIP build (tgsf_backend() begins with "hip"): a stray TGSF_LIB never turns a GPU run into a CPU run."""
+    explicit = path is not None
     path = path or os.environ.get("TGSF_LIB") or DEFAULT_LIB
     if path in _LIBS:
+        if not explicit and not _LIBS[path].tgsf_backend().startswith(b"hip"):
+            raise RuntimeError(f"{path} is not the HIP build of libtgsf (there is no CPU fallback; is TGSF_LIB set by accident?)")
         return _LIBS[path]
     if not os.path.exists(path):
         raise FileNotFoundError(
@@ -42,6 +48,7 @@ def load(path: str | None = None):
     L = C.CDLL(path)
     vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
     L.tgsf_abi_version.restype = C.c_int
+    L.tgsf_backend.restype = C.c_char_p
     L.tgsf_prepare_device.argtypes = [C.c_int]
     L.tgsf_device_location.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int)]
     L.tgsf_create.argtypes = [C.POINTER(abi.Params), C.c_int, C.POINTER(vp)]
@@ -66,6 +73,9 @@ def load(path: str | None = None):
     L.tgsf_last_error.restype = C.c_char_p
     if L.tgsf_abi_version() != abi.ABI_VERSION:
         raise RuntimeError("libtgsf ABI version mismatch")
+    if not explicit and not L.tgsf_backend().startswith(b"hip"):
+        raise RuntimeError(f"{path} is the {L.tgsf_backend().decode()!r} build of libtgsf, not the HIP build "
+                           "(there is no CPU fallback; is TGSF_LIB set by accident?)")
     _LIBS[path] = L
     return L
 

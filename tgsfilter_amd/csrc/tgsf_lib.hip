@@ -237,6 +237,7 @@ static int build_tables(tgsf_ctx* c)
 // create / destroy
 // ---------------------------------------------------------------------------
 extern "C" int tgsf_abi_version(void) { return TGSF_ABI_VERSION; }
+extern "C" const char* tgsf_backend(void) { return kTgsfEmul ? "emulation" : "hip:gfx950"; }
 
 #if !defined(TGSF_EMUL)
 __global__ void k_noop(int* p) { if (p) *p = 0; }

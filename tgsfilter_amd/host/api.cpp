@@ -14,6 +14,12 @@
 #ifndef TGSF_LIB_REL
 #define TGSF_LIB_REL "../libtgsf.so"        // relative to the executable (tgsfilter_amd/bin/tgsfilter)
 #endif
+// What tgsf_backend() of the library must begin with.  The product runs on the HIP build only; the test builds of this
+// program (make emul / asan / tsan) are compiled to expect the emulation instead -- a property of the executable, not of
+// the environment: TGSF_LIB says where the library is, never what kind of library is acceptable.
+#ifndef TGSF_EXPECT_BACKEND
+#define TGSF_EXPECT_BACKEND "hip"
+#endif
 
 namespace host {
 
@@ -47,6 +53,7 @@ void load(std::vector<int> devices)
     g_api.field = reinterpret_cast<decltype(g_api.field)>(dlsym(h, sym)); \
     if (!g_api.field) { g_error = std::string("symbol ") + sym + " missing in " + path; return; }
     BIND(abi_version, "tgsf_abi_version")
+    BIND(backend, "tgsf_backend")
     BIND(prepare_device, "tgsf_prepare_device")
     BIND(create, "tgsf_create")
     BIND(destroy, "tgsf_destroy")
@@ -64,6 +71,15 @@ void load(std::vector<int> devices)
     BIND(counters_merge, "tgsf_counters_merge")
 #undef BIND
     if (g_api.abi_version() != TGSF_ABI_VERSION) { g_error = path + ": ABI version mismatch"; return; }
+    {
+        const char* b = g_api.backend();
+        const std::string want = TGSF_EXPECT_BACKEND;
+        if (!b || std::string(b).compare(0, want.size(), want) != 0) {
+            g_error = path + " is the \"" + (b ? b : "?") + "\" build of the library; this program runs on the \"" + want +
+                      "\" build only (there is no CPU fallback; is TGSF_LIB set by accident?)";
+            return;
+        }
+    }
     g_load_s = now_s() - t0;
     // every device on a thread of its own (a device takes 0.1-0.3 s to come up); failures surface at tgsf_create, with
     // its message

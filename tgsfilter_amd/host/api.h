@@ -13,6 +13,7 @@ namespace host {
 
 struct Api {
     decltype(&tgsf_abi_version) abi_version;
+    decltype(&tgsf_backend) backend;
     decltype(&tgsf_prepare_device) prepare_device;
     decltype(&tgsf_create) create;
     decltype(&tgsf_destroy) destroy;
