@@ -3,7 +3,7 @@
 # end-to-end pre-pass resolves (C2: -5 79 -3 0; C3: -5 7 -3 8), one batch in flight and three:
 #   direct      TGSF_CLEAN_TABLES=direct  (round 4's way for trimmed reads: every kept fragment scanned a second time)
 #   by-product  default                   (round 5: the raw pass tallies the expected fragment; corrections only)
-# and the 4-adapter shapes.  Run on the GPU box: tools/r5_ab_clean.sh > gpurun_out/r5_ab_clean.txt
+# and the 4-adapter shapes.  Run on the GPU box: tools/ab_clean.sh > gpurun_out/r5_ab_clean.txt
 export TGSF_DEBUG_KNOBS=1   # the test settings below are read only under this switch
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R

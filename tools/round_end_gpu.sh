@@ -5,7 +5,7 @@
 #   tools/round_end_gpu.sh profile <tag>   kernel trace + PMC passes of the four kernel-path shapes (tools/profile_round.sh:
 #                                          C2 and C3 with the pre-pass's trims, C5, 4 adapters), their traffic.json merged,
 #                                          the short-adapter shapes
-#   tools/round_end_gpu.sh ab <tag>        the clean-table A/B (tools/r5_ab_clean.sh)
+#   tools/round_end_gpu.sh ab <tag>        the clean-table A/B (tools/ab_clean.sh)
 #   tools/round_end_gpu.sh bench           the full bench line as the driver runs it + --config c3 + --config c5
 #   tools/round_end_gpu.sh shard           rank processes sharing the one GPU against the single process (tests/manual/e2e_shard.py)
 cd $GRAFT_REPO_ROOT
@@ -25,7 +25,7 @@ profile)
   python3 bench.py --no-e2e --no-cpu-baseline --short-adapters --streams 1 > gpurun_out/${tag}_a2short_bench.json 2> gpurun_out/a2short.err
   tail -c 300 gpurun_out/${tag}_a4short_bench.json ;;
 ab)
-  bash tools/r5_ab_clean.sh > gpurun_out/${tag}_clean_tables_ab.txt 2>&1; head -30 gpurun_out/${tag}_clean_tables_ab.txt ;;
+  bash tools/ab_clean.sh > gpurun_out/${tag}_clean_tables_ab.txt 2>&1; head -30 gpurun_out/${tag}_clean_tables_ab.txt ;;
 bench)
   python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${tag}_bench.json 2> gpurun_out/bench.err; tail -c 600 gpurun_out/${tag}_bench.json
   python bench.py --config c3 --steps 3 --warmup 1 > gpurun_out/${tag}_bench_c3.json 2> gpurun_out/bench_c3.err; tail -c 400 gpurun_out/${tag}_bench_c3.json
