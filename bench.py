@@ -192,6 +192,21 @@ def parse_timing(err):
             m = re.search(r"kernels ([0-9.]+) s", l)
             if m:
                 t["gpu_kernel_s_summed"] = float(m.group(1))
+        elif l.startswith("CPU:"):
+            # CPU seconds by stage (host/cputime.h): thread CPU time, user + system (a sharded job prints one line per rank: summed)
+            m = re.match(r"CPU: ([0-9.]+) s of CPU time \(user \+ system\) for ([0-9.]+) Gbases", l)
+            if m:
+                t["cpu_s"] = t.get("cpu_s", 0.0) + float(m.group(1))
+                t["cpu_gbases"] = t.get("cpu_gbases", 0.0) + float(m.group(2))
+                st = t.setdefault("cpu_s_by_stage", {})
+                for part in l.split("|")[1].split(","):
+                    mm = re.match(r"\s*(.+?) ([0-9.]+)\s*$", part)
+                    if mm:
+                        st[mm.group(1)] = round(st.get(mm.group(1), 0.0) + float(mm.group(2)), 3)
+                mm = re.search(r"threads of the runtime and others (-?[0-9.]+)", l)
+                if mm:
+                    st["runtime threads and others"] = round(st.get("runtime threads and others", 0.0) + float(mm.group(1)), 3)
+                t["cpu_s_per_gbase"] = t["cpu_s"] / t["cpu_gbases"] if t["cpu_gbases"] else None
     return t
 
 

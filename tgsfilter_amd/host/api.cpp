@@ -1,4 +1,5 @@
 #include "api.h"
+#include "cputime.h"
 #include "fatal.h"
 
 #include <dlfcn.h>
@@ -45,6 +46,7 @@ std::string lib_path()
 
 void load(std::vector<int> devices)
 {
+    CpuScope cpu(CPU_LOADER);
     const double t0 = now_s();
     const std::string path = lib_path();
     void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
@@ -87,7 +89,7 @@ void load(std::vector<int> devices)
     for (size_t i = 1; i < devices.size(); i++) {
         bool seen = false;
         for (size_t j = 0; j < i; j++) seen = seen || devices[j] == devices[i];
-        if (!seen) up.emplace_back([d = devices[i]] { (void)g_api.prepare_device(d); });
+        if (!seen) up.emplace_back([d = devices[i]] { CpuScope c2(CPU_LOADER); (void)g_api.prepare_device(d); });
     }
     if (!devices.empty()) (void)g_api.prepare_device(devices[0]);
     for (std::thread& t : up) t.join();

@@ -1,4 +1,5 @@
 #include "fastx.h"
+#include "cputime.h"
 
 #include "fatal.h"
 
@@ -115,6 +116,7 @@ LineScanner::~LineScanner()
 
 void LineScanner::work()
 {
+    CpuScope cpu(CPU_INDEX_LINES);
     std::vector<const char*> found;
     for (;;) {
         size_t b;
@@ -259,6 +261,7 @@ RecordIndex::~RecordIndex()
 
 void RecordIndex::produce(const char* data, size_t size, bool fastq, int threads)
 {
+    CpuScope cpu(CPU_INDEX_RECORDS);
     std::string msg;
     {
         FastxReader rd(data, size, fastq, threads, &msg);

@@ -276,6 +276,7 @@ int main(int argc, char** argv)
                                    (uint64_t)text_size >= early_min;
         if (may_map_early && sink.open(out_path, 4 * (uint64_t)text_size + (1ull << 30), true))
             early = std::thread([&] {
+                CpuScope cpu(CPU_FALLOCATE);
                 const uint64_t limit = (uint64_t)text_size / 4;        // what a run keeps is not known yet; a surplus is cut off at the end
                 while (!early_stop.load() && sink.reserved() < limit)
                     if (!sink.reserve_to(std::min<uint64_t>(limit, sink.reserved() + (256u << 20)), false)) break;   // (a nearly full file system: not this thread's call)
@@ -285,6 +286,7 @@ int main(int argc, char** argv)
 
     // ---- pre-pass, :3058-3126 ----
     PrepassResult pp;
+    std::unique_ptr<CpuScope> cpu_prepass(new CpuScope(CPU_PREPASS));
     if (sharded && link.rank > 0) {
         // (rank 0 looks at the first reads of the WHOLE input, as the reference does, and broadcasts what it found: below)
     } else if (streaming) {
@@ -322,6 +324,7 @@ int main(int argc, char** argv)
         BlobIn r(b.s);
         r.pod(pp.qtype); r.pod(pp.trim5p); r.pod(pp.trim3p); r.pod(pp.depth5p); r.pod(pp.depth3p); r.pod(o.min_q); r.str(pp.adapter5p); r.str(pp.adapter3p);
     }
+    cpu_prepass.reset();
     t_prepass = now_s() - t_start;
     std::vector<std::string> adapters;
     if (o.filter) {
@@ -517,6 +520,7 @@ int main(int argc, char** argv)
     std::atomic<uint64_t> stream_text{0};                             // streamed input: text handed out so far ...
     std::atomic<double> stream_share{0.0};                            // ... out of this share of the file's bytes
     std::thread reader([&] {                                           // read_fastx, :1845-1870 (batches of indexed records)
+        CpuScope cpu(CPU_BATCHER);
         if (!run_filter_pass) { for (size_t d = 0; d < ctxs.size(); d++) to_gpu.put(nullptr); return; }
         std::unique_ptr<RecordIndex::Cursor> rd;
         if (!streaming) rd.reset(new RecordIndex::Cursor(*records_p));
@@ -601,6 +605,7 @@ int main(int argc, char** argv)
     std::vector<double> dev_submit_s(ctx_dev.size(), 0.0);
     std::vector<uint64_t> dev_bytes(ctx_dev.size(), 0), dev_batches(ctx_dev.size(), 0);
     auto feed = [&](size_t k) {                                        // filter_sequence, :1919-2064, one batch per call
+        CpuScope cpu(CPU_FEEDER);
         if (numa_bind) {
             int node = -1;
             char bus[64];
@@ -671,7 +676,7 @@ int main(int argc, char** argv)
     int populate_threads = std::max(1, std::min(o.n_thread, 32));      // short bursts between two fallocates: the more the shorter
     // (the pages of a reserved stride are mapped by many threads BETWEEN two fallocates: beside one, page faults on the file
     // take its inode's lock and both crawl -- measured, DESIGN appendix)
-    Pool populate(sink.is_open() ? populate_threads : 0);
+    Pool populate(sink.is_open() ? populate_threads : 0, CPU_POPULATE);
     // (a streamed input is decoder-bound: small strides keep the mapped part of the output -- it counts as resident -- small)
     uint64_t stride_bytes = streaming ? (128ull << 20) : (2ull << 30);
     if (const char* e = knob("TGSF_STRIDE_BYTES")) { const long long v = atoll(e); if (v > 0) stride_bytes = (uint64_t)v; }   // tuning / test knob
@@ -694,7 +699,7 @@ int main(int argc, char** argv)
         std::unique_ptr<MappedSink> d(new MappedSink);
         if (!d->open(out_path, capacity)) return false;
         dsink = std::move(d);
-        dpop.reset(new Pool(populate_threads));
+        dpop.reset(new Pool(populate_threads, CPU_POPULATE));
         dres.reset(new Reserver(*dsink, *dpop, stride_bytes, false));
         dres->start(speculative);
         return true;
@@ -721,6 +726,7 @@ int main(int argc, char** argv)
     const uint64_t release_piece = 16u << 20;
     Channel<std::pair<const char*, uint64_t>> to_release(1 << 16);
     std::thread releaser([&] {
+        CpuScope cpu(CPU_RELEASER);
         for (;;) {
             const std::pair<const char*, uint64_t> r = to_release.get();
             if (!r.first) break;
@@ -736,6 +742,7 @@ int main(int argc, char** argv)
         store.put(std::move(b));
     };
     std::thread writer([&] {
+        CpuScope cpu(CPU_PLANNER);
         const std::string lead(1, fastq_out ? '@' : '>'), nl("\n"), sep("\n+\n");
         std::string name;
         std::map<uint64_t, std::shared_ptr<Batch>> held;               // batches that arrived ahead of their turn
@@ -1035,6 +1042,7 @@ int main(int argc, char** argv)
         const bool in_place = kept_span > 0 && (force ? !strcmp(force, "text") : kept_bytes * 12 >= kept_span);   // (packing runs at a tenth of the copy to the device)
         d_in_place = in_place; d_kept = (double)kept_bytes; d_span = (double)kept_span;
         std::thread qc_pass([&] {
+            CpuScope cpu(CPU_DOWNSAMPLE);
             const double q0 = now_s();
             if (L.create(&qp, o.devices[0], &qctx) != TGSF_OK) die(L.last_error(nullptr));
             t_dcreate = now_s() - q0;
@@ -1067,10 +1075,11 @@ int main(int argc, char** argv)
                 };
                 std::thread second;
                 if (workers == 2) second = std::thread([&] {
+                    CpuScope cpu2(CPU_DOWNSAMPLE);
                     if (L.create(&qp, o.devices[0], &qctx2) != TGSF_OK) die(L.last_error(nullptr));
                     work(qctx2);
                 });
-                std::thread first([&] { work(qctx); });
+                std::thread first([&] { CpuScope cpu2(CPU_DOWNSAMPLE); work(qctx); });
                 std::shared_ptr<TextBatch> tb(new TextBatch);
                 auto flush_text = [&] {
                     if (tb->len.empty()) return;
@@ -1144,6 +1153,7 @@ int main(int argc, char** argv)
                 // (one process: the mappings of written pieces are dropped behind the fill jobs by one thread, as in the filter pass)
                 Channel<std::pair<const char*, uint64_t>> dropped(1 << 12);
                 std::thread dropper([&] {
+                    CpuScope cpu2(CPU_RELEASER);
                     for (;;) {
                         const std::pair<const char*, uint64_t> r = dropped.get();
                         if (!r.first) break;
@@ -1443,6 +1453,25 @@ int main(int argc, char** argv)
                     o.devices[di], (unsigned long long)nb2, by * 1e-9, nf2, sub, sub > 0 ? by * 1e-9 / sub : 0.0, t_pipe > 0 ? by * 1e-9 / t_pipe : 0.0, t_pipe,
                     node >= 0 ? (" (feeders bound to NUMA node " + std::to_string(node) + ")").c_str() : "");
         }
+    }
+    if (timing) {
+        // CPU seconds by stage (cputime.h): what the threads that have ended charged, the main thread's share up to here, and
+        // what the process used beyond both (the runtime's own threads).  ONE write (ranks share this stderr).
+        const double proc = process_cpu_s();
+        double own = 0;
+        std::string line;
+        char piece[160];
+        for (int s = 0; s < CPU_N; s++) {
+            double v = (double)cpu_ns()[s].load() * 1e-9;
+            if (s == CPU_MAIN) v += (double)thread_cpu_ns() * 1e-9 - (double)cpu_ns()[CPU_PREPASS].load() * 1e-9;      // (the main thread is still running)
+            own += v;
+            if (v >= 0.0005) { snprintf(piece, sizeof piece, "%s %s %.3f", line.empty() ? "" : ",", cpu_stage_name(s), v); line += piece; }
+        }
+        snprintf(piece, sizeof piece, "CPU: %.3f s of CPU time (user + system) for %.3f Gbases = %.4f CPU-s per Gbase |", proc, (double)raw_bases * 1e-9,
+                 raw_bases ? proc / ((double)raw_bases * 1e-9) : 0.0);
+        std::string head = piece;
+        snprintf(piece, sizeof piece, " | threads of the runtime and others %.3f\n", proc - own);
+        fputs((head + line + piece).c_str(), stderr);
     }
     if (timing && o.downsample)
         fprintf(stderr, "DOWN: selection %.3f | QC pass over the kept reads (%s, %.2f GB of them in %.2f GB of text): context %.3f, batches + submits %.3f (its own thread; %d submits %.3f, the first %.3f) | writing them %.3f (%s) | closing the output %.3f\n",

@@ -32,6 +32,7 @@
 #include <unordered_map>
 #include <unordered_set>
 
+#include "cputime.h"
 #include "fatal.h"
 #include "fastx.h"
 #include "options.h"
@@ -428,7 +429,7 @@ inline void stream_fence() {}
 // worker threads for the fill jobs
 class Pool {
 public:
-    explicit Pool(int n) { for (int i = 0; i < n; i++) th_.emplace_back([this] { run(); }); }
+    explicit Pool(int n, int cpu_stage = CPU_FILL) : stage_(cpu_stage) { for (int i = 0; i < n; i++) th_.emplace_back([this] { run(); }); }
     double busy_s() { std::lock_guard<std::mutex> l(m_); return busy_; }
     void add(std::function<void()> f) {
         { std::lock_guard<std::mutex> l(m_); q_.push_back(std::move(f)); open_++; }
@@ -446,6 +447,7 @@ public:
     }
 private:
     void run() {
+        CpuScope cpu(stage_);
         for (;;) {
             std::function<void()> f;
             {
@@ -471,6 +473,7 @@ private:
         }
     }
     double busy_ = 0;
+    const int stage_;
 public:
     double destroy_ = 0, longest_ = 0, first_ = 0, last_ = 0;
     size_t jobs_ = 0;
@@ -524,6 +527,7 @@ private:
         ready_cv_.notify_all();
     }
     void run() {
+        CpuScope cpu(CPU_FALLOCATE);
         uint64_t at = 0;                        // pages of [0, at) are instantiated and their mapping is under way or done
         for (;;) {
             uint64_t goal, need;
