@@ -674,6 +674,7 @@ int main(int argc, char** argv)
     if (const char* e = knob("TGSF_FILL_MIN_BYTES")) { const long long v = atoll(e); if (v > 0) fill_min = (uint64_t)v; }   // test knob
     Pool pool(sink.is_open() ? fill_threads : 1);
     int populate_threads = std::max(1, std::min(o.n_thread, 32));      // short bursts between two fallocates: the more the shorter
+    if (const char* e = knob("TGSF_POPULATE_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) populate_threads = v; }   // tuning knob (tests/manual/e2e_cpu.py)
     // (the pages of a reserved stride are mapped by many threads BETWEEN two fallocates: beside one, page faults on the file
     // take its inode's lock and both crawl -- measured, DESIGN appendix)
     Pool populate(sink.is_open() ? populate_threads : 0, CPU_POPULATE);

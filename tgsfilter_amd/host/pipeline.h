@@ -362,6 +362,10 @@ public:
     }
     // map the (instantiated) pages of [at, at+n) into the address space now, so that storing into them later takes no
     // page fault -- page faults on this file while fallocate() runs on it slow both down to a crawl
+    // (MADV_POPULATE_READ would do on tmpfs -- a shared writable mapping of a tmpfs file needs no write notification, its
+    // page-table entries are writable whichever fault installs them -- but on the MI355X host it costs MORE than the write
+    // fault: 37-42 CPU-s and 1.9-2.2 s of wall time for 72 GB on 32 threads against 15-16 CPU-s and 0.9-1.0 s, 11-12 against
+    // 7-8 CPU-s on 4 threads; profiles/r06_cpu_populate_read.txt.  Measured in round 6, not used.)
     void populate(uint64_t at, uint64_t n) {
         char* p = map_ + (at & ~uint64_t(4095));
         const size_t len = (size_t)(((at + n + 4095) & ~uint64_t(4095)) - (at & ~uint64_t(4095)));
