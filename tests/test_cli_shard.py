@@ -84,7 +84,7 @@ def test_cli_sharded_ranks_hand_their_stderr_lines_over_whole(binary, golden_dir
     none lands in the middle of another (bench.py reads the INFO, SHARD and TIMING lines of a job)."""
     fin = tmp_path / "in.fq"
     fin.write_bytes(gzip.open(os.path.join(golden_dir, "ont_zoo.in.fq.gz"), "rb").read())
-    known = ("INFO:", "SHARD ", "TIMING:", "POOL:", "GPU:", "RESERVE:", "DEVICE ", "DOWN:", "CLOCK:", "Warning:", "PREPASS:")
+    known = ("INFO:", "SHARD ", "TIMING:", "POOL:", "GPU:", "RESERVE:", "DEVICE ", "DOWN:", "CLOCK:", "Warning:", "PREPASS:", "CPU:")
     for _ in range(25):
         p = subprocess.run([binary, "-i", str(fin), "-o", str(tmp_path / "o.fq"), "-x", "ont", "-t", "12", "--ranks", "6"],
                            capture_output=True, timeout=120, env=dict(os.environ, TGSF_TIMING="1"))

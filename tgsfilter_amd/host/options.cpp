@@ -104,6 +104,29 @@ int file_type(const std::string& path)
     return 3;
 }
 
+// the flags that take a value (the keys of parse_args's table: checked there)
+static const char* const kWithValue[] = {"i", "o", "x", "l", "L", "q", "Q", "n", "e", "b", "5", "3", "a", "N", "E", "m", "M", "T", "s", "S", "g", "d",
+                                         "r", "R", "k", "p", "c", "t", "device", "ranks", "rendezvous", "shard", "devices"};
+
+int shard_rank_on_command_line(int argc, char** argv)
+{
+    // the walk of parse_args below: a token in flag position names its flag with every '-' taken out; a flag with a value
+    // takes the next token whatever that looks like (`-o shard` is an output file)
+    for (int i = 1; i < argc; i++) {
+        if (argv[i][0] != '-') return -1;                    // (parse_args stops with an error there)
+        std::string flag = argv[i];
+        flag.erase(std::remove(flag.begin(), flag.end(), '-'), flag.end());
+        const bool takes = std::find(std::begin(kWithValue), std::end(kWithValue), flag) != std::end(kWithValue);
+        if (!takes) continue;
+        if (i + 1 == argc) return -1;
+        const char* v = argv[++i];
+        if (flag != "shard") continue;
+        if (!strcmp(v, "env")) { const char* r = getenv("RANK"); return r ? atoi(r) : -1; }
+        return strchr(v, '/') ? atoi(v) : -1;                // "r/N", as parse_args reads it
+    }
+    return -1;
+}
+
 int parse_args(int argc, char** argv, Options& o)
 {
     if (argc <= 2) { print_usage(); return 1; }
@@ -178,6 +201,8 @@ int parse_args(int argc, char** argv, Options& o)
         {"qc", [&] { o.only_qc = true; }},
         {"f", [&] { o.fasta_out = true; }},
     };
+    for (const char* k : kWithValue) if (!with_value.count(k)) { std::cerr << "Error: option table out of step: " << k << std::endl; return 1; }
+    if (with_value.size() != sizeof kWithValue / sizeof kWithValue[0]) { std::cerr << "Error: option table out of step" << std::endl; return 1; }
     for (int i = 1; i < argc; i++) {
         if (argv[i][0] != '-') {
             std::cerr << "Error: command option error! please check." << std::endl;

@@ -56,6 +56,10 @@ int print_usage();
 // Returns 0 to continue, 1 to stop with exit status 1 (same contract as TGSFilter_cmd);
 // calls exit(-1) where the reference does.
 int parse_args(int argc, char** argv, Options& o);
+// The rank `--shard r/N` / `--shard env` names on this command line, or -1 (no such option, or one parse_args will refuse): main
+// needs it BEFORE parse_args prints its own INFO lines, which a rank above 0 leaves to rank 0.  Walks the tokens as parse_args
+// does, so that a VALUE that happens to read "shard" (`-o shard`) is not taken for the option.
+int shard_rank_on_command_line(int argc, char** argv);
 
 std::string file_extension(const std::string& path);      // :814-822
 std::string file_prefix(const std::string& path);         // :824-837
