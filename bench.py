@@ -347,7 +347,7 @@ def e2e_leg(args, n_gpus):
 
     def rm(path):
         t0 = time.perf_counter()
-        for p in [path] + ["%s.part%d" % (path, r) for r in range(64)]:
+        for p in [path, path + ".parts"] + ["%s.part%d" % (path, r) for r in range(64)]:
             if os.path.isfile(p) and not os.path.islink(p):
                 os.remove(p)          # dropping a previous run's GBs of tmpfs pages is not part of a run
         phase["remove_outputs"] += time.perf_counter() - t0

@@ -202,7 +202,8 @@ static int obtain_alignment_length(const uint8_t* q, int Q, const uint8_t* t, in
     int len = -1;
     if (h >= 0) {
         const int ls = h == 0 ? lw : L[h], rs = h == Q ? rw : Rr[Q - h];
-        len = obtain_alignment_length(q, h, t, lw, ls) + obtain_alignment_length(q + h, Q - h, t + lw, rw, rs);
+        const int a = obtain_alignment_length(q, h, t, lw, ls), b = obtain_alignment_length(q + h, Q - h, t + lw, rw, rs);
+        len = (a < 0 || b < 0) ? -1 : a + b;               /* (a quadrant without a cut: the whole alignment has none) */
     }
     free(L); free(Rr);
     return len;           /* (-1: no cut adds up to `best` -- the reference returns EDLIB_STATUS_ERROR; never seen) */

@@ -106,12 +106,18 @@ def test_cli_sharded_more_ranks_than_reads(binary, golden_dir, tmp_path):
     fin.write_bytes(b"\n".join(recs[:4 * 5]) + b"\n")                # five reads
     common = ["-i", str(fin), "-x", "ont", "-l", "500", "-q", "7", "-5", "0", "-3", "0"]
     p1 = subprocess.run([binary, "-o", str(tmp_path / "one.fq")] + common, capture_output=True, timeout=300)
-    for k in (9, 10, 12):                                             # parts 9 and 10 of an earlier, larger job (12: not in line, stays)
-        (tmp_path / ("nine.fq.part%d" % k)).write_bytes(b"@old\nA\n+\n!\n")
+    # an earlier, larger job of this tool (11 ranks) leaves its parts and its list; a file of the user's that merely has such a name
+    p11 = subprocess.run([binary, "-o", str(tmp_path / "nine.fq"), "--ranks", "11"] + common, capture_output=True, timeout=300)
+    assert p11.returncode == 0 and len(list(tmp_path.glob("nine.fq.part*"))) == 12             # 11 parts + the list
+    assert (tmp_path / "nine.fq.parts").read_text().splitlines()[1:] == [str(tmp_path / ("nine.fq.part%d" % k)) for k in range(11)]
+    (tmp_path / "nine.fq.part12").write_bytes(b"@mine\nA\n+\n!\n")
     p9 = subprocess.run([binary, "-o", str(tmp_path / "nine.fq"), "--ranks", "9"] + common, capture_output=True, timeout=300)
     assert p1.returncode == 0 and p9.returncode == 0, p9.stderr.decode()[-2000:]
-    assert sorted(f.name for f in tmp_path.glob("nine.fq.part*")) == sorted(["nine.fq.part%d" % k for k in list(range(9)) + [12]])
+    # parts 9 and 10 -- named by the earlier job's list -- are gone; part12, which no list names, stays, with a warning
+    assert sorted(f.name for f in tmp_path.glob("nine.fq.part*")) == sorted(["nine.fq.part%d" % k for k in list(range(9)) + [12]] + ["nine.fq.parts"])
     assert p9.stderr.count(b"of an earlier job with more ranks, was removed") == 2
+    assert p9.stderr.count(b"nine.fq.part12 exists and is not a part of this job") == 1
+    assert (tmp_path / "nine.fq.parts").read_text().splitlines()[1:] == [str(tmp_path / ("nine.fq.part%d" % k)) for k in range(9)]
     parts = b"".join((tmp_path / ("nine.fq.part%d" % r)).read_bytes() for r in range(9))
     assert parts == (tmp_path / "one.fq").read_bytes() and len(parts) > 0
     info = lambda e: [l for l in e.decode().splitlines() if l.startswith("INFO:") and "written to" not in l]
@@ -215,6 +221,32 @@ def test_cli_shard_env_as_torchrun_sets_it(binary, golden_dir, tmp_path):
     parts = b"".join((tmp_path / ("o.fq.part%d" % r)).read_bytes() for r in range(2))
     assert parts == gzip.open(os.path.join(golden_dir, "hifi_auto.out.fq.gz"), "rb").read()
     assert b"INFO:" in errs[0] and b"INFO:" not in errs[1]           # rank 0 speaks for the job
+    # the default rendezvous is in a directory of this user's alone -- $XDG_RUNTIME_DIR when it is one, else
+    # /tmp/tgsfilter-<uid> (0700) --, never a predictable name straight in /tmp
+    assert not os.path.exists("/tmp/tgsfilter.%s.sock" % port)
+    xdg = os.environ.get("XDG_RUNTIME_DIR")
+    if not (xdg and os.path.isdir(xdg) and os.stat(xdg).st_uid == os.geteuid() and os.stat(xdg).st_mode & 0o77 == 0):
+        d = "/tmp/tgsfilter-%d" % os.geteuid()
+        assert os.path.isdir(d) and os.stat(d).st_mode & 0o777 == 0o700
+
+
+def test_cli_shard_a_live_rendezvous_socket_is_not_taken_away(binary, golden_dir, tmp_path):
+    """rank 0 removes a socket a killed job left behind -- but not one somebody is still listening on (another job)."""
+    import socket
+    fin = tmp_path / "in.fq"
+    fin.write_bytes(gzip.open(os.path.join(golden_dir, "ont_zoo.in.fq.gz"), "rb").read())
+    path = str(tmp_path / "rdv.sock")
+    live = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    live.bind(path)
+    live.listen(4)
+    args = [binary, "-i", str(fin), "-o", str(tmp_path / "o.fq"), "-x", "ont", "--shard", "0/2", "--rendezvous", path]
+    p = subprocess.run(args, capture_output=True, timeout=120)
+    assert p.returncode != 0 and b"another job is listening" in p.stderr and os.path.exists(path)
+    live.close()                                                      # now it is a stale one: it goes, and the job waits for its ranks
+    q = subprocess.Popen(args, stderr=subprocess.PIPE)
+    r1 = subprocess.run(args[:-4] + ["--shard", "1/2", "--rendezvous", path], capture_output=True, timeout=300)
+    err0 = q.communicate(timeout=300)[1]
+    assert q.returncode == 0 and r1.returncode == 0, (err0[-1000:], r1.stderr[-1000:])
 
 
 def test_cli_sharded_job_ends_when_a_rank_fails(binary, golden_dir, tmp_path):
@@ -269,6 +301,38 @@ def test_cli_gpu_a_communicator_that_does_not_come_up_does_not_hold_the_job(gold
     assert (tmp_path / "o.fq.part0").read_bytes() == gzip.open(os.path.join(golden_dir, "hifi_auto.out.fq.gz"), "rb").read()
     ref_info = [l for l in open(os.path.join(golden_dir, "hifi_auto.stderr.txt")).read().splitlines() if l.startswith("INFO:") and "written to" not in l]
     assert [l for l in p.stderr.decode().splitlines() if l.startswith("INFO:") and "written to" not in l] == ref_info
+
+
+@pytest.mark.gpu
+def test_cli_gpu_an_all_reduce_that_hangs_does_not_hold_the_job_and_rccl_is_checked(golden_dir, tmp_path):
+    """the tally all-reduce runs on a helper thread under a deadline of its own (here: a helper that sleeps, and
+    no patience): a warning, the sum over the ranks' sockets, the same output.  And when the collective does run, rank 0
+    compares its result with that sum and says so in the SHARD line."""
+    import time
+    if not os.path.exists(os.path.join(ROOT, "tgsfilter_amd", "libtgsf_rccl.so")):
+        pytest.skip("libtgsf_rccl.so not built (no librccl)")
+    fin = tmp_path / "in.fq"
+    fin.write_bytes(gzip.open(os.path.join(golden_dir, "hifi_auto.in.fq.gz"), "rb").read())
+    cmd = json.load(open(os.path.join(golden_dir, "hifi_auto.cmd.json")))
+    want = gzip.open(os.path.join(golden_dir, "hifi_auto.out.fq.gz"), "rb").read()
+    args = [GPU_BINARY, "-i", str(fin), "-o", str(tmp_path / "o.fq"), "-t", "1"] + cmd["flags"].split() + ["--ranks", "1"]
+    env = dict(os.environ, TGSF_DEBUG_KNOBS="1", TGSF_RCCL_ALLREDUCE_STALL_S="60", TGSF_RCCL_ALLREDUCE_TIMEOUT_S="0.5", TGSF_TIMING="1")
+    env.pop("TGSF_SHARD_EXCHANGE", None)
+    t0 = time.time()
+    p = subprocess.run(args, capture_output=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert time.time() - t0 < 45
+    assert b"the tally all-reduce had not returned" in p.stderr and b"summed on rank 0 over the ranks' sockets" in p.stderr
+    assert (tmp_path / "o.fq.part0").read_bytes() == want
+    # ... and with TGSF_SHARD_EXCHANGE=rccl the same hang is an error, not a fall-back
+    p = subprocess.run(args, capture_output=True, timeout=300, env=dict(env, TGSF_SHARD_EXCHANGE="rccl"))
+    assert p.returncode != 0 and b"the tally all-reduce had not returned" in p.stderr
+    # the collective as it runs: checked against the sockets' sum
+    env2 = dict(os.environ, TGSF_TIMING="1", TGSF_SHARD_EXCHANGE="rccl")
+    p = subprocess.run(args, capture_output=True, timeout=300, env=env2)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert b"RCCL all-reduce on the devices, equal to the sum over the ranks' sockets" in p.stderr
+    assert (tmp_path / "o.fq.part0").read_bytes() == want
 
 
 @pytest.mark.gpu

@@ -212,7 +212,7 @@ TGSF_HD uint32_t flat_stretch(uint32_t T, uint32_t pmax, uint32_t pmin, uint32_t
 enum DevStatus : uint32_t {
     DS_OK = 0,
     DS_BAD_LEN = 1,        // read length 0 or > max_read_len
-    DS_BAD_QUAL = 2,       // (no longer raised: a quality byte of 128 and above stands for its value - 256, as in the reference)
+    DS_RESERVED_2 = 2,     // (was DS_BAD_QUAL until round 5: a quality byte of 128 and above stands for its value - 256, as in the reference)
     DS_POOL_FULL = 3,      // candidate pool overflow
     DS_TOO_MANY_REGIONS = 4,
     DS_FRAG_CAP = 5,

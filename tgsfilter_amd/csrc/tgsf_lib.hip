@@ -1026,7 +1026,6 @@ static int check_status(tgsf_ctx* c)
     rt_sync(c->stream);
     switch (code) {
     case DS_BAD_LEN: return fail(c, TGSF_E_DATA, "read %u: length 0 or above max_read_len %u", detail, c->max_read_len);
-    case DS_BAD_QUAL: return fail(c, TGSF_E_DATA, "quality byte >= 128 in the batch (outside the supported domain)");
     case DS_TOO_MANY_REGIONS: return fail(c, TGSF_E_CAPACITY, "read %u has more than %d disjoint drop regions", detail, kMaxRegions);
     case DS_FRAG_CAP: return fail(c, TGSF_E_CAPACITY, "fragment capacity exceeded (%u)", detail);
     case DS_BAD_MEANQ: return fail(c, TGSF_E_DATA, "read %u: mean quality outside [0,256)", detail);

@@ -3,9 +3,11 @@
 // values are taken with atoi/atof, messages and exit codes are the reference's.
 #include "options.h"
 
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -104,6 +106,22 @@ int file_type(const std::string& path)
     return 3;
 }
 
+// where `--shard env` puts the job's rendezvous socket when --rendezvous does not say: never a predictable name in a directory
+// everybody can write to
+static std::string private_socket_dir()
+{
+    const char* x = getenv("XDG_RUNTIME_DIR");
+    struct stat st;
+    if (x && *x && stat(x, &st) == 0 && S_ISDIR(st.st_mode) && st.st_uid == geteuid() && (st.st_mode & 077) == 0) return x;
+    const std::string d = "/tmp/tgsfilter-" + std::to_string((unsigned)geteuid());
+    if (mkdir(d.c_str(), 0700) != 0 && errno != EEXIST) { std::cerr << "Error: --shard env: cannot create " << d << ": " << strerror(errno) << " (give --rendezvous)" << std::endl; exit(-1); }
+    if (lstat(d.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != geteuid() || (st.st_mode & 077) != 0) {
+        std::cerr << "Error: --shard env: " << d << " is not a directory of this user's alone (give --rendezvous)" << std::endl;
+        exit(-1);
+    }
+    return d;
+}
+
 // the flags that take a value (the keys of parse_args's table: checked there)
 static const char* const kWithValue[] = {"i", "o", "x", "l", "L", "q", "Q", "n", "e", "b", "5", "3", "a", "N", "E", "m", "M", "T", "s", "S", "g", "d",
                                          "r", "R", "k", "p", "c", "t", "device", "ranks", "rendezvous", "shard", "devices"};
@@ -177,7 +195,8 @@ int parse_args(int argc, char** argv, Options& o)
                  if (l) o.device = atoi(l);
                  // (a launcher that hands out RANK / WORLD_SIZE also names the job by its rendezvous port: the ranks of one node
                  // meet at a socket named after it unless --rendezvous says where)
-                 if (o.rendezvous.empty()) { const char* port = getenv("MASTER_PORT"); if (port && *port) o.rendezvous = std::string("/tmp/tgsfilter.") + port + ".sock"; }
+                 // -- in the user's own runtime directory ($XDG_RUNTIME_DIR), else in a directory only this user can enter
+                 if (o.rendezvous.empty()) { const char* port = getenv("MASTER_PORT"); if (port && *port) o.rendezvous = private_socket_dir() + "/tgsfilter." + port + ".sock"; }
              } else {
                  const char* slash = strchr(v, '/');
                  if (!slash) { std::cerr << "Error: --shard takes <rank>/<ranks>" << std::endl; return 1; }

@@ -90,6 +90,7 @@ struct Run {
     std::shared_ptr<RcclUp> rccl_state = std::make_shared<RcclUp>();
     std::thread rccl_up;
     bool use_rccl = false;
+    bool ranks_own_gpus = false;        // a sharded job whose ranks sit on distinct devices (from the gather of their bus ids)
     tgsf_params p;
     std::vector<int> ctx_dev;
     std::vector<tgsf_ctx*> ctxs;

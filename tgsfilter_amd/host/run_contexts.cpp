@@ -148,31 +148,36 @@ void Run::make_contexts()
         mine.str(bus);
         mine.pod<int>(R ? 1 : 0);
         const std::vector<std::string> all = link.gather(mine.s);
-        std::string verdict(1, '0');
+        // verdict: [0] a GPU per rank (what the NUMA binding of the feeders goes by), [1] the RCCL exchange is on (+ the communicator's id)
+        std::string verdict(2, '0');
         if (link.rank == 0) {
             std::vector<std::string> seen;
-            bool ok = R != nullptr;
+            bool ok = R != nullptr, own = true;
             for (const std::string& a : all) {
                 BlobIn in2(a);
                 std::string b2; int have = 0;
                 in2.str(b2); in2.pod(have);
-                ok = ok && have && std::find(seen.begin(), seen.end(), b2) == seen.end();
+                own = own && std::find(seen.begin(), seen.end(), b2) == seen.end();
+                ok = ok && have;
                 seen.push_back(b2);
             }
+            ok = ok && own;
+            verdict[0] = own ? '1' : '0';
             if (ok) {
                 char id[TGSF_RCCL_ID_BYTES];
-                if (R->unique_id(id) == TGSF_OK) { verdict.assign(1, '1'); verdict.append(id, sizeof id); }
+                if (R->unique_id(id) == TGSF_OK) { verdict[1] = '1'; verdict.append(id, sizeof id); }
                 else if (ex && !strcmp(ex, "rccl")) die(std::string("TGSF_SHARD_EXCHANGE=rccl: ") + R->last_error());
             } else if (ex && !strcmp(ex, "rccl")) die("TGSF_SHARD_EXCHANGE=rccl: ranks share a GPU, or libtgsf_rccl.so does not load on every rank");
         }
         link.bcast(verdict);
-        use_rccl = verdict[0] == '1' && verdict.size() == 1 + TGSF_RCCL_ID_BYTES;
+        ranks_own_gpus = verdict.size() >= 2 && verdict[0] == '1';
+        use_rccl = verdict.size() == 2 + TGSF_RCCL_ID_BYTES && verdict[1] == '1';
         if (use_rccl)
             // (the helper owns its state: should the communicator never come up, the run goes on without it -- below -- and the
             // helper is left behind where it waits)
             rccl_up = std::thread([R = R, up = rccl_state, verdict, device = o.device, rank = link.rank, world = link.world] {
                 if (const char* e = knob("TGSF_RCCL_STALL_S")) usleep((useconds_t)(atof(e) * 1e6));       // test knob: a communicator that is late
-                up->rc = R->comm_init(device, verdict.data() + 1, rank, world, &up->comm);
+                up->rc = R->comm_init(device, verdict.data() + 2, rank, world, &up->comm);
                 if (up->rc != TGSF_OK) up->err = R->last_error();       // (thread-local text: taken on this thread)
                 up->done.store(1, std::memory_order_release);
             });

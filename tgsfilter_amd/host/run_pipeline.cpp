@@ -185,7 +185,7 @@ void Run::filter_pass()
     // on the CPUs of the GPU's own NUMA node, so that no feeder pushes its copies across the socket link.  With one GPU
     // binding was measured within noise and is left off; TGSF_NUMA=1 / 0 forces it on / off.
     // (a job of rank processes on GPUs of their own is the same case, one device per process)
-    numa_bind = o.devices.size() > 1 || (link.world > 1 && shard_may_use_rccl);
+    numa_bind = o.devices.size() > 1 || (link.world > 1 && ranks_own_gpus);     // (decided from the ranks' bus ids, make_contexts: ranks that share a GPU are not bound)
     if (const char* e = getenv("TGSF_NUMA")) numa_bind = atoi(e) > 0;
     dev_node.assign(ctx_dev.size(), -1);
     dev_submit_s.assign(ctx_dev.size(), 0.0);

@@ -34,6 +34,32 @@ void add_rows(std::vector<uint64_t>& v, const std::vector<uint64_t>& ru, int32_t
     for (int q = 0; q < 4; q++) v[TGSF_CTR_ROWS + q] = rows[q];
 }
 
+// this context's tallies added into v (sums; the four "rows used" words are maxima); of the bin tables only the rows in use travel
+static void add_context(const Api& L, tgsf_ctx* c, std::vector<uint64_t>& v, std::vector<uint64_t>& part, int32_t bc, uint32_t nbins)
+{
+    uint64_t used[2] = {0, 0};
+    if (L.counters_used(c, part.data(), part.size(), used) != TGSF_OK) die(L.last_error(c));
+    uint64_t rows[4];
+    for (int k = 0; k < 4; k++) rows[k] = std::max(v[TGSF_CTR_ROWS + k], part[TGSF_CTR_ROWS + k]);
+    const size_t head = tgsf_ctr_bin_table(0, bc, nbins);
+    for (size_t i = 0; i < head; i++) v[i] += part[i];
+    for (int b = 0; b < 4; b++) {
+        const size_t at = tgsf_ctr_bin_table(b, bc, nbins), n = (size_t)used[b >> 1] * 5;
+        for (size_t i = 0; i < n; i++) v[at + i] += part[at + i];
+    }
+    for (int k = 0; k < 4; k++) v[TGSF_CTR_ROWS + k] = rows[k];
+}
+
+// One process per GPU: the job's tallies = the sum over the ranks (src/TGSFilter.cpp:3208-3213 across GPUs).
+//   * Every rank sums its contexts on the host and sends rank 0 the rows in use over the ranks' sockets: rank 0's sum of those is
+//     what the job reports when nothing else is available (ranks sharing a GPU, no RCCL on the box, TGSF_SHARD_EXCHANGE=socket).
+//   * With a GPU per rank the contexts are also folded into one vector in HBM and the job makes ONE all-reduce of it over
+//     RCCL / xGMI (include/tgsf_rccl.h; every rank entered tgsf_create with the same table rows).  The collective runs on a
+//     helper thread under a deadline -- a fabric that does not answer must not hold a finished job -- and rank 0 compares its
+//     result, row for row, with the sum that came over the sockets (a few hundred KB: it costs nothing to have both).  They are
+//     the same numbers by construction; until the collective path has run on real multi-GPU hardware often enough, a
+//     difference (a layout slip, a rank that entered with other rows) is reported and the sockets' sum is what the job uses
+//     (ADVICE r5).  TGSF_SHARD_EXCHANGE=rccl turns every such fall-back into an error (the tests' way of seeing that RCCL ran).
 void Run::sum_tallies()
 {
     const Api& L = *api;
@@ -44,15 +70,16 @@ void Run::sum_tallies()
     L.counters_len(ctx, &nw, &bc, &nbins);
     t.assign(nw, 0);
     std::vector<uint64_t> part(nw);
-    // One process per GPU: the job's tallies = the sum over the ranks (src/TGSFilter.cpp:3208-3213 across GPUs).  With a
-    // GPU per rank: this rank's contexts folded into one vector in HBM, then ONE all-reduce of it over RCCL / xGMI
-    // (include/tgsf_rccl.h; every rank has entered tgsf_create with the same table rows, see max_read_len above).
     t_x0 = now_s();
-    std::vector<tgsf_ctx*> sum_ctxs = ctxs;
-    if (sharded && use_rccl) {
+    const char* ex = getenv("TGSF_SHARD_EXCHANGE");
+    const bool must_rccl = ex && !strcmp(ex, "rccl");
+    for (tgsf_ctx* c : ctxs) add_context(L, c, t, part, bc, nbins);    // this rank's (or this process's) own sums, before anything is merged on the device
+    if (!sharded) return;
+
+    if (use_rccl) {
         // The communicator has had the whole run to come up.  One that is still not there some time after the filtering is
         // over (a peer that cannot be reached, a fabric that does not answer) must not hold the job for ever: this rank says
-        // so below, every rank then sums over the sockets, and the helper is left where it waits (the process leaves with _exit).
+        // so below, every rank then goes on without it, and the helper is left where it waits (the process leaves with _exit).
         double rccl_patience = 120.0;
         if (const char* e = knob("TGSF_RCCL_INIT_TIMEOUT_S")) rccl_patience = atof(e);          // test knob
         while (!rccl_state->done.load(std::memory_order_acquire) && now_s() - t_x0 < rccl_patience) usleep(2000);
@@ -65,70 +92,92 @@ void Run::sum_tallies()
             rccl_err = "the communicator was not up " + std::to_string((int)rccl_patience) + " s after the filtering ended";
         }
         t_rccl_wait = now_s() - t_x0;
-        // the communicator came up on every rank, or nobody uses it: the sockets carry the rows in use instead (the run's
-        // results do not depend on which way the tallies travel)
+        // the communicator came up on every rank, or nobody uses it
         if (link.max_u64(rccl_rc != TGSF_OK ? 1 : 0) != 0) {
-            const char* ex = getenv("TGSF_SHARD_EXCHANGE");
-            if (ex && !strcmp(ex, "rccl")) die("RCCL communicator: " + (rccl_err.empty() ? std::string("it failed on another rank") : rccl_err));
+            if (must_rccl) die("RCCL communicator: " + (rccl_err.empty() ? std::string("it failed on another rank") : rccl_err));
             if (rccl_rc != TGSF_OK) std::cerr << "Warning: rank " << link.rank << ": RCCL communicator: " << rccl_err << " -- the tallies are summed over the ranks' sockets" << std::endl;
             // (a communicator that did come up here is left as it is: taking it down may wait for peers that are stuck)
             rccl_comm = nullptr;
             use_rccl = false;
         }
     }
-    if (sharded && use_rccl) {
+    std::vector<uint64_t> reduced;                                     // the all-reduced vector as this rank's device holds it
+    if (use_rccl) {
         for (size_t k = 1; k < ctxs.size(); k++)
             if (L.counters_merge(ctxs[0], ctxs[k]) != TGSF_OK) die(L.last_error(ctxs[0]));
+        // the collective on a helper thread, under a deadline of its own (a peer that died between the communicator's
+        // start and here, a link that hangs): the helper owns what it touches, and is left behind if it does not come back
+        struct Reduce { std::atomic<int> done{0}; int rc = TGSF_OK; std::string err; double s = 0; };
+        const std::shared_ptr<Reduce> rd = std::make_shared<Reduce>();
+        double patience = 60.0;
+        if (const char* e = knob("TGSF_RCCL_ALLREDUCE_TIMEOUT_S")) patience = atof(e);              // test knob
         const double a0 = now_s();
-        if (R->allreduce_counters(ctxs[0], rccl_comm, link.rank, link.world, 0, nullptr) != TGSF_OK) die(std::string("tally all-reduce: ") + R->last_error());
-        t_allreduce = now_s() - a0;
-        (void)R->comm_count(rccl_comm, &rccl_ranks);
-        sum_ctxs.assign(1, ctxs[0]);                                   // (it holds the whole job's totals now, on every rank)
-    }
-    for (tgsf_ctx* c : sum_ctxs) {                                     // sums; the four "rows used" words are maxima
-        uint64_t used[2] = {0, 0};                                     // of the bin tables only the rows in use travel
-        if (L.counters_used(c, part.data(), nw, used) != TGSF_OK) die(L.last_error(c));
-        uint64_t rows[4];
-        for (int k = 0; k < 4; k++) rows[k] = std::max(t[TGSF_CTR_ROWS + k], part[TGSF_CTR_ROWS + k]);
-        const size_t head = tgsf_ctr_bin_table(0, bc, nbins);
-        for (size_t i = 0; i < head; i++) t[i] += part[i];
-        for (int b = 0; b < 4; b++) {
-            const size_t at = tgsf_ctr_bin_table(b, bc, nbins), n = (size_t)used[b >> 1] * 5;
-            for (size_t i = 0; i < n; i++) t[at + i] += part[at + i];
+        std::thread helper([R = R, rd, c0 = ctxs[0], rccl_comm, rank = link.rank, world = link.world, a0] {
+            if (const char* e = knob("TGSF_RCCL_ALLREDUCE_STALL_S")) usleep((useconds_t)(atof(e) * 1e6));   // test knob: a collective that hangs
+            rd->rc = R->allreduce_counters(c0, rccl_comm, rank, world, 0, nullptr);
+            if (rd->rc != TGSF_OK) rd->err = R->last_error();          // (thread-local text: taken on this thread)
+            rd->s = now_s() - a0;
+            rd->done.store(1, std::memory_order_release);
+        });
+        while (!rd->done.load(std::memory_order_acquire) && now_s() - a0 < patience) usleep(500);
+        int bad = 0;
+        if (rd->done.load(std::memory_order_acquire)) {
+            helper.join();
+            t_allreduce = rd->s;
+            if (rd->rc != TGSF_OK) { bad = 1; rccl_err = "tally all-reduce: " + rd->err; }
+        } else {
+            helper.detach();
+            bad = 1;
+            rccl_err = "the tally all-reduce had not returned after " + std::to_string((int)patience) + " s";
         }
-        for (int k = 0; k < 4; k++) t[TGSF_CTR_ROWS + k] = rows[k];
-    }
-    // Rank 0 of a sharded job receives every rank's read lengths (the statistics need them sorted: N50 and the like) and
-    // -- when the tallies were not summed on the devices -- its tally rows in use; it alone prints the run's statistics
-    // and writes the report.
-    if (sharded) {
-        BlobOut mine;
-        mine.pod(raw_bases); mine.pod(clean_bases);
-        mine.vec(raw_lens); mine.vec(clean_lens);                      // (each sorted already, beside the pipeline)
-        std::vector<uint64_t> rows_used;
-        if (!use_rccl) rows_used = pack_rows(t, bc, nbins);
-        mine.vec(rows_used);
-        const std::vector<std::string> all = link.gather(mine.s);
-        for (int k = 1; k < (int)all.size(); k++) {                    // (rank 0 only)
-            BlobIn in2(all[(size_t)k]);
-            uint64_t rb = 0, cb = 0;
-            std::vector<int> rl, cl;
-            std::vector<uint64_t> ru;
-            in2.pod(rb); in2.pod(cb); in2.vec(rl); in2.vec(cl); in2.vec(ru);
-            raw_bases += rb; clean_bases += cb;
-            const size_t r0 = raw_lens.size(), c0 = clean_lens.size();
-            raw_lens.insert(raw_lens.end(), rl.begin(), rl.end());
-            clean_lens.insert(clean_lens.end(), cl.begin(), cl.end());
-            std::inplace_merge(raw_lens.begin(), raw_lens.begin() + (long)r0, raw_lens.end());
-            if (!o.downsample) std::inplace_merge(clean_lens.begin(), clean_lens.begin() + (long)c0, clean_lens.end());   // (a downsampling run reports the selected reads' lengths instead)
-            if (!use_rccl) add_rows(t, ru, bc, nbins);
+        if (link.max_u64((uint64_t)bad) != 0) {
+            if (must_rccl) die(rccl_err.empty() ? std::string("tally all-reduce: it failed on another rank") : rccl_err);
+            if (bad) std::cerr << "Warning: rank " << link.rank << ": " << rccl_err << " -- the tallies summed over the ranks' sockets are used" << std::endl;
+            use_rccl = false;                                          // (the communicator is left as it is)
+        } else {
+            (void)R->comm_count(rccl_comm, &rccl_ranks);
+            reduced.assign(nw, 0);
+            add_context(L, ctxs[0], reduced, part, bc, nbins);        // (it holds the whole job's totals now, on every rank)
         }
-        if (timing)
-            fprintf(stderr, "SHARD %d/%d: bytes [%zu, %zu) of the text on device %d -> %s | tallies: %s (communicator ready after %.3f s of waiting, all-reduce %.4f s, %d ranks in it), exchange + gather %.3f s\n",
-                    link.rank, link.world, text_off, text_off + text_size, o.device, out_path.c_str(),
-                    use_rccl ? "RCCL all-reduce on the devices" : "summed on rank 0 over the ranks' sockets", t_rccl_wait, t_allreduce, rccl_ranks, now_s() - t_x0);
-        if (use_rccl) R->comm_destroy(rccl_comm);
     }
+    // Rank 0 receives every rank's read lengths (the statistics need them sorted: N50 and the like) and its tally rows in
+    // use; it alone prints the run's statistics and writes the report.
+    BlobOut mine;
+    mine.pod(raw_bases); mine.pod(clean_bases);
+    mine.vec(raw_lens); mine.vec(clean_lens);                          // (each sorted already, beside the pipeline)
+    mine.vec(pack_rows(t, bc, nbins));
+    const std::vector<std::string> all = link.gather(mine.s);
+    for (int k = 1; k < (int)all.size(); k++) {                        // (rank 0 only)
+        BlobIn in2(all[(size_t)k]);
+        uint64_t rb = 0, cb = 0;
+        std::vector<int> rl, cl;
+        std::vector<uint64_t> ru;
+        in2.pod(rb); in2.pod(cb); in2.vec(rl); in2.vec(cl); in2.vec(ru);
+        raw_bases += rb; clean_bases += cb;
+        const size_t r0 = raw_lens.size(), c0 = clean_lens.size();
+        raw_lens.insert(raw_lens.end(), rl.begin(), rl.end());
+        clean_lens.insert(clean_lens.end(), cl.begin(), cl.end());
+        std::inplace_merge(raw_lens.begin(), raw_lens.begin() + (long)r0, raw_lens.end());
+        if (!o.downsample) std::inplace_merge(clean_lens.begin(), clean_lens.begin() + (long)c0, clean_lens.end());   // (a downsampling run reports the selected reads' lengths instead)
+        add_rows(t, ru, bc, nbins);
+    }
+    tally_route = "summed on rank 0 over the ranks' sockets";
+    if (use_rccl) {
+        // the same numbers twice: the devices' all-reduce and (rank 0) the sum that came over the sockets
+        tally_route = "RCCL all-reduce on the devices";
+        if (link.rank == 0) {
+            if (pack_rows(reduced, bc, nbins) == pack_rows(t, bc, nbins)) { t.swap(reduced); tally_route += ", equal to the sum over the ranks' sockets"; }
+            else {
+                if (must_rccl) die("the all-reduced tally vector differs from the sum of the ranks' vectors over their sockets");
+                std::cerr << "Warning: the all-reduced tally vector differs from the sum of the ranks' vectors over their sockets -- the sockets' sum is used" << std::endl;
+                tally_route += " (DIFFERENT from the sum over the ranks' sockets, which is used)";
+            }
+        }
+    }
+    if (timing)
+        fprintf(stderr, "SHARD %d/%d: bytes [%zu, %zu) of the text on device %d -> %s | tallies: %s (communicator ready after %.3f s of waiting, all-reduce %.4f s, %d ranks in it), exchange + gather %.3f s\n",
+                link.rank, link.world, text_off, text_off + text_size, o.device, out_path.c_str(), tally_route.c_str(), t_rccl_wait, t_allreduce, rccl_ranks, now_s() - t_x0);
+    if (use_rccl) R->comm_destroy(rccl_comm);
 }
 
 void Run::report()
@@ -182,14 +231,40 @@ void Run::report()
             }
         }
     }
-    // (parts of an earlier job with MORE ranks beside this job's would end up in a `cat <out>.part*`: they go, with a word)
-    if (reports() && sharded && !o.out_file.empty() && !o.only_qc && !o.only_adapters)
-        for (int k = link.world;; k++) {
-            const std::string stale = o.out_file + ".part" + std::to_string(k);
-            struct stat st;
-            if (lstat(stale.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) break;
-            if (unlink(stale.c_str()) == 0) std::cerr << "Warning: " << stale << ", a part of an earlier job with more ranks, was removed." << std::endl;
+    // The parts of a job are listed in <out>.parts (written by rank 0 when everything is there).  Parts of an EARLIER job with
+    // more ranks would end up in a `cat <out>.part*` beside this job's: the ones that job's own list names go, with a word; a
+    // file that merely has such a name and that no list of this tool names is the user's -- it stays, with a warning.
+    if (reports() && sharded && !o.out_file.empty() && !o.only_qc && !o.only_adapters) {
+        const std::string list = o.out_file + ".parts";
+        std::vector<std::string> earlier;
+        {
+            std::ifstream f(list);
+            std::string line;
+            if (f && std::getline(f, line) && line == "# tgsfilter parts, in order")
+                while (std::getline(f, line)) if (!line.empty()) earlier.push_back(line);
         }
+        std::vector<std::string> mine;
+        for (int k = 0; k < link.world; k++) mine.push_back(o.out_file + ".part" + std::to_string(k));
+        for (const std::string& e : earlier) {
+            if (std::find(mine.begin(), mine.end(), e) != mine.end()) continue;
+            // (only names of this output's own numbered parts: a list is text anyone can edit)
+            const std::string stem = o.out_file + ".part";
+            if (e.compare(0, stem.size(), stem) != 0 || e.size() == stem.size() || e.find_first_not_of("0123456789", stem.size()) != std::string::npos) continue;
+            struct stat st;
+            if (lstat(e.c_str(), &st) == 0 && S_ISREG(st.st_mode) && unlink(e.c_str()) == 0)
+                std::cerr << "Warning: " << e << ", a part of an earlier job with more ranks, was removed." << std::endl;
+        }
+        for (int k = link.world; k < link.world + 1024; k++) {
+            const std::string other = o.out_file + ".part" + std::to_string(k);
+            struct stat st;
+            if (lstat(other.c_str(), &st) != 0) { if (k >= link.world + 64) break; else continue; }
+            std::cerr << "Warning: " << other << " exists and is not a part of this job (nor of an earlier one this tool listed): `cat " << o.out_file
+                      << ".part*` would take it in -- the parts of this job are listed in " << list << "." << std::endl;
+        }
+        std::ofstream f(list, std::ios::trunc);
+        f << "# tgsfilter parts, in order\n";
+        for (const std::string& m : mine) f << m << "\n";
+    }
     if (o.downsample && reports()) {                                     // :3240-3279
         if (down_lens.empty()) die("no reads to downsample");
         std::sort(down_lens.begin(), down_lens.end());

@@ -61,7 +61,13 @@ public:
             struct stat st;
             if (lstat(path.c_str(), &st) == 0) {        // a socket a job that was killed left behind goes; anything else is the user's
                 if (!S_ISSOCK(st.st_mode)) die("--rendezvous: " + path + " exists and is not a socket");
-                unlink(path.c_str());
+                if (st.st_uid != geteuid()) die("--rendezvous: the socket at " + path + " belongs to another user");
+                // ... and one that somebody still listens on is a LIVE job's: it stays
+                const int probe = socket(AF_UNIX, SOCK_STREAM, 0);
+                const bool live = probe >= 0 && connect(probe, (sockaddr*)&sa, sizeof sa) == 0;
+                if (probe >= 0) ::close(probe);
+                if (live) die("--rendezvous: another job is listening at " + path + " (give this one its own --rendezvous path)");
+                if (unlink(path.c_str()) != 0) die("--rendezvous: cannot remove the stale socket at " + path + ": " + strerror(errno));
             }
             const int ls = socket(AF_UNIX, SOCK_STREAM, 0);
             if (ls < 0 || bind(ls, (sockaddr*)&sa, sizeof sa) != 0 || listen(ls, w) != 0)
@@ -73,7 +79,7 @@ public:
                 const int c = accept(ls, nullptr, nullptr);
                 int32_t who = -1;
                 pollfd pc{c, POLLIN, 0};                // (a peer that connects and says nothing does not hold the job for ever)
-                if (c < 0 || poll(&pc, 1, (int)(timeout_s * 1000)) <= 0 || !io(c, &who, sizeof who, false) || who < 1 || who >= w || fds_[(size_t)who] >= 0) { unlink(path.c_str()); die("--rendezvous: bad greeting at " + path); }
+                if (c < 0 || !same_user(c) || poll(&pc, 1, (int)(timeout_s * 1000)) <= 0 || !io(c, &who, sizeof who, false) || who < 1 || who >= w || fds_[(size_t)who] >= 0) { unlink(path.c_str()); die("--rendezvous: bad greeting at " + path + " (a peer of another user, or not a rank of this job)"); }
                 fds_[(size_t)who] = c;
             }
             ::close(ls);
@@ -88,6 +94,8 @@ public:
                 usleep(50000);
             }
             const int32_t who = r;
+            // (the constants of the run -- trims, adapters, the quality threshold -- come from whoever listens there: the same user only)
+            if (!same_user(c)) die("--rendezvous: the process listening at " + path + " belongs to another user");
             if (!io(c, &who, sizeof who, true)) die("--rendezvous: cannot greet rank 0");
             fds_.assign(1, c);
         }
@@ -126,6 +134,12 @@ public:
     void barrier() { (void)max_u64(0); }
     void close_all() { for (int& f : fds_) if (f >= 0) { ::close(f); f = -1; } }
 private:
+    // the peer of a connected unix socket runs as this process's user (SO_PEERCRED)
+    static bool same_user(int fd) {
+        struct ucred cr;
+        socklen_t len = sizeof cr;
+        return getsockopt(fd, SOL_SOCKET, SO_PEERCRED, &cr, &len) == 0 && len == sizeof cr && cr.uid == geteuid();
+    }
     static bool io(int fd, const void* p, size_t n, bool wr) {
         char* c = (char*)const_cast<void*>(p);
         while (n) {
@@ -143,9 +157,12 @@ private:
     void recv_blob(int fd, std::string& b, int peer) {
         uint64_t n = 0;
         if (!io(fd, &n, sizeof n, false)) lost(peer);
+        // (what the ranks exchange is small: constants, 4 bytes per read of lengths, names of kept fragments, tally rows)
+        if (n > kMaxBlob) die("rank " + std::to_string(rank) + ": a message of " + std::to_string(n) + " bytes from rank " + std::to_string(peer) + ": not one of this job's");
         b.resize((size_t)n);
         if (n && !io(fd, &b[0], (size_t)n, false)) lost(peer);
     }
+    static constexpr uint64_t kMaxBlob = 16ull << 30;
     [[noreturn]] void lost(int peer) { die("rank " + std::to_string(rank) + ": rank " + std::to_string(peer) + " of the job is gone (it ended with an error, or was killed)"); }
     std::vector<int> fds_;
 };
