@@ -111,6 +111,20 @@ def by_product_run(lib_path, kind, head, tail, *, monkeypatch, mode="byproduct",
         ctx.close()
 
 
+def by_product_high_quality_bytes(lib_path, head, tail, monkeypatch, large=False):
+    """The split-bin by-product (round 6) with quality bytes of 128 and above in head pieces, tail pieces and behind the
+    speculated fragment: 256 per such byte comes back out of the raw row AND of the clean row its piece belongs to."""
+    monkeypatch.setenv("TGSF_CLEAN_TABLES", "byproduct")
+    reads = high_quality_byte_reads(seed=62 + head, n=600 if large else 40, kind="ont")
+    for align in (16, 1):
+        p = sized(abi.make_params("ont", adapters=[synth.ONT_RAPID, synth.ONT_RAPID_RC], min_q=7.0, head_trim=head, tail_trim=tail), reads)
+        ctx = capi.Context(p, 0, lib_path)
+        try:
+            compare_batch(ctx, p, reads, align=align)
+        finally:
+            ctx.close()
+
+
 def golden_case(lib_path, golden_dir, name):
     case = hostmodel.GoldenCase(golden_dir, name)
     p = sized(case.params(), case.reads)

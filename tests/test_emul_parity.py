@@ -409,6 +409,11 @@ def test_emul_clean_tables_as_a_by_product_of_the_raw_pass(emul, kind, head, tai
     parity.by_product_run(emul, kind, head, tail, monkeypatch=monkeypatch, mode=mode)
 
 
+@pytest.mark.parametrize("head,tail", [(79, 0), (250, 31), (100, 3), (3, 120)])
+def test_emul_by_product_with_quality_bytes_of_128_and_above(emul, head, tail, monkeypatch):
+    parity.by_product_high_quality_bytes(emul, head, tail, monkeypatch)
+
+
 @pytest.mark.parametrize("kind,head,tail", [("ont", 79, 0), ("hifi", 7, 8)])
 def test_emul_by_product_when_most_reads_are_kept_as_expected(emul, kind, head, tail, monkeypatch):
     """Few adapters: nearly every read is kept as [head_trim, L - tail_trim) and nothing of it is scanned a second time."""

@@ -31,8 +31,6 @@ constexpr int kWideNW = kMaxQ / 64;   // words per symbol in the wide tables (bu
 constexpr int kBin = 100;          // CalcAvgQuality bin width
 constexpr int kTileBins = 64;      // one bin per lane
 constexpr int kTileBases = kBin * kTileBins;   // 6400 bases per stats tile
-constexpr int kBpExtra = 112;                  // bytes of the read beyond a tile that the raw pass of a speculating batch stages with it: the clean
-                                               // bins are the raw ones shifted by head_trim mod 100 (< 100 bytes, rounded up to whole 16-byte chunks)
 constexpr int kSegCols = 1024;     // columns of the read middle owned by one lane of the infix scan
 constexpr int kMidThreads = 256;   // lanes of a workgroup of the middle scans (k_mid_flat, k_mid_scan1): their launch bound
 constexpr int kMaxRegions = 64;    // disjoint drop regions per read the region kernel can hold

@@ -96,11 +96,16 @@ struct DevBatch {
 
     // stats work lists (raw: items are reads; clean: items are fragments [0,fcap) and, in the
     // "difference" strategy, whole reads to take back out, numbered fcap + read)
-    uint32_t* tile_hist;       // [max_tiles+2]
-    uint32_t* tile_cnt;        // [max_tiles+2]  cnt[t] = #items with more than t tiles
-    uint32_t* tile_base;       // [max_tiles+2]  exclusive prefix of cnt
-    uint32_t* tile_fill;       // [max_tiles+2]
-    uint32_t* perm;            // items sorted by tile count, descending
+    // Two SEGMENTS (round 6): the raw pass of a context that may speculate (bp_allowed) lists the items the batch
+    // speculates on first (segment 0) and the others behind them (segment 1), each sorted by tile count and laid out tile
+    // index major, so that a wave of k_stats changes between the two kinds of item at most once.  Every other pass has
+    // segment 0 only.  Segment s's buckets sit at [s * (max_tiles + 2), ...).
+    uint32_t* tile_hist;       // [2][max_tiles+2]
+    uint32_t* tile_cnt;        // [2][max_tiles+2]  cnt[t] = #items (of the segment) with more than t tiles
+    uint32_t* tile_base;       // [2][max_tiles+2]  exclusive prefix of cnt
+    uint32_t* tile_fill;       // [2][max_tiles+2]
+    uint32_t* seg_info;        // [4] written by k_tile_scan: [0] first slot of segment 1 in perm, [1] work items of segment 0, [2] work items of both
+    uint32_t* perm;            // items sorted by (segment,) tile count, descending
     uint4*    work;            // [2*work_cap] stats work items: {seq addr lo, hi, bases | tile<<13, item}, {qual addr lo, hi, 0, 0}
     uint32_t  work_cap;
     uint32_t  max_tiles;

@@ -79,9 +79,12 @@ TGSF_D void held_range(const DevParams& P, const DevBatch& B, uint32_t r, uint32
 }
 // Items of a stats pass.  RAW: read i.  CLEAN: fragment i (< fcap), or read i - fcap to be taken back out.
 // Length 0 = not part of the pass.
+// (RAW, a read the batch speculates on: the raw pass goes as far as the speculated fragment does, [0, L - tail_trim) -- so
+// that a lane's tallies of such a read are all of the fragment or in front of it --, the tail_trim bytes behind it are
+// tallied by k_tail_fix)
 template <bool CLEAN>
 TGSF_D uint32_t stats_item_len(const DevParams& P, const DevBatch& B, uint32_t item, bool diff) {
-    if (!CLEAN) return B.len[item];
+    if (!CLEAN) return B.len[item] - ((B.bp_allowed && B.spec[item]) ? (uint32_t)P.tail_trim : 0u);
     if (item >= B.fcap) {
         if (!diff || B.whole[item - B.fcap]) return 0u;
         uint32_t s, e;
@@ -91,6 +94,15 @@ TGSF_D uint32_t stats_item_len(const DevParams& P, const DevBatch& B, uint32_t i
     if (B.frag_flags[item] & TGSF_FF_REPEAT) return 0u;          // dropped before CalcAvgQuality (:1982-1989)
     if (diff && B.whole[B.frag_read[item]]) return 0u;
     return B.frag_len[item];
+}
+// Segments of a pass's work list (DevBatch::tile_hist).  The raw pass of a context that may speculate: the reads the batch
+// speculates on, then the others.  The clean pass: the fragments, then the reads to be taken back out -- k_stats flushes
+// its tallies whenever the sign of the items changes, and with the two kinds mixed as the counting sort leaves them that
+// happened at every other item (measured, round 6: 7.8 M atomics in a pass of 48 000 work items, 0.80 ms; in two segments
+// a wave changes sign once at most).
+template <bool CLEAN> TGSF_D uint32_t stats_segments(const DevBatch& B) { return (CLEAN || B.bp_allowed) ? 2u : 1u; }
+template <bool CLEAN> TGSF_D uint32_t stats_segment_of(const DevBatch& B, uint32_t item) {
+    return CLEAN ? (item >= B.fcap ? 1u : 0u) : ((B.bp_allowed && !B.spec[item]) ? 1u : 0u);
 }
 // i-th candidate of the clean pass -> item number
 TGSF_D uint32_t clean_item(const DevBatch& B, uint32_t i, uint32_t nf) { return i < nf ? i : B.fcap + (i - nf); }
@@ -121,7 +133,8 @@ TGSF_KERNEL k_prepare(DevParams P, DevBatch B, uint32_t max_read_len)
 {
     TGSF_SHARED uint32_t h[kHistLds];
     const int A = P.n_adapters;
-    const uint32_t nbuck = B.max_tiles + 2;
+    const uint32_t seg_stride = B.max_tiles + 2;
+    const uint32_t nbuck = seg_stride * stats_segments<false>(B);
     const bool use_lds = nbuck <= kHistLds;
     if (use_lds) for (uint32_t i = TGSF_COOP_BEGIN; i < nbuck; i += TGSF_COOP_STRIDE) h[i] = 0;
     TGSF_BLOCK_SYNC();
@@ -147,8 +160,6 @@ TGSF_KERNEL k_prepare(DevParams P, DevBatch B, uint32_t max_read_len)
         B.nfr[r] = 0;
         for (int a = 0; a < A; a++) { B.clip5[(size_t)r * A + a] = 0; B.clip3[(size_t)r * A + a] = -1; B.mid_best[(size_t)r * A + a] = 0x7FFFFFFF; }
         if (L == 0 || L > max_read_len) { set_status(B, DS_BAD_LEN, r); B.len[r] = 0; continue; }
-        const uint32_t v = (L + kTileBases - 1) / kTileBases;
-        if (use_lds) atomicAdd(&h[v], 1u); else atomicAdd(&B.tile_hist[v], 1u);
         uint32_t rw = L / kBin + 1;                                     // src/TGSFilter.cpp:1445
         rows = rw > rows ? rw : rows;
         uint32_t er = (uint32_t)P.bc_len < L ? (uint32_t)P.bc_len : L;  // :1490-1493
@@ -172,6 +183,10 @@ TGSF_KERNEL k_prepare(DevParams P, DevBatch B, uint32_t max_read_len)
             }
             B.spec[r] = sp ? 1u : 0u;
         }
+        // (the read's place in the raw pass: its segment and the tiles of what that pass covers of it)
+        const uint32_t Ls = stats_item_len<false>(P, B, r, false);
+        const uint32_t v = (Ls + kTileBases - 1) / kTileBases + stats_segment_of<false>(B, r) * seg_stride;
+        if (use_lds) atomicAdd(&h[v], 1u); else atomicAdd(&B.tile_hist[v], 1u);
     }
     wave_max_u64(&B.ctr[TGSF_CTR_ROWS + 0], rows);
     wave_max_u64(&B.plan[0], rows);
@@ -212,21 +227,20 @@ TGSF_KERNEL k_clean_plan(DevParams P, DevBatch B)
     wave_add_u64(&B.plan[3], diff);
 }
 
-// How the batch's speculation fared decides whether the next batch of this context speculates.  The by-product is not
-// free: the raw pass puts every speculated read's bytes through the SWAR column a second time (the clean bins are the raw
-// ones shifted by head_trim), which makes it VALU-bound -- measured on the C2 / C3 shapes (profiles/r05_clean_tables_ab.txt):
-// raw pass 2.1 -> 3.5 ms / 1.8 -> 3.5 ms, clean pass 1.47 -> 0.83 ms / 2.1 -> 0.37 ms.  It pays (a little: +1..4 % with three
-// batches in flight, 8 GB less fetched per batch) where nearly every read is kept as expected -- HiFi-shaped batches -- and
-// loses 8 % on C2's, where a fifth to two fifths of the kept bases are looked at again anyway (adapters reaching beyond
-// the 5' trim).  So: go on only while the bases scanned a second time (ranges taken back out + the real fragments of those
-// reads) stay below 1/32 of what scanning every fragment costs.  (A batch that did not speculate tries again after a while.)
+// How the batch's speculation fared decides whether the next batch of this context speculates.  Since round 6 the by-product
+// costs the raw pass little (the split-bin form: one pass over the bytes, 2.1 -> 2.3-2.4 ms on the C2 shape, 1.8 -> ~2 ms on
+// C3's; profiles/r06_clean_tables_ab.txt) -- round 5's form ran the SWAR column twice over every speculated read and paid only
+// where nearly every read was kept as expected.  What it still costs is the second look at the reads that turned out
+// otherwise: their speculated range is taken back out and their real fragments put in, about twice their bases, where the
+// direct way scans every kept fragment once.  So: go on while those bases (plan[3]) stay below three quarters of what
+// scanning every fragment costs (plan[2]).  (A batch that did not speculate tries again after a while.)
 TGSF_KERNEL k_clean_plan_next(DevBatch B)
 {
     if (gtid() != 0 || !B.bp_allowed || B.clean_force) return;
     if (pool_overflowed(B)) return;
     if (clean_by_product(B)) {
         const uint64_t direct = B.plan[2], again = B.plan[3];
-        B.bp_state[0] = (32 * again <= direct) ? 1u : 0u;
+        B.bp_state[0] = (4 * again <= 3 * direct) ? 1u : 0u;
         B.bp_state[2] = 0;
     } else if (++B.bp_state[2] >= 64u) { B.bp_state[0] = 1u; B.bp_state[2] = 0; }     // (inputs change: look again now and then)
 }
@@ -257,7 +271,8 @@ TGSF_KERNEL k_frag_prepare(DevParams P, DevBatch B)
 {
     if (pool_overflowed(B)) return;
     TGSF_SHARED uint32_t h[kHistLds];
-    const uint32_t nbuck = B.max_tiles + 2;
+    const uint32_t seg_stride = B.max_tiles + 2;
+    const uint32_t nbuck = seg_stride * stats_segments<true>(B);
     const bool use_lds = nbuck <= kHistLds;
     if (use_lds) for (uint32_t i = TGSF_COOP_BEGIN; i < nbuck; i += TGSF_COOP_STRIDE) h[i] = 0;
     TGSF_BLOCK_SYNC();
@@ -273,7 +288,7 @@ TGSF_KERNEL k_frag_prepare(DevParams P, DevBatch B)
         }
         const uint32_t L = stats_item_len<true>(P, B, item, diff);
         if (!L) continue;
-        const uint32_t v = (L + kTileBases - 1) / kTileBases;
+        const uint32_t v = (L + kTileBases - 1) / kTileBases + stats_segment_of<true>(B, item) * seg_stride;
         if (use_lds) atomicAdd(&h[v], 1u); else atomicAdd(&B.tile_hist[v], 1u);
     }
     wave_max_u64(&B.ctr[TGSF_CTR_ROWS + 1], rows);
@@ -292,7 +307,7 @@ TGSF_KERNEL k_frag_prepare(DevParams P, DevBatch B)
 // One block; thread i owns a contiguous chunk of buckets; chunk sums are combined
 // by thread 0 (a few hundred buckets in all).
 // ---------------------------------------------------------------------------
-TGSF_KERNEL k_tile_scan(DevBatch B)
+TGSF_KERNEL k_tile_scan(DevBatch B, uint32_t nseg)
 {
     TGSF_SHARED uint32_t part[1024];
     const uint32_t mt = B.max_tiles;
@@ -302,25 +317,38 @@ TGSF_KERNEL k_tile_scan(DevBatch B)
     const uint32_t lo = threadIdx.x * per;
     uint32_t hi = lo + per;
     if (hi > nb) hi = nb;
-    // suffix sums: cnt[v] = sum_{u>v} hist[u]
-    uint32_t s = 0;
-    for (uint32_t v = lo; v < hi; v++) s += B.tile_hist[v];
-    part[threadIdx.x] = s;
-    TGSF_BLOCK_SYNC();
-    if (threadIdx.x == 0) { uint32_t run = 0; for (int i = (int)T - 1; i >= 0; i--) { uint32_t x = part[i]; part[i] = run; run += x; } }
-    TGSF_BLOCK_SYNC();
-    uint32_t run = part[threadIdx.x];                    // sum of hist over all buckets above this chunk
-    uint32_t csum = 0;
-    for (int v = (int)hi - 1; v >= (int)lo; v--) { uint32_t hv = B.tile_hist[v]; B.tile_cnt[v] = run; csum += run; run += hv; }
-    if (threadIdx.x == 0) B.tile_cnt[mt + 1] = 0;
-    TGSF_BLOCK_SYNC();
-    // prefix sums of cnt: base[t] = sum_{u<t} cnt[u]
-    part[threadIdx.x] = csum;
-    TGSF_BLOCK_SYNC();
-    if (threadIdx.x == 0) { uint32_t acc = 0; for (uint32_t i = 0; i < T; i++) { uint32_t x = part[i]; part[i] = acc; acc += x; } B.tile_base[mt + 1] = acc; }
-    TGSF_BLOCK_SYNC();
-    uint32_t acc = part[threadIdx.x];
-    for (uint32_t v = lo; v < hi; v++) { B.tile_base[v] = acc; acc += B.tile_cnt[v]; }
+    for (uint32_t sg = 0; sg < nseg; sg++) {
+        uint32_t* const hist = B.tile_hist + sg * (mt + 2);
+        uint32_t* const cnt = B.tile_cnt + sg * (mt + 2);
+        uint32_t* const base = B.tile_base + sg * (mt + 2);
+        // suffix sums: cnt[v] = sum_{u>v} hist[u]
+        uint32_t s = 0;
+        for (uint32_t v = lo; v < hi; v++) s += hist[v];
+        part[threadIdx.x] = s;
+        TGSF_BLOCK_SYNC();
+        if (threadIdx.x == 0) { uint32_t run = 0; for (int i = (int)T - 1; i >= 0; i--) { uint32_t x = part[i]; part[i] = run; run += x; } }
+        TGSF_BLOCK_SYNC();
+        uint32_t run = part[threadIdx.x];                    // sum of hist over all buckets above this chunk
+        uint32_t csum = 0;
+        for (int v = (int)hi - 1; v >= (int)lo; v--) { uint32_t hv = hist[v]; cnt[v] = run; csum += run; run += hv; }
+        if (threadIdx.x == 0) cnt[mt + 1] = 0;
+        TGSF_BLOCK_SYNC();
+        // prefix sums of cnt: base[t] = sum_{u<t} cnt[u]
+        part[threadIdx.x] = csum;
+        TGSF_BLOCK_SYNC();
+        if (threadIdx.x == 0) { uint32_t acc = 0; for (uint32_t i = 0; i < T; i++) { uint32_t x = part[i]; part[i] = acc; acc += x; } base[mt + 1] = acc; }
+        TGSF_BLOCK_SYNC();
+        uint32_t acc = part[threadIdx.x];
+        for (uint32_t v = lo; v < hi; v++) { base[v] = acc; acc += cnt[v]; }
+        TGSF_BLOCK_SYNC();
+    }
+    if (threadIdx.x == 0) {
+        // (cnt[0] counts the items with more than 0 tiles: all of the segment's that take part)
+        const uint32_t w0 = B.tile_base[mt + 1], w1 = nseg > 1 ? B.tile_base[(mt + 2) + mt + 1] : 0u;
+        B.seg_info[0] = B.tile_cnt[0];
+        B.seg_info[1] = w0;
+        B.seg_info[2] = w0 + w1;
+    }
 }
 
 template <bool CLEAN>
@@ -329,7 +357,8 @@ TGSF_KERNEL k_tile_scatter(DevParams P, DevBatch B)
     if (CLEAN && pool_overflowed(B)) return;
     TGSF_SHARED uint32_t h[kHistLds];
     TGSF_SHARED uint32_t hb[kHistLds];
-    const uint32_t nbuck = B.max_tiles + 2;
+    const uint32_t seg_stride = B.max_tiles + 2;
+    const uint32_t nbuck = seg_stride * stats_segments<CLEAN>(B);
     const bool use_lds = nbuck <= kHistLds;
     const uint32_t nf = CLEAN ? stored_frags(B) : 0u;
     const bool diff = CLEAN && clean_by_difference(B);
@@ -338,11 +367,13 @@ TGSF_KERNEL k_tile_scatter(DevParams P, DevBatch B)
         const uint32_t i = i0 + threadIdx.x;
         if (use_lds) for (uint32_t k = TGSF_COOP_BEGIN; k < nbuck; k += TGSF_COOP_STRIDE) h[k] = 0;
         TGSF_BLOCK_SYNC();
-        uint32_t L = 0, v = 0, local = 0, item = 0;
+        uint32_t L = 0, v = 0, local = 0, item = 0, first = 0;
         if (i < n) {
             item = CLEAN ? clean_item(B, i, nf) : i;
             L = stats_item_len<CLEAN>(P, B, item, diff);
-            v = (L + kTileBases - 1) / kTileBases;
+            const uint32_t sg = stats_segment_of<CLEAN>(B, item);
+            v = (L + kTileBases - 1) / kTileBases + sg * seg_stride;
+            first = sg ? B.seg_info[0] : 0u;                  // where the segment's items begin in perm
             if (L && use_lds) local = atomicAdd(&h[v], 1u);
         }
         TGSF_BLOCK_SYNC();
@@ -351,8 +382,8 @@ TGSF_KERNEL k_tile_scatter(DevParams P, DevBatch B)
                 if (h[k]) hb[k] = atomicAdd(&B.tile_fill[k], h[k]);
         TGSF_BLOCK_SYNC();
         if (L) {
-            const uint32_t slot = use_lds ? B.tile_cnt[v] + hb[v] + local
-                                          : B.tile_cnt[v] + atomicAdd(&B.tile_fill[v], 1u);
+            const uint32_t slot = first + (use_lds ? B.tile_cnt[v] + hb[v] + local
+                                                   : B.tile_cnt[v] + atomicAdd(&B.tile_fill[v], 1u));
             B.perm[slot] = item;
         }
         TGSF_BLOCK_SYNC();
@@ -376,33 +407,31 @@ TGSF_KERNEL k_tile_scatter(DevParams P, DevBatch B)
 // ---------------------------------------------------------------------------
 constexpr int kStatsWaves = 4;
 constexpr int kTileChunks = kTileBases / 16 + 2;   // +1 misalignment, +1 zero guard
-constexpr int kTileChunksBP = (kTileBases + kBpExtra) / 16 + 2;   // a speculating batch's raw pass: kBpExtra bytes beyond the tile
 constexpr int kLaneChunks = (kTileChunks + 63) / 64;   // 16-byte chunks a lane stages per stream
-static_assert((kTileChunksBP + 63) / 64 == kLaneChunks, "the few chunks beyond a tile cost no further staging register");
 
 // work[2w] = { seq address lo, hi, bases | tile << 13, item },  work[2w+1] = { qual address lo, hi, 0, 0 }
-// (BP: the raw pass of a speculating batch: a tile is staged with up to kBpExtra bytes of the read beyond it, which the
-// clean bins -- shifted by head_trim against the raw ones -- of the tile's last lanes reach into)
-template <bool CLEAN, bool BP = false>
+template <bool CLEAN>
 TGSF_KERNEL k_build_work(DevParams P, DevBatch B)
 {
     if (CLEAN && pool_overflowed(B)) return;
     const uint32_t mt = B.max_tiles;
-    const uint32_t W = B.tile_base[mt + 1];
+    const uint32_t W0 = B.seg_info[1], W = B.seg_info[2], first1 = B.seg_info[0];
     const bool diff = CLEAN && clean_by_difference(B);
     (void)diff;
     for (uint32_t w = gtid(); w < W && w < B.work_cap; w += gsize()) {
-        const uint32_t t = find_owner(B.tile_base, mt + 1, w);
-        const uint32_t item = B.perm[w - B.tile_base[t]];
+        const uint32_t sg = w >= W0 ? 1u : 0u;                         // (segment 1: see stats_segments)
+        const uint32_t* base = B.tile_base + sg * (mt + 2);
+        const uint32_t ws = w - sg * W0;
+        const uint32_t t = find_owner(base, mt + 1, ws);
+        const uint32_t item = B.perm[sg * first1 + ws - base[t]];
         const bool frag = CLEAN && item < B.fcap;
         const uint32_t rd = CLEAN ? item - B.fcap : item;
-        uint32_t hs = 0, he = frag ? 0u : B.len[rd];                   // a read taken back out: the range the tables hold of it
+        uint32_t hs = 0, he = frag ? 0u : stats_item_len<false>(P, B, rd, false);     // a read taken back out: the range the tables hold of it
         if (CLEAN && !frag) held_range(P, B, rd, hs, he);
         const uint32_t L = frag ? B.frag_len[item] : he - hs;
         const uint64_t a0 = (frag ? B.frag_off[item] : B.off[rd] + hs) + (uint64_t)t * kTileBases;
         uint32_t nb = L - t * kTileBases;
-        const uint32_t most = BP ? (uint32_t)(kTileBases + kBpExtra) : (uint32_t)kTileBases;
-        if (nb > most) nb = most;
+        if (nb > (uint32_t)kTileBases) nb = (uint32_t)kTileBases;
         const uint64_t aq = (frag ? B.frag_qoff[item] : B.qoff[rd] + hs) + (uint64_t)t * kTileBases;
         uint4 e, q;
         e.x = (uint32_t)a0; e.y = (uint32_t)(a0 >> 32); e.z = nb | (t << 13); e.w = item;
@@ -416,20 +445,25 @@ TGSF_KERNEL k_build_work(DevParams P, DevBatch B)
 // (the 14 staging registers per stream plus the work-list words spill at the default 128).
 // NT: the text is fetched with non-temporal loads (each byte is wanted once by this kernel; what the later kernels of the
 // batch re-read has long left the caches by then: a batch is GBs, the caches are MBs)
-// BP (raw pass only): the clean tables as a by-product (DevBatch::spec).  A read the batch speculates on has, for every
-// clean bin j, the bytes [head_trim + 100 j, ...) of the read tallied into clean row j: in tile coordinates that is the
-// lane's raw bin shifted by b = head_trim mod 100 bytes (and by q = head_trim / 100 rows) -- the same 100 bytes of LDS
-// reads and the same SWAR column a second time, into a second set of ten tallies, while the tile is there anyway.
+// BP (raw pass only): the clean tables as a by-product (DevBatch::spec), round 6's split-bin form.  A read the batch
+// speculates on is expected to be kept as [head_trim, L - tail_trim): its clean bin j is the bytes [head_trim + 100 j, ...),
+// i.e. with b = head_trim mod 100 and q = head_trim / 100 the TAIL piece [100 R + b, 100 R + 100) of raw bin R = q + j and
+// the HEAD piece [100 (R+1), 100 (R+1) + b) of the next one.  So a lane tallies its raw bin of such a read in two pieces,
+// split at b (launch-uniform) -- ONE pass over the bytes, two sets of ten tallies -- and when the tallies go to the tables
+// raw row R gets head + tail, clean row R - q the tail and clean row R - q - 1 the head: no byte goes through the SWAR
+// column twice (round 5's form ran the column again over the shifted window: the raw pass turned VALU-bound, 2.1 -> 3.5 ms),
+// and nothing crosses lanes.  The raw pass covers such a read up to L - tail_trim only (stats_item_len; k_tail_fix tallies
+// the rest), and the work list has the speculated reads first (DevBatch::tile_hist): a wave changes between the two kinds
+// of item once at most, so both kinds share one set of accumulators.
 template <bool CLEAN, bool NT = false, bool BP = false>
 TGSF_KERNEL TGSF_BOUNDS(256, 3) k_stats(DevParams P, DevBatch B)
 {
     static_assert(!(CLEAN && BP), "the by-product belongs to the raw pass");
     if (CLEAN && pool_overflowed(B)) return;
-    TGSF_SHARED uint4 lds[kStatsWaves][2][BP ? kTileChunksBP : kTileChunks];
+    TGSF_SHARED uint4 lds[kStatsWaves][2][kTileChunks];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t gw = blockIdx.x * kStatsWaves + wave, nw = gridDim.x * kStatsWaves;
-    const uint32_t mt = B.max_tiles;
-    uint32_t W = B.tile_base[mt + 1];
+    uint32_t W = B.seg_info[2];
     if (W > B.work_cap) W = B.work_cap;
     const uint32_t per = (W + nw - 1) / nw;
     uint32_t w0 = gw * per, w1 = w0 + per;
@@ -445,51 +479,53 @@ TGSF_KERNEL TGSF_BOUNDS(256, 3) k_stats(DevParams P, DevBatch B)
     bool neg = false;                                  // accumulated tallies are to be taken OUT of the tables
     const QcConsts kc = qc_consts();
 
+    // the lane's bin of the items gone through since the last flush -- (BP) of a speculated item: its tail piece
     uint32_t cnt[4] = {0, 0, 0, 0}, qs[5] = {0, 0, 0, 0, 0}, call = 0, since = 0;
-    // (BP) the clean bins' tallies, rows shifted by bp_q against this lane's raw row
-    uint32_t ccnt[4] = {0, 0, 0, 0}, cqs[5] = {0, 0, 0, 0, 0}, ccall = 0;
+    // (BP) ... and its head piece, the first bp_b bytes of the bin
+    uint32_t hcnt[4] = {0, 0, 0, 0}, hqs[5] = {0, 0, 0, 0, 0}, hcall = 0;
+    bool cur_sp = false;                               // (BP) the accumulated items are speculated ones
     const uint32_t bp_b = BP ? (uint32_t)P.head_trim % (uint32_t)kBin : 0u, bp_q = BP ? (uint32_t)P.head_trim / (uint32_t)kBin : 0u;
     uint64_t* ctab_q = B.ctr + ctr_bin_table(TGSF_B_CLEAN_QUAL, P.bc_len, P.n_bins);
     uint64_t* ctab_c = B.ctr + ctr_bin_table(TGSF_B_CLEAN_CNT, P.bc_len, P.n_bins);
-    (void)ccall; (void)ctab_q; (void)ctab_c; (void)bp_b; (void)bp_q;
+    (void)hcall; (void)ctab_q; (void)ctab_c; (void)bp_b; (void)bp_q; (void)cur_sp;
     uint32_t t_acc = 0xFFFFFFFFu;
     uint32_t* S = reinterpret_cast<uint32_t*>(&lds[wave][0][0]);
     uint32_t* Qd = reinterpret_cast<uint32_t*>(&lds[wave][1][0]);
 
-    auto flush = [&](uint32_t tt) {
-        if (call) {
-            size_t row = ((size_t)tt * kTileBins + lane) * 5;
+    // ten tallies into a row of a pair of tables
+    auto put = [&](uint64_t* tc, uint64_t* tq, size_t row, const uint32_t* cn, const uint32_t* qv, uint32_t all, bool minus) TGSF_INLINE_LAMBDA {
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                if (cnt[c]) {
-                    const int64_t dc = (int64_t)cnt[c], dq = (int64_t)(qs[c] >> 7) - qt * (int64_t)cnt[c];
-                    atomicAdd((ull*)&tab_c[row + c], (ull)(neg ? -dc : dc));
-                    atomicAdd((ull*)&tab_q[row + c], (ull)(neg ? -dq : dq));
-                }
+        for (int c = 0; c < 4; c++) {
+            if (cn[c]) {
+                const int64_t dc = (int64_t)cn[c], dq = (int64_t)(qv[c] >> 7) - qt * (int64_t)cn[c];
+                atomicAdd((ull*)&tc[row + c], (ull)(minus ? -dc : dc));
+                atomicAdd((ull*)&tq[row + c], (ull)(minus ? -dq : dq));
             }
-            const int64_t dc = (int64_t)call, dq = (int64_t)qs[4] - qt * (int64_t)call;
-            atomicAdd((ull*)&tab_c[row + 4], (ull)(neg ? -dc : dc));
-            atomicAdd((ull*)&tab_q[row + 4], (ull)(neg ? -dq : dq));
         }
+        const int64_t dc = (int64_t)all, dq = (int64_t)qv[4] - qt * (int64_t)all;
+        atomicAdd((ull*)&tc[row + 4], (ull)(minus ? -dc : dc));
+        atomicAdd((ull*)&tq[row + 4], (ull)(minus ? -dq : dq));
+    };
+    auto flush = [&](uint32_t tt) {
+        const uint32_t R = tt * kTileBins + lane;                      // the lane's row of the raw table
+        if (BP && cur_sp && !B.replay) {
+            // (a second run of the batch after a pool overflow: its first run has put these there already)
+            if (call && R >= bp_q) put(ctab_c, ctab_q, (size_t)(R - bp_q) * 5, cnt, qs, call, false);
+            if (hcall && R >= bp_q + 1u) put(ctab_c, ctab_q, (size_t)(R - bp_q - 1u) * 5, hcnt, hqs, hcall, false);
+        }
+        if (BP && hcall) {                                             // raw row R: head + tail
+#pragma unroll
+            for (int c = 0; c < 4; c++) { cnt[c] += hcnt[c]; qs[c] += hqs[c]; }       // (128 * sums of bytes: exact)
+            qs[4] += hqs[4]; call += hcall;
+        }
+        if (call) put(tab_c, tab_q, (size_t)R * 5, cnt, qs, call, neg);
         cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0;
         qs[0] = qs[1] = qs[2] = qs[3] = qs[4] = 0;
         call = 0; since = 0;
         if (BP) {
-            // (a second run of the batch after a pool overflow: its first run has put these there already)
-            if (ccall && !B.replay) {
-                const size_t row = ((size_t)tt * kTileBins + lane - bp_q) * 5;      // (ccall > 0: the row is not negative)
-#pragma unroll
-                for (int c = 0; c < 4; c++)
-                    if (ccnt[c]) {
-                        atomicAdd((ull*)&ctab_c[row + c], (ull)ccnt[c]);
-                        atomicAdd((ull*)&ctab_q[row + c], (ull)((int64_t)(cqs[c] >> 7) - qt * (int64_t)ccnt[c]));
-                    }
-                atomicAdd((ull*)&ctab_c[row + 4], (ull)ccall);
-                atomicAdd((ull*)&ctab_q[row + 4], (ull)((int64_t)cqs[4] - qt * (int64_t)ccall));
-            }
-            ccnt[0] = ccnt[1] = ccnt[2] = ccnt[3] = 0;
-            cqs[0] = cqs[1] = cqs[2] = cqs[3] = cqs[4] = 0;
-            ccall = 0;
+            hcnt[0] = hcnt[1] = hcnt[2] = hcnt[3] = 0;
+            hqs[0] = hqs[1] = hqs[2] = hqs[3] = hqs[4] = 0;
+            hcall = 0;
         }
     };
 
@@ -600,10 +636,12 @@ TGSF_KERNEL TGSF_BOUNDS(256, 3) k_stats(DevParams P, DevBatch B)
             const uint64_t ca0 = a0, caq = aq; const uint32_t cnb = nb, ctt = tt, citem = item;
             if (i + 1 < ng) { entry(i + 1, a0, aq, nb, tt, item); issue(a0, aq, nb); }   // in flight during the reduce
             const bool ineg = CLEAN && citem >= B.fcap;         // a read being taken back out
-            if (ctt != t_acc || ineg != neg || since >= 1024) { // qs[c] carries 128*sum of bytes up to 255: stay below 2^32
+            const bool sp = BP && B.spec[citem] != 0u;          // (wave-uniform) a read the batch speculates on
+            if (ctt != t_acc || ineg != neg || since >= 1024 || (BP && sp != cur_sp)) { // qs[c] carries 128*sum of bytes up to 255: stay below 2^32
                 if (t_acc != 0xFFFFFFFFu) flush(t_acc);
                 t_acc = ctt;
                 neg = ineg;
+                cur_sp = sp;
             }
             ++since;
             // nv bytes of the tile from byte `at` on (a lane's 100-base bin, or less at an item's end) into ten tallies;
@@ -683,48 +721,91 @@ TGSF_KERNEL TGSF_BOUNDS(256, 3) k_stats(DevParams P, DevBatch B)
                 }
                 return (int32_t)hq[4];
             };
-            const uint32_t raw_nb = BP && cnb > (uint32_t)kTileBases ? (uint32_t)kTileBases : cnb;   // (BP: the tile is staged with bytes beyond it)
-            const int nvalid = (int)raw_nb - (int)lane * kBin;  // bases of this lane's bin in the tile
-            const uint32_t q4_before = qs[4];
-            int nv = 0;
-            uint32_t qor = 0;                                   // OR of this bin's quality dwords
+            const int nvalid = (int)cnb - (int)lane * kBin;     // bases of this lane's bin in the tile
+            const uint32_t q4_before = qs[4] + (BP ? hqs[4] : 0u), q4t_before = qs[4], q4h_before = BP ? hqs[4] : 0u;
+            (void)q4t_before; (void)q4h_before;
+            int nv = 0, nh = 0;                                 // bytes of the bin; (BP, a speculated read) of its head piece
+            uint32_t qor = 0, qorh = 0;                         // OR of the quality dwords of the (tail piece of the) bin / of the head piece
             if (nvalid > 0) {
                 nv = nvalid > kBin ? kBin : nvalid;
-                qor = bin(lane * kBin, nv, cnt, qs);
-                call += (uint32_t)nv;
-            }
-            int32_t high_all = 0;
-            if (wave_or(qor & 0x80808080u) && nv > 0 && (qor & 0x80808080u))
-                high_all = high_bytes(lane * kBin, nv, tab_q, ((size_t)ctt * kTileBins + lane) * 5, ineg);
-            // sumQ of the item: sum over the tile of (qual - qType), two's complement in u64 (:1457-1458)
-            const int32_t part = (int32_t)(qs[4] - q4_before) - (int32_t)qt * nv - 256 * high_all;
-            const int32_t tot = wave_sum_i32(part);
-            if (BP) {
-                // the clean bin of this lane: row j of the speculated fragment [head_trim, L - tail_trim) of the read
-                const uint32_t sp = B.spec[citem];              // (wave-uniform)
-                if (sp) {
-                    const int64_t j = (int64_t)ctt * kTileBins + lane - bp_q;
-                    const int64_t keep = (int64_t)B.len[citem] - P.head_trim - P.tail_trim;
-                    int cnv = 0;
-                    if (j >= 0 && j * kBin < keep) cnv = (int)(keep - j * kBin > kBin ? kBin : keep - j * kBin);
-                    const uint32_t c4_before = cqs[4];
-                    uint32_t cqor = 0;
-                    if (cnv > 0) {
-                        cqor = bin(lane * kBin + bp_b, cnv, ccnt, cqs);
-                        ccall += (uint32_t)cnv;
-                    }
-                    int32_t chigh = 0;
-                    if (wave_or(cqor & 0x80808080u) && cnv > 0 && (cqor & 0x80808080u))
-                        chigh = high_bytes(lane * kBin + bp_b, cnv, B.replay ? nullptr : ctab_q, (size_t)(j > 0 ? j : 0) * 5, false);
-                    const int32_t cpart = (int32_t)(cqs[4] - c4_before) - (int32_t)qt * cnv - 256 * chigh;
-                    const int32_t ctot = wave_sum_i32(cpart);
-                    if (wave_leader()) atomicAdd((ull*)&B.spec_sum[citem], (ull)(int64_t)ctot);
+                if (BP && sp && bp_b) {
+                    nh = nv < (int)bp_b ? nv : (int)bp_b;
+                    // (two calls of the general loop.  One pass over the bin's 25 dwords that changes tallies at the split was
+                    // built and measured beside this, round 6: the raw pass took the same 2.3 ms either way)
+                    qorh = bin(lane * kBin, nh, hcnt, hqs);
+                    if (nv > nh) qor = bin(lane * kBin + bp_b, nv - nh, cnt, qs);
+                    hcall += (uint32_t)nh;
+                    call += (uint32_t)(nv - nh);
+                } else {
+                    qor = bin(lane * kBin, nv, cnt, qs);
+                    call += (uint32_t)nv;
                 }
+            }
+            const uint32_t R = ctt * kTileBins + lane;
+            int32_t high_all = 0;
+            if (wave_or((qor | qorh) & 0x80808080u) && nv > 0 && ((qor | qorh) & 0x80808080u))
+                high_all = high_bytes(lane * kBin, nv, tab_q, (size_t)R * 5, ineg);
+            // sumQ of the item: sum over the tile of (qual - qType), two's complement in u64 (:1457-1458)
+            const int32_t part = (int32_t)(qs[4] + (BP ? hqs[4] : 0u) - q4_before) - (int32_t)qt * nv - 256 * high_all;
+            const int32_t tot = wave_sum_i32(part);
+            if (BP && sp) {
+                // the same bytes as clean tallies: the tail piece belongs to clean row R - q, the head piece to row R - q - 1
+                // (pieces in front of head_trim -- rows below those -- belong to no clean row); their share of the read's clean sum
+                const bool t_in = R >= bp_q, h_in = R >= bp_q + 1u;
+                int32_t chigh = 0;
+                if (wave_or((qor | qorh) & 0x80808080u) && nv > 0) {     // (quality bytes of 128 and above: 256 each comes back out, as in the raw row)
+                    uint64_t* const ct = B.replay ? nullptr : ctab_q;
+                    if (nh > 0 && h_in && (qorh & 0x80808080u)) chigh += high_bytes(lane * kBin, nh, ct, (size_t)(R - bp_q - 1u) * 5, false);
+                    if (nv > nh && t_in && (qor & 0x80808080u)) chigh += high_bytes(lane * kBin + (uint32_t)nh, nv - nh, ct, (size_t)(R - bp_q) * 5, false);
+                }
+                int32_t cpart = -256 * chigh;
+                if (t_in) cpart += (int32_t)(qs[4] - q4t_before) - (int32_t)qt * (nv - nh);
+                if (h_in) cpart += (int32_t)(hqs[4] - q4h_before) - (int32_t)qt * nh;
+                const int32_t ctot = wave_sum_i32(cpart);
+                if (wave_leader()) atomicAdd((ull*)&B.spec_sum[citem], (ull)(int64_t)ctot);
             }
             if (!ineg && wave_leader()) atomicAdd((ull*)&it_sum[citem], (ull)(int64_t)tot);
         }
     }
     if (t_acc != 0xFFFFFFFFu) flush(t_acc);
+}
+
+// ---------------------------------------------------------------------------
+// k_tail_fix: the raw pass of a read the batch speculates on stops at L - tail_trim (stats_item_len): the tail_trim bytes behind
+// are tallied here, one lane a read, into the batch's raw table and the read's quality sum (CalcAvgQuality,
+// src/TGSFilter.cpp:1436-1479, on those bytes).  A few bytes per read: the 3' trims the pre-pass finds are below 150.
+// ---------------------------------------------------------------------------
+TGSF_KERNEL k_tail_fix(DevParams P, DevBatch B)
+{
+    if (!B.bp_allowed || P.tail_trim <= 0) return;
+    uint64_t* const tab_q = B.raw_tab;
+    uint64_t* const tab_c = B.raw_tab + (size_t)P.n_bins * 5;
+    for (uint32_t r = gtid(); r < B.n; r += gsize()) {
+        const uint32_t L = B.len[r];
+        if (!L || !B.spec[r]) continue;
+        const uint8_t* sq = B.seq + B.off[r];
+        const uint8_t* ql = B.qual + B.qoff[r];
+        int64_t sum = 0;
+        uint32_t row = 0xFFFFFFFFu, cn[5] = {0, 0, 0, 0, 0};
+        int64_t qv[5] = {0, 0, 0, 0, 0};
+        auto put = [&] {
+            if (row == 0xFFFFFFFFu) return;
+            for (int c = 0; c < 5; c++)
+                if (cn[c]) { atomicAdd((ull*)&tab_c[(size_t)row * 5 + c], (ull)cn[c]); atomicAdd((ull*)&tab_q[(size_t)row * 5 + c], (ull)qv[c]); cn[c] = 0; qv[c] = 0; }
+        };
+        for (uint32_t i = L - (uint32_t)P.tail_trim; i < L; i++) {
+            if (i / (uint32_t)kBin != row) { put(); row = i / (uint32_t)kBin; }
+            const uint32_t b = (uint32_t)sq[i] & 0xDFu;
+            const int c = (sq[i] & 0x80u) ? 4 : b == 'A' ? 0 : b == 'T' ? 1 : b == 'G' ? 2 : b == 'C' ? 3 : 4;
+            // `qual[i] - qType` on a signed char (:1455-1457); records without qualities: 0
+            const int64_t q = P.no_qual ? 0 : (int64_t)(int8_t)ql[i] - (int64_t)P.qtype;
+            if (c < 4) { cn[c]++; qv[c] += q; }
+            cn[4]++; qv[4] += q;
+            sum += q;
+        }
+        put();
+        atomicAdd((ull*)&B.sumq[r], (ull)sum);
+    }
 }
 
 // ---------------------------------------------------------------------------

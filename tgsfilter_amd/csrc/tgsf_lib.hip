@@ -319,8 +319,11 @@ extern "C" void tgsf_destroy(tgsf_ctx* c)
     if (!c) return;
     if (c->B.bp_allowed && c->B.bp_state && knob("TGSF_TRACE_BP")) {     // how often the clean tables came as a by-product
         uint32_t w[4] = {0, 0, 0, 0};
-        if (!rt_d2h(w, c->B.bp_state, sizeof w, c->stream) && !rt_sync(c->stream))
-            fprintf(stderr, "tgsf: clean tables as a by-product of the raw pass: %u batches speculated; the next would%s\n", w[1], w[0] ? "" : " not");
+        uint64_t pl[4] = {0, 0, 0, 0};
+        uint32_t sg[4] = {0, 0, 0, 0};
+        if (!rt_d2h(w, c->B.bp_state, sizeof w, c->stream) && !rt_d2h(pl, c->B.plan, sizeof pl, c->stream) && !rt_d2h(sg, c->B.seg_info, sizeof sg, c->stream) && !rt_sync(c->stream))
+            fprintf(stderr, "tgsf: clean tables as a by-product of the raw pass: %u batches speculated; the next would%s; the last batch: %llu bases a direct clean pass scans, "
+                            "%llu bases its own did, %u work items in that pass\n", w[1], w[0] ? "" : " not", (unsigned long long)pl[2], (unsigned long long)pl[3], sg[2]);
     }
 #if !defined(TGSF_EMUL)
     (void)hipSetDevice(c->device);
@@ -529,10 +532,11 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
         B.rep_max_plog = kRepMaxPlog;
         if (const char* ev = knob("TGSF_REP_MAX_PLOG")) { int v = atoi(ev); if (v >= 0 && v <= 20) B.rep_max_plog = (uint32_t)v; }   // test knob
     }
-    if (!e) e = dev_alloc(c, &B.tile_hist, (size_t)B.max_tiles + 2);
-    if (!e) e = dev_alloc(c, &B.tile_cnt, (size_t)B.max_tiles + 2);
-    if (!e) e = dev_alloc(c, &B.tile_base, (size_t)B.max_tiles + 2);
-    if (!e) e = dev_alloc(c, &B.tile_fill, (size_t)B.max_tiles + 2);
+    if (!e) e = dev_alloc(c, &B.tile_hist, 2 * ((size_t)B.max_tiles + 2));     // (two segments: DevBatch::tile_hist)
+    if (!e) e = dev_alloc(c, &B.tile_cnt, 2 * ((size_t)B.max_tiles + 2));
+    if (!e) e = dev_alloc(c, &B.tile_base, 2 * ((size_t)B.max_tiles + 2));
+    if (!e) e = dev_alloc(c, &B.tile_fill, 2 * ((size_t)B.max_tiles + 2));
+    if (!e) e = dev_alloc(c, &B.seg_info, 4);
     if (!e) e = dev_alloc(c, &B.perm, nitems);
     B.work_cap = (uint32_t)std::min<uint64_t>(2 * (c->cap_bases / kTileBases) + nitems + 16, 0x7FFFFFF0ull);
     if (!e) e = dev_alloc(c, &B.work, 2 * (size_t)B.work_cap);
@@ -552,7 +556,7 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     // (its verdict comes after the raw pass); the work list words hold a staged length of 13 bits
     B.bp_allowed = (p->filter && !p->only_qc && p->min_repeat <= 0 && (p->head_trim > 0 || p->tail_trim > 0) &&
                     p->head_trim >= 0 && p->tail_trim >= 0) ? 1u : 0u;
-    static_assert(kTileBases + kBpExtra < (1 << 13), "staged bytes of a tile fit the work list's 13 bits");
+    static_assert(kTileBases < (1 << 13), "staged bytes of a tile fit the work list's 13 bits");
     if (const char* f = knob("TGSF_CLEAN_TABLES")) {      // test knob: "direct" | "difference" | "byproduct" (always speculate)
         if (!strcmp(f, "direct")) { B.clean_force = 1; B.bp_allowed = 0; }
         else if (!strcmp(f, "difference") && !p->only_qc) { B.clean_force = 2; B.bp_allowed = 0; }
@@ -687,7 +691,7 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     c->last_stream = st;
     const unsigned gsmall = grid_cap(std::min(blocks_for(n, T), 2048u));
     const unsigned gstats = grid_cap(c->stats_grid);   // 3 blocks (12 waves) per CU on 256 CUs: LDS-limited
-    const size_t tl = ((size_t)B.max_tiles + 2) * 4;
+    const size_t tl = 2 * ((size_t)B.max_tiles + 2) * 4;          // (both segments)
     const unsigned gfold = grid_cap(std::min(blocks_for((uint64_t)P.n_bins * 5, T), 1024u));
     int stage = 0;
 #if !defined(TGSF_EMUL)
@@ -717,16 +721,17 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     rt_memset(B.pool_n, 0, 4, st);
     rt_memset(B.plan, 0, 32, st);
     TGSF_LAUNCH(k_prepare, gsmall, T, st, P, B, c->max_read_len);
-    TGSF_LAUNCH_COOP(k_tile_scan, 1, 64, st, B);       // a few hundred buckets: one wave
+    TGSF_LAUNCH_COOP(k_tile_scan, 1, 64, st, B, B.bp_allowed ? 2u : 1u);       // a few hundred buckets: one wave
     TGSF_LAUNCH(k_tile_scatter<false>, gsmall, T, st, P, B);
-    if (B.bp_allowed) TGSF_LAUNCH((k_build_work<false, true>), gwork, T, st, P, B);
-    else TGSF_LAUNCH((k_build_work<false, false>), gwork, T, st, P, B);
+    TGSF_LAUNCH(k_build_work<false>, gwork, T, st, P, B);
     STAGE_MARK();
     // -- raw stats
     // (a context that may speculate -- DevBatch::spec -- runs the variant of the raw pass that tallies the clean bins too;
     // the text is fetched with non-temporal loads: 2.24 -> 2.06 ms, 5.4 -> 5.8 TB/s, round 3)
-    if (B.bp_allowed) TGSF_LAUNCH((k_stats<false, true, true>), gstats, 64 * kStatsWaves, st, P, B);
-    else TGSF_LAUNCH((k_stats<false, true>), gstats, 64 * kStatsWaves, st, P, B);
+    if (B.bp_allowed) {
+        TGSF_LAUNCH((k_stats<false, true, true>), gstats, 64 * kStatsWaves, st, P, B);
+        if (P.tail_trim > 0) TGSF_LAUNCH(k_tail_fix, gsmall, T, st, P, B);       // (the bytes behind a speculated fragment)
+    } else TGSF_LAUNCH((k_stats<false, true>), gstats, 64 * kStatsWaves, st, P, B);
     if (!redo) TGSF_LAUNCH(k_fold_raw<false>, gfold, T, st, P, B);   // (a second run: the batch's raw tallies are in the tables already)
     STAGE_MARK();
     TGSF_LAUNCH(k_gate_reads, gsmall, T, st, P, B);
@@ -963,9 +968,9 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     if (B.bp_allowed && !redo) TGSF_LAUNCH(k_clean_plan_next, 1, 64, st, B);
     TGSF_LAUNCH(k_fold_raw<true>, gfold, T, st, P, B);
     TGSF_LAUNCH(k_frag_prepare, gfr, T, st, P, B);
-    TGSF_LAUNCH_COOP(k_tile_scan, 1, 64, st, B);       // a few hundred buckets: one wave
+    TGSF_LAUNCH_COOP(k_tile_scan, 1, 64, st, B, 2u);   // a few hundred buckets: one wave (fragments; reads to take back out)
     TGSF_LAUNCH(k_tile_scatter<true>, gfr, T, st, P, B);
-    TGSF_LAUNCH((k_build_work<true, false>), gwork, T, st, P, B);
+    TGSF_LAUNCH(k_build_work<true>, gwork, T, st, P, B);
     TGSF_LAUNCH((k_stats<true, true>), gstats, 64 * kStatsWaves, st, P, B);
     STAGE_MARK();
     TGSF_LAUNCH(k_gate_frags, gfr, T, st, P, B);
