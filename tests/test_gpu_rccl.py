@@ -13,32 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def test_library_loads_and_exports():
-    from tgsfilter_amd import rccl
-    lib = rccl.load()
-    assert hasattr(lib, "tgsf_rccl_allreduce_counters") and hasattr(lib, "tgsf_rccl_last_error")
-
-
-def test_one_rank_communicator_is_identity():
-    import torch
-    from tests import parity
-    from tgsfilter_amd import abi, capi, rccl, synth
-    torch.cuda.set_device(0)
-    reads = synth.make_reads(5, 200, "ont", mean_len=4000, zoo=True, pmid=0.1)
-    p = parity.sized(abi.make_params("ont", adapters=[synth.ONT_RAPID, synth.ONT_RAPID_RC], min_q=9.0), reads)
-    ctx = capi.Context(p, 0)
-    seq, qual, off, ln = synth.pack(reads)
-    ctx.submit(seq, qual, off[:-1].copy(), ln)
-    before = ctx.counters()
-    comm = rccl.comm_init_rank(rccl.unique_id(), 0, 1)
-    rccl.allreduce_counters(ctx, comm, 0, 1)
-    after = ctx.counters()
-    rccl.comm_destroy(comm)
-    ctx.close()
-    assert np.array_equal(before, after)
-    assert before[abi.CTR_ROWS:abi.CTR_ROWS + 4].min() > 0
-
-
+# (the two-GPU test first: a box with several GPUs reaches it early under -x)
 WORKER = r'''
 import os, sys, pickle
 import numpy as np
@@ -88,3 +63,29 @@ def test_two_gpus_two_processes(tmp_path):
     _, _, ectr = orc.filter_batch(p, seq, qual, off, ln, n_bins=abi.n_bins(p.max_read_len))
     assert np.array_equal(parts[0]["total"], parts[1]["total"])
     assert np.array_equal(parts[0]["total"], ectr)
+
+
+def test_library_loads_and_exports():
+    from tgsfilter_amd import rccl
+    lib = rccl.load()
+    assert hasattr(lib, "tgsf_rccl_allreduce_counters") and hasattr(lib, "tgsf_rccl_last_error")
+
+
+def test_one_rank_communicator_is_identity():
+    import torch
+    from tests import parity
+    from tgsfilter_amd import abi, capi, rccl, synth
+    torch.cuda.set_device(0)
+    reads = synth.make_reads(5, 200, "ont", mean_len=4000, zoo=True, pmid=0.1)
+    p = parity.sized(abi.make_params("ont", adapters=[synth.ONT_RAPID, synth.ONT_RAPID_RC], min_q=9.0), reads)
+    ctx = capi.Context(p, 0)
+    seq, qual, off, ln = synth.pack(reads)
+    ctx.submit(seq, qual, off[:-1].copy(), ln)
+    before = ctx.counters()
+    comm = rccl.comm_init_rank(rccl.unique_id(), 0, 1)
+    rccl.allreduce_counters(ctx, comm, 0, 1)
+    after = ctx.counters()
+    rccl.comm_destroy(comm)
+    ctx.close()
+    assert np.array_equal(before, after)
+    assert before[abi.CTR_ROWS:abi.CTR_ROWS + 4].min() > 0

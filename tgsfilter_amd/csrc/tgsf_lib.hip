@@ -307,7 +307,18 @@ extern "C" int tgsf_device_location(int device, char* bus_id, int len, int* numa
     }
     return TGSF_OK;
 #else
-    (void)device;
+    // (emulation: a made-up place per device -- "emul:<n>", and the n-th entry of TGSF_EMUL_NUMA as its node -- so that the host
+    // side's one-rank-per-GPU paths, the bus-id gather and the NUMA binding, can be tested on a box without a GPU)
+    if (bus_id && len > 0) snprintf(bus_id, (size_t)len, "emul:%d", device);
+    if (numa_node)
+        if (const char* e = knob("TGSF_EMUL_NUMA")) {
+            int k = 0;
+            for (const char* c = e; *c; k++) {
+                if (k == device) { *numa_node = atoi(c); break; }
+                while (*c && *c != ',') c++;
+                if (*c == ',') c++;
+            }
+        }
     return TGSF_OK;
 #endif
 }

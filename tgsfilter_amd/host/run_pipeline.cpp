@@ -95,7 +95,8 @@ void Run::bind_to_node_of(size_t k)
     int node = -1;
     char bus[64];
     if (L.device_location(ctx_dev[k], bus, (int)sizeof bus, &node) == TGSF_OK && node >= 0) {
-        std::ifstream f("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist");
+        const char* sysfs = knob("TGSF_SYSFS_NODES");                  // test knob: another directory in place of /sys/devices/system/node
+        std::ifstream f(std::string(sysfs ? sysfs : "/sys/devices/system/node") + "/node" + std::to_string(node) + "/cpulist");
         std::string list;
         cpu_set_t set;
         CPU_ZERO(&set);
