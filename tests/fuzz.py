@@ -68,12 +68,24 @@ def random_case(seed: int, n_reads: int):
         if rng.random() < 0.5:
             kw.update(mid_match_len=int(rng.choice([12, 16, 18, 22])))       # within reach of the short adapters
         kw["_pool_cap"] = int(rng.choice([0, 0, 0, 3, 40]))                   # 0: the context's own sizing
+    if os.environ.get("TGSF_FUZZ_TRIMS") == "1":
+        # (round 6, the split-bin by-product: trims on every seam of a bin -- drawn from a stream of their own, so that the
+        # cases of the other campaigns and of the recorded findings stay what they were)
+        r2 = np.random.default_rng(seed ^ 0x5EED7A11)
+        kw.update(head_trim=int(r2.choice([0, 1, 3, 4, 79, 99, 100, 101, 137, 250, 6400, 6401])), tail_trim=int(r2.choice([0, 0, 1, 8, 99, 100, 120])),
+                  filter=True, min_len=int(r2.choice([100, 500, 1000])))
+        kw.pop("min_repeat", None); kw.pop("kmer", None)
+        kw["_force_by_product"] = bool(r2.random() < 0.7)
     return kind, reads, kw
 
 
 def run_case(lib_path, seed: int, n_reads: int):
     kind, reads, kw = random_case(seed, n_reads)
     pool_cap = kw.pop("_pool_cap", 0)
+    force_bp = kw.pop("_force_by_product", False)
+    outer_ct = os.environ.get("TGSF_CLEAN_TABLES")
+    if force_bp:
+        os.environ["TGSF_CLEAN_TABLES"] = "byproduct"
     p = parity.sized(abi.make_params(kind, **kw), reads)
     outer = os.environ.get("TGSF_POOL_CAP")                 # (a campaign may set one for every case: keep it)
     if pool_cap:
@@ -85,6 +97,11 @@ def run_case(lib_path, seed: int, n_reads: int):
             os.environ.pop("TGSF_POOL_CAP", None)
         else:
             os.environ["TGSF_POOL_CAP"] = outer
+        if force_bp:
+            if outer_ct is None:
+                os.environ.pop("TGSF_CLEAN_TABLES", None)
+            else:
+                os.environ["TGSF_CLEAN_TABLES"] = outer_ct
     try:
         parity.compare_batch(ctx, p, reads, align=int(np.random.default_rng(seed).choice([1, 16])),
                              explicit_lengths=True)

@@ -409,7 +409,9 @@ constexpr int kStatsWaves = 4;
 constexpr int kTileChunks = kTileBases / 16 + 2;   // +1 misalignment, +1 zero guard
 constexpr int kLaneChunks = (kTileChunks + 63) / 64;   // 16-byte chunks a lane stages per stream
 
-// work[2w] = { seq address lo, hi, bases | tile << 13, item },  work[2w+1] = { qual address lo, hi, 0, 0 }
+// work[2w] = { seq address lo, hi, bases | tile << 13, item },  work[2w+1] = { qual address lo, hi, speculated?, 0 }
+// (whether the batch speculates on the item's read travels with the entry: k_stats needs it before it touches the tile, and a
+// load of its own per tile sat in front of every tile's work -- measured on the C3 shape, round 6)
 template <bool CLEAN>
 TGSF_KERNEL k_build_work(DevParams P, DevBatch B)
 {
@@ -435,7 +437,7 @@ TGSF_KERNEL k_build_work(DevParams P, DevBatch B)
         const uint64_t aq = (frag ? B.frag_qoff[item] : B.qoff[rd] + hs) + (uint64_t)t * kTileBases;
         uint4 e, q;
         e.x = (uint32_t)a0; e.y = (uint32_t)(a0 >> 32); e.z = nb | (t << 13); e.w = item;
-        q.x = (uint32_t)aq; q.y = (uint32_t)(aq >> 32); q.z = 0; q.w = 0;
+        q.x = (uint32_t)aq; q.y = (uint32_t)(aq >> 32); q.z = (!CLEAN && B.bp_allowed) ? B.spec[item] : 0u; q.w = 0;
         B.work[2 * (size_t)w] = e;
         B.work[2 * (size_t)w + 1] = q;
     }
@@ -613,30 +615,31 @@ TGSF_KERNEL TGSF_BOUNDS(256, 3) k_stats(DevParams P, DevBatch B)
 #else
         if (lane < ng) { me = B.work[2 * (size_t)(g0 + lane)]; mq = B.work[2 * (size_t)(g0 + lane) + 1]; }
 #endif
-        auto entry = [&](uint32_t i, uint64_t& a0, uint64_t& aq, uint32_t& nb, uint32_t& tt, uint32_t& item) {
+        auto entry = [&](uint32_t i, uint64_t& a0, uint64_t& aq, uint32_t& nb, uint32_t& tt, uint32_t& item, uint32_t& spz) {
 #if defined(TGSF_EMUL)
             const uint4 e = B.work[2 * (size_t)(g0 + i)], q = B.work[2 * (size_t)(g0 + i) + 1];
             a0 = (uint64_t)e.x | ((uint64_t)e.y << 32); nb = e.z & 0x1FFFu; tt = e.z >> 13; item = e.w;
-            aq = (uint64_t)q.x | ((uint64_t)q.y << 32);
+            aq = (uint64_t)q.x | ((uint64_t)q.y << 32); spz = q.z;
 #else
             const uint32_t x = wave_pick(me.x, i), y = wave_pick(me.y, i), z = wave_pick(me.z, i);
             const uint32_t qx = wave_pick(mq.x, i), qy = wave_pick(mq.y, i);
             item = wave_pick(me.w, i);
+            spz = BP ? wave_pick(mq.z, i) : 0u;
             a0 = (uint64_t)x | ((uint64_t)y << 32); nb = z & 0x1FFFu; tt = z >> 13;
             aq = (uint64_t)qx | ((uint64_t)qy << 32);
 #endif
         };
-        uint64_t a0, aq; uint32_t nb, tt, item;
-        entry(0, a0, aq, nb, tt, item);
+        uint64_t a0, aq; uint32_t nb, tt, item, spz;
+        entry(0, a0, aq, nb, tt, item, spz);
         issue(a0, aq, nb);
         for (uint32_t i = 0; i < ng; i++) {
             TGSF_WAVE_SYNC();                                  // previous tile fully consumed
             commit(a0, aq, nb);
             TGSF_WAVE_SYNC();
-            const uint64_t ca0 = a0, caq = aq; const uint32_t cnb = nb, ctt = tt, citem = item;
-            if (i + 1 < ng) { entry(i + 1, a0, aq, nb, tt, item); issue(a0, aq, nb); }   // in flight during the reduce
+            const uint64_t ca0 = a0, caq = aq; const uint32_t cnb = nb, ctt = tt, citem = item, cspz = spz;
+            if (i + 1 < ng) { entry(i + 1, a0, aq, nb, tt, item, spz); issue(a0, aq, nb); }   // in flight during the reduce
             const bool ineg = CLEAN && citem >= B.fcap;         // a read being taken back out
-            const bool sp = BP && B.spec[citem] != 0u;          // (wave-uniform) a read the batch speculates on
+            const bool sp = BP && cspz != 0u;                   // (wave-uniform) a read the batch speculates on
             if (ctt != t_acc || ineg != neg || since >= 1024 || (BP && sp != cur_sp)) { // qs[c] carries 128*sum of bytes up to 255: stay below 2^32
                 if (t_acc != 0xFFFFFFFFu) flush(t_acc);
                 t_acc = ctt;
@@ -775,37 +778,53 @@ TGSF_KERNEL TGSF_BOUNDS(256, 3) k_stats(DevParams P, DevBatch B)
 // are tallied here, one lane a read, into the batch's raw table and the read's quality sum (CalcAvgQuality,
 // src/TGSFilter.cpp:1436-1479, on those bytes).  A few bytes per read: the 3' trims the pre-pass finds are below 150.
 // ---------------------------------------------------------------------------
+// The reads of a batch are of similar length where such a trim exists (HiFi: 3' trims of a few bases), so their tails fall
+// into a few dozen rows of the table: tallied straight into it, 262 144 reads spent 0.53 ms queueing at those rows' atomics.
+// A workgroup tallies into LDS first (tables of up to kTailRows rows; longer tables -- reads spread over thousands of rows --
+// go straight to memory) and adds what it gathered once.
+constexpr int kTailRows = 1024;
 TGSF_KERNEL k_tail_fix(DevParams P, DevBatch B)
 {
+    TGSF_SHARED int32_t acc[kTailRows][10];            // [row][5 counts, 5 sums of (quality - qType)]
     if (!B.bp_allowed || P.tail_trim <= 0) return;
     uint64_t* const tab_q = B.raw_tab;
     uint64_t* const tab_c = B.raw_tab + (size_t)P.n_bins * 5;
+    const bool in_lds = P.n_bins <= (uint32_t)kTailRows;
+    int32_t* const flat = &acc[0][0];
+    if (in_lds) for (uint32_t i = TGSF_COOP_BEGIN; i < (uint32_t)kTailRows * 10u; i += TGSF_COOP_STRIDE) flat[i] = 0;
+    TGSF_BLOCK_SYNC();
     for (uint32_t r = gtid(); r < B.n; r += gsize()) {
         const uint32_t L = B.len[r];
         if (!L || !B.spec[r]) continue;
         const uint8_t* sq = B.seq + B.off[r];
         const uint8_t* ql = B.qual + B.qoff[r];
         int64_t sum = 0;
-        uint32_t row = 0xFFFFFFFFu, cn[5] = {0, 0, 0, 0, 0};
-        int64_t qv[5] = {0, 0, 0, 0, 0};
-        auto put = [&] {
-            if (row == 0xFFFFFFFFu) return;
-            for (int c = 0; c < 5; c++)
-                if (cn[c]) { atomicAdd((ull*)&tab_c[(size_t)row * 5 + c], (ull)cn[c]); atomicAdd((ull*)&tab_q[(size_t)row * 5 + c], (ull)qv[c]); cn[c] = 0; qv[c] = 0; }
-        };
         for (uint32_t i = L - (uint32_t)P.tail_trim; i < L; i++) {
-            if (i / (uint32_t)kBin != row) { put(); row = i / (uint32_t)kBin; }
+            const uint32_t row = i / (uint32_t)kBin;
             const uint32_t b = (uint32_t)sq[i] & 0xDFu;
             const int c = (sq[i] & 0x80u) ? 4 : b == 'A' ? 0 : b == 'T' ? 1 : b == 'G' ? 2 : b == 'C' ? 3 : 4;
             // `qual[i] - qType` on a signed char (:1455-1457); records without qualities: 0
-            const int64_t q = P.no_qual ? 0 : (int64_t)(int8_t)ql[i] - (int64_t)P.qtype;
-            if (c < 4) { cn[c]++; qv[c] += q; }
-            cn[4]++; qv[4] += q;
+            const int32_t q = P.no_qual ? 0 : (int32_t)(int8_t)ql[i] - (int32_t)P.qtype;
+            if (in_lds) {
+                if (c < 4) { atomicAdd(&acc[row][c], 1); atomicAdd(&acc[row][5 + c], q); }
+                atomicAdd(&acc[row][4], 1); atomicAdd(&acc[row][9], q);
+            } else {
+                if (c < 4) { atomicAdd((ull*)&tab_c[(size_t)row * 5 + c], (ull)1); atomicAdd((ull*)&tab_q[(size_t)row * 5 + c], (ull)(int64_t)q); }
+                atomicAdd((ull*)&tab_c[(size_t)row * 5 + 4], (ull)1); atomicAdd((ull*)&tab_q[(size_t)row * 5 + 4], (ull)(int64_t)q);
+            }
             sum += q;
         }
-        put();
         atomicAdd((ull*)&B.sumq[r], (ull)sum);
     }
+    TGSF_BLOCK_SYNC();
+    if (in_lds)
+        for (uint32_t i = TGSF_COOP_BEGIN; i < P.n_bins * 5u; i += TGSF_COOP_STRIDE) {
+            const uint32_t row = i / 5u, c = i % 5u;
+            const int32_t cn = acc[row][c];
+            if (!cn) continue;
+            atomicAdd((ull*)&tab_c[(size_t)row * 5 + c], (ull)(int64_t)cn);
+            atomicAdd((ull*)&tab_q[(size_t)row * 5 + c], (ull)(int64_t)acc[row][5 + c]);
+        }
 }
 
 // ---------------------------------------------------------------------------

@@ -741,7 +741,8 @@ static int run_pipeline(tgsf_ctx* c, const tgsf_batch_in* in, tgsf_read_result* 
     // the text is fetched with non-temporal loads: 2.24 -> 2.06 ms, 5.4 -> 5.8 TB/s, round 3)
     if (B.bp_allowed) {
         TGSF_LAUNCH((k_stats<false, true, true>), gstats, 64 * kStatsWaves, st, P, B);
-        if (P.tail_trim > 0) TGSF_LAUNCH(k_tail_fix, gsmall, T, st, P, B);       // (the bytes behind a speculated fragment)
+        // (the bytes behind a speculated fragment: few, large workgroups -- each adds its LDS tallies to the table once)
+        if (P.tail_trim > 0) TGSF_LAUNCH(k_tail_fix, grid_cap(std::min(blocks_for(n, 1024), 128u)), 1024, st, P, B);
     } else TGSF_LAUNCH((k_stats<false, true>), gstats, 64 * kStatsWaves, st, P, B);
     if (!redo) TGSF_LAUNCH(k_fold_raw<false>, gfold, T, st, P, B);   // (a second run: the batch's raw tallies are in the tables already)
     STAGE_MARK();

@@ -100,6 +100,7 @@ struct Run {
     std::unique_ptr<Channel<std::shared_ptr<Batch>>> to_gpu, to_writer;
     std::vector<int> raw_lens, clean_lens;
     uint64_t raw_bases = 0, clean_bases = 0;
+    uint64_t own_raw_bases = 0;         // what THIS process read (a sharded job's rank 0 ends with the job's total in raw_bases)
     std::vector<CleanRec> clean_recs;   // only filled when downsampling follows
     BatchStore store;
     std::atomic<uint64_t> stream_text{0};   // streamed input: text handed out so far ...

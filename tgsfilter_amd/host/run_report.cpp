@@ -71,6 +71,7 @@ void Run::sum_tallies()
     t.assign(nw, 0);
     std::vector<uint64_t> part(nw);
     t_x0 = now_s();
+    own_raw_bases = raw_bases;                                         // (rank 0's raw_bases becomes the job's below)
     const char* ex = getenv("TGSF_SHARD_EXCHANGE");
     const bool must_rccl = ex && !strcmp(ex, "rccl");
     for (tgsf_ctx* c : ctxs) add_context(L, c, t, part, bc, nbins);    // this rank's (or this process's) own sums, before anything is merged on the device
@@ -348,8 +349,8 @@ void Run::timing_lines()
             own += v;
             if (v >= 0.0005) { snprintf(piece, sizeof piece, "%s %s %.3f", line.empty() ? "" : ",", cpu_stage_name(s), v); line += piece; }
         }
-        snprintf(piece, sizeof piece, "CPU: %.3f s of CPU time (user + system) for %.3f Gbases = %.4f CPU-s per Gbase |", proc, (double)raw_bases * 1e-9,
-                 raw_bases ? proc / ((double)raw_bases * 1e-9) : 0.0);
+        snprintf(piece, sizeof piece, "CPU: %.3f s of CPU time (user + system) for %.3f Gbases = %.4f CPU-s per Gbase |", proc, (double)own_raw_bases * 1e-9,
+                 own_raw_bases ? proc / ((double)own_raw_bases * 1e-9) : 0.0);
         std::string head = piece;
         snprintf(piece, sizeof piece, " | threads of the runtime and others %.3f\n", proc - own);
         fputs((head + line + piece).c_str(), stderr);
