@@ -25,7 +25,10 @@ CLI = os.path.join(ROOT, "tgsfilter_amd", "bin", "tgsfilter")
 def main():
     args = sys.argv[1:]
     n = int(args.pop(0)) if args and args[0].isdigit() else 1_333_334
-    sweeps = [(a.split("=", 1)[0], a.split("=", 1)[1].split(",")) for a in args]
+    # VAR=v1,v2 (one run per value) or A=x+B=y (one run with both set)
+    combos = [dict(kv.split("=", 1) for kv in a.split("+")) for a in args if "+" in a]
+    sweeps = [(a.split("=", 1)[0], a.split("=", 1)[1].split(",")) for a in args if "+" not in a]
+    ranks = int(os.environ.get("RANKS", "0"))
     reps = int(os.environ.get("REPS", "2"))
     print("box: shmem_enabled = %s | cpu.max = %s" % (open("/sys/kernel/mm/transparent_hugepage/shmem_enabled").read().strip(),
                                                      bench.cgroup_limits()["cpus"]), flush=True)
@@ -39,12 +42,13 @@ def main():
 
         def run(tag, extra_env, sink=out):
             for _ in range(reps):
-                if os.path.isfile(out) and not os.path.islink(out):
-                    os.remove(out)
+                for f in [out] + ["%s.part%d" % (out, r) for r in range(64)]:
+                    if os.path.isfile(f) and not os.path.islink(f):
+                        os.remove(f)
                 env = dict(os.environ, TGSF_TIMING="1", TGSF_DEBUG_KNOBS="1", **extra_env)
                 c0 = bench.cgroup_cpu()
                 t0 = time.perf_counter()
-                p = subprocess.run([CLI, "-i", fq, "-o", sink] + flags, capture_output=True, env=env)
+                p = subprocess.run([CLI, "-i", fq, "-o", sink] + flags + (["--ranks", str(ranks), "--devices", "0"] if ranks else []), capture_output=True, env=env)
                 dt = time.perf_counter() - t0
                 c1 = bench.cgroup_cpu()
                 if p.returncode:
@@ -61,9 +65,15 @@ def main():
         for var, values in sweeps:
             for v in values:
                 run("%s=%s" % (var, v), {var: v})
+        for c in combos:
+            run("+".join("%s=%s" % (k, os.path.basename(v)) for k, v in c.items()), c)
         null = os.path.join(td, "null.fq")
         os.symlink("/dev/null", null)
+        for r in range(ranks):
+            os.symlink("/dev/null", "%s.part%d" % (null, r))
         run("baseline -> /dev/null", {}, null)
+        for c in combos:
+            run("+".join("%s=%s" % (k, os.path.basename(v)) for k, v in c.items()) + " -> /dev/null", c, null)
     finally:
         shutil.rmtree(td, ignore_errors=True)
 
