@@ -242,11 +242,26 @@ extern "C" const char* tgsf_backend(void) { return kTgsfEmul ? "emulation" : "hi
 #if !defined(TGSF_EMUL)
 __global__ void k_noop(int* p) { if (p) *p = 0; }
 #endif
+#if !defined(TGSF_EMUL)
+// How a host thread waits for the device (hipStreamSynchronize / hipEventSynchronize inside tgsf_submit and tgsf_wait).  The
+// runtime's default spins where it sees spare CPUs; the library asks for waits that SLEEP when it is the one that brings the
+// device up (a process that initialised the device before -- PyTorch in bench.py's kernel path -- keeps what it chose: the
+// call then fails and is ignored).  Measured on the MI355X host, one of C2's files (profiles/r06_cpu_blocking_sync.txt): the
+// feeders' CPU time 7.6 -> 5.8 s in one process and 21 -> 7-10 s in three rank processes sharing the GPU, wall time unchanged --
+// what a job of N ranks under a CPU quota needs.  TGSF_SYNC=spin keeps the runtime's default.
+static void set_wait_mode(int device)
+{
+    const char* e = getenv("TGSF_SYNC");
+    if (e && !strcmp(e, "spin")) return;
+    if (hipSetDevice(device) == hipSuccess) { (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); (void)hipGetLastError(); }
+}
+#endif
 extern "C" int tgsf_prepare_device(int device)
 {
 #if !defined(TGSF_EMUL)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return TGSF_E_NO_DEVICE;
+    set_wait_mode(device);
     if (hipSetDevice(device) != hipSuccess) return TGSF_E_HIP;
     hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, 0, (int*)nullptr);      // loads the code object
     if (hipDeviceSynchronize() != hipSuccess) return TGSF_E_HIP;
@@ -408,6 +423,7 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
         return fail(nullptr, TGSF_E_NO_DEVICE, "no HIP device available (%s); libtgsf has no CPU fallback", hipGetErrorString(he));
     }
     if (device < 0 || device >= ndev) { delete c; return fail(nullptr, TGSF_E_NO_DEVICE, "device %d out of range (%d devices)", device, ndev); }
+    set_wait_mode(device);
     if ((he = hipSetDevice(device)) != hipSuccess) { delete c; return fail(nullptr, TGSF_E_HIP, "hipSetDevice: %s", hipGetErrorString(he)); }
     if ((he = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
         delete c; return fail(nullptr, TGSF_E_HIP, "hipStreamCreate: %s", hipGetErrorString(he));

@@ -16,7 +16,7 @@ namespace host {
 // is read) force small batches, strides and rare paths in the tests.  They are read only when TGSF_DEBUG_KNOBS=1 is in the
 // environment -- the test suite sets it --: a stray variable never changes what a user's run does.  The settings a user may
 // give are the few README.md lists (TGSF_TIMING, TGSF_DETACH, TGSF_NUMA, TGSF_WRITER, TGSF_CTX_PER_DEVICE, TGSF_SHARD_EXCHANGE,
-// TGSF_LIB, TGSF_ASSETS) and are read with getenv where they apply.
+// TGSF_LIB, TGSF_ASSETS; the library reads TGSF_SYNC) and are read with getenv where they apply.
 inline const char* knob(const char* name)
 {
     static const bool on = [] { const char* e = getenv("TGSF_DEBUG_KNOBS"); return e && e[0] == '1'; }();
