@@ -4,21 +4,25 @@
 Contract (see the driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
 torch.distributed.run, one rank per GPU.
 
+STDOUT carries ONE line of at most 4 kB (the contract's keys, `roofline`, `cpu_baseline`, the speed-up, `scaling_figures`);
+everything else this program measures goes to `--detail-file` (default: bench_detail.json beside this file) and to stderr.
+
 HEADLINE (`value`): the END-TO-END metric of BASELINE.json / SURVEY 8(d) -- input bases / wall seconds of the
-whole command line (tgsfilter_amd/bin/tgsfilter) on a FASTQ text file of config C2's shape held on tmpfs:
-process start, library load, index, pre-pass, H2D, kernels, D2H of reads and fragments, formatting, output file
-written and closed, report written.  A step = one whole run of the command line over that file; W warm-up runs,
-K timed runs.  The reference binary (oracle/_ref/tgsfilter_ref -t <cores>) runs on the SAME file with the SAME
-flags and the SAME sink in the same bench run: that is `cpu_baseline`; the two output files are compared as
-multisets of records (the reference's order is nondeterministic with -t > 1) and the INFO counters line by line.
-Both sinks SURVEY 8(d) allows are measured (a tmpfs file -- the headline -- and /dev/null), see `e2e`.
+whole command line (tgsfilter_amd/bin/tgsfilter) on FASTQ text of config C2's shape held on tmpfs: process start,
+library load, index, pre-pass, H2D, kernels, D2H of reads and fragments, formatting, output file written and closed,
+report written.  C2's 4 M reads are staged as consecutive files (the box's memory control group does not hold them at
+once); a STEP = one run of the command line over ONE staged file, the K timed steps dealt over the files in staging
+order (see e2e_leg).  The reference binary (oracle/_ref/tgsfilter_ref -t <cores>) runs on the SAME files with the SAME
+flags and the SAME sink in the same bench run: that is `cpu_baseline`; the output files are compared as multisets of
+records (the reference's order is nondeterministic with -t > 1) and the INFO lines one by one.  Both sinks SURVEY 8(d)
+allows are measured (a tmpfs file -- the headline -- and /dev/null), see `e2e` in the detail file.
 
 `kernel_path`: the device-resident figure (batches already in HBM, tgsf_submit_device), kept separate; the
 `roofline` block is measured on it with HIP events on the launch stream inside the library.
 
-N > 1: the end-to-end runs use `--devices 0..N-1` (rank 0 drives the command line; one feeder set per GPU, tallies
-merged once); the kernel path runs the FIXED C4 job (31 batches = 4.06 M reads) dealt over the ranks -- strong
-scaling -- with ONE all-reduce (RCCL) of the tally vector inside the timed region.
+N > 1: the end-to-end runs are `tgsfilter --ranks N --devices 0..N-1` (one rank process per GPU, a part file each, one
+all-reduce of the tallies; no reference at N > 1); the kernel path runs the FIXED C4 job (31 batches = 4.06 M reads)
+dealt over the ranks -- strong scaling -- with ONE all-reduce (RCCL) of the tally vector inside the timed region.
 """
 from __future__ import annotations
 

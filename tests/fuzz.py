@@ -74,7 +74,8 @@ def random_case(seed: int, n_reads: int):
         r2 = np.random.default_rng(seed ^ 0x5EED7A11)
         kw.update(head_trim=int(r2.choice([0, 1, 3, 4, 79, 99, 100, 101, 137, 250, 6400, 6401])), tail_trim=int(r2.choice([0, 0, 1, 8, 99, 100, 120])),
                   filter=True, min_len=int(r2.choice([100, 500, 1000])))
-        kw.pop("min_repeat", None); kw.pop("kmer", None)
+        if r2.random() < 0.5:                                             # (the by-product beside the repeat gate: round 6)
+            kw.pop("min_repeat", None); kw.pop("kmer", None)
         kw["_force_by_product"] = bool(r2.random() < 0.7)
     return kind, reads, kw
 

@@ -579,9 +579,11 @@ extern "C" int tgsf_create(const tgsf_params* p, int device, tgsf_ctx** out)
     if (!e) e = dev_alloc(c, &B.plan, 4);
     B.clean_force = p->only_qc ? 1u : 0u;
     // the clean tables as a by-product of the raw pass (DevBatch::spec): a filtering run with fixed trims in front of the
-    // keep region (without trims a read kept whole is what the difference strategy handles already) and no repeat gate
-    // (its verdict comes after the raw pass); the work list words hold a staged length of 13 bits
-    B.bp_allowed = (p->filter && !p->only_qc && p->min_repeat <= 0 && (p->head_trim > 0 || p->tail_trim > 0) &&
+    // keep region (without trims a read kept whole is what the difference strategy handles already); the work list words hold
+    // a staged length of 13 bits.  (Round 6: also with the repeat gate, -p.  Its verdict comes after the raw pass, and a
+    // fragment it drops never reaches CalcAvgQuality, :1982-1994 -- but that is one more way for a read to turn out otherwise:
+    // k_clean_plan finds such a read not `whole` and its speculated range is taken back out like any other's.)
+    B.bp_allowed = (p->filter && !p->only_qc && (p->head_trim > 0 || p->tail_trim > 0) &&
                     p->head_trim >= 0 && p->tail_trim >= 0) ? 1u : 0u;
     static_assert(kTileBases < (1 << 13), "staged bytes of a tile fit the work list's 13 bits");
     if (const char* f = knob("TGSF_CLEAN_TABLES")) {      // test knob: "direct" | "difference" | "byproduct" (always speculate)
