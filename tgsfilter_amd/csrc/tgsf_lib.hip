@@ -244,15 +244,16 @@ __global__ void k_noop(int* p) { if (p) *p = 0; }
 #endif
 #if !defined(TGSF_EMUL)
 // How a host thread waits for the device (hipStreamSynchronize / hipEventSynchronize inside tgsf_submit and tgsf_wait).  The
-// runtime's default spins where it sees spare CPUs; the library asks for waits that SLEEP when it is the one that brings the
-// device up (a process that initialised the device before -- PyTorch in bench.py's kernel path -- keeps what it chose: the
-// call then fails and is ignored).  Measured on the MI355X host, one of C2's files (profiles/r06_cpu_blocking_sync.txt): the
-// feeders' CPU time 7.6 -> 5.8 s in one process and 21 -> 7-10 s in three rank processes sharing the GPU, wall time unchanged --
-// what a job of N ranks under a CPU quota needs.  TGSF_SYNC=spin keeps the runtime's default.
+// runtime's default spins where it sees spare CPUs.  TGSF_SYNC=blocking makes the waits SLEEP: the library then sets the
+// device's scheduling flag before it brings the device up.  It is the HOST PROGRAM's choice, not the library's: the command
+// line asks for it (host/main.cpp; measured on the MI355X host, one of C2's files, profiles/r06_cpu_blocking_sync.txt: the
+// feeders' CPU time 7.6 -> 5.8 s in one process and 21 -> 7-10 s in three rank processes sharing the GPU, wall time
+// unchanged -- what a job of N ranks under a CPU quota needs); a process that shares the device with another user of the
+// runtime must not -- with PyTorch active in the same process (bench.py's kernel path) changing the flag hung the next wait.
 static void set_wait_mode(int device)
 {
     const char* e = getenv("TGSF_SYNC");
-    if (e && !strcmp(e, "spin")) return;
+    if (!e || strcmp(e, "blocking") != 0) return;
     if (hipSetDevice(device) == hipSuccess) { (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); (void)hipGetLastError(); }
 }
 #endif

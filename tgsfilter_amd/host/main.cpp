@@ -129,6 +129,10 @@ int main(int argc, char** argv)
         const int r = shard_rank_on_command_line(argc, argv);
         if (r >= 0) std::cerr.rdbuf(new InfoFilter(std::cerr.rdbuf(), r > 0));
     }
+    // the library's waits for the GPU sleep instead of spinning (tgsf_lib.hip, set_wait_mode): this program is the device's only
+    // user in its process, and under a CPU quota shared by N ranks a spinning feeder is a CPU the fill threads do not get.
+    // TGSF_SYNC=spin in the environment keeps the runtime's default.
+    setenv("TGSF_SYNC", "blocking", 0);
     Options o;
     if (parse_args(argc, argv, o)) return 1;
     Run run(o);
