@@ -219,6 +219,11 @@ const char* tgsf_backend(void);
  * Optional: bring the HIP runtime up on `device` and load the library's kernels (first use costs a few
  * tenths of a second).  Thread-safe; a host program can call it from a helper thread while it is still
  * reading its parameters, so that tgsf_create and the first batch do not pay for it.
+ *
+ * How host threads wait for the device inside tgsf_submit / tgsf_wait is the HOST PROGRAM's choice: with TGSF_SYNC=blocking in
+ * the environment when the library brings a device up (here or in tgsf_create) the waits sleep (hipDeviceScheduleBlockingSync)
+ * instead of spinning -- fewer CPU seconds at the same wall time; the tgsfilter command line sets it.  Leave it unset in a
+ * process that shares the device with another user of the HIP runtime (PyTorch ...): the flag is the device's, not the library's.
  */
 int tgsf_prepare_device(int device);
 
