@@ -73,10 +73,17 @@ TGSF_D uint64_t wave_sum(uint64_t v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// The sum over the wave's 64 lanes, in every lane.  Six DPP adds (VALU, no LDS round trips: __shfl_xor is a ds_bpermute, and six
+// of those in a row sat in front of every tile of k_stats, twice for a speculated read): within quads, within rows of 16, then
+// row 0 into row 1 and row 2 into row 3 (row_bcast:15), rows 0-1 into rows 2-3 (row_bcast:31); lane 63 holds the total.
 TGSF_D int32_t wave_sum_i32(int32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);     // quad_perm:[1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);     // quad_perm:[2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);    // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);    // row_mirror: every lane of a row holds the row's sum
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);    // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);    // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
 }
 TGSF_D uint32_t wave_max(uint32_t v) {
 #pragma unroll

@@ -733,8 +733,9 @@ TGSF_KERNEL TGSF_BOUNDS(256, 3) k_stats(DevParams P, DevBatch B)
                 nv = nvalid > kBin ? kBin : nvalid;
                 if (BP && sp && bp_b) {
                     nh = nv < (int)bp_b ? nv : (int)bp_b;
-                    // (two calls of the general loop.  One pass over the bin's 25 dwords that changes tallies at the split was
-                    // built and measured beside this, round 6: the raw pass took the same 2.3 ms either way)
+                    // (two calls of the general loop.  Built and measured beside this, round 6, with the same raw-pass time either way: one
+                    // pass over the bin's 25 dwords that changes tallies at the split; and, for a piece of a few bytes (C3's 5' trim of
+                    // 7), the whole bin through the plain pass's unrolled loop + the small piece once more, the other piece as the difference)
                     qorh = bin(lane * kBin, nh, hcnt, hqs);
                     if (nv > nh) qor = bin(lane * kBin + bp_b, nv - nh, cnt, qs);
                     hcall += (uint32_t)nh;
@@ -746,7 +747,8 @@ TGSF_KERNEL TGSF_BOUNDS(256, 3) k_stats(DevParams P, DevBatch B)
             }
             const uint32_t R = ctt * kTileBins + lane;
             int32_t high_all = 0;
-            if (wave_or((qor | qorh) & 0x80808080u) && nv > 0 && ((qor | qorh) & 0x80808080u))
+            const bool any_high = wave_any(((qor | qorh) & 0x80808080u) != 0u);          // (one ballot: no lane-to-lane reduction)
+            if (any_high && nv > 0 && ((qor | qorh) & 0x80808080u))
                 high_all = high_bytes(lane * kBin, nv, tab_q, (size_t)R * 5, ineg);
             // sumQ of the item: sum over the tile of (qual - qType), two's complement in u64 (:1457-1458)
             const int32_t part = (int32_t)(qs[4] + (BP ? hqs[4] : 0u) - q4_before) - (int32_t)qt * nv - 256 * high_all;
@@ -756,7 +758,7 @@ TGSF_KERNEL TGSF_BOUNDS(256, 3) k_stats(DevParams P, DevBatch B)
                 // (pieces in front of head_trim -- rows below those -- belong to no clean row); their share of the read's clean sum
                 const bool t_in = R >= bp_q, h_in = R >= bp_q + 1u;
                 int32_t chigh = 0;
-                if (wave_or((qor | qorh) & 0x80808080u) && nv > 0) {     // (quality bytes of 128 and above: 256 each comes back out, as in the raw row)
+                if (any_high && nv > 0) {                                // (quality bytes of 128 and above: 256 each comes back out, as in the raw row)
                     uint64_t* const ct = B.replay ? nullptr : ctab_q;
                     if (nh > 0 && h_in && (qorh & 0x80808080u)) chigh += high_bytes(lane * kBin, nh, ct, (size_t)(R - bp_q - 1u) * 5, false);
                     if (nv > nh && t_in && (qor & 0x80808080u)) chigh += high_bytes(lane * kBin + (uint32_t)nh, nv - nh, ct, (size_t)(R - bp_q) * 5, false);
