@@ -125,6 +125,21 @@ def by_product_high_quality_bytes(lib_path, head, tail, monkeypatch, large=False
             ctx.close()
 
 
+def tail_fix_long_tables(lib_path, monkeypatch):
+    """k_tail_fix's other way (round 6): a context whose per-100-bp tables are longer than its LDS tallies hold (reads of more
+    than 102 400 bp may come) adds the bytes behind a speculated fragment straight to the tables in memory."""
+    monkeypatch.setenv("TGSF_CLEAN_TABLES", "byproduct")
+    reads = synth.make_reads(77, 60, "ont", mean_len=4000, zoo=True, pmid=0.05, p5=0.3)
+    p = sized(abi.make_params("ont", adapters=[synth.ONT_RAPID, synth.ONT_RAPID_RC], min_q=7.0, head_trim=79, tail_trim=13), reads)
+    p.max_read_len = 250_000                                          # 2 501 rows
+    ctx = capi.Context(p, 0, lib_path)
+    try:
+        assert ctx.n_bins > 1024
+        compare_batch(ctx, p, reads, align=16)
+    finally:
+        ctx.close()
+
+
 def golden_case(lib_path, golden_dir, name):
     case = hostmodel.GoldenCase(golden_dir, name)
     p = sized(case.params(), case.reads)

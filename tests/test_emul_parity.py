@@ -409,6 +409,10 @@ def test_emul_clean_tables_as_a_by_product_of_the_raw_pass(emul, kind, head, tai
     parity.by_product_run(emul, kind, head, tail, monkeypatch=monkeypatch, mode=mode)
 
 
+def test_emul_tail_fix_with_tables_longer_than_its_lds_tallies(emul, monkeypatch):
+    parity.tail_fix_long_tables(emul, monkeypatch)
+
+
 @pytest.mark.parametrize("head,tail", [(79, 0), (250, 31), (100, 3), (3, 120)])
 def test_emul_by_product_with_quality_bytes_of_128_and_above(emul, head, tail, monkeypatch):
     parity.by_product_high_quality_bytes(emul, head, tail, monkeypatch)

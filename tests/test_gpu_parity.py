@@ -434,6 +434,10 @@ def test_gpu_clean_tables_as_a_by_product_of_the_raw_pass(kind, head, tail, mode
     parity.by_product_run(None, kind, head, tail, monkeypatch=monkeypatch, mode=mode)
 
 
+def test_gpu_tail_fix_with_tables_longer_than_its_lds_tallies(monkeypatch):
+    parity.tail_fix_long_tables(None, monkeypatch)
+
+
 @pytest.mark.parametrize("head,tail", [(79, 0), (250, 31), (100, 3), (3, 120)])
 def test_gpu_by_product_with_quality_bytes_of_128_and_above(head, tail, monkeypatch):
     parity.by_product_high_quality_bytes(None, head, tail, monkeypatch, large=True)
